@@ -1,0 +1,74 @@
+"""ctypes binding of the C-ABI HIP library (include/gsr.h -> gaustar_amd/libgsr_hip.so).
+
+There is deliberately NO fallback: if the shared library is missing or fails to load, every
+entry point raises.  The product path never touches oracle/.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
+
+ABI_VERSION = 1
+ALLOC_FN = ctypes.CFUNCTYPE(c_void_p, c_void_p, c_size_t)
+
+# name -> (restype, argtypes); mirrors include/gsr.h one to one (tests check both directions).
+SIGNATURES = {
+    "gsr_abi_version": (c_int, []),
+    "gsr_last_error": (c_char_p, []),
+    "gsr_geom_bytes": (c_size_t, [c_int]),
+    "gsr_image_bytes": (c_size_t, [c_int, c_int]),
+    "gsr_binning_bytes": (c_size_t, [c_int]),
+    "gsr_forward_stage1": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float,
+                                   c_int, c_void_p, c_void_p, c_void_p, POINTER(c_int), POINTER(c_int), c_void_p]),
+    "gsr_forward_stage2": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p]),
+    "gsr_forward": (c_int, [ALLOC_FN, ALLOC_FN, ALLOC_FN, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int,
+                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
+                            c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, POINTER(c_int),
+                            c_void_p]),
+    "gsr_backward": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                             c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gsr_mark_visible": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gsr_debug_export": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+class GsrError(RuntimeError):
+    """A C-ABI call returned non-zero (message from gsr_last_error)."""
+
+
+def load():
+    """Load libgsr_hip.so (once).  Raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"gaustar_amd: HIP extension not found at {LIB_PATH}. Build it with "
+            "`python -m gaustar_amd.build` (hipcc, gfx950). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.gsr_abi_version()
+    if v != ABI_VERSION:
+        raise ImportError(f"gaustar_amd: libgsr_hip.so has ABI {v}, Python side expects {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().gsr_last_error()
+        raise GsrError(f"{what} failed: {msg.decode() if msg else rc}")

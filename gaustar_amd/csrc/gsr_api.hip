@@ -1,0 +1,240 @@
+// gsr_api.hip -- the C ABI (include/gsr.h): stage drivers, scratch sizing, error reporting.
+// Host-side counterpart of CudaRasterizer::Rasterizer::{forward,backward,markVisible}
+// (DGR/cuda_rasterizer/rasterizer_impl.cu:141-153, :198-336, :340-434).
+#include "../../include/gsr.h"
+#include "gsr_internal.h"
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+using namespace gsr;
+
+namespace {
+thread_local std::string g_err;
+thread_local uint32_t* g_pinned = nullptr;   // 16-byte pinned landing pad for the stage-1 read-back
+
+int fail(const char* where, hipError_t e)
+{
+    g_err = std::string(where) + ": " + hipGetErrorString(e);
+    return 1;
+}
+int fail_msg(const char* msg)
+{
+    g_err = msg;
+    return 2;
+}
+#define GSR_CHECK(expr)                                   \
+    do {                                                  \
+        hipError_t e__ = (expr);                          \
+        if (e__ != hipSuccess) return fail(#expr, e__);   \
+    } while (0)
+#define GSR_CHECK_LAUNCH(name)                            \
+    do {                                                  \
+        hipError_t e__ = hipGetLastError();               \
+        if (e__ != hipSuccess) return fail(name, e__);    \
+    } while (0)
+}  // namespace
+
+extern "C" {
+
+int gsr_abi_version(void) { return 1; }
+
+const char* gsr_last_error(void) { return g_err.c_str(); }
+
+size_t gsr_geom_bytes(int P) { return carve_geom(nullptr, P > 0 ? P : 0).bytes; }
+size_t gsr_image_bytes(int W, int H) { return carve_image(nullptr, W, H).bytes; }
+size_t gsr_binning_bytes(int R) { return carve_bin(nullptr, R > 0 ? R : 0).bytes; }
+
+int gsr_forward_stage1(int P, int D, int M, const float* means3D, const float* shs, const float* colors_precomp,
+                       const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                       const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                       const float* campos, int W, int H, float tan_fovx, float tan_fovy, int prefiltered, int* radii,
+                       void* geom_buffer, void* image_buffer, int* num_rendered, int* max_tile_instances,
+                       gsr_stream_t stream)
+{
+    (void)prefiltered;   // the reference only uses it to trap on a culled point (auxiliary.h:156-160)
+    g_err.clear();
+    if (!num_rendered || !max_tile_instances) return fail_msg("gsr_forward_stage1: null output pointer");
+    *num_rendered = 0;
+    *max_tile_instances = 0;
+    if (W <= 0 || H <= 0) return fail_msg("gsr_forward_stage1: image size must be positive");
+    if (P < 0) return fail_msg("gsr_forward_stage1: negative P");
+    if (!image_buffer) return fail_msg("gsr_forward_stage1: image_buffer is null");
+    if (P > 0) {
+        if (!means3D || !opacities || !viewmatrix || !projmatrix || !campos || !radii || !geom_buffer)
+            return fail_msg("gsr_forward_stage1: required pointer is null");
+        if ((shs == nullptr) == (colors_precomp == nullptr))
+            return fail_msg("gsr_forward_stage1: provide exactly one of shs / colors_precomp");
+        if (shs && (D < 0 || D > 3 || (D + 1) * (D + 1) > M))
+            return fail_msg("gsr_forward_stage1: sh degree must be 0..3 and fit in M coefficients");
+        if ((cov3D_precomp == nullptr) == (scales == nullptr || rotations == nullptr))
+            return fail_msg("gsr_forward_stage1: provide exactly one of scales+rotations / cov3D_precomp");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const Tiles t = tiles_of(W, H);
+    ImageState im = carve_image(image_buffer, W, H);
+    GSR_CHECK(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * (size_t)t.T, st));
+    if (P > 0) {
+        GeomState g = carve_geom(geom_buffer, P);
+        launch_preprocess(P, D, M, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                          cov3D_precomp, viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, radii, g, im, st);
+        GSR_CHECK_LAUNCH("preprocess_kernel");
+    }
+    launch_tile_scan(im, t.T, st);
+    GSR_CHECK_LAUNCH("tile_scan_kernel");
+    if (!g_pinned) GSR_CHECK(hipHostMalloc((void**)&g_pinned, 64, hipHostMallocDefault));
+    GSR_CHECK(hipMemcpyAsync(g_pinned, im.totals, 16, hipMemcpyDeviceToHost, st));
+    GSR_CHECK(hipStreamSynchronize(st));   // the forward's single host sync (cf. rasterizer_impl.cu:281)
+    *num_rendered = (int)g_pinned[0];
+    *max_tile_instances = (int)g_pinned[1];
+    return 0;
+}
+
+int gsr_forward_stage2(int P, int R, int max_tile_instances, int W, int H, const float* background,
+                       const float* colors_precomp, void* geom_buffer, void* binning_buffer, void* image_buffer,
+                       float* out_color, gsr_stream_t stream)
+{
+    g_err.clear();
+    if (W <= 0 || H <= 0) return fail_msg("gsr_forward_stage2: image size must be positive");
+    if (!background || !out_color || !image_buffer) return fail_msg("gsr_forward_stage2: required pointer is null");
+    if (R > 0 && (!binning_buffer || !geom_buffer)) return fail_msg("gsr_forward_stage2: scratch buffer is null");
+    hipStream_t st = (hipStream_t)stream;
+    ImageState im = carve_image(image_buffer, W, H);
+    GeomState g = carve_geom(geom_buffer, P > 0 ? P : 0);
+    BinState b = carve_bin(binning_buffer, R > 0 ? R : 0);
+    if (R > 0) {
+        launch_scatter(P, W, H, g, im, b, st);
+        GSR_CHECK_LAUNCH("scatter_kernel");
+        launch_tile_sort(W, H, (uint32_t)max_tile_instances, im, b, st);
+        GSR_CHECK_LAUNCH("tile_sort_kernel");
+    }
+    const float* feats = colors_precomp ? colors_precomp : g.rgb;
+    launch_blend_fwd(W, H, background, feats, g, im, b, out_color, st);
+    GSR_CHECK_LAUNCH("blend_fwd_kernel");
+    return 0;
+}
+
+int gsr_forward(gsr_alloc_fn geometry_buffer, gsr_alloc_fn binning_buffer, gsr_alloc_fn image_buffer, void* alloc_ctx,
+                int P, int D, int M, const float* background, int W, int H, const float* means3D, const float* shs,
+                const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                const float* campos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color, int* radii,
+                int* num_rendered, gsr_stream_t stream)
+{
+    g_err.clear();
+    if (!geometry_buffer || !binning_buffer || !image_buffer) return fail_msg("gsr_forward: null allocator callback");
+    if (!num_rendered) return fail_msg("gsr_forward: num_rendered is null");
+    void* geom = geometry_buffer(alloc_ctx, gsr_geom_bytes(P));
+    void* img = image_buffer(alloc_ctx, gsr_image_bytes(W, H));
+    if (!geom || !img) return fail_msg("gsr_forward: allocator callback returned null");
+    int R = 0, maxc = 0;
+    int rc = gsr_forward_stage1(P, D, M, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                                cov3D_precomp, viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, prefiltered,
+                                radii, geom, img, &R, &maxc, stream);
+    if (rc) return rc;
+    void* bin = binning_buffer(alloc_ctx, gsr_binning_bytes(R));
+    if (!bin) return fail_msg("gsr_forward: allocator callback returned null");
+    rc = gsr_forward_stage2(P, R, maxc, W, H, background, colors_precomp, geom, bin, img, out_color, stream);
+    *num_rendered = R;
+    return rc;
+}
+
+int gsr_backward(int P, int D, int M, int R, const float* background, int W, int H, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                 const float* campos, float tan_fovx, float tan_fovy, const int* radii, const void* geom_buffer,
+                 const void* binning_buffer, const void* image_buffer, const float* dL_dpix, float* dL_dmean2D,
+                 float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
+                 float* dL_dsh, float* dL_dscale, float* dL_drot, gsr_stream_t stream)
+{
+    g_err.clear();
+    if (P <= 0) return 0;
+    if (W <= 0 || H <= 0) return fail_msg("gsr_backward: image size must be positive");
+    if (!means3D || !viewmatrix || !projmatrix || !campos || !radii || !geom_buffer || !image_buffer || !dL_dpix ||
+        !background)
+        return fail_msg("gsr_backward: required pointer is null");
+    if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
+        return fail_msg("gsr_backward: required gradient pointer is null");
+    if (shs && !dL_dsh) return fail_msg("gsr_backward: dL_dsh is null in SH mode");
+    if (!cov3D_precomp && (!scales || !rotations || !dL_dscale || !dL_drot))
+        return fail_msg("gsr_backward: scales/rotations and their gradients are required without cov3D_precomp");
+    if (R > 0 && !binning_buffer) return fail_msg("gsr_backward: binning_buffer is null");
+    hipStream_t st = (hipStream_t)stream;
+    ImageState im = carve_image(const_cast<void*>(image_buffer), W, H);
+    GeomState g = carve_geom(const_cast<void*>(geom_buffer), P);
+    BinState b = carve_bin(const_cast<void*>(binning_buffer), R > 0 ? R : 0);
+    // Zero the four atomic-accumulation targets; everything else is written outright by geom_bwd.
+    GSR_CHECK(hipMemsetAsync(dL_dmean2D, 0, sizeof(float) * 3 * (size_t)P, st));
+    GSR_CHECK(hipMemsetAsync(dL_dconic, 0, sizeof(float) * 4 * (size_t)P, st));
+    GSR_CHECK(hipMemsetAsync(dL_dopacity, 0, sizeof(float) * (size_t)P, st));
+    GSR_CHECK(hipMemsetAsync(dL_dcolor, 0, sizeof(float) * 3 * (size_t)P, st));
+    const float* feats = colors_precomp ? colors_precomp : g.rgb;
+    if (R > 0) {
+        launch_blend_bwd(W, H, background, feats, g, im, b, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, st);
+        GSR_CHECK_LAUNCH("blend_bwd_kernel");
+    }
+    launch_geom_bwd(P, D, M, means3D, shs, cov3D_precomp ? nullptr : scales, scale_modifier,
+                    cov3D_precomp ? nullptr : rotations, cov3D_precomp, viewmatrix, projmatrix, campos, W, H, tan_fovx,
+                    tan_fovy, radii, dL_dmean2D, dL_dconic, dL_dcolor, dL_dmean3D, dL_dcov3D, shs ? dL_dsh : nullptr,
+                    cov3D_precomp ? nullptr : dL_dscale, cov3D_precomp ? nullptr : dL_drot, st);
+    GSR_CHECK_LAUNCH("geom_bwd_kernel");
+    return 0;
+}
+
+int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                     gsr_stream_t stream)
+{
+    (void)projmatrix;   // the reference's frustum test only uses the view matrix (auxiliary.h:154)
+    g_err.clear();
+    if (P <= 0) return 0;
+    if (!means3D || !viewmatrix || !present) return fail_msg("gsr_mark_visible: required pointer is null");
+    launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
+    GSR_CHECK_LAUNCH("mark_visible_kernel");
+    return 0;
+}
+
+// ---- introspection -----------------------------------------------------------------------------
+__global__ void export_geom_kernel(int P, const float4* g0, const float4* g1, const float* depth, const float* rgb_in,
+                                   float* means2D, float* conic_opacity, float* depths, float* rgb)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float4 a = g0[i], b = g1[i];
+    if (means2D) { means2D[2 * i] = a.x; means2D[2 * i + 1] = a.y; }
+    if (conic_opacity) {
+        conic_opacity[4 * i] = a.z; conic_opacity[4 * i + 1] = a.w; conic_opacity[4 * i + 2] = b.x;
+        conic_opacity[4 * i + 3] = b.y;
+    }
+    if (depths) depths[i] = depth[i];
+    if (rgb) { rgb[3 * i] = rgb_in[3 * i]; rgb[3 * i + 1] = rgb_in[3 * i + 1]; rgb[3 * i + 2] = rgb_in[3 * i + 2]; }
+}
+
+int gsr_debug_export(int P, int R, int W, int H, const void* geom_buffer, const void* binning_buffer,
+                     const void* image_buffer, float* means2D, float* conic_opacity, float* depths, float* rgb,
+                     uint32_t* tile_ranges, uint32_t* point_list, float* final_T, uint32_t* n_contrib,
+                     gsr_stream_t stream)
+{
+    g_err.clear();
+    hipStream_t st = (hipStream_t)stream;
+    const Tiles t = tiles_of(W, H);
+    if (P > 0 && geom_buffer && (means2D || conic_opacity || depths || rgb)) {
+        GeomState g = carve_geom(const_cast<void*>(geom_buffer), P);
+        export_geom_kernel<<<(P + 255) / 256, 256, 0, st>>>(P, g.g0, g.g1, g.depth, g.rgb, means2D, conic_opacity,
+                                                            depths, rgb);
+        GSR_CHECK_LAUNCH("export_geom_kernel");
+    }
+    if (image_buffer) {
+        ImageState im = carve_image(const_cast<void*>(image_buffer), W, H);
+        const size_t N = (size_t)W * H;
+        if (tile_ranges) GSR_CHECK(hipMemcpyAsync(tile_ranges, im.ranges, 8 * (size_t)t.T, hipMemcpyDeviceToDevice, st));
+        if (final_T) GSR_CHECK(hipMemcpyAsync(final_T, im.final_T, 4 * N, hipMemcpyDeviceToDevice, st));
+        if (n_contrib) GSR_CHECK(hipMemcpyAsync(n_contrib, im.n_contrib, 4 * N, hipMemcpyDeviceToDevice, st));
+    }
+    if (R > 0 && binning_buffer && point_list) {
+        BinState b = carve_bin(const_cast<void*>(binning_buffer), R);
+        GSR_CHECK(hipMemcpyAsync(point_list, b.point_list, 4 * (size_t)R, hipMemcpyDeviceToDevice, st));
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,116 @@
+// gsr_blend_fwd.hip -- forward alpha compositing.
+//
+// Same per-pixel arithmetic and control flow as the reference's renderCUDA
+// (DGR/cuda_rasterizer/forward.cu:261-374), re-organised for CDNA4:
+//
+//  * One wave64 owns an 8x8 pixel block; a 16x16 tile is four independent waves (no workgroup
+//    barriers, each wave stops as soon as its own 64 pixels are saturated).
+//  * Each wave walks the tile's depth-sorted list 64 instances at a time: lane i fetches instance i
+//    (coalesced id load + two 16-byte record gathers), tests its alpha >= 1/255 bounding box against
+//    the wave's 8x8 block, and the survivors are compacted into a per-wave LDS queue with a
+//    ballot + prefix-popcount.  With surface splats of ~4 px radius this drops most of the
+//    (Gaussian, pixel) pairs the reference evaluates only to reject.
+//  * The blend loop then reads one survivor per iteration from LDS at a wave-uniform address
+//    (broadcast ds_read_b128) -- position, conic, opacity AND colour come from LDS; the reference
+//    gathers colour from global memory per pixel (forward.cu:355).
+//
+// n_contrib stores the 1-based list position of the last blended instance, as the reference does.
+#include "gsr_internal.h"
+
+namespace gsr {
+
+struct __attribute__((aligned(16))) Slot {   // 48 B per queued instance
+    float4 a;   // x, y, conic_a, conic_b
+    float4 b;   // conic_c, opacity, r, g
+    float4 c;   // blue, list position + 1 (as uint bits), -, -
+};
+
+__global__ void __launch_bounds__(256)
+blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                 const float4* __restrict__ g0, const float4* __restrict__ g1, const float* __restrict__ feats,
+                 const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ final_T,
+                 uint32_t* __restrict__ n_contrib)
+{
+    __shared__ Slot queue[4][64];
+    const int tile = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tx = tile % gx, ty = tile / gx;
+    const int sx = tx * TILE + (wave & 1) * SUB, sy = ty * TILE + (wave >> 1) * SUB;
+    const int px = sx + (lane & 7), py = sy + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float bx0 = (float)sx, bx1 = (float)(sx + SUB - 1), by0 = (float)sy, by1 = (float)(sy + SUB - 1);
+
+    const uint2 rg = ranges[tile];
+    const uint32_t n = rg.y - rg.x;
+    Slot* q = queue[wave];
+
+    float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f;
+    uint32_t last = 0;
+    bool done = !inside;
+
+    for (uint32_t base = 0; base < n; base += 64) {
+        if (__ballot(!done) == 0ull) break;
+        const uint32_t k = base + lane;
+        bool keep = false;
+        float4 ra, rb;
+        uint32_t gid = 0;
+        if (k < n) {
+            gid = point_list[rg.x + k];
+            ra = g0[gid];
+            rb = g1[gid];
+            // distance from the splat centre to the wave's pixel block, per axis
+            const float ddx = fmaxf(fmaxf(bx0 - ra.x, ra.x - bx1), 0.0f);
+            const float ddy = fmaxf(fmaxf(by0 - ra.y, ra.y - by1), 0.0f);
+            keep = ddx <= rb.z && ddy <= rb.w;
+        }
+        const unsigned long long m = __ballot(keep);
+        const int cnt = __popcll(m);
+        if (keep) {
+            const int slot = __popcll(m & ((1ull << lane) - 1ull));
+            const float fr = feats[3 * (size_t)gid], fg = feats[3 * (size_t)gid + 1], fb = feats[3 * (size_t)gid + 2];
+            q[slot].a = ra;
+            q[slot].b = make_float4(rb.x, rb.y, fr, fg);
+            q[slot].c = make_float4(fb, __uint_as_float(k + 1), 0.f, 0.f);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int j = 0; j < cnt; j++) {
+            const float4 A = q[j].a, B = q[j].b, Cc = q[j].c;
+            const float dx = A.x - pxf, dy = A.y - pyf;
+            const float power = pair_power(A.z, A.w, B.x, dx, dy);
+            const float alpha = fminf(ALPHA_MAX, B.y * __expf(power));
+            const float test_T = T * (1.0f - alpha);
+            const bool live = !done && power <= 0.0f && alpha >= ALPHA_MIN;
+            if (live) {
+                if (test_T < T_EPS) {
+                    done = true;
+                } else {
+                    const float w = alpha * T;
+                    Cr += B.z * w; Cg += B.w * w; Cb += Cc.x * w;
+                    T = test_T;
+                    last = __float_as_uint(Cc.y);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (inside) {
+        const size_t pix = (size_t)W * py + px;
+        const size_t HW = (size_t)H * W;
+        final_T[pix] = T;
+        n_contrib[pix] = last;
+        out_color[pix] = Cr + T * bg[0];
+        out_color[HW + pix] = Cg + T * bg[1];
+        out_color[2 * HW + pix] = Cb + T * bg[2];
+    }
+}
+
+void launch_blend_fwd(int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
+                      float* out_color, hipStream_t st)
+{
+    const Tiles t = tiles_of(W, H);
+    blend_fwd_kernel<<<t.T, 256, 0, st>>>(W, H, t.gx, im.ranges, b.point_list, g.g0, g.g1, feats, bg, out_color,
+                                          im.final_T, im.n_contrib);
+}
+
+}  // namespace gsr

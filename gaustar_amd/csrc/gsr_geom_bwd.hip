@@ -1,0 +1,221 @@
+// gsr_geom_bwd.hip -- per-Gaussian backward, ONE kernel.
+//
+// Fuses what the reference runs as computeCov2DCUDA (DGR/cuda_rasterizer/backward.cu:144-274) and
+// preprocessCUDA-backward (:346-396, with computeColorFromSH bwd :20-139 and computeCov3D bwd
+// :278-341), plus the zero-fill of every gradient tensor that only this stage writes
+// (DGR/rasterize_points.cu:151-159): each thread writes its Gaussian's dL_dmean3D / dL_dcov3D /
+// dL_dscale / dL_drot / dL_dsh outright -- zeros when the Gaussian was culled (radii == 0).
+//
+// Nothing is read back from the forward's geometry state: the 3D covariance, the EWA rows and the
+// SH basis are recomputed from the inputs (the reference re-reads cov3D and the `clamped` flags it
+// stored, 27 B/Gaussian of extra state traffic each way).
+#include "gsr_internal.h"
+
+namespace gsr {
+
+__global__ void __launch_bounds__(256)
+geom_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
+                const float* __restrict__ scales, float scale_modifier, const float* __restrict__ rotations,
+                const float* __restrict__ cov3D_precomp, const float* __restrict__ view,
+                const float* __restrict__ proj, const float* __restrict__ campos, float tan_fovx, float tan_fovy,
+                float focal_x, float focal_y, const int* __restrict__ radii, const float* __restrict__ dL_dmean2D,
+                const float* __restrict__ dL_dconic, float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D,
+                float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
+                float* __restrict__ dL_drot)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    const size_t i = (size_t)idx;
+
+    if (!(radii[idx] > 0)) {
+        dL_dmean3D[3 * i] = 0.f; dL_dmean3D[3 * i + 1] = 0.f; dL_dmean3D[3 * i + 2] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; k++) dL_dcov3D[6 * i + k] = 0.f;
+        if (dL_dscale) { dL_dscale[3 * i] = 0.f; dL_dscale[3 * i + 1] = 0.f; dL_dscale[3 * i + 2] = 0.f; }
+        if (dL_drot) reinterpret_cast<float4*>(dL_drot)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (dL_dsh)
+            for (int k = 0; k < 3 * M; k++) dL_dsh[i * 3 * M + k] = 0.f;
+        return;
+    }
+
+    const Vec3 mean = load3(means3D, i);
+
+    // ---------------- conic -> cov2D -> {cov3D, view-space mean}  (backward.cu:144-274)
+    float c3[6];
+    float4 quat = make_float4(1.f, 0.f, 0.f, 0.f);
+    Vec3 scl{1.f, 1.f, 1.f};
+    if (cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) c3[k] = cov3D_precomp[6 * i + k];
+    } else {
+        quat = reinterpret_cast<const float4*>(rotations)[i];
+        scl = load3(scales, i);
+        cov3d_from_scale_rot(scl, scale_modifier, quat, c3);
+    }
+    const Ewa e = ewa_rows(mean, view, focal_x, focal_y, tan_fovx, tan_fovy);
+    float v0[3], v1[3], a, b, c;
+    cov2d_from(e, c3, v0, v1, a, b, c);
+
+    const float4 dcon = reinterpret_cast<const float4*>(dL_dconic)[i];   // (xx, xy, -, yy)
+    const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
+    const float x_grad_mul = (e.txtz < -limx || e.txtz > limx) ? 0.f : 1.f;
+    const float y_grad_mul = (e.tytz < -limy || e.tytz > limy) ? 0.f : 1.f;
+
+    const float denom = a * c - b * b;
+    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+    float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (denom2inv != 0.f) {
+        dL_da = denom2inv * (-c * c * dcon.x + 2 * b * c * dcon.y + (denom - a * c) * dcon.w);
+        dL_dc = denom2inv * (-a * a * dcon.w + 2 * a * b * dcon.y + (denom - a * c) * dcon.x);
+        dL_db = denom2inv * 2 * (b * c * dcon.x - (denom + 2 * b * b) * dcon.y + a * b * dcon.w);
+        const float* a0 = e.a0; const float* a1 = e.a1;
+        dcov[0] = a0[0] * a0[0] * dL_da + a0[0] * a1[0] * dL_db + a1[0] * a1[0] * dL_dc;
+        dcov[3] = a0[1] * a0[1] * dL_da + a0[1] * a1[1] * dL_db + a1[1] * a1[1] * dL_dc;
+        dcov[5] = a0[2] * a0[2] * dL_da + a0[2] * a1[2] * dL_db + a1[2] * a1[2] * dL_dc;
+        dcov[1] = 2 * a0[0] * a0[1] * dL_da + (a0[0] * a1[1] + a0[1] * a1[0]) * dL_db + 2 * a1[0] * a1[1] * dL_dc;
+        dcov[2] = 2 * a0[0] * a0[2] * dL_da + (a0[0] * a1[2] + a0[2] * a1[0]) * dL_db + 2 * a1[0] * a1[2] * dL_dc;
+        dcov[4] = 2 * a0[2] * a0[1] * dL_da + (a0[1] * a1[2] + a0[2] * a1[1]) * dL_db + 2 * a1[1] * a1[2] * dL_dc;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) dL_dcov3D[6 * i + k] = dcov[k];
+
+    float dT0[3], dT1[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        dT0[k] = 2 * v0[k] * dL_da + v1[k] * dL_db;
+        dT1[k] = 2 * v1[k] * dL_dc + v0[k] * dL_db;
+    }
+    const float dL_dJ00 = view[0] * dT0[0] + view[4] * dT0[1] + view[8] * dT0[2];
+    const float dL_dJ02 = view[2] * dT0[0] + view[6] * dT0[1] + view[10] * dT0[2];
+    const float dL_dJ11 = view[1] * dT1[0] + view[5] * dT1[1] + view[9] * dT1[2];
+    const float dL_dJ12 = view[2] * dT1[0] + view[6] * dT1[1] + view[10] * dT1[2];
+    const float tz = 1.f / e.t.z, tz2 = tz * tz, tz3 = tz2 * tz;
+    const float dL_dtx = x_grad_mul * -focal_x * tz2 * dL_dJ02;
+    const float dL_dty = y_grad_mul * -focal_y * tz2 * dL_dJ12;
+    const float dL_dtz = -focal_x * tz2 * dL_dJ00 - focal_y * tz2 * dL_dJ11 + (2 * focal_x * e.t.x) * tz3 * dL_dJ02 +
+                         (2 * focal_y * e.t.y) * tz3 * dL_dJ12;
+    // W^T * dL_dt  (auxiliary.h:89-97)
+    float gmx = view[0] * dL_dtx + view[1] * dL_dty + view[2] * dL_dtz;
+    float gmy = view[4] * dL_dtx + view[5] * dL_dty + view[6] * dL_dtz;
+    float gmz = view[8] * dL_dtx + view[9] * dL_dty + view[10] * dL_dtz;
+
+    // ---------------- mean2D -> mean3D through the perspective divide (backward.cu:370-387)
+    {
+        const float m_w = 1.0f / (xform4w(mean, proj) + 0.0000001f);
+        const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
+        const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
+        const float gx2 = dL_dmean2D[3 * i], gy2 = dL_dmean2D[3 * i + 1];
+        gmx += (proj[0] * m_w - proj[3] * mul1) * gx2 + (proj[1] * m_w - proj[3] * mul2) * gy2;
+        gmy += (proj[4] * m_w - proj[7] * mul1) * gx2 + (proj[5] * m_w - proj[7] * mul2) * gy2;
+        gmz += (proj[8] * m_w - proj[11] * mul1) * gx2 + (proj[9] * m_w - proj[11] * mul2) * gy2;
+    }
+
+    // ---------------- colour -> SH coefficients and view direction (backward.cu:20-139)
+    if (shs) {
+        const float ox = mean.x - campos[0], oy = mean.y - campos[1], oz = mean.z - campos[2];
+        const float inv = 1.0f / sqrtf(ox * ox + oy * oy + oz * oz);
+        const float x = ox * inv, y = oy * inv, z = oz * inv;
+        float basis[16];
+        sh_basis(D, x, y, z, basis);
+        const int nb = (D + 1) * (D + 1);
+        const float* sh = shs + i * M * 3;
+        // recompute the clamp decision of the forward (forward.cu:63-70)
+        float col[3] = {0.f, 0.f, 0.f};
+        for (int k = 0; k < nb; k++) { col[0] += basis[k] * sh[3 * k]; col[1] += basis[k] * sh[3 * k + 1]; col[2] += basis[k] * sh[3 * k + 2]; }
+        float dRGB[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) dRGB[ch] = (col[ch] + 0.5f < 0.f) ? 0.f : dL_dcolor[3 * i + ch];
+        float* dsh = dL_dsh + i * M * 3;
+        for (int k = 0; k < M; k++) {
+            const float bk = k < nb ? basis[k] : 0.f;
+            dsh[3 * k] = bk * dRGB[0]; dsh[3 * k + 1] = bk * dRGB[1]; dsh[3 * k + 2] = bk * dRGB[2];
+        }
+        // d(colour)/d(direction)
+        float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+#define SHD(k) (sh[3 * (k)] * dRGB[0] + sh[3 * (k) + 1] * dRGB[1] + sh[3 * (k) + 2] * dRGB[2])
+        if (D > 0) {
+            ddx = -kSH1 * SHD(3); ddy = -kSH1 * SHD(1); ddz = kSH1 * SHD(2);
+            if (D > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                const float s4 = SHD(4), s5 = SHD(5), s6 = SHD(6), s7 = SHD(7), s8 = SHD(8);
+                ddx += kSH2[0] * y * s4 + kSH2[2] * 2.f * -x * s6 + kSH2[3] * z * s7 + kSH2[4] * 2.f * x * s8;
+                ddy += kSH2[0] * x * s4 + kSH2[1] * z * s5 + kSH2[2] * 2.f * -y * s6 + kSH2[4] * 2.f * -y * s8;
+                ddz += kSH2[1] * y * s5 + kSH2[2] * 2.f * 2.f * z * s6 + kSH2[3] * x * s7;
+                if (D > 2) {
+                    const float s9 = SHD(9), s10 = SHD(10), s11 = SHD(11), s12 = SHD(12), s13 = SHD(13), s14 = SHD(14),
+                                s15 = SHD(15);
+                    ddx += kSH3[0] * s9 * 3.f * 2.f * xy + kSH3[1] * s10 * yz + kSH3[2] * s11 * -2.f * xy +
+                           kSH3[3] * s12 * -3.f * 2.f * xz + kSH3[4] * s13 * (-3.f * xx + 4.f * zz - yy) +
+                           kSH3[5] * s14 * 2.f * xz + kSH3[6] * s15 * 3.f * (xx - yy);
+                    ddy += kSH3[0] * s9 * 3.f * (xx - yy) + kSH3[1] * s10 * xz + kSH3[2] * s11 * (-3.f * yy + 4.f * zz - xx) +
+                           kSH3[3] * s12 * -3.f * 2.f * yz + kSH3[4] * s13 * -2.f * xy + kSH3[5] * s14 * -2.f * yz +
+                           kSH3[6] * s15 * -3.f * 2.f * xy;
+                    ddz += kSH3[1] * s10 * xy + kSH3[2] * s11 * 4.f * 2.f * yz + kSH3[3] * s12 * 3.f * (2.f * zz - xx - yy) +
+                           kSH3[4] * s13 * 4.f * 2.f * xz + kSH3[5] * s14 * (xx - yy);
+                }
+            }
+        }
+#undef SHD
+        // through the normalisation of the view direction (auxiliary.h:107-117)
+        const float sum2 = ox * ox + oy * oy + oz * oz;
+        const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+        gmx += ((sum2 - ox * ox) * ddx - oy * ox * ddy - oz * ox * ddz) * invsum32;
+        gmy += (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * invsum32;
+        gmz += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
+    }
+    dL_dmean3D[3 * i] = gmx; dL_dmean3D[3 * i + 1] = gmy; dL_dmean3D[3 * i + 2] = gmz;
+
+    // ---------------- cov3D -> scale, raw quaternion (backward.cu:278-341)
+    if (!cov3D_precomp) {
+        float R[3][3];
+        quat_R(quat, R);
+        const float s[3] = {scale_modifier * scl.x, scale_modifier * scl.y, scale_modifier * scl.z};
+        float Mm[3][3];
+#pragma unroll
+        for (int r_ = 0; r_ < 3; r_++)
+#pragma unroll
+            for (int c_ = 0; c_ < 3; c_++) Mm[r_][c_] = s[r_] * R[c_][r_];
+        const float dS[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
+                                {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
+                                {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+        float dM[3][3];
+#pragma unroll
+        for (int r_ = 0; r_ < 3; r_++)
+#pragma unroll
+            for (int c_ = 0; c_ < 3; c_++)
+                dM[r_][c_] = 2.0f * (Mm[r_][0] * dS[0][c_] + Mm[r_][1] * dS[1][c_] + Mm[r_][2] * dS[2][c_]);
+        float ds[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) ds[k] = R[0][k] * dM[k][0] + R[1][k] * dM[k][1] + R[2][k] * dM[k][2];
+        dL_dscale[3 * i] = ds[0]; dL_dscale[3 * i + 1] = ds[1]; dL_dscale[3 * i + 2] = ds[2];
+        float G[3][3];
+#pragma unroll
+        for (int r_ = 0; r_ < 3; r_++)
+#pragma unroll
+            for (int c_ = 0; c_ < 3; c_++) G[r_][c_] = s[r_] * dM[r_][c_];
+        const float qr = quat.x, qx = quat.y, qy = quat.z, qz = quat.w;
+        float4 dq;
+        dq.x = 2 * qz * (G[0][1] - G[1][0]) + 2 * qy * (G[2][0] - G[0][2]) + 2 * qx * (G[1][2] - G[2][1]);
+        dq.y = 2 * qy * (G[1][0] + G[0][1]) + 2 * qz * (G[2][0] + G[0][2]) + 2 * qr * (G[1][2] - G[2][1]) - 4 * qx * (G[2][2] + G[1][1]);
+        dq.z = 2 * qx * (G[1][0] + G[0][1]) + 2 * qr * (G[2][0] - G[0][2]) + 2 * qz * (G[1][2] + G[2][1]) - 4 * qy * (G[2][2] + G[0][0]);
+        dq.w = 2 * qr * (G[0][1] - G[1][0]) + 2 * qx * (G[2][0] + G[0][2]) + 2 * qy * (G[1][2] + G[2][1]) - 4 * qz * (G[1][1] + G[0][0]);
+        reinterpret_cast<float4*>(dL_drot)[i] = dq;
+    }
+}
+
+void launch_geom_bwd(int P, int D, int M, const float* means3D, const float* shs, const float* scales,
+                     float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* view,
+                     const float* proj, const float* campos, int W, int H, float tan_fovx, float tan_fovy,
+                     const int* radii, const float* dL_dmean2D, const float* dL_dconic, float* dL_dcolor,
+                     float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                     hipStream_t st)
+{
+    const float focal_y = H / (2.0f * tan_fovy), focal_x = W / (2.0f * tan_fovx);   // rasterizer_impl.cu:381-382
+    geom_bwd_kernel<<<(P + 255) / 256, 256, 0, st>>>(P, D, M, means3D, shs, scales, scale_modifier, rotations,
+                                                     cov3D_precomp, view, proj, campos, tan_fovx, tan_fovy, focal_x,
+                                                     focal_y, radii, dL_dmean2D, dL_dconic, dL_dcolor, dL_dmean3D,
+                                                     dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+}
+
+}  // namespace gsr

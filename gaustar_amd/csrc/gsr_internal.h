@@ -1,0 +1,247 @@
+// gsr_internal.h -- scratch layout, launch prototypes and shared device math of the
+// MI355X-native rasterizer.  gfx950 only (wave64, 256 CUs, 160 KB LDS/CU).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace gsr {
+
+constexpr int TILE = 16;          // binning tile edge in pixels (matches the reference's BLOCK_X/Y so that the
+                                  // reference's 3-sigma tile-rect truncation is reproduced exactly)
+constexpr int SUB = 8;            // one wave64 blends an 8x8 pixel block (4 waves per tile)
+constexpr float NEAR_Z = 0.2f;    // auxiliary.h:154
+constexpr float ALPHA_MIN = 1.0f / 255.0f;
+constexpr float ALPHA_MAX = 0.99f;
+constexpr float T_EPS = 0.0001f;
+
+struct Tiles { int gx, gy, T; };
+__host__ __device__ inline Tiles tiles_of(int W, int H)
+{
+    Tiles t; t.gx = (W + TILE - 1) / TILE; t.gy = (H + TILE - 1) / TILE; t.T = t.gx * t.gy; return t;
+}
+
+// ---------------------------------------------------------------- scratch carving
+// 256-byte aligned sub-allocations; layout is a pure function of (P), (W,H), (R) so that
+// backward can rebuild it (rasterizer_impl.cu:371-373 does the same with fromChunk).
+__host__ __device__ inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct GeomState {           // per Gaussian
+    float4* g0;              // {pix_x, pix_y, conic_a, conic_b}
+    float4* g1;              // {conic_c, opacity, cull_hx, cull_hy}
+    float* depth;            // view-space z (sort key)
+    ushort4* rect;           // tile rect {min_x, min_y, max_x, max_y} actually binned (empty => no instances)
+    float* rgb;              // SH-evaluated colours [P,3] (SH mode only, but always carved)
+    size_t bytes;
+};
+inline GeomState carve_geom(void* base, int P)
+{
+    GeomState s; size_t o = 0; char* b = (char*)base;
+    s.g0 = (float4*)(b + o); o = align_up(o + sizeof(float4) * (size_t)P);
+    s.g1 = (float4*)(b + o); o = align_up(o + sizeof(float4) * (size_t)P);
+    s.depth = (float*)(b + o); o = align_up(o + sizeof(float) * (size_t)P);
+    s.rect = (ushort4*)(b + o); o = align_up(o + sizeof(ushort4) * (size_t)P);
+    s.rgb = (float*)(b + o); o = align_up(o + sizeof(float) * 3 * (size_t)P);
+    s.bytes = o + 256;
+    return s;
+}
+
+struct ImageState {          // per pixel / per tile
+    float* final_T;          // [H*W]
+    uint32_t* n_contrib;     // [H*W] 1-based position in the tile list of the last blended instance
+    uint2* ranges;           // [T] {start, end} into point_list
+    uint32_t* tile_count;    // [T] instances per tile (atomics in preprocess)
+    uint32_t* tile_cursor;   // [T] scatter cursors
+    uint32_t* totals;        // [4] {R, max tile count, 0, 0}
+    size_t bytes;
+};
+inline ImageState carve_image(void* base, int W, int H)
+{
+    ImageState s; size_t o = 0; char* b = (char*)base;
+    const size_t N = (size_t)W * H; const size_t T = (size_t)tiles_of(W, H).T;
+    s.final_T = (float*)(b + o); o = align_up(o + 4 * N);
+    s.n_contrib = (uint32_t*)(b + o); o = align_up(o + 4 * N);
+    s.ranges = (uint2*)(b + o); o = align_up(o + 8 * T);
+    s.tile_count = (uint32_t*)(b + o); o = align_up(o + 4 * T);
+    s.tile_cursor = (uint32_t*)(b + o); o = align_up(o + 4 * T);
+    s.totals = (uint32_t*)(b + o); o = align_up(o + 16);
+    s.bytes = o + 256;
+    return s;
+}
+
+struct BinState {            // per instance
+    uint64_t* keys;          // [R] (depth_bits << 32) | gaussian, bucketed by tile, unsorted within the bucket
+    uint32_t* point_list;    // [R] gaussian ids, tile-major, depth-ascending, ties by ascending id
+    size_t bytes;
+};
+inline BinState carve_bin(void* base, int R)
+{
+    BinState s; size_t o = 0; char* b = (char*)base;
+    s.keys = (uint64_t*)(b + o); o = align_up(o + 8 * (size_t)R);
+    s.point_list = (uint32_t*)(b + o); o = align_up(o + 4 * (size_t)R);
+    s.bytes = o + 256;
+    return s;
+}
+
+// ---------------------------------------------------------------- kernel launchers (one per .hip file)
+struct Camera {              // passed by value to kernels (lands in SGPRs / kernarg)
+    float view[16];
+    float proj[16];
+    float campos[3];
+    float tan_fovx, tan_fovy, focal_x, focal_y;
+    int W, H;
+};
+
+void launch_preprocess(int P, int D, int M, const float* means3D, const float* shs, const float* colors_precomp,
+                       const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                       const float* cov3D_precomp, const float* view, const float* proj, const float* campos, int W,
+                       int H, float tan_fovx, float tan_fovy, int* radii, GeomState g, ImageState im,
+                       hipStream_t st);
+void launch_tile_scan(ImageState im, int T, hipStream_t st);
+void launch_scatter(int P, int W, int H, GeomState g, ImageState im, BinState b, hipStream_t st);
+void launch_tile_sort(int W, int H, uint32_t max_count, ImageState im, BinState b, hipStream_t st);
+void launch_blend_fwd(int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
+                      float* out_color, hipStream_t st);
+void launch_blend_bwd(int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
+                      const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                      float* dL_dcolor, hipStream_t st);
+void launch_geom_bwd(int P, int D, int M, const float* means3D, const float* shs, const float* scales,
+                     float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* view,
+                     const float* proj, const float* campos, int W, int H, float tan_fovx, float tan_fovy,
+                     const int* radii, const float* dL_dmean2D, const float* dL_dconic, float* dL_dcolor,
+                     float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                     hipStream_t st);
+void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t st);
+
+// ---------------------------------------------------------------- shared device math
+#ifdef __HIPCC__
+// Spherical-harmonics constants (real SH, deg <= 3), as auxiliary.h:22-39.
+__device__ constexpr float kSH0 = 0.28209479177387814f;
+__device__ constexpr float kSH1 = 0.4886025119029199f;
+__device__ constexpr float kSH2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                      -1.0925484305920792f, 0.5462742152960396f};
+__device__ constexpr float kSH3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                      0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                      -0.5900435899266435f};
+
+struct Vec3 { float x, y, z; };
+
+__device__ __forceinline__ Vec3 load3(const float* p, size_t i) { return Vec3{p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
+
+// Column-major 4x4 times point (auxiliary.h:58-77).
+__device__ __forceinline__ Vec3 xform43(const Vec3 p, const float* m)
+{
+    return Vec3{m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+                m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]};
+}
+__device__ __forceinline__ float xform4w(const Vec3 p, const float* m)
+{
+    return m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15];
+}
+
+// Rotation of the RAW quaternion (r,x,y,z) -- callers normalise (forward.cu:127).
+__device__ __forceinline__ void quat_R(const float4 q, float R[3][3])
+{
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z); R[0][2] = 2.f * (x * z + r * y);
+    R[1][0] = 2.f * (x * y + r * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
+    R[2][0] = 2.f * (x * z - r * y); R[2][1] = 2.f * (y * z + r * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+
+// Sigma = R S^2 R^T, upper triangle {xx,xy,xz,yy,yz,zz} (forward.cu:118-152).
+__device__ __forceinline__ void cov3d_from_scale_rot(const Vec3 s_in, float mod, const float4 q, float c[6])
+{
+    float R[3][3];
+    quat_R(q, R);
+    const float s[3] = {mod * s_in.x, mod * s_in.y, mod * s_in.z};
+    float M[3][3];   // M = S R^T
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) M[i][j] = s[i] * R[j][i];
+    c[0] = M[0][0] * M[0][0] + M[1][0] * M[1][0] + M[2][0] * M[2][0];
+    c[1] = M[0][0] * M[0][1] + M[1][0] * M[1][1] + M[2][0] * M[2][1];
+    c[2] = M[0][0] * M[0][2] + M[1][0] * M[1][2] + M[2][0] * M[2][2];
+    c[3] = M[0][1] * M[0][1] + M[1][1] * M[1][1] + M[2][1] * M[2][1];
+    c[4] = M[0][1] * M[0][2] + M[1][1] * M[1][2] + M[2][1] * M[2][2];
+    c[5] = M[0][2] * M[0][2] + M[1][2] * M[1][2] + M[2][2] * M[2][2];
+}
+
+// EWA projection (forward.cu:74-113 / backward.cu:161-199): rows a0,a1 of J*R_w2c with the
+// view-space point clamped to +-1.3*tanfov before the Jacobian is formed.
+struct Ewa {
+    float a0[3], a1[3];
+    Vec3 t;            // clamped view-space mean
+    float txtz, tytz;  // unclamped ratios (for the clamp-gradient masks)
+};
+__device__ __forceinline__ Ewa ewa_rows(const Vec3 mean, const float* view, float fx, float fy, float tan_fovx,
+                                         float tan_fovy)
+{
+    Ewa e;
+    Vec3 t = xform43(mean, view);
+    const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
+    e.txtz = t.x / t.z;
+    e.tytz = t.y / t.z;
+    t.x = fminf(limx, fmaxf(-limx, e.txtz)) * t.z;
+    t.y = fminf(limy, fmaxf(-limy, e.tytz)) * t.z;
+    const float J00 = fx / t.z, J02 = -(fx * t.x) / (t.z * t.z);
+    const float J11 = fy / t.z, J12 = -(fy * t.y) / (t.z * t.z);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        e.a0[k] = view[4 * k + 0] * J00 + view[4 * k + 2] * J02;
+        e.a1[k] = view[4 * k + 1] * J11 + view[4 * k + 2] * J12;
+    }
+    e.t = t;
+    return e;
+}
+
+// cov2D = A Sigma A^T + 0.3 I ; also returns v0 = Sigma a0, v1 = Sigma a1 (needed by backward).
+__device__ __forceinline__ void cov2d_from(const Ewa& e, const float c[6], float v0[3], float v1[3], float& a, float& b,
+                                            float& cc)
+{
+    v0[0] = c[0] * e.a0[0] + c[1] * e.a0[1] + c[2] * e.a0[2];
+    v0[1] = c[1] * e.a0[0] + c[3] * e.a0[1] + c[4] * e.a0[2];
+    v0[2] = c[2] * e.a0[0] + c[4] * e.a0[1] + c[5] * e.a0[2];
+    v1[0] = c[0] * e.a1[0] + c[1] * e.a1[1] + c[2] * e.a1[2];
+    v1[1] = c[1] * e.a1[0] + c[3] * e.a1[1] + c[4] * e.a1[2];
+    v1[2] = c[2] * e.a1[0] + c[4] * e.a1[1] + c[5] * e.a1[2];
+    a = e.a0[0] * v0[0] + e.a0[1] * v0[1] + e.a0[2] * v0[2] + 0.3f;
+    b = e.a0[0] * v1[0] + e.a0[1] * v1[1] + e.a0[2] * v1[2];
+    cc = e.a1[0] * v1[0] + e.a1[1] * v1[1] + e.a1[2] * v1[2] + 0.3f;
+}
+
+// Real-SH basis values for direction d (deg <= 3): b[0..(deg+1)^2).
+__device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float b[16])
+{
+    b[0] = kSH0;
+    if (deg > 0) {
+        b[1] = -kSH1 * y; b[2] = kSH1 * z; b[3] = -kSH1 * x;
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            b[4] = kSH2[0] * xy; b[5] = kSH2[1] * yz; b[6] = kSH2[2] * (2.0f * zz - xx - yy);
+            b[7] = kSH2[3] * xz; b[8] = kSH2[4] * (xx - yy);
+            if (deg > 2) {
+                b[9] = kSH3[0] * y * (3.0f * xx - yy); b[10] = kSH3[1] * xy * z;
+                b[11] = kSH3[2] * y * (4.0f * zz - xx - yy); b[12] = kSH3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+                b[13] = kSH3[4] * x * (4.0f * zz - xx - yy); b[14] = kSH3[5] * z * (xx - yy);
+                b[15] = kSH3[6] * x * (xx - 3.0f * yy);
+            }
+        }
+    }
+}
+
+// Gaussian exponent of one (pixel, splat) pair: -0.5*(a dx^2 + c dy^2) - b dx dy (forward.cu:334).
+// Written with explicit fused steps and contraction disabled so that the forward and the backward
+// blend kernels round identically (they must agree on every alpha >= 1/255 decision).
+__device__ __forceinline__ float pair_power(float ca, float cb, float cc, float dx, float dy)
+{
+#pragma clang fp contract(off)
+    const float q = __builtin_fmaf(cc * dy, dy, (ca * dx) * dx);
+    return __builtin_fmaf(-(cb * dx), dy, -0.5f * q);
+}
+
+// Pixel centre of an NDC coordinate; evaluated in double like auxiliary.h:41-44.
+__device__ __forceinline__ float ndc2pix(float v, int S) { return (float)((((double)v + 1.0) * S - 1.0) * 0.5); }
+#endif  // __HIPCC__
+
+}  // namespace gsr

@@ -1,0 +1,153 @@
+// gsr_preprocess.hip -- per-Gaussian forward stage + tile counting, and markVisible.
+//
+// Computes what the reference's preprocessCUDA (DGR/cuda_rasterizer/forward.cu:155-256)
+// computes, with identical culling decisions and identical `radii`, but writes a different,
+// smaller geometry state (40 B/Gaussian, 52 in SH mode, vs the reference's 79) laid out for the
+// wave-per-8x8 blend kernels: two float4 records gathered per instance, plus the binned tile
+// rect so that the count pass (here) and the scatter pass agree on the instance set by
+// construction.
+//
+// Tile set actually binned = reference rect (auxiliary.h:46-56, 3-sigma circle)  INTERSECT
+// a conservative bounding box of the region where alpha can reach 1/255.  Dropped tiles could
+// only hold pairs the reference skips at forward.cu:340-342, so results are unchanged while
+// num_rendered (library-internal) shrinks.
+#include "gsr_internal.h"
+
+namespace gsr {
+
+__global__ void __launch_bounds__(256)
+preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
+                  const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
+                  const float* __restrict__ scales, float scale_modifier, const float* __restrict__ rotations,
+                  const float* __restrict__ cov3D_precomp, const float* __restrict__ view,
+                  const float* __restrict__ proj, const float* __restrict__ campos, int W, int H, float tan_fovx,
+                  float tan_fovy, float focal_x, float focal_y, int gx, int gy, int* __restrict__ radii,
+                  float4* __restrict__ g0, float4* __restrict__ g1, float* __restrict__ depth,
+                  ushort4* __restrict__ rect, float* __restrict__ rgb, uint32_t* __restrict__ tile_count)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+
+    int out_radius = 0;
+    ushort4 out_rect = make_ushort4(0, 0, 0, 0);
+
+    const Vec3 p = load3(means3D, idx);
+    const Vec3 p_view = xform43(p, view);
+    // Near-plane cull only (auxiliary.h:154; the NDC side test is dead code there).
+    if (p_view.z > NEAR_Z) {
+        const Vec3 ph = xform43(p, proj);
+        const float pw = 1.0f / (xform4w(p, proj) + 0.0000001f);
+        const float ndc_x = ph.x * pw, ndc_y = ph.y * pw;
+
+        float c3[6];
+        if (cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) c3[k] = cov3D_precomp[6 * (size_t)idx + k];
+        } else {
+            const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+            cov3d_from_scale_rot(load3(scales, idx), scale_modifier, q, c3);
+        }
+        const Ewa e = ewa_rows(p, view, focal_x, focal_y, tan_fovx, tan_fovy);
+        float v0[3], v1[3], ca, cb, cc;
+        cov2d_from(e, c3, v0, v1, ca, cb, cc);
+
+        const float det = ca * cc - cb * cb;
+        if (det != 0.0f) {
+            const float det_inv = 1.f / det;
+            const float conic_a = cc * det_inv, conic_b = -cb * det_inv, conic_c = ca * det_inv;
+            const float mid = 0.5f * (ca + cc);
+            const float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float lambda1 = mid + disc, lambda2 = mid - disc;
+            const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+            const float px = ndc2pix(ndc_x, W), py = ndc2pix(ndc_y, H);
+            const int r = (int)my_radius;
+            // Reference tile rect (C truncation toward zero, clamped to the grid).
+            int rx0 = min(gx, max(0, (int)((px - r) / TILE)));
+            int ry0 = min(gy, max(0, (int)((py - r) / TILE)));
+            int rx1 = min(gx, max(0, (int)((px + r + TILE - 1) / TILE)));
+            int ry1 = min(gy, max(0, (int)((py + r + TILE - 1) / TILE)));
+            if ((rx1 - rx0) * (ry1 - ry0) != 0) {
+                out_radius = r;
+                const float op = opacities[idx];
+                // alpha = min(0.99, op*exp(power)) >= 1/255  <=>  power >= -ln(255*op).
+                // tau carries an absolute safety margin far above any exp rounding error.
+                float hx = -1.f, hy = -1.f;
+                if (op * 255.0f * 1.0001f >= 1.0f) {
+                    const float tau = __logf(255.0f * op) + 0.02f;
+                    hx = sqrtf(2.0f * tau * ca) * 1.0005f + 0.01f;   // half extents of {d : d^T C d <= 2 tau}
+                    hy = sqrtf(2.0f * tau * cc) * 1.0005f + 0.01f;
+                    // Tiles holding an integer pixel coordinate within [p - h, p + h].
+                    const int ix0 = (int)ceilf(px - hx), ix1 = (int)floorf(px + hx);
+                    const int iy0 = (int)ceilf(py - hy), iy1 = (int)floorf(py + hy);
+                    if (ix1 < ix0 || iy1 < iy0 || ix1 < 0 || iy1 < 0) {
+                        rx1 = rx0; ry1 = ry0;
+                    } else {
+                        rx0 = max(rx0, max(ix0, 0) / TILE);
+                        ry0 = max(ry0, max(iy0, 0) / TILE);
+                        rx1 = min(rx1, ix1 / TILE + 1);
+                        ry1 = min(ry1, iy1 / TILE + 1);
+                        if (rx1 < rx0) rx1 = rx0;
+                        if (ry1 < ry0) ry1 = ry0;
+                    }
+                } else {
+                    rx1 = rx0; ry1 = ry0;   // can never reach alpha >= 1/255 anywhere
+                }
+                if (colors_precomp == nullptr) {
+                    // SH -> RGB (forward.cu:20-71), +0.5 and clamp at 0.
+                    const float dx = p.x - campos[0], dy = p.y - campos[1], dz = p.z - campos[2];
+                    const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+                    float basis[16];
+                    sh_basis(D, dx * inv, dy * inv, dz * inv, basis);
+                    const int nb = (D + 1) * (D + 1);
+                    const float* sh = shs + (size_t)idx * M * 3;
+                    float cr = 0.f, cg = 0.f, cbb = 0.f;
+                    for (int k = 0; k < nb; k++) {
+                        cr += basis[k] * sh[3 * k]; cg += basis[k] * sh[3 * k + 1]; cbb += basis[k] * sh[3 * k + 2];
+                    }
+                    rgb[3 * (size_t)idx + 0] = fmaxf(cr + 0.5f, 0.0f);
+                    rgb[3 * (size_t)idx + 1] = fmaxf(cg + 0.5f, 0.0f);
+                    rgb[3 * (size_t)idx + 2] = fmaxf(cbb + 0.5f, 0.0f);
+                }
+                g0[idx] = make_float4(px, py, conic_a, conic_b);
+                g1[idx] = make_float4(conic_c, op, hx, hy);
+                depth[idx] = p_view.z;
+                out_rect = make_ushort4((unsigned short)rx0, (unsigned short)ry0, (unsigned short)rx1,
+                                        (unsigned short)ry1);
+                for (int y = ry0; y < ry1; y++)
+                    for (int x = rx0; x < rx1; x++) atomicAdd(&tile_count[y * gx + x], 1u);
+            }
+        }
+    }
+    radii[idx] = out_radius;
+    rect[idx] = out_rect;
+}
+
+void launch_preprocess(int P, int D, int M, const float* means3D, const float* shs, const float* colors_precomp,
+                       const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                       const float* cov3D_precomp, const float* view, const float* proj, const float* campos, int W,
+                       int H, float tan_fovx, float tan_fovy, int* radii, GeomState g, ImageState im, hipStream_t st)
+{
+    const Tiles t = tiles_of(W, H);
+    const float focal_y = H / (2.0f * tan_fovy), focal_x = W / (2.0f * tan_fovx);   // rasterizer_impl.cu:222-223
+    preprocess_kernel<<<(P + 255) / 256, 256, 0, st>>>(P, D, M, means3D, shs, colors_precomp, opacities, scales,
+                                                       scale_modifier, rotations, cov3D_precomp, view, proj, campos, W,
+                                                       H, tan_fovx, tan_fovy, focal_x, focal_y, t.gx, t.gy, radii,
+                                                       g.g0, g.g1, g.depth, g.rect, g.rgb, im.tile_count);
+}
+
+// rasterizer_impl.cu:54-66 (checkFrustum): present = view-space z > 0.2.
+__global__ void __launch_bounds__(256)
+mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ view, uint8_t* __restrict__ present)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    const Vec3 pv = xform43(load3(means3D, idx), view);
+    present[idx] = pv.z > NEAR_Z ? 1 : 0;
+}
+
+void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t st)
+{
+    mark_visible_kernel<<<(P + 255) / 256, 256, 0, st>>>(P, means3D, view, present);
+}
+
+}  // namespace gsr

@@ -1,0 +1,289 @@
+"""Python surface of the rasterizer -- a drop-in for the reference package
+`diff_gaussian_rasterization` (DGR/diff_gaussian_rasterization/__init__.py):
+
+    GaussianRasterizationSettings   NamedTuple, same 12 fields            (ref :157-169)
+    GaussianRasterizer              nn.Module, forward(...) / markVisible (ref :171-220)
+    rasterize_gaussians             functional entry                      (ref :21-42)
+    _RasterizeGaussians             autograd.Function, same arg order and
+                                    same gradient tuple order             (ref :44-155)
+
+Below this file sits the C ABI of include/gsr.h instead of the reference's pybind11 module `_C`;
+the glue that the reference keeps in C++ (DGR/rasterize_points.cu: shape check, .contiguous(),
+output / scratch / gradient allocation) lives here, with PyTorch owning every byte of device
+memory.  No CPU fallback exists: tensors must be on a HIP device and the extension must load.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def cpu_deep_copy_tuple(input_tuple):
+    copied_tensors = [item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple]
+    return tuple(copied_tensors)
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _ptr(t):
+    """Device pointer of an optional tensor; 0-element tensors are 'absent' (NULL), as in the
+    reference where data_ptr() of an empty tensor is nullptr (rasterize_points.cu:94-111)."""
+    if t is None or t.numel() == 0:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _dev_f32(t, device):
+    """float32, contiguous, on `device` (the reference calls .contiguous() on every argument;
+    viewmatrix in particular arrives as a transposed view, sugar_model.py:1149-1150)."""
+    if t is None:
+        return None
+    if t.numel() == 0:
+        return t
+    if t.device != device:
+        t = t.to(device)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_gpu(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"gaustar_amd: {what} must live on a HIP (cuda) device -- there is no CPU path")
+
+
+# --------------------------------------------------------------------------------------------
+# Binding-level functions: same positional signatures as the reference's `_C` module
+# (DGR/rasterize_points.h:17-66), implemented over the C ABI.
+# --------------------------------------------------------------------------------------------
+def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rotations, scale_modifier,
+                               cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
+                               image_width, sh, degree, campos, prefiltered, debug):
+    """-> (num_rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer), like
+    RasterizeGaussiansCUDA (DGR/rasterize_points.cu:35-115), plus a 7th element: the longest
+    per-tile instance list (informational)."""
+    lib = _lib.load()
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")   # rasterize_points.cu:57-59
+    _require_gpu(means3D, "means3D")
+    dev = means3D.device
+    P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
+    with torch.cuda.device(dev):
+        byte_opts = dict(dtype=torch.uint8, device=dev)
+        if P == 0:
+            # rasterize_points.cu:68-81: zero-filled image, no rasterization at all
+            return (0, torch.zeros(3, H, W, dtype=torch.float32, device=dev),
+                    torch.zeros(0, dtype=torch.int32, device=dev), torch.empty(0, **byte_opts),
+                    torch.empty(0, **byte_opts), torch.empty(0, **byte_opts), 0)
+        means3D = _dev_f32(means3D, dev)
+        background, viewmatrix, projmatrix, campos = (_dev_f32(x, dev) for x in (background, viewmatrix, projmatrix, campos))
+        colors, opacity, scales, rotations, cov3D_precomp, sh = (
+            _dev_f32(x, dev) for x in (colors, opacity, scales, rotations, cov3D_precomp, sh))
+        M = int(sh.size(1)) if sh is not None and sh.numel() != 0 else 0
+        out_color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+        radii = torch.empty(P, dtype=torch.int32, device=dev)
+        geom = torch.empty(lib.gsr_geom_bytes(P), **byte_opts)
+        img = torch.empty(lib.gsr_image_bytes(W, H), **byte_opts)
+        R, maxc = ctypes.c_int(0), ctypes.c_int(0)
+        st = _stream()
+        _lib.check(lib.gsr_forward_stage1(
+            P, int(degree), M, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales),
+            float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix),
+            _ptr(campos), W, H, float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(radii), _ptr(geom),
+            _ptr(img), ctypes.byref(R), ctypes.byref(maxc), st), "gsr_forward_stage1")
+        binning = torch.empty(lib.gsr_binning_bytes(R.value), **byte_opts)
+        _lib.check(lib.gsr_forward_stage2(
+            P, R.value, maxc.value, W, H, _ptr(background), _ptr(colors), _ptr(geom), _ptr(binning), _ptr(img),
+            _ptr(out_color), st), "gsr_forward_stage2")
+        if debug:
+            torch.cuda.synchronize(dev)   # surface asynchronous faults here, like CHECK_CUDA(..., debug)
+    return R.value, out_color, radii, geom, binning, img, maxc.value
+
+
+def rasterize_gaussians_backward_native(background, means3D, radii, colors, scales, rotations, scale_modifier,
+                                        cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
+                                        sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+    """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
+    dL_drotations), like RasterizeGaussiansBackwardCUDA (DGR/rasterize_points.cu:117-196)."""
+    lib = _lib.load()
+    dev = means3D.device
+    P = int(means3D.size(0))
+    H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
+    M = int(sh.size(1)) if sh is not None and sh.numel() != 0 else 0
+    f32 = dict(dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        if P == 0:
+            z = lambda *s: torch.zeros(*s, **f32)
+            return z(0, 3), z(0, 3), z(0, 1), z(0, 3), z(0, 6), z(0, M, 3), z(0, 3), z(0, 4)
+        means3D = _dev_f32(means3D, dev)
+        background, viewmatrix, projmatrix, campos = (_dev_f32(x, dev) for x in (background, viewmatrix, projmatrix, campos))
+        colors, scales, rotations, cov3D_precomp, sh = (_dev_f32(x, dev) for x in (colors, scales, rotations, cov3D_precomp, sh))
+        dL_dout_color = _dev_f32(dL_dout_color, dev)
+        has_cov = cov3D_precomp is not None and cov3D_precomp.numel() != 0
+        # torch.empty: the library fills whatever it needs zeroed (rasterize_points.cu:151-159 uses zeros).
+        dL_dmeans3D = torch.empty(P, 3, **f32)
+        dL_dmeans2D = torch.empty(P, 3, **f32)
+        dL_dcolors = torch.empty(P, 3, **f32)
+        dL_dconic = torch.empty(P, 2, 2, **f32)
+        dL_dopacity = torch.empty(P, 1, **f32)
+        dL_dcov3D = torch.empty(P, 6, **f32)
+        dL_dsh = torch.empty(P, M, 3, **f32)
+        dL_dscales = torch.zeros(P, 3, **f32) if has_cov else torch.empty(P, 3, **f32)
+        dL_drotations = torch.zeros(P, 4, **f32) if has_cov else torch.empty(P, 4, **f32)
+        _lib.check(lib.gsr_backward(
+            P, int(degree), M, int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(scales),
+            float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix),
+            _ptr(campos), float(tan_fovx), float(tan_fovy), _ptr(radii), _ptr(geomBuffer), _ptr(binningBuffer),
+            _ptr(imageBuffer), _ptr(dL_dout_color), _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity),
+            _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales),
+            _ptr(dL_drotations), _stream()), "gsr_backward")
+        if debug:
+            torch.cuda.synchronize(dev)
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def mark_visible_native(means3D, viewmatrix, projmatrix):
+    """-> bool[P], like markVisible (DGR/rasterize_points.cu:198-217)."""
+    lib = _lib.load()
+    _require_gpu(means3D, "positions")
+    dev = means3D.device
+    P = int(means3D.size(0))
+    present = torch.zeros(P, dtype=torch.bool, device=dev)
+    if P:
+        with torch.cuda.device(dev):
+            means3D, viewmatrix, projmatrix = (_dev_f32(x, dev) for x in (means3D, viewmatrix, projmatrix))
+            _lib.check(lib.gsr_mark_visible(P, _ptr(means3D), _ptr(viewmatrix), _ptr(projmatrix),
+                                            ctypes.c_void_p(present.data_ptr()), _stream()), "gsr_mark_visible")
+    return present
+
+
+# --------------------------------------------------------------------------------------------
+# The reference's Python layer, unchanged in shape.
+# --------------------------------------------------------------------------------------------
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        # Same argument restructuring as the reference (ref :60-80).
+        args = (raster_settings.bg, means3D, colors_precomp, opacities, scales, rotations,
+                raster_settings.scale_modifier, cov3Ds_precomp, raster_settings.viewmatrix,
+                raster_settings.projmatrix, raster_settings.tanfovx, raster_settings.tanfovy,
+                raster_settings.image_height, raster_settings.image_width, sh, raster_settings.sh_degree,
+                raster_settings.campos, raster_settings.prefiltered, raster_settings.debug)
+        if raster_settings.debug:
+            cpu_args = cpu_deep_copy_tuple(args)   # copy them before they can be corrupted (ref :83-90)
+            try:
+                out = rasterize_gaussians_native(*args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise ex
+        else:
+            out = rasterize_gaussians_native(*args)
+        num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, _max_tile = out
+        ctx.raster_settings = raster_settings
+        ctx.num_rendered = num_rendered
+        ctx.opacity_shape = opacities.shape
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
+                              binningBuffer, imgBuffer)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _):
+        num_rendered = ctx.num_rendered
+        raster_settings = ctx.raster_settings
+        (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
+         imgBuffer) = ctx.saved_tensors
+        args = (raster_settings.bg, means3D, radii, colors_precomp, scales, rotations,
+                raster_settings.scale_modifier, cov3Ds_precomp, raster_settings.viewmatrix,
+                raster_settings.projmatrix, raster_settings.tanfovx, raster_settings.tanfovy, grad_out_color, sh,
+                raster_settings.sh_degree, raster_settings.campos, geomBuffer, num_rendered, binningBuffer,
+                imgBuffer, raster_settings.debug)
+        if raster_settings.debug:
+            cpu_args = cpu_deep_copy_tuple(args)
+            try:
+                grads_native = rasterize_gaussians_backward_native(*args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_bw.dump")
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise ex
+        else:
+            grads_native = rasterize_gaussians_backward_native(*args)
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations) = grads_native
+
+        def present(inp, g):   # absent optionals were 0-element placeholders: they get no gradient
+            return g if inp is not None and inp.numel() != 0 else None
+
+        # Same order as the reference (ref :143-153).  opacities arrive as [P,1] from both callers
+        # (sugar_model.py:1215, gaussian_renderer/__init__.py:49) and the reference returns [P,1].
+        return (grad_means3D, grad_means2D, present(sh, grad_sh), present(colors_precomp, grad_colors_precomp),
+                grad_opacities.reshape(ctx.opacity_shape), present(scales, grad_scales),
+                present(rotations, grad_rotations), present(cov3Ds_precomp, grad_cov3Ds_precomp), None)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        # Mark visible points (based on frustum culling for camera) with a boolean
+        with torch.no_grad():
+            raster_settings = self.raster_settings
+            visible = mark_visible_native(positions, raster_settings.viewmatrix, raster_settings.projmatrix)
+        return visible
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        raster_settings = self.raster_settings
+
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+
+        if shs is None:
+            shs = torch.Tensor([])
+        if colors_precomp is None:
+            colors_precomp = torch.Tensor([])
+        if scales is None:
+            scales = torch.Tensor([])
+        if rotations is None:
+            rotations = torch.Tensor([])
+        if cov3D_precomp is None:
+            cov3D_precomp = torch.Tensor([])
+
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, raster_settings)

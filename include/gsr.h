@@ -1,0 +1,118 @@
+/*
+ * gsr.h -- C ABI of the MI355X-native differentiable surface-Gaussian rasterizer.
+ *
+ * This is the drop-in boundary below the reference's Python API
+ * (DGR = gaussian_splatting/submodules/diff-gaussian-rasterization).  Each entry
+ * point names the reference interface it replaces.  Plain pointers, sizes and a HIP
+ * stream only: no torch types, no C++ types.  All pointers are DEVICE pointers unless
+ * marked [host].  All arrays are fp32 row-major and contiguous; matrices are the
+ * reference's transposed (column-major) 4x4s (DGR/cuda_rasterizer/auxiliary.h:58-77).
+ * "Absent" optional inputs are NULL (the reference passes data_ptr() of a 0-element
+ * tensor, DGR/rasterize_points.cu:94-111).
+ *
+ * Ownership (as DGR/rasterize_points.cu:68-78): the caller owns every buffer including
+ * the three scratch buffers; the library keeps no state between calls, so backward
+ * re-derives its view of the scratch from (P, R, W, H) alone
+ * (DGR/cuda_rasterizer/rasterizer_impl.cu:371-373).
+ *
+ * Every function returns 0 on success, non-zero on failure; gsr_last_error() then
+ * holds a message for the calling thread.
+ */
+#ifndef GSR_H_INCLUDED
+#define GSR_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* gsr_stream_t; /* a hipStream_t; NULL = the default stream */
+
+/* Growable-buffer callback: must return a device pointer to at least `bytes` bytes that
+ * stays valid until the matching backward has run.  Mirrors the three
+ * std::function<char*(size_t)> of CudaRasterizer::Rasterizer::forward
+ * (DGR/cuda_rasterizer/rasterizer.h:32-34; DGR/rasterize_points.cu:27-33). */
+typedef void* (*gsr_alloc_fn)(void* ctx, size_t bytes);
+
+/* ABI version of this header (bumped on any signature change). */
+int gsr_abi_version(void);
+
+/* Message of the last failure on this thread ("" if none). */
+const char* gsr_last_error(void);
+
+/* Scratch sizes in bytes.  Replace CudaRasterizer::required<GeometryState|ImageState|
+ * BinningState>() (DGR/cuda_rasterizer/rasterizer_impl.h:66-72). */
+size_t gsr_geom_bytes(int P);
+size_t gsr_image_bytes(int W, int H);
+size_t gsr_binning_bytes(int R);
+
+/* Forward, first half: per-Gaussian projection/culling/covariance/SH->RGB, tile counting and
+ * the tile-offset scan; reads back num_rendered (= Gaussian x tile instances this library will
+ * blend) -- the one host synchronisation of the forward, like
+ * DGR/cuda_rasterizer/rasterizer_impl.cu:281.  Replaces rasterizer_impl.cu:198-281
+ * (FORWARD::preprocess, forward.cu:155-256, + InclusiveSum).
+ *   radii [P] int32 out (same values as the reference's), geom/image scratch sized by
+ *   gsr_geom_bytes / gsr_image_bytes.  *num_rendered [host] out; *max_tile_instances [host] out =
+ *   the longest per-tile list (lets stage 2 pick its LDS sort capacity without a second sync). */
+int gsr_forward_stage1(int P, int D, int M, const float* means3D, const float* shs, const float* colors_precomp,
+                       const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                       const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                       const float* campos, int W, int H, float tan_fovx, float tan_fovy, int prefiltered,
+                       int* radii, void* geom_buffer, void* image_buffer, int* num_rendered,
+                       int* max_tile_instances, gsr_stream_t stream);
+
+/* Forward, second half: instance scatter into per-tile buckets, per-tile depth sort, alpha
+ * blend.  Replaces rasterizer_impl.cu:283-335 (duplicateWithKeys, SortPairs,
+ * identifyTileRanges, FORWARD::render = forward.cu:261-374).
+ *   out_color [3,H,W] planar; binning scratch sized by gsr_binning_bytes(R). */
+int gsr_forward_stage2(int P, int R, int max_tile_instances, int W, int H, const float* background,
+                       const float* colors_precomp, void* geom_buffer, void* binning_buffer, void* image_buffer,
+                       float* out_color, gsr_stream_t stream);
+
+/* One-call forward with the reference's allocator-callback shape.  Replaces
+ * CudaRasterizer::Rasterizer::forward (DGR/cuda_rasterizer/rasterizer.h:31-55).
+ * Returns num_rendered through *num_rendered [host]. */
+int gsr_forward(gsr_alloc_fn geometry_buffer, gsr_alloc_fn binning_buffer, gsr_alloc_fn image_buffer, void* alloc_ctx,
+                int P, int D, int M, const float* background, int W, int H, const float* means3D, const float* shs,
+                const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                const float* campos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color, int* radii,
+                int* num_rendered, gsr_stream_t stream);
+
+/* Backward.  Replaces CudaRasterizer::Rasterizer::backward
+ * (DGR/cuda_rasterizer/rasterizer.h:57-83; rasterizer_impl.cu:340-434; backward.cu).
+ * Output gradient arrays need NOT be zeroed by the caller (the reference requires zeroed
+ * tensors, DGR/rasterize_points.cu:151-159; here the fill is part of the call):
+ *   dL_dmean2D [P,3], dL_dconic [P,4] (xx, xy, -, yy), dL_dopacity [P], dL_dcolor [P,3],
+ *   dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3] (NULL when M == 0), dL_dscale [P,3],
+ *   dL_drot [P,4] (both NULL when cov3D_precomp is given). */
+int gsr_backward(int P, int D, int M, int R, const float* background, int W, int H, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                 const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                 const void* geom_buffer, const void* binning_buffer, const void* image_buffer, const float* dL_dpix,
+                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, gsr_stream_t stream);
+
+/* Near-plane visibility test.  Replaces CudaRasterizer::Rasterizer::markVisible
+ * (DGR/cuda_rasterizer/rasterizer.h:24-29; rasterizer_impl.cu:54-66, :141-153).
+ * present [P] uint8 (bool) out. */
+int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present, gsr_stream_t stream);
+
+/* Introspection for tests/benchmarks: copies library-internal per-stage results out of the
+ * scratch buffers into caller-provided DEVICE arrays (any may be NULL):
+ *   means2D [P,2], conic_opacity [P,4], depths [P], rgb [P,3] (SH mode only),
+ *   tile_ranges [T,2] uint32, point_list [R] uint32, final_T [H*W], n_contrib [H*W] uint32.
+ * No reference counterpart (the reference exposes its scratch only as opaque bytes). */
+int gsr_debug_export(int P, int R, int W, int H, const void* geom_buffer, const void* binning_buffer,
+                     const void* image_buffer, float* means2D, float* conic_opacity, float* depths, float* rgb,
+                     uint32_t* tile_ranges, uint32_t* point_list, float* final_T, uint32_t* n_contrib,
+                     gsr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H_INCLUDED */
