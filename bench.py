@@ -1,0 +1,240 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's metric: rasterizer views/s, forward+backward, 1920x1080,
+491 520 mesh-bound surface Gaussians (config C), one view per GPU per step.
+
+    python bench.py --gpus 1 --steps 40 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one view per rank: GaussianRasterizer forward + backward
+through the public API (all inputs already resident in HBM), and for N > 1 the SUM all-reduce of the
+rasterizer-input gradients over RCCL that precedes the optimiser step.  Rank r renders camera
+(step * N + r) mod 160 of the rig -- views shard, nothing else is exchanged.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      dominant kernel (the one with the largest summed time), algorithmic bytes per launch
+                (SURVEY.md 8d per-unit figures x the units the launch processed) / its mean launch
+                duration, measured with HIP events on the launch stream in a second, instrumented
+                pass over the same K steps (gsr_profile_*), plus per-kernel means for every stage;
+  cpu_baseline  the C oracle (oracle/gsr_oracle.c, a port of the reference algorithm -- the
+                reference has no CPU path) timed on the host cores on a bounded sample: the first
+                few views of the same workload at full size.  N = 1 / rank 0 only.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as tdist  # noqa: E402
+
+from gaustar_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib, scene  # noqa: E402
+from gaustar_amd import dist as gdist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def algorithmic_bytes(P, R, W, H, M=0):
+    """B_alg = P*beta_P + R*beta_R + N_pix*40 + T*16 per view (fwd+bwd), and the
+    share of each kernel of this library under the same per-unit figures."""
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    N = W * H
+    beta_P = 464 if M == 0 else 494 + 48 * M
+    total = P * beta_P + R * 160 + N * 40 + T * 16
+    sh_in = 12 * M if M else 12
+    per_kernel = {
+        # reads 44 (+colours/SH) + writes 60 per Gaussian, + scan 8
+        "preprocess_kernel": P * (44 + sh_in + 60 + (15 if M else 0) + 8),
+        "tile_scan_kernel": T * 16,
+        # key-emit reads 20 per Gaussian, key+value write 12 per instance
+        "scatter_kernel": P * 20 + R * 12,
+        # one logical sort pass (read + write) 24 + range detect 8 per instance
+        "tile_sort_kernel": R * 32,
+        # list fetch 28 + colour 12 per instance; 20 B written per pixel; ranges read
+        "blend_fwd_kernel": R * 40 + N * 20 + T * 8,
+        "zero_fill": P * (108 + 12 * M),
+        # fetch 40 + one reduced 9-float flush 36 per instance; 20 B read per pixel; ranges read
+        "blend_bwd_kernel": R * 76 + N * 20 + T * 8,
+        # cov2D-bwd 56 in / 36 out + preprocess-bwd 92 in / 40 out (+SH)
+        "geom_bwd_kernel": P * (56 + 36 + 92 + 40 + ((24 * M + 15) if M else 0)),
+    }
+    return total, per_kernel
+
+
+def build_workload(device, rank):
+    gs, cams, bg = scene.config_C()
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(device)
+    params = dict(means3D=t(gs.means3D), opacities=t(gs.opacities), colors=t(gs.colors_precomp), scales=t(gs.scales),
+                  rotations=t(gs.rotations))
+    for p in params.values():
+        p.requires_grad_(True)
+    means2D = torch.zeros(gs.P, 3, device=device, requires_grad=True)
+    bg_t = t(bg)
+    rasters = []
+    for cam in cams:   # camera tensors are built once and stay resident (the reference re-uploads per call)
+        s = GaussianRasterizationSettings(cam.H, cam.W, cam.tanfovx, cam.tanfovy, bg_t, 1.0, t(cam.viewmatrix),
+                                          t(cam.projmatrix), 0, t(cam.campos), False, False)
+        rasters.append(GaussianRasterizer(s))
+    W, H = cams[0].W, cams[0].H
+    dpix = torch.randn(3, H, W, device=device, generator=torch.Generator(device=device).manual_seed(1234 + rank))
+    return gs, cams, bg, params, means2D, rasters, dpix
+
+
+def one_step(step, rank, world, params, means2D, rasters, dpix, reducer):
+    r = rasters[(step * world + rank) % len(rasters)]
+    for p in params.values():
+        p.grad = None
+    means2D.grad = None
+    color, radii = r(means3D=params["means3D"], means2D=means2D, opacities=params["opacities"],
+                     colors_precomp=params["colors"], scales=params["scales"], rotations=params["rotations"])
+    color.backward(dpix)
+    if reducer is not None:
+        reducer()
+    return color
+
+
+def timed(fn, steps, world, device):
+    if world > 1:
+        tdist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for s in range(steps):
+        fn(s)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        tdist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        tdist.all_reduce(tt, op=tdist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt
+
+
+def cpu_baseline(gs, cams, bg, budget_s=20.0):
+    """The oracle (CPU port of the reference algorithm) on the host cores, same workload, full size."""
+    from oracle import oracle
+    ncores = os.cpu_count() or 1
+    oracle.set_threads(ncores)
+    rng = np.random.default_rng(0)
+    dpix = rng.normal(size=(3, cams[0].H, cams[0].W)).astype(np.float32)
+    t_total, n = 0.0, 0
+    while n < 8 and (n == 0 or t_total + t_total / n < budget_s):
+        cam = cams[n]
+        t0 = time.perf_counter()
+        st = oracle.forward(gs.means3D, gs.opacities, cam.viewmatrix, cam.projmatrix, cam.campos, cam.W, cam.H,
+                            cam.tanfovx, cam.tanfovy, bg, colors_precomp=gs.colors_precomp, scales=gs.scales,
+                            rotations=gs.rotations)
+        oracle.backward(st, dpix)
+        t_total += time.perf_counter() - t0
+        n += 1
+    return {"value": n / t_total, "unit": "views/s", "cores": ncores, "kind": "port",
+            "sample": f"first {n} of the 160 views of the same workload (491520 Gaussians, 1920x1080, fwd+bwd), "
+                      f"C restatement of the reference algorithm with OpenMP over {ncores} threads, {t_total:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = gdist.init_from_env("nccl")
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    device = torch.device("cuda", local if world > 1 else 0)
+    torch.cuda.set_device(device)
+    lib = _lib.load()
+
+    gs, cams, bg, params, means2D, rasters, dpix = build_workload(device, rank)
+    reducer = gdist.GradAllReducer(list(params.values())) if world > 1 else None
+    step = lambda s: one_step(s, rank, world, params, means2D, rasters, dpix, reducer)
+
+    for s in range(args.warmup):
+        step(s)
+    dt = timed(step, args.steps, world, device)
+    ms_per_step = dt / args.steps * 1e3
+    value = args.steps * world / dt
+
+    # instrumented pass: per-kernel HIP-event durations over the same K steps (rank 0's launches)
+    nst = lib.gsr_num_stages()
+    names = [lib.gsr_stage_name(i).decode() for i in range(nst)]
+    ms = (ctypes.c_float * nst)()
+    cnt = (ctypes.c_int * nst)()
+    lib.gsr_profile_enable(1)
+    dt_prof = timed(step, args.steps, world, device)
+    _lib.check(lib.gsr_profile_read(ms, cnt, 1), "gsr_profile_read")
+    lib.gsr_profile_enable(0)
+
+    # num_rendered of the views this rank rendered (for the algorithmic byte count)
+    from gaustar_amd import rasterizer as rz
+    R_list = []
+    for s in range(min(args.steps, len(rasters))):
+        rs = rasters[(s * world + rank) % len(rasters)].raster_settings
+        e = torch.Tensor([])
+        out = rz.rasterize_gaussians_native(rs.bg, params["means3D"].detach(), params["colors"].detach(),
+                                            params["opacities"].detach(), params["scales"].detach(),
+                                            params["rotations"].detach(), 1.0, e, rs.viewmatrix, rs.projmatrix,
+                                            rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, e, 0, rs.campos,
+                                            False, False)
+        R_list.append(out[0])
+    R_mean = float(np.mean(R_list))
+
+    if rank == 0:
+        W, H = cams[0].W, cams[0].H
+        total_b, per_kernel_b = algorithmic_bytes(gs.P, R_mean, W, H)
+        kern = {}
+        for i, nme in enumerate(names):
+            if cnt[i]:
+                launches_per_step = cnt[i] / args.steps
+                mean_ms = ms[i] / cnt[i]
+                kern[nme] = {"ms_per_launch": round(mean_ms, 5), "launches_per_step": launches_per_step,
+                             "alg_bytes_per_step": int(per_kernel_b.get(nme, 0)),
+                             "GBps": round(per_kernel_b.get(nme, 0) / launches_per_step / (mean_ms * 1e-3) / 1e9, 1)}
+        dom = max(kern, key=lambda k: kern[k]["ms_per_launch"] * kern[k]["launches_per_step"])
+        ach = kern[dom]["GBps"]
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc_file):
+            try:
+                traffic = json.load(open(pmc_file)).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        path_gbs = total_b / (ms_per_step * 1e-3) / 1e9 if world == 1 else total_b * world / (ms_per_step * 1e-3) / 1e9
+        out = {
+            "metric": "views/sec fwd+bwd @1920x1080, 500k Gaussians; HBM GB/s vs roofline",
+            "value": round(value, 2), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "config C: 491520 mesh-bound surface Gaussians (icosphere level 6, 6/face), "
+                                   "160-camera rig @1920x1080, colours precomputed (M=0), one view per GPU per step, "
+                                   "fwd+bwd" + (", + RCCL all-reduce of 27.5 MB input gradients" if world > 1 else ""),
+                       "gaussians": gs.P, "width": W, "height": H, "views_per_step": world,
+                       "num_rendered_mean": R_mean, "parallelism": f"view-parallel x{world}"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "path_alg_bytes_per_view": int(total_b), "path_achieved": round(path_gbs, 1),
+                         "path_frac": round(path_gbs / HBM_PEAK_GBS / world, 5),
+                         "instrumented_ms_per_step": round(dt_prof / args.steps * 1e3, 4), "kernels": kern},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(gs, cams, bg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        tdist.barrier()
+        tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

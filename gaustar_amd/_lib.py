@@ -38,6 +38,10 @@ SIGNATURES = {
     "gsr_mark_visible": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsr_debug_export": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gsr_num_stages": (c_int, []),
+    "gsr_stage_name": (c_char_p, [c_int]),
+    "gsr_profile_enable": (c_int, [c_int]),
+    "gsr_profile_read": (c_int, [POINTER(c_float), POINTER(c_int), c_int]),
 }
 
 _lib = None

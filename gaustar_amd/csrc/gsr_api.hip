@@ -6,12 +6,45 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 using namespace gsr;
 
 namespace {
 thread_local std::string g_err;
 thread_local uint32_t* g_pinned = nullptr;   // 16-byte pinned landing pad for the stage-1 read-back
+
+// ---- optional per-kernel timing (gsr_profile_*): HIP events on the launch stream around every stage.
+enum Stage { ST_PREPROCESS = 0, ST_TILE_SCAN, ST_SCATTER, ST_TILE_SORT, ST_BLEND_FWD, ST_ZERO_FILL, ST_BLEND_BWD,
+             ST_GEOM_BWD, ST_COUNT };
+const char* const kStageNames[ST_COUNT] = {"preprocess_kernel", "tile_scan_kernel", "scatter_kernel",
+                                           "tile_sort_kernel", "blend_fwd_kernel", "zero_fill", "blend_bwd_kernel",
+                                           "geom_bwd_kernel"};
+struct Rec { int stage; hipEvent_t a, b; };
+struct Profiler {
+    bool on = false;
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get()
+    {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+};
+thread_local Profiler g_prof;
+struct Scope {
+    int stage; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    Scope(int stage_, hipStream_t st_) : stage(stage_), st(st_)
+    {
+        if (g_prof.on) { a = g_prof.get(); b = g_prof.get(); (void)hipEventRecord(a, st); }
+    }
+    ~Scope()
+    {
+        if (a) { (void)hipEventRecord(b, st); g_prof.recs.push_back(Rec{stage, a, b}); }
+    }
+};
 
 int fail(const char* where, hipError_t e)
 {
@@ -76,11 +109,17 @@ int gsr_forward_stage1(int P, int D, int M, const float* means3D, const float* s
     GSR_CHECK(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * (size_t)t.T, st));
     if (P > 0) {
         GeomState g = carve_geom(geom_buffer, P);
-        launch_preprocess(P, D, M, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
-                          cov3D_precomp, viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, radii, g, im, st);
+        {
+            Scope sc(ST_PREPROCESS, st);
+            launch_preprocess(P, D, M, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                              cov3D_precomp, viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, radii, g, im, st);
+        }
         GSR_CHECK_LAUNCH("preprocess_kernel");
     }
-    launch_tile_scan(im, t.T, st);
+    {
+        Scope sc(ST_TILE_SCAN, st);
+        launch_tile_scan(im, t.T, st);
+    }
     GSR_CHECK_LAUNCH("tile_scan_kernel");
     if (!g_pinned) GSR_CHECK(hipHostMalloc((void**)&g_pinned, 64, hipHostMallocDefault));
     GSR_CHECK(hipMemcpyAsync(g_pinned, im.totals, 16, hipMemcpyDeviceToHost, st));
@@ -103,13 +142,22 @@ int gsr_forward_stage2(int P, int R, int max_tile_instances, int W, int H, const
     GeomState g = carve_geom(geom_buffer, P > 0 ? P : 0);
     BinState b = carve_bin(binning_buffer, R > 0 ? R : 0);
     if (R > 0) {
-        launch_scatter(P, W, H, g, im, b, st);
+        {
+            Scope sc(ST_SCATTER, st);
+            launch_scatter(P, W, H, g, im, b, st);
+        }
         GSR_CHECK_LAUNCH("scatter_kernel");
-        launch_tile_sort(W, H, (uint32_t)max_tile_instances, im, b, st);
+        {
+            Scope sc(ST_TILE_SORT, st);
+            launch_tile_sort(W, H, (uint32_t)max_tile_instances, im, b, st);
+        }
         GSR_CHECK_LAUNCH("tile_sort_kernel");
     }
     const float* feats = colors_precomp ? colors_precomp : g.rgb;
-    launch_blend_fwd(W, H, background, feats, g, im, b, out_color, st);
+    {
+        Scope sc(ST_BLEND_FWD, st);
+        launch_blend_fwd(W, H, background, feats, g, im, b, out_color, st);
+    }
     GSR_CHECK_LAUNCH("blend_fwd_kernel");
     return 0;
 }
@@ -164,19 +212,30 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int W, int
     GeomState g = carve_geom(const_cast<void*>(geom_buffer), P);
     BinState b = carve_bin(const_cast<void*>(binning_buffer), R > 0 ? R : 0);
     // Zero the four atomic-accumulation targets; everything else is written outright by geom_bwd.
-    GSR_CHECK(hipMemsetAsync(dL_dmean2D, 0, sizeof(float) * 3 * (size_t)P, st));
-    GSR_CHECK(hipMemsetAsync(dL_dconic, 0, sizeof(float) * 4 * (size_t)P, st));
-    GSR_CHECK(hipMemsetAsync(dL_dopacity, 0, sizeof(float) * (size_t)P, st));
-    GSR_CHECK(hipMemsetAsync(dL_dcolor, 0, sizeof(float) * 3 * (size_t)P, st));
+    {
+        Scope sc(ST_ZERO_FILL, st);
+        GSR_CHECK(hipMemsetAsync(dL_dmean2D, 0, sizeof(float) * 3 * (size_t)P, st));
+        GSR_CHECK(hipMemsetAsync(dL_dconic, 0, sizeof(float) * 4 * (size_t)P, st));
+        GSR_CHECK(hipMemsetAsync(dL_dopacity, 0, sizeof(float) * (size_t)P, st));
+        GSR_CHECK(hipMemsetAsync(dL_dcolor, 0, sizeof(float) * 3 * (size_t)P, st));
+    }
     const float* feats = colors_precomp ? colors_precomp : g.rgb;
     if (R > 0) {
-        launch_blend_bwd(W, H, background, feats, g, im, b, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, st);
+        {
+            Scope sc(ST_BLEND_BWD, st);
+            launch_blend_bwd(W, H, background, feats, g, im, b, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
+                             st);
+        }
         GSR_CHECK_LAUNCH("blend_bwd_kernel");
     }
-    launch_geom_bwd(P, D, M, means3D, shs, cov3D_precomp ? nullptr : scales, scale_modifier,
-                    cov3D_precomp ? nullptr : rotations, cov3D_precomp, viewmatrix, projmatrix, campos, W, H, tan_fovx,
-                    tan_fovy, radii, dL_dmean2D, dL_dconic, dL_dcolor, dL_dmean3D, dL_dcov3D, shs ? dL_dsh : nullptr,
-                    cov3D_precomp ? nullptr : dL_dscale, cov3D_precomp ? nullptr : dL_drot, st);
+    {
+        Scope sc(ST_GEOM_BWD, st);
+        launch_geom_bwd(P, D, M, means3D, shs, cov3D_precomp ? nullptr : scales, scale_modifier,
+                        cov3D_precomp ? nullptr : rotations, cov3D_precomp, viewmatrix, projmatrix, campos, W, H,
+                        tan_fovx, tan_fovy, radii, dL_dmean2D, dL_dconic, dL_dcolor, dL_dmean3D, dL_dcov3D,
+                        shs ? dL_dsh : nullptr, cov3D_precomp ? nullptr : dL_dscale, cov3D_precomp ? nullptr : dL_drot,
+                        st);
+    }
     GSR_CHECK_LAUNCH("geom_bwd_kernel");
     return 0;
 }
@@ -190,6 +249,35 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
     if (!means3D || !viewmatrix || !present) return fail_msg("gsr_mark_visible: required pointer is null");
     launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
     GSR_CHECK_LAUNCH("mark_visible_kernel");
+    return 0;
+}
+
+// ---- per-kernel timing --------------------------------------------------------------------------
+int gsr_num_stages(void) { return ST_COUNT; }
+const char* gsr_stage_name(int stage) { return (stage >= 0 && stage < ST_COUNT) ? kStageNames[stage] : ""; }
+
+int gsr_profile_enable(int on)
+{
+    g_prof.on = on != 0;
+    return 0;
+}
+
+int gsr_profile_read(float* ms, int* counts, int reset)
+{
+    g_err.clear();
+    if (!ms || !counts) return fail_msg("gsr_profile_read: null output pointer");
+    for (int i = 0; i < ST_COUNT; i++) { ms[i] = 0.f; counts[i] = 0; }
+    for (const Rec& r : g_prof.recs) {
+        GSR_CHECK(hipEventSynchronize(r.b));
+        float t = 0.f;
+        GSR_CHECK(hipEventElapsedTime(&t, r.a, r.b));
+        ms[r.stage] += t;
+        counts[r.stage] += 1;
+    }
+    if (reset) {
+        for (const Rec& r : g_prof.recs) { g_prof.pool.push_back(r.a); g_prof.pool.push_back(r.b); }
+        g_prof.recs.clear();
+    }
     return 0;
 }
 

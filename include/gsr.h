@@ -112,6 +112,16 @@ int gsr_debug_export(int P, int R, int W, int H, const void* geom_buffer, const 
                      uint32_t* tile_ranges, uint32_t* point_list, float* final_T, uint32_t* n_contrib,
                      gsr_stream_t stream);
 
+/* Per-kernel timing for benchmarks (no reference counterpart; the reference has no profiling hooks,
+ * SURVEY.md section 5).  While enabled, every stage this thread launches is bracketed by HIP events
+ * recorded on the launch stream.  gsr_profile_read waits for the recorded events and returns, per
+ * stage (0 .. gsr_num_stages()-1, names from gsr_stage_name), the summed milliseconds and the number
+ * of launches since the last reset.  ms, counts: [host] arrays of gsr_num_stages() entries. */
+int gsr_num_stages(void);
+const char* gsr_stage_name(int stage);
+int gsr_profile_enable(int on);
+int gsr_profile_read(float* ms, int* counts, int reset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,83 @@
+"""The C-ABI boundary: include/gsr.h, the ctypes table and the built library must agree, the
+library must export every declared symbol, and argument validation must fail loudly -- all
+without a GPU (no compute is launched)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "gsr.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\b([A-Za-z_][\w \*]*?)\b(gsr_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if "typedef" in ret:
+            continue
+        n = 0 if args in ("void", "") else len([a for a in args.split(",") if a.strip()])
+        decls[name] = (ret, n, args)
+    return decls
+
+
+def test_header_declares_the_expected_entry_points():
+    d = _declared()
+    for name in ("gsr_abi_version", "gsr_last_error", "gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes",
+                 "gsr_forward_stage1", "gsr_forward_stage2", "gsr_forward", "gsr_backward", "gsr_mark_visible",
+                 "gsr_debug_export"):
+        assert name in d, name
+    src = open(HEADER).read()
+    # every entry point cites the reference interface it replaces
+    assert src.count("rasterizer.h:") >= 3 and "rasterize_points.cu" in src
+    assert "torch" not in src.replace("no torch types", "")
+
+
+def test_ctypes_table_matches_header():
+    from gaustar_amd import _lib
+    d = _declared()
+    assert set(d) == set(_lib.SIGNATURES), set(d) ^ set(_lib.SIGNATURES)
+    for name, (ret, n, args) in d.items():
+        res, argtypes = _lib.SIGNATURES[name]
+        assert len(argtypes) == n, f"{name}: header has {n} parameters, ctypes table {len(argtypes)}"
+        # floats sit at the same positions on both sides
+        hdr_float = [i for i, a in enumerate(args.split(",")) if re.match(r"\s*float\s+\w+$", a)]
+        tab_float = [i for i, t in enumerate(argtypes) if t is ctypes.c_float]
+        assert hdr_float == tab_float, f"{name}: float parameter positions differ"
+
+
+def test_library_loads_and_exports_every_symbol(hip_lib):
+    for name in _declared():
+        assert hasattr(hip_lib, name), name
+    assert hip_lib.gsr_abi_version() == 1
+
+
+def test_scratch_sizes(hip_lib):
+    # 44 B/Gaussian geometry state + 12 B SH-colour slot, 8 B/pixel, 12 B/instance (+ alignment slack)
+    g = hip_lib.gsr_geom_bytes(500_000)
+    assert 56 * 500_000 <= g <= 56 * 500_000 + 4096
+    i = hip_lib.gsr_image_bytes(1920, 1080)
+    assert 8 * 1920 * 1080 <= i <= 8 * 1920 * 1080 + 16 * 8160 + 8192
+    b = hip_lib.gsr_binning_bytes(1_000_000)
+    assert 12_000_000 <= b <= 12_000_000 + 2048
+    assert hip_lib.gsr_geom_bytes(0) > 0 and hip_lib.gsr_binning_bytes(0) > 0
+
+
+def test_validation_errors_without_gpu(hip_lib):
+    R, mx = ctypes.c_int(7), ctypes.c_int(7)
+    null = None
+    rc = hip_lib.gsr_forward_stage1(10, 0, 0, null, null, null, null, null, 1.0, null, null, null, null, null, 64, 64,
+                                    0.5, 0.5, 0, null, null, null, ctypes.byref(R), ctypes.byref(mx), null)
+    assert rc != 0 and b"null" in hip_lib.gsr_last_error()
+    rc = hip_lib.gsr_forward_stage1(10, 0, 0, null, null, null, null, null, 1.0, null, null, null, null, null, 0, 64,
+                                    0.5, 0.5, 0, null, null, null, ctypes.byref(R), ctypes.byref(mx), null)
+    assert rc != 0 and b"positive" in hip_lib.gsr_last_error()
+    assert R.value == 0
+    rc = hip_lib.gsr_backward(5, 0, 0, 0, null, 8, 8, *([null] * 4), 1.0, *([null] * 5), 0.5, 0.5, *([null] * 15))
+    assert rc != 0 and hip_lib.gsr_last_error()
+    # P == 0 backward is a no-op success (rasterize_points.cu:161)
+    assert hip_lib.gsr_backward(0, 0, 0, 0, null, 8, 8, *([null] * 4), 1.0, *([null] * 5), 0.5, 0.5, *([null] * 15)) == 0

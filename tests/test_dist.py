@@ -1,0 +1,69 @@
+"""View-parallel gradient all-reduce (gaustar_amd/dist.py) on CPU: world_size 2, gloo backend."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from gaustar_amd import dist as gd
+    r, w, _ = gd.init_from_env("gloo")
+    assert (r, w) == (rank, world) and gd.world_size() == world
+    torch.manual_seed(0)
+    # three "parameter groups" incl. one bigger than a bucket and one with no grad on rank 1
+    params = [torch.zeros(1000, 3, requires_grad=True), torch.zeros(70_000, requires_grad=True),
+              torch.zeros(5, 4, requires_grad=True)]
+    for i, p in enumerate(params):
+        if not (rank == 1 and i == 2):
+            p.grad = torch.full_like(p, float((rank + 1) * (i + 1)))
+    red = gd.GradAllReducer(params, bucket_bytes=64 << 10, average=True)
+    assert len(red.buckets) >= 2 and red.payload_bytes() == (3000 + 70_000 + 20) * 4
+    red()
+    want = [1.5 * 1, 1.5 * 2, (1 * 3 + 0) / 2]
+    ok = all(torch.allclose(p.grad, torch.full_like(p, w_)) for p, w_ in zip(params, want))
+    # second call re-uses the flat buffers and keeps averaging correctly
+    for p in params:
+        p.grad = torch.ones_like(p) * (rank + 1)
+    red()
+    ok = ok and all(torch.allclose(p.grad, torch.full_like(p, 1.5)) for p in params)
+    # both ranks walk the same permutation and never collide within a step
+    views = [gd.shard_views(160, s) for s in range(80)]
+    q.put((rank, ok, views))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_grad_allreduce_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    v0, v1 = res[0][2], res[1][2]
+    assert all(a != b for a, b in zip(v0, v1))
+    assert len(set(v0) | set(v1)) == 160        # one epoch of 80 steps x 2 ranks covers all 160 cameras
+
+
+def test_single_process_is_a_noop():
+    from gaustar_amd import dist as gd
+    p = torch.zeros(4, requires_grad=True)
+    p.grad = torch.ones(4)
+    gd.GradAllReducer([p])()
+    assert torch.equal(p.grad, torch.ones(4)) and gd.world_size() == 1 and gd.rank() == 0

@@ -1,0 +1,278 @@
+"""Parity tests proper (-m gpu): the HIP path, called through the public Python API -> C ABI,
+against (1) the committed golden vectors of the reference, (2) the C oracle run on the host CPU on
+seeded inputs, (3) -- when oracle/_ref travelled to the box -- the reference build itself at
+BASELINE.json's full sizes, plus (4) size-independent properties at full size and the edge cases.
+Tolerances: parity.py (1e-4, fp32)."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import parity
+from conftest import ROOT, golden_names
+
+pytestmark = pytest.mark.gpu
+
+
+def _kw(gs, cam, bg, sm=1.0):
+    return dict(means3D=gs.means3D, opacities=gs.opacities, view=cam.viewmatrix, proj=cam.projmatrix,
+                campos=cam.campos, W=cam.W, H=cam.H, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg, shs=gs.shs,
+                colors_precomp=gs.colors_precomp, scales=gs.scales, rotations=gs.rotations,
+                cov3D_precomp=gs.cov3D_precomp, sh_degree=gs.sh_degree, scale_modifier=sm)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _native_loaded(hip_lib):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return hip_lib
+
+
+# ------------------------------------------------------------------ (1) golden vectors of the reference
+@pytest.mark.parametrize("name", golden_names())
+def test_hip_matches_reference_golden(name):
+    kw, d = parity.load_golden(name)
+    hip = parity.run_hip(kw, d["in_dL_dpix"])
+    ref_grads = {k: d["grad_" + k] for k in parity.GRAD_KEYS}
+    parity.compare_hip_to(hip, d["out_color"], d["out_radii"], ref_grads, what=name)
+
+
+@pytest.mark.parametrize("name", ["edge_cases", "mesh_sphere", "sh3_random"])
+def test_hip_internal_state_matches_reference(name, hip_lib):
+    """Stage-level parity: projected means, conics, depths, SH colours, per-pixel transmittance, and
+    the depth-sorted per-tile lists (compared as lists of contributing Gaussians per tile, since this
+    library bins a subset of the reference's instances -- only ones that can reach alpha >= 1/255)."""
+    import torch
+    from gaustar_amd import rasterizer as R
+    kw, d = parity.load_golden(name)
+    dev = torch.device("cuda:0")
+    t = lambda x: None if x is None else torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
+    e = torch.Tensor([])
+    P, W, H = len(kw["means3D"]), kw["W"], kw["H"]
+    opt = lambda k: t(kw[k]) if kw.get(k) is not None else e
+    out = R.rasterize_gaussians_native(t(kw["bg"]), t(kw["means3D"]), opt("colors_precomp"), t(kw["opacities"]),
+                                       opt("scales"), opt("rotations"), kw["scale_modifier"], opt("cov3D_precomp"),
+                                       t(kw["view"]), t(kw["proj"]), kw["tanfovx"], kw["tanfovy"], H, W, opt("shs"),
+                                       kw["sh_degree"], t(kw["campos"]), False, False)
+    Rn, color, radii, geom, binning, img, maxc = out
+    assert 0 < Rn <= int(d["out_num_rendered"]) and 0 < maxc <= Rn
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    m2 = torch.zeros(P, 2, device=dev); co = torch.zeros(P, 4, device=dev); dp = torch.zeros(P, device=dev)
+    rgb = torch.zeros(P, 3, device=dev)
+    rng_ = torch.zeros(T, 2, dtype=torch.int32, device=dev); pl = torch.zeros(max(Rn, 1), dtype=torch.int32, device=dev)
+    fT = torch.zeros(H, W, device=dev); nc = torch.zeros(H, W, dtype=torch.int32, device=dev)
+    p = lambda x: ctypes.c_void_p(x.data_ptr())
+    rc = hip_lib.gsr_debug_export(P, Rn, W, H, p(geom), p(binning), p(img), p(m2), p(co), p(dp),
+                                  p(rgb) if kw["shs"] is not None else None, p(rng_), p(pl), p(fT), p(nc), None)
+    assert rc == 0, hip_lib.gsr_last_error()
+    torch.cuda.synchronize()
+    vis = d["state_visible"] & (d["in_opacities"].reshape(-1) * 255.0 >= 1.0)
+    np.testing.assert_allclose(m2.cpu().numpy()[vis], d["state_means2D"][vis], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(dp.cpu().numpy()[vis], d["state_depths"][vis], rtol=1e-6, atol=1e-6)
+    b = d["state_conic_opacity"][vis]
+    np.testing.assert_allclose(co.cpu().numpy()[vis], b, rtol=2e-4, atol=1e-6 * max(1.0, float(np.abs(b).max())))
+    if kw["shs"] is not None:
+        np.testing.assert_allclose(rgb.cpu().numpy()[vis], d["state_rgb"][vis], rtol=0, atol=2e-6)
+    parity.check_image(fT.cpu().numpy(), d["state_final_T"], name + " final_T")
+    # sorted lists: ours must be a subsequence of the reference's per tile, in the same order
+    ours_r, ours_l = rng_.cpu().numpy().astype(np.int64), pl.cpu().numpy().astype(np.int64)
+    ref_r, ref_l = d["state_ranges"].astype(np.int64), d["state_point_list"].astype(np.int64)
+    assert ours_r[-1, 1] == Rn and (ours_r[1:, 0] == ours_r[:-1, 1]).all()
+    depth = d["state_depths"]
+    for tile in range(T):
+        a = ours_l[ours_r[tile, 0]:ours_r[tile, 1]]
+        bb = ref_l[ref_r[tile, 0]:ref_r[tile, 1]]
+        assert (np.diff(depth[a]) >= 0).all(), f"tile {tile}: list not depth sorted"
+        it = iter(bb.tolist())
+        assert all(x in it for x in a.tolist()), f"tile {tile}: not an ordered subset of the reference list"
+
+
+# ------------------------------------------------------------------ (2) C oracle on the host, seeded inputs
+@pytest.mark.parametrize("seed,P,W,H,deg", [(1, 4000, 256, 192, 0), (2, 3000, 200, 200, 3), (3, 6000, 333, 127, 0)])
+def test_hip_matches_oracle_seeded(seed, P, W, H, deg):
+    from gaustar_amd import scene
+    rng = np.random.default_rng(seed)
+    gs = scene.random_gaussians(P, rng, sh_degree=deg, with_sh=deg > 0, scale_range=(0.01, 0.15))
+    cam = scene.look_at_camera((0.3, -0.2, -4.0), (0, 0, 0), W, H, fovx=0.9, znear=0.01)
+    kw = _kw(gs, cam, np.array([0.2, 0.4, 0.6], np.float32))
+    dpix = rng.normal(size=(3, H, W)).astype(np.float32)
+    st, g = parity.run_oracle(kw, dpix)
+    hip = parity.run_hip(kw, dpix)
+    assert (hip["radii"] != st["radii"]).sum() <= 1
+    hip["radii"] = st["radii"]
+    parity.compare_hip_to(hip, st["color"], st["radii"], g, what=f"seed{seed}")
+
+
+def test_config_A_against_oracle():
+    """BASELINE.json configs[0]: 10k random Gaussians, 1 cam @512x512, SH deg 0."""
+    from gaustar_amd import scene
+    gs, cam, bg = scene.config_A()
+    kw = _kw(gs, cam, bg)
+    dpix = np.random.default_rng(0).normal(size=(3, cam.H, cam.W)).astype(np.float32)
+    st, g = parity.run_oracle(kw, dpix)
+    hip = parity.run_hip(kw, dpix)
+    assert (hip["radii"] != st["radii"]).sum() <= 1
+    hip["radii"] = st["radii"]
+    parity.compare_hip_to(hip, st["color"], st["radii"], g, what="config A")
+
+
+# ------------------------------------------------------------------ (3) the reference build itself, full sizes
+def _ref_or_skip():
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref/libgsr_ref.so did not travel to this box")
+    return ref
+
+
+@pytest.mark.parametrize("cfg", ["B", "C", "D", "D_depth"])
+def test_full_size_configs_against_reference_build(cfg):
+    """BASELINE.json configs[1..3] at full size: 200k / 491k / 1M mesh-bound Gaussians @1080p."""
+    ref = _ref_or_skip()
+    from gaustar_amd import scene
+    if cfg == "B":
+        gs, cam, bg = scene.config_B()
+    elif cfg == "C":
+        gs, cams, bg = scene.config_C()
+        cam = cams[37]
+    else:
+        gs, cam, bg = scene.config_D()
+        if cfg == "D_depth":          # refine.py:603-607 second pass: depth as colour, bg = 10
+            gs.shs, gs.sh_degree = None, 0
+            gs.colors_precomp = scene.view_depth_colors(gs, cam)
+            bg = np.array([10.0, 10.0, 10.0], np.float32)
+    kw = _kw(gs, cam, bg)
+    dpix = np.random.default_rng(5).normal(size=(3, cam.H, cam.W)).astype(np.float32)
+    rr = ref.RefRasterizer()
+    color, radii, R = rr.forward(**kw)
+    g = rr.backward(dpix)
+    hip = parity.run_hip(kw, dpix)
+    radii = radii.cpu().numpy()
+    assert (hip["radii"] != radii).sum() <= max(2, gs.P // 100_000), "radii differ beyond ulp-level ceil() flips"
+    hip["radii"] = radii
+    parity.compare_hip_to(hip, color.cpu().numpy(), radii, {k: v.cpu().numpy() for k, v in g.items()}, what=cfg)
+
+
+def test_mark_visible_matches_reference_build():
+    ref = _ref_or_skip()
+    import torch
+    from gaustar_amd import GaussianRasterizationSettings, GaussianRasterizer
+    kw, d = parity.load_golden("edge_cases")
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
+    s = GaussianRasterizationSettings(kw["H"], kw["W"], kw["tanfovx"], kw["tanfovy"], t(kw["bg"]), 1.0, t(kw["view"]),
+                                      t(kw["proj"]), 0, t(kw["campos"]), False, False)
+    ours = GaussianRasterizer(s).markVisible(t(kw["means3D"]))
+    theirs = ref.mark_visible(kw["means3D"], kw["view"], kw["proj"])
+    assert ours.dtype == torch.bool and torch.equal(ours, theirs) and 0 < int(ours.sum()) < len(ours)
+
+
+# ------------------------------------------------------------------ (4) size-independent properties, full size
+def test_full_size_properties():
+    """Config C geometry @1080p: determinism of the forward, background linearity
+    (C(bg1) - C(bg2) = T_final * (bg1 - bg2)), linearity of the backward in dL_dpix."""
+    from gaustar_amd import scene
+    gs, cams, bg = scene.config_C()
+    cam = cams[5]
+    kw = _kw(gs, cam, bg)
+    rng = np.random.default_rng(0)
+    dpix = rng.normal(size=(3, cam.H, cam.W)).astype(np.float32)
+    a = parity.run_hip(kw, dpix)
+    b = parity.run_hip(kw, dpix)
+    assert np.array_equal(a["color"], b["color"]) and np.array_equal(a["radii"], b["radii"])
+    for k in parity.GRAD_KEYS:
+        parity.check_grad(a[k], b[k], "rerun " + k, tol=2e-6, max_outlier_frac=0.0)
+    kw2 = dict(kw, bg=np.array([0.7, 0.1, 0.4], np.float32))
+    c = parity.run_hip(kw2)
+    dbg = (kw2["bg"] - kw["bg"]).reshape(3, 1, 1)
+    Tf = (c["color"] - a["color"])[0] / dbg[0]
+    assert Tf.min() > -1e-5 and Tf.max() < 1 + 1e-5
+    np.testing.assert_allclose(c["color"] - a["color"], Tf[None] * dbg, atol=3e-6)
+    assert (Tf > 0.999).mean() > 0.3 and (Tf < 0.01).mean() > 0.1       # empty background and opaque subject
+    h = parity.run_hip(kw, 2.0 * dpix)
+    for k in parity.GRAD_KEYS:
+        parity.check_grad(h[k], 2.0 * a[k], "linearity " + k, tol=1e-5, max_outlier_frac=0.0)
+
+
+# ------------------------------------------------------------------ edge cases and ABI variants
+def test_empty_and_all_culled():
+    import torch
+    from gaustar_amd import GaussianRasterizationSettings, GaussianRasterizer
+    dev = torch.device("cuda:0")
+    kw, _ = parity.load_golden("colors_rgb")
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
+    s = GaussianRasterizationSettings(40, 56, kw["tanfovx"], kw["tanfovy"], t(kw["bg"]), 1.0, t(kw["view"]),
+                                      t(kw["proj"]), 0, t(kw["campos"]), False, True)
+    r = GaussianRasterizer(s)
+    z = lambda *sh: torch.zeros(*sh, device=dev, requires_grad=True)
+    # P == 0: zero image (NOT background), like rasterize_points.cu:68-81
+    color, radii = r(z(0, 3), z(0, 3), z(0, 1), colors_precomp=z(0, 3), scales=z(0, 3), rotations=z(0, 4))
+    assert color.shape == (3, 40, 56) and not color.any() and radii.numel() == 0
+    # everything behind the camera: background everywhere, zero gradients
+    m = torch.tensor(np.tile([[0.0, 0.0, -10.0]], (50, 1)), dtype=torch.float32, device=dev, requires_grad=True)
+    o, c = torch.full((50, 1), 0.5, device=dev, requires_grad=True), torch.rand(50, 3, device=dev, requires_grad=True)
+    sc, q = torch.full((50, 3), 0.1, device=dev, requires_grad=True), torch.tensor([[1.0, 0, 0, 0]] * 50, device=dev, requires_grad=True)
+    color, radii = r(m, z(50, 3), o, colors_precomp=c, scales=sc, rotations=q)
+    assert not radii.any()
+    np.testing.assert_allclose(color.detach().cpu().numpy(), np.broadcast_to(kw["bg"].reshape(3, 1, 1), (3, 40, 56)))
+    color.sum().backward()
+    for x in (m, o, c, sc, q):
+        assert x.grad is not None and not x.grad.any()
+
+
+def test_callback_forward_equals_staged(hip_lib):
+    """gsr_forward (allocator callbacks, the reference's Rasterizer::forward shape) == stage1 + stage2."""
+    import torch
+    from gaustar_amd import _lib
+    kw, d = parity.load_golden("mesh_sphere")
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
+    P, W, H = len(kw["means3D"]), kw["W"], kw["H"]
+    keep = []
+
+    def alloc(ctx, n):
+        buf = torch.empty(max(int(n), 1), dtype=torch.uint8, device=dev)
+        keep.append(buf)
+        return buf.data_ptr()
+
+    cb = _lib.ALLOC_FN(alloc)
+    ten = {k: t(kw[k]) for k in ("bg", "means3D", "colors_precomp", "opacities", "scales", "rotations", "view", "proj", "campos")}
+    p = lambda k: ctypes.c_void_p(ten[k].data_ptr())
+    out, radii, R = torch.empty(3, H, W, device=dev), torch.empty(P, dtype=torch.int32, device=dev), ctypes.c_int(0)
+    rc = hip_lib.gsr_forward(cb, cb, cb, None, P, 0, 0, p("bg"), W, H, p("means3D"), None, p("colors_precomp"),
+                             p("opacities"), p("scales"), 1.0, p("rotations"), None, p("view"), p("proj"), p("campos"),
+                             kw["tanfovx"], kw["tanfovy"], 0, ctypes.c_void_p(out.data_ptr()),
+                             ctypes.c_void_p(radii.data_ptr()), ctypes.byref(R), None)
+    assert rc == 0, hip_lib.gsr_last_error()
+    torch.cuda.synchronize()
+    assert len(keep) == 3 and 0 < R.value <= int(d["out_num_rendered"])
+    staged = parity.run_hip(kw)
+    assert np.array_equal(out.cpu().numpy(), staged["color"]) and np.array_equal(radii.cpu().numpy(), staged["radii"])
+
+
+def test_sort_fallback_path_gives_identical_images():
+    """Tiles longer than the LDS sort capacity take the global-memory network; force it with a tiny cap."""
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import parity;"
+            "kw, d = parity.load_golden('colors_rgb'); h = parity.run_hip(kw, d['in_dL_dpix']);"
+            "parity.compare_hip_to(h, d['out_color'], d['out_radii'], {k: d['grad_' + k] for k in parity.GRAD_KEYS}, 'fallback');"
+            "print('FALLBACK_OK')") % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, GSR_DEBUG_SORT_CAP="64")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert "FALLBACK_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_long_tile_lists_use_the_big_lds_sort():
+    """> 2048 instances in one tile: 3000 splats stacked on the same pixel block."""
+    from gaustar_amd import scene
+    rng = np.random.default_rng(4)
+    gs = scene.random_gaussians(3000, rng, scale_range=(0.02, 0.05), box=((-0.05, 0.05), (-0.05, 0.05), (-0.5, 0.5)))
+    gs.opacities[:] = rng.uniform(0.004, 0.02, (3000, 1)).astype(np.float32)
+    cam = scene.look_at_camera((0, 0, -4.0), (0, 0, 0), 64, 64, fovx=0.5, znear=0.01)
+    kw = _kw(gs, cam, np.zeros(3, np.float32))
+    dpix = rng.normal(size=(3, 64, 64)).astype(np.float32)
+    st, g = parity.run_oracle(kw, dpix)
+    assert (st["ranges"][:, 1] - st["ranges"][:, 0]).max() > 2048
+    hip = parity.run_hip(kw, dpix)
+    parity.compare_hip_to(hip, st["color"], st["radii"], g, what="long lists")

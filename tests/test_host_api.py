@@ -1,0 +1,72 @@
+"""Host-side mirror of the reference's Python API (DGR/diff_gaussian_rasterization/__init__.py):
+names, fields, argument checks and error behaviour.  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+
+def test_drop_in_import_names():
+    import diff_gaussian_rasterization as dgr
+    from gaustar_amd import GaussianRasterizationSettings, GaussianRasterizer
+    assert dgr.GaussianRasterizer is GaussianRasterizer
+    assert dgr.GaussianRasterizationSettings is GaussianRasterizationSettings
+    assert callable(dgr.rasterize_gaussians)
+    # ref :157-169 -- same 12 fields, same order
+    assert GaussianRasterizationSettings._fields == (
+        "image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix", "projmatrix",
+        "sh_degree", "campos", "prefiltered", "debug")
+
+
+def _settings():
+    from gaustar_amd import GaussianRasterizationSettings
+    return GaussianRasterizationSettings(32, 32, np.float64(0.5), np.float32(0.5), torch.zeros(3), 1.0, torch.eye(4),
+                                         torch.eye(4), 0, torch.zeros(1, 3), False, False)
+
+
+def test_optional_argument_checks_raise_like_the_reference():
+    from gaustar_amd import GaussianRasterizer
+    r = GaussianRasterizer(_settings())
+    m, m2, o = torch.zeros(4, 3), torch.zeros(4, 3), torch.zeros(4, 1)
+    s, q, c, sh = torch.ones(4, 3), torch.ones(4, 4), torch.ones(4, 3), torch.ones(4, 1, 3)
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        r(m, m2, o, scales=s, rotations=q)
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        r(m, m2, o, shs=sh, colors_precomp=c, scales=s, rotations=q)
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        r(m, m2, o, colors_precomp=c, scales=s)
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        r(m, m2, o, colors_precomp=c, scales=s, rotations=q, cov3D_precomp=torch.ones(4, 6))
+
+
+def test_no_cpu_fallback_and_shape_check():
+    from gaustar_amd import GaussianRasterizer
+    r = GaussianRasterizer(_settings())
+    m, m2, o = torch.zeros(4, 3), torch.zeros(4, 3), torch.zeros(4, 1)
+    s, q, c = torch.ones(4, 3), torch.ones(4, 4), torch.ones(4, 3)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        r(m, m2, o, colors_precomp=c, scales=s, rotations=q)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        r.markVisible(m)
+    with pytest.raises(RuntimeError, match=r"means3D must have dimensions \(num_points, 3\)"):
+        r(torch.zeros(4, 2), m2, o, colors_precomp=c, scales=s, rotations=q)
+
+
+def test_missing_extension_fails_loudly(monkeypatch, tmp_path):
+    from gaustar_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    import os
+    import re
+    from conftest import ROOT
+    pkg = os.path.join(ROOT, "gaustar_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "gsr_oracle" not in src and "libgsr_ref" not in src, f
