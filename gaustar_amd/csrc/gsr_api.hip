@@ -7,6 +7,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <atomic>
+#include <mutex>
 
 using namespace gsr;
 
@@ -21,28 +23,35 @@ const char* const kStageNames[ST_COUNT] = {"preprocess_kernel", "tile_scan_kerne
                                            "tile_sort_kernel", "blend_fwd_kernel", "zero_fill", "blend_bwd_kernel",
                                            "geom_bwd_kernel"};
 struct Rec { int stage; hipEvent_t a, b; };
+// Process-wide (PyTorch runs backward on its own autograd thread), guarded by a mutex.
 struct Profiler {
-    bool on = false;
+    std::atomic<bool> on{false};
+    std::mutex mu;
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
     hipEvent_t get()
     {
+        std::lock_guard<std::mutex> lk(mu);
         if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
         hipEvent_t e = nullptr;
         (void)hipEventCreate(&e);
         return e;
     }
 };
-thread_local Profiler g_prof;
+Profiler g_prof;
 struct Scope {
     int stage; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
     Scope(int stage_, hipStream_t st_) : stage(stage_), st(st_)
     {
-        if (g_prof.on) { a = g_prof.get(); b = g_prof.get(); (void)hipEventRecord(a, st); }
+        if (g_prof.on.load(std::memory_order_relaxed)) { a = g_prof.get(); b = g_prof.get(); (void)hipEventRecord(a, st); }
     }
     ~Scope()
     {
-        if (a) { (void)hipEventRecord(b, st); g_prof.recs.push_back(Rec{stage, a, b}); }
+        if (a) {
+            (void)hipEventRecord(b, st);
+            std::lock_guard<std::mutex> lk(g_prof.mu);
+            g_prof.recs.push_back(Rec{stage, a, b});
+        }
     }
 };
 
@@ -258,7 +267,7 @@ const char* gsr_stage_name(int stage) { return (stage >= 0 && stage < ST_COUNT) 
 
 int gsr_profile_enable(int on)
 {
-    g_prof.on = on != 0;
+    g_prof.on.store(on != 0);
     return 0;
 }
 
@@ -267,6 +276,7 @@ int gsr_profile_read(float* ms, int* counts, int reset)
     g_err.clear();
     if (!ms || !counts) return fail_msg("gsr_profile_read: null output pointer");
     for (int i = 0; i < ST_COUNT; i++) { ms[i] = 0.f; counts[i] = 0; }
+    std::lock_guard<std::mutex> lk(g_prof.mu);
     for (const Rec& r : g_prof.recs) {
         GSR_CHECK(hipEventSynchronize(r.b));
         float t = 0.f;

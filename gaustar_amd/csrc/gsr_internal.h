@@ -139,6 +139,18 @@ __device__ __forceinline__ float xform4w(const Vec3 p, const float* m)
     return m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15];
 }
 
+// View-space depth.  The per-tile blend order is a discontinuous function of these bits (near-coplanar
+// surface splats tie or differ by one ulp), so the operation order is pinned -- contraction off, explicit
+// fma -- to the one the reference's transformPoint4x3(...).z (auxiliary.h:58-66) compiles to in its
+// gfx950 build: fma(m2, x, m6*y) + m10*z + m14.
+__device__ __forceinline__ float view_depth(const Vec3 p, const float* m)
+{
+#pragma clang fp contract(off)
+    const float yz = m[6] * p.y;
+    const float zz = m[10] * p.z;
+    return (__builtin_fmaf(m[2], p.x, yz) + zz) + m[14];
+}
+
 // Rotation of the RAW quaternion (r,x,y,z) -- callers normalise (forward.cu:127).
 __device__ __forceinline__ void quat_R(const float4 q, float R[3][3])
 {

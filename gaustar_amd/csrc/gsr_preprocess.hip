@@ -32,9 +32,9 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
     ushort4 out_rect = make_ushort4(0, 0, 0, 0);
 
     const Vec3 p = load3(means3D, idx);
-    const Vec3 p_view = xform43(p, view);
+    const float view_z = view_depth(p, view);
     // Near-plane cull only (auxiliary.h:154; the NDC side test is dead code there).
-    if (p_view.z > NEAR_Z) {
+    if (view_z > NEAR_Z) {
         const Vec3 ph = xform43(p, proj);
         const float pw = 1.0f / (xform4w(p, proj) + 0.0000001f);
         const float ndc_x = ph.x * pw, ndc_y = ph.y * pw;
@@ -110,7 +110,7 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
                 }
                 g0[idx] = make_float4(px, py, conic_a, conic_b);
                 g1[idx] = make_float4(conic_c, op, hx, hy);
-                depth[idx] = p_view.z;
+                depth[idx] = view_z;
                 out_rect = make_ushort4((unsigned short)rx0, (unsigned short)ry0, (unsigned short)rx1,
                                         (unsigned short)ry1);
                 for (int y = ry0; y < ry1; y++)
@@ -141,8 +141,7 @@ mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __res
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= P) return;
-    const Vec3 pv = xform43(load3(means3D, idx), view);
-    present[idx] = pv.z > NEAR_Z ? 1 : 0;
+    present[idx] = view_depth(load3(means3D, idx), view) > NEAR_Z ? 1 : 0;
 }
 
 void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t st)

@@ -71,7 +71,9 @@ def test_hip_internal_state_matches_reference(name, hip_lib):
     torch.cuda.synchronize()
     vis = d["state_visible"] & (d["in_opacities"].reshape(-1) * 255.0 >= 1.0)
     np.testing.assert_allclose(m2.cpu().numpy()[vis], d["state_means2D"][vis], rtol=0, atol=2e-4)
-    np.testing.assert_allclose(dp.cpu().numpy()[vis], d["state_depths"][vis], rtol=1e-6, atol=1e-6)
+    # depth is the sort key: bit-identical to the reference build (the blend order of near-coplanar surface
+    # splats depends on single ulps of it)
+    assert np.array_equal(dp.cpu().numpy()[vis].view(np.uint32), d["state_depths"][vis].view(np.uint32))
     b = d["state_conic_opacity"][vis]
     np.testing.assert_allclose(co.cpu().numpy()[vis], b, rtol=2e-4, atol=1e-6 * max(1.0, float(np.abs(b).max())))
     if kw["shs"] is not None:
