@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 ALLOC_FN = ctypes.CFUNCTYPE(c_void_p, c_void_p, c_size_t)
 
 # name -> (restype, argtypes); mirrors include/gsr.h one to one (tests check both directions).
@@ -22,6 +22,7 @@ SIGNATURES = {
     "gsr_geom_bytes": (c_size_t, [c_int]),
     "gsr_image_bytes": (c_size_t, [c_int, c_int]),
     "gsr_binning_bytes": (c_size_t, [c_int]),
+    "gsr_grad_scratch_bytes": (c_size_t, [c_int]),
     "gsr_forward_stage1": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float,
                                    c_int, c_void_p, c_void_p, c_void_p, POINTER(c_int), POINTER(c_int), c_void_p]),

@@ -79,13 +79,14 @@ int fail_msg(const char* msg)
 
 extern "C" {
 
-int gsr_abi_version(void) { return 1; }
+int gsr_abi_version(void) { return 2; }
 
 const char* gsr_last_error(void) { return g_err.c_str(); }
 
 size_t gsr_geom_bytes(int P) { return carve_geom(nullptr, P > 0 ? P : 0).bytes; }
 size_t gsr_image_bytes(int W, int H) { return carve_image(nullptr, W, H).bytes; }
 size_t gsr_binning_bytes(int R) { return carve_bin(nullptr, R > 0 ? R : 0).bytes; }
+size_t gsr_grad_scratch_bytes(int P) { return (size_t)48 * (size_t)(P > 0 ? P : 0) + 256; }
 
 int gsr_forward_stage1(int P, int D, int M, const float* means3D, const float* shs, const float* colors_precomp,
                        const float* opacities, const float* scales, float scale_modifier, const float* rotations,
@@ -200,8 +201,8 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int W, int
                  const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
                  const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                  const float* campos, float tan_fovx, float tan_fovy, const int* radii, const void* geom_buffer,
-                 const void* binning_buffer, const void* image_buffer, const float* dL_dpix, float* dL_dmean2D,
-                 float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
+                 const void* binning_buffer, const void* image_buffer, const float* dL_dpix, void* grad_scratch,
+                 float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
                  float* dL_dsh, float* dL_dscale, float* dL_drot, gsr_stream_t stream)
 {
     g_err.clear();
@@ -210,7 +211,7 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int W, int
     if (!means3D || !viewmatrix || !projmatrix || !campos || !radii || !geom_buffer || !image_buffer || !dL_dpix ||
         !background)
         return fail_msg("gsr_backward: required pointer is null");
-    if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
+    if (!grad_scratch || !dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
         return fail_msg("gsr_backward: required gradient pointer is null");
     if (shs && !dL_dsh) return fail_msg("gsr_backward: dL_dsh is null in SH mode");
     if (!cov3D_precomp && (!scales || !rotations || !dL_dscale || !dL_drot))
@@ -220,20 +221,18 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int W, int
     ImageState im = carve_image(const_cast<void*>(image_buffer), W, H);
     GeomState g = carve_geom(const_cast<void*>(geom_buffer), P);
     BinState b = carve_bin(const_cast<void*>(binning_buffer), R > 0 ? R : 0);
-    // Zero the four atomic-accumulation targets; everything else is written outright by geom_bwd.
+    // Zero the packed moment records (the only atomic targets); every output tensor is written outright
+    // by geom_bwd (cf. the nine zeroed tensors of rasterize_points.cu:151-159).
+    float* grad_acc = static_cast<float*>(grad_scratch);
     {
         Scope sc(ST_ZERO_FILL, st);
-        GSR_CHECK(hipMemsetAsync(dL_dmean2D, 0, sizeof(float) * 3 * (size_t)P, st));
-        GSR_CHECK(hipMemsetAsync(dL_dconic, 0, sizeof(float) * 4 * (size_t)P, st));
-        GSR_CHECK(hipMemsetAsync(dL_dopacity, 0, sizeof(float) * (size_t)P, st));
-        GSR_CHECK(hipMemsetAsync(dL_dcolor, 0, sizeof(float) * 3 * (size_t)P, st));
+        GSR_CHECK(hipMemsetAsync(grad_acc, 0, gsr_grad_scratch_bytes(P), st));
     }
     const float* feats = colors_precomp ? colors_precomp : g.rgb;
     if (R > 0) {
         {
             Scope sc(ST_BLEND_BWD, st);
-            launch_blend_bwd(W, H, background, feats, g, im, b, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
-                             st);
+            launch_blend_bwd(W, H, background, feats, g, im, b, dL_dpix, grad_acc, st);
         }
         GSR_CHECK_LAUNCH("blend_bwd_kernel");
     }
@@ -241,8 +240,8 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int W, int
         Scope sc(ST_GEOM_BWD, st);
         launch_geom_bwd(P, D, M, means3D, shs, cov3D_precomp ? nullptr : scales, scale_modifier,
                         cov3D_precomp ? nullptr : rotations, cov3D_precomp, viewmatrix, projmatrix, campos, W, H,
-                        tan_fovx, tan_fovy, radii, dL_dmean2D, dL_dconic, dL_dcolor, dL_dmean3D, dL_dcov3D,
-                        shs ? dL_dsh : nullptr, cov3D_precomp ? nullptr : dL_dscale, cov3D_precomp ? nullptr : dL_drot,
+                        tan_fovx, tan_fovy, radii, g, grad_acc, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D,
+                        dL_dcov3D, shs ? dL_dsh : nullptr, cov3D_precomp ? nullptr : dL_dscale, cov3D_precomp ? nullptr : dL_drot,
                         st);
     }
     GSR_CHECK_LAUNCH("geom_bwd_kernel");

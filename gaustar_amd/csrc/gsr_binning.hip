@@ -24,14 +24,22 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
 }
 
 // One workgroup scans all T tile counts: ranges[t] = {start, start+count}, cursor[t] = start,
-// totals = {R, max count}.
+// totals = {R, max count, #non-empty tiles}, and builds `order`: a counting sort of the tiles by
+// descending list length in 32-entry buckets (empty tiles last).
+constexpr int NBUCKET = 66;   // bucket 0 = longest (>= 2048 entries) ... bucket 64 = 1..32 entries, bucket 65 = empty
+__device__ __forceinline__ int length_bucket(uint32_t c)
+{
+    return c == 0 ? 65 : 64 - (int)min(64u, (c + 31u) >> 5);
+}
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges,
-                 uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ totals)
+                 uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ totals, uint32_t* __restrict__ order)
 {
     __shared__ uint32_t wave_sum[16];
     __shared__ uint32_t wave_max[16];
     __shared__ uint32_t carry_s;
+    __shared__ uint32_t bucket_n[NBUCKET];
+    if (threadIdx.x < NBUCKET) bucket_n[threadIdx.x] = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) carry_s = 0;
     uint32_t vmax = 0;
@@ -40,6 +48,7 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
         const int t = base + tid;
         const uint32_t c = t < T ? tile_count[t] : 0u;
         vmax = max(vmax, c);
+        if (t < T) atomicAdd(&bucket_n[length_bucket(c)], 1u);
         const uint32_t incl = wave_incl_scan(c, lane);
         if (lane == 63) wave_sum[wave] = incl;
         __syncthreads();
@@ -65,37 +74,56 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
         for (int w = 0; w < 16; w++) m = max(m, wave_max[w]);
         totals[0] = carry_s;
         totals[1] = m;
-        totals[2] = 0;
+        totals[2] = (uint32_t)T - bucket_n[NBUCKET - 1];
         totals[3] = 0;
+        // exclusive prefix over the buckets -> start offsets (in place)
+        uint32_t run = 0;
+        for (int b = 0; b < NBUCKET; b++) { const uint32_t c = bucket_n[b]; bucket_n[b] = run; run += c; }
     }
+    __syncthreads();
+    for (int t = tid; t < T; t += 1024) order[atomicAdd(&bucket_n[length_bucket(tile_count[t])], 1u)] = (uint32_t)t;
 }
 
 void launch_tile_scan(ImageState im, int T, hipStream_t st)
 {
-    tile_scan_kernel<<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.tile_cursor, im.totals);
+    tile_scan_kernel<<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.tile_cursor, im.totals, im.order);
 }
 
-// One thread per Gaussian: claim a slot in every touched tile's bucket and store the sort key.
+// One thread per Gaussian: claim a slot in every reachable tile's bucket and store the sort key.  Walks exactly
+// the tiles preprocess counted (same stored inputs, same contraction-free test) with the same wave
+// aggregation: the wave's leader for a tile reserves popcount(mask) slots with ONE returning atomic and
+// every lane of the mask takes its own slot by prefix popcount.
 __global__ void __launch_bounds__(256)
-scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float* __restrict__ depth,
-               uint32_t* __restrict__ tile_cursor, uint64_t* __restrict__ keys)
+scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __restrict__ g0,
+               const float4* __restrict__ g1, const float* __restrict__ depth, uint32_t* __restrict__ tile_cursor,
+               uint64_t* __restrict__ keys)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P) return;
-    const ushort4 r = rect[idx];
-    if (r.z <= r.x || r.w <= r.y) return;
-    const uint64_t key = ((uint64_t)__float_as_uint(depth[idx]) << 32) | (uint32_t)idx;
-    for (int y = r.y; y < r.w; y++)
-        for (int x = r.x; x < r.z; x++) {
-            const uint32_t slot = atomicAdd(&tile_cursor[y * gx + x], 1u);
-            keys[slot] = key;
+    const int lane = threadIdx.x & 63;
+    ushort4 r = make_ushort4(0, 0, 0, 0);
+    float4 a = make_float4(0.f, 0.f, 1.f, 0.f), b = make_float4(1.f, 0.f, -1.f, 0.f);
+    uint64_t key = 0;
+    if (idx < P) {
+        r = rect[idx];
+        if (r.z > r.x && r.w > r.y) {
+            a = g0[idx];
+            b = g1[idx];
+            key = ((uint64_t)__float_as_uint(depth[idx]) << 32) | (uint32_t)idx;
         }
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for_each_tile_aggregated(r, a.x, a.y, a.z, a.w, b.x, b.z, gx, [&](int tile, unsigned long long m, int leader) {
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&tile_cursor[tile], (uint32_t)__popcll(m));
+        base = __shfl(base, leader, 64);
+        if ((m >> lane) & 1ull) keys[base + (uint32_t)__popcll(m & lt)] = key;
+    });
 }
 
 void launch_scatter(int P, int W, int H, GeomState g, ImageState im, BinState b, hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);
-    scatter_kernel<<<(P + 255) / 256, 256, 0, st>>>(P, t.gx, g.rect, g.depth, im.tile_cursor, b.keys);
+    scatter_kernel<<<(P + 255) / 256, 256, 0, st>>>(P, t.gx, g.rect, g.g0, g.g1, g.depth, im.tile_cursor, b.keys);
 }
 
 // ---- per-tile bitonic sort of 64-bit keys in LDS.
@@ -104,11 +132,12 @@ void launch_scatter(int P, int W, int H, GeomState g, ImageState im, BinState b,
 // (same network, one workgroup, workgroup-scope fences) -- correct for any size, only slower.
 template <int CAP, int LOWER, bool FALLBACK>
 __global__ void __launch_bounds__(256)
-tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list)
+tile_sort_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ order, uint64_t* __restrict__ keys,
+                 uint32_t* __restrict__ point_list)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
-    const uint2 rg = ranges[blockIdx.x];
+    const uint2 rg = ranges[order[blockIdx.x]];
     const uint32_t n = rg.y - rg.x;
     if (n <= (uint32_t)LOWER) return;
     if (!FALLBACK && n > (uint32_t)CAP) return;
@@ -169,10 +198,10 @@ void launch_tile_sort(int W, int H, uint32_t max_count, ImageState im, BinState 
     // GSR_DEBUG_SORT_CAP=64 forces the global-memory fallback for every tile above 64 instances (tests).
     static const char* dbg = getenv("GSR_DEBUG_SORT_CAP");
     if (dbg && dbg[0] == '6') {
-        tile_sort_kernel<64, 0, true><<<t.T, 256, 64 * 8, st>>>(im.ranges, b.keys, b.point_list);
+        tile_sort_kernel<64, 0, true><<<t.T, 256, 64 * 8, st>>>(im.ranges, im.order, b.keys, b.point_list);
         return;
     }
-    tile_sort_kernel<2048, 0, false><<<t.T, 256, 2048 * 8, st>>>(im.ranges, b.keys, b.point_list);
+    tile_sort_kernel<2048, 0, false><<<t.T, 256, 2048 * 8, st>>>(im.ranges, im.order, b.keys, b.point_list);
     if (max_count > 2048) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -180,7 +209,7 @@ void launch_tile_sort(int W, int H, uint32_t max_count, ImageState im, BinState 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
             attr_set = true;
         }
-        tile_sort_kernel<16384, 2048, true><<<t.T, 256, 16384 * 8, st>>>(im.ranges, b.keys, b.point_list);
+        tile_sort_kernel<16384, 2048, true><<<t.T, 256, 16384 * 8, st>>>(im.ranges, im.order, b.keys, b.point_list);
     }
 }
 

@@ -1,17 +1,28 @@
-// gsr_blend_bwd.hip -- backward alpha compositing: dL/d{colour, mean2D, conic, opacity} per Gaussian.
+// gsr_blend_bwd.hip -- backward alpha compositing: per-Gaussian sums of the per-(pixel,Gaussian) terms.
 //
 // Per-pair arithmetic is the reference's renderCUDA backward (DGR/cuda_rasterizer/backward.cu:399-557;
 // SURVEY.md section 9 item 10): back-to-front replay, T recovered by division, accum_rec recurrence,
-// background term with T_final/(1-alpha), 0.5*W / 0.5*H pixel->NDC scale on the mean gradient, the
-// 0.99 alpha clamp passing gradient as if unclamped.
+// background term with T_final/(1-alpha), the 0.99 alpha clamp passing gradient as if unclamped.
 //
 // What differs is how the per-pair terms reach memory.  The reference issues 9 global float
-// atomicAdds per contributing (pixel, Gaussian) pair (backward.cu:523, :545-554).  Here a wave64
-// owns an 8x8 pixel block, every lane evaluates the same queued instance, the nine partial sums are
-// reduced across the 64 lanes in registers with DPP row shifts / row broadcasts, and one lane issues
-// the nine atomics -- at most one flush per (Gaussian, 8x8 block), skipped entirely when no lane of
-// the wave contributed.  Instances whose alpha >= 1/255 box misses the block never enter the queue.
+// atomicAdds per contributing (pixel, Gaussian) pair (backward.cu:523, :545-554).  Here
+//
+//  * a wave64 owns an 8x8 pixel block and walks the tile list back-to-front 64 instances at a time
+//    (next batch fetched one step ahead); instances that cannot reach alpha >= 1/255 inside the block
+//    (exact test, block_min_half_quad) never enter the per-wave LDS queue;
+//  * for a queued instance every lane evaluates its pixel; what is summed over pixels is reduced to
+//    NINE linear moments  {sum w*dL_dpix_rgb, sum r, sum r*dx, sum r*dy, sum r*dx^2, sum r*dx*dy, sum r*dy^2}
+//    (w = alpha*T, r = G*dL_dalpha): dL_dcolor, dL_dopacity, dL_dmean2D and dL_dconic are fixed linear
+//    maps of them with per-Gaussian coefficients, applied once per Gaussian in geom_bwd instead of once
+//    per pair here;
+//  * the nine values are reduced across the 64 lanes in registers by a TRANSPOSING reduction:
+//    v_permlane32_swap / v_permlane16_swap + add fold eight values into one register (8 lanes per
+//    value), three DPP steps finish it -- 18 VALU ops for 8 values instead of 8 x 6 shuffle-adds;
+//  * totals are parked in a per-wave LDS table (one row per queued instance) and flushed once per batch
+//    with lane = instance: nine wave-wide atomic instructions per 64 instances instead of nine
+//    single-lane atomics per instance.  Target = the packed 48-byte record grad_acc[gaussian][12].
 #include "gsr_internal.h"
+#include <cstdlib>
 
 namespace gsr {
 
@@ -21,22 +32,72 @@ struct __attribute__((aligned(16))) SlotB {   // 48 B per queued instance
     float4 c;   // blue, list position (0-based, uint bits), gaussian id (uint bits), -
 };
 
-// Sum over the 64 lanes of a wave; the total lands in lane 63 (classic GCN DPP reduction:
-// row_shr 1,2,3 + row_shr 4,8 with bank masks, then row_bcast 15 / 31).
-template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
-__device__ __forceinline__ float dpp_add(float v)
+struct FetchedB { float4 a, b; float fr, fg, fb; uint32_t gid; };
+
+__device__ __forceinline__ FetchedB fetch_instance_b(int k, const uint32_t* __restrict__ list,
+                                                     const float4* __restrict__ g0, const float4* __restrict__ g1,
+                                                     const float* __restrict__ feats)
 {
-    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false);
-    return v + __int_as_float(moved);
+    FetchedB f;
+    f.a = make_float4(0.f, 0.f, 1.f, 0.f);
+    f.b = make_float4(1.f, 0.f, -1.f, 0.f);   // tau = -1: never kept
+    f.fr = f.fg = f.fb = 0.f;
+    f.gid = 0;
+    if (k >= 0) {
+        f.gid = list[k];
+        f.a = g0[f.gid];
+        f.b = g1[f.gid];
+        f.fr = feats[3 * (size_t)f.gid]; f.fg = feats[3 * (size_t)f.gid + 1]; f.fb = feats[3 * (size_t)f.gid + 2];
+    }
+    return f;
 }
-__device__ __forceinline__ float wave_sum_to_lane63(float v)
+
+// ---- cross-lane helpers -----------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_perm(float v)   // full-wave lane permutation (no masked lanes)
 {
-    v = dpp_add<0x111>(v);               // row_shr:1
-    v = dpp_add<0x112>(v);               // row_shr:2
-    v = dpp_add<0x114, 0xf, 0xe>(v);     // row_shr:4  bank_mask 0xe
-    v = dpp_add<0x118, 0xf, 0xc>(v);     // row_shr:8  bank_mask 0xc
-    v = dpp_add<0x142, 0xa, 0xf>(v);     // row_bcast:15 row_mask 0xa
-    v = dpp_add<0x143, 0xc, 0xf>(v);     // row_bcast:31 row_mask 0xc
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// lanes 0-31: a[l] + a[l+32]   |   lanes 32-63: b[l-32] + b[l]
+__device__ __forceinline__ float fold32(float a, float b)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// even rows: a[row] + a[row+1]   |   odd rows: b[row-1] + b[row]      (rows of 16 lanes)
+__device__ __forceinline__ float fold16(float a, float b)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// Sum eight per-lane values over the wave; afterwards lane l holds the total of value (l >> 3).
+__device__ __forceinline__ float reduce8(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
+                                         float v7, bool hi8)
+{
+    const float a0 = fold32(v0, v4), a1 = fold32(v1, v5), a2 = fold32(v2, v6), a3 = fold32(v3, v7);
+    const float b0 = fold16(a0, a2);   // rows: v0 v2 v4 v6
+    const float b1 = fold16(a1, a3);   // rows: v1 v3 v5 v7
+    const float keep = hi8 ? b1 : b0, send = hi8 ? b0 : b1;
+    float c = keep + dpp_perm<0x128>(send);   // row_ror:8  -> lanes 0-7 of a row: even value, 8-15: odd value
+    c += dpp_perm<0x141>(c);                  // row_half_mirror
+    c += dpp_perm<0xB1>(c);                   // quad_perm [1,0,3,2]
+    c += dpp_perm<0x4E>(c);                   // quad_perm [2,3,0,1]
+    return c;
+}
+// Sum one per-lane value over the wave; the total lands in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add_masked(float v)
+{
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float reduce1_to_lane63(float v)
+{
+    v += dpp_perm<0x111>(v);              // row_shr:1 (bound_ctrl: lanes shifted in from outside the row read 0)
+    v += dpp_perm<0x112>(v);              // row_shr:2
+    v += dpp_perm<0x114>(v);              // row_shr:4
+    v += dpp_perm<0x118>(v);              // row_shr:8   -> lane 15 of each row = row total
+    v = dpp_add_masked<0x142, 0xa>(v);    // row_bcast:15 into rows 1,3
+    v = dpp_add_masked<0x143, 0xc>(v);    // row_bcast:31 into rows 2,3
     return v;
 }
 
@@ -45,16 +106,19 @@ __device__ __forceinline__ void atomic_add_f32(float* p, float v)
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+constexpr int ACC_STRIDE = 9;   // odd stride: conflict-free row-per-lane reads in the flush
+
 __global__ void __launch_bounds__(256)
-blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ order,
+                 const uint32_t* __restrict__ point_list,
                  const float4* __restrict__ g0, const float4* __restrict__ g1, const float* __restrict__ feats,
                  const float* __restrict__ bg, const float* __restrict__ final_T,
                  const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                 float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
-                 float* __restrict__ dL_dcolor)
+                 float* __restrict__ grad_acc)
 {
     __shared__ SlotB queue[4][64];
-    const int tile = blockIdx.x;
+    __shared__ float totals[4][64 * ACC_STRIDE];
+    const int tile = (int)order[blockIdx.x];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tx = tile % gx, ty = tile / gx;
     const int sx = tx * TILE + (wave & 1) * SUB, sy = ty * TILE + (wave >> 1) * SUB;
@@ -62,9 +126,12 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
     const float bx0 = (float)sx, bx1 = (float)(sx + SUB - 1), by0 = (float)sy, by1 = (float)(sy + SUB - 1);
+    const bool hi8 = (lane & 8) != 0;
 
     const uint2 rg = ranges[tile];
+    const uint32_t* list = point_list + rg.x;
     SlotB* q = queue[wave];
+    float* tot = totals[wave];
 
     const size_t pix = (size_t)W * py + px;
     const size_t HW = (size_t)H * W;
@@ -73,7 +140,6 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     float dpr = 0.f, dpg = 0.f, dpb = 0.f;
     if (inside) { dpr = dL_dpix[pix]; dpg = dL_dpix[HW + pix]; dpb = dL_dpix[2 * HW + pix]; }
     const float bg_dot_dpixel = bg[0] * dpr + bg[1] * dpg + bg[2] * dpb;
-    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
 
     // Nothing behind the deepest contributor of this wave can matter.
     uint32_t wave_last = my_last;
@@ -84,30 +150,24 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     float T = T_final;
     float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, last_alpha = 0.f, last_r = 0.f, last_g = 0.f, last_b = 0.f;
 
+    // lane l takes list position hi-1-l: queue order == back-to-front order
+    FetchedB nxt = fetch_instance_b((int)wave_last - 1 - lane, list, g0, g1, feats);
     for (int hi = (int)wave_last; hi > 0; hi -= 64) {
-        // lane l takes list position hi-1-l: queue order == back-to-front order
+        const FetchedB cur = nxt;
         const int k = hi - 1 - lane;
-        bool keep = false;
-        float4 ra, rb;
-        uint32_t gid = 0;
-        if (k >= 0) {
-            gid = point_list[rg.x + k];
-            ra = g0[gid];
-            rb = g1[gid];
-            const float ddx = fmaxf(fmaxf(bx0 - ra.x, ra.x - bx1), 0.0f);
-            const float ddy = fmaxf(fmaxf(by0 - ra.y, ra.y - by1), 0.0f);
-            keep = ddx <= rb.z && ddy <= rb.w;
-        }
+        nxt = fetch_instance_b(k - 64, list, g0, g1, feats);
+        const bool keep = block_min_half_quad(cur.a.z, cur.a.w, cur.b.x, bx0 - cur.a.x, bx1 - cur.a.x, by0 - cur.a.y,
+                                              by1 - cur.a.y) <= cur.b.z;
         const unsigned long long m = __ballot(keep);
         const int cnt = __popcll(m);
         if (keep) {
             const int slot = __popcll(m & ((1ull << lane) - 1ull));
-            const float fr = feats[3 * (size_t)gid], fg = feats[3 * (size_t)gid + 1], fb = feats[3 * (size_t)gid + 2];
-            q[slot].a = ra;
-            q[slot].b = make_float4(rb.x, rb.y, fr, fg);
-            q[slot].c = make_float4(fb, __uint_as_float((uint32_t)k), __uint_as_float(gid), 0.f);
+            q[slot].a = cur.a;
+            q[slot].b = make_float4(cur.b.x, cur.b.y, cur.fr, cur.fg);
+            q[slot].c = make_float4(cur.fb, __uint_as_float((uint32_t)k), __uint_as_float(cur.gid), 0.f);
         }
         __builtin_amdgcn_wave_barrier();
+        unsigned long long touched = 0ull;
         for (int j = 0; j < cnt; j++) {
             const float4 A = q[j].a, B = q[j].b, Cc = q[j].c;
             const uint32_t pos = __float_as_uint(Cc.y);
@@ -118,59 +178,52 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             const bool live = pos < my_last && power <= 0.0f && alpha >= ALPHA_MIN;
             if (__ballot(live) == 0ull) continue;
 
-            float v_cr = 0.f, v_cg = 0.f, v_cb = 0.f, v_mx = 0.f, v_my = 0.f, v_ca = 0.f, v_cb2 = 0.f, v_cc = 0.f,
-                  v_op = 0.f;
+            float v_cr = 0.f, v_cg = 0.f, v_cb = 0.f, v_r = 0.f, v_rx = 0.f, v_ry = 0.f, v_rxx = 0.f, v_rxy = 0.f,
+                  v_ryy = 0.f;
             if (live) {
-                T = T / (1.f - alpha);
-                const float dchannel_dcolor = alpha * T;
+                const float rinv = __builtin_amdgcn_rcpf(1.f - alpha);
+                T = T * rinv;
+                const float w = alpha * T;
                 acc_r = last_alpha * last_r + (1.f - last_alpha) * acc_r;
                 acc_g = last_alpha * last_g + (1.f - last_alpha) * acc_g;
                 acc_b = last_alpha * last_b + (1.f - last_alpha) * acc_b;
                 last_r = B.z; last_g = B.w; last_b = Cc.x;
                 float dL_dalpha = (B.z - acc_r) * dpr + (B.w - acc_g) * dpg + (Cc.x - acc_b) * dpb;
-                v_cr = dchannel_dcolor * dpr; v_cg = dchannel_dcolor * dpg; v_cb = dchannel_dcolor * dpb;
                 dL_dalpha *= T;
                 last_alpha = alpha;
-                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
-                const float dL_dG = B.y * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * A.z - gdy * A.w;
-                const float dG_ddely = -gdy * B.x - gdx * A.w;
-                v_mx = dL_dG * dG_ddelx * ddelx_dx;
-                v_my = dL_dG * dG_ddely * ddely_dy;
-                v_ca = -0.5f * gdx * dx * dL_dG;
-                v_cb2 = -0.5f * gdx * dy * dL_dG;
-                v_cc = -0.5f * gdy * dy * dL_dG;
-                v_op = G * dL_dalpha;
+                dL_dalpha -= (T_final * rinv) * bg_dot_dpixel;
+                v_cr = w * dpr; v_cg = w * dpg; v_cb = w * dpb;
+                v_r = G * dL_dalpha;
+                v_rx = v_r * dx; v_ry = v_r * dy;
+                v_rxx = v_rx * dx; v_rxy = v_rx * dy; v_ryy = v_ry * dy;
             }
-            v_cr = wave_sum_to_lane63(v_cr); v_cg = wave_sum_to_lane63(v_cg); v_cb = wave_sum_to_lane63(v_cb);
-            v_mx = wave_sum_to_lane63(v_mx); v_my = wave_sum_to_lane63(v_my);
-            v_ca = wave_sum_to_lane63(v_ca); v_cb2 = wave_sum_to_lane63(v_cb2); v_cc = wave_sum_to_lane63(v_cc);
-            v_op = wave_sum_to_lane63(v_op);
-            if (lane == 63) {
-                const size_t g = __float_as_uint(Cc.z);
-                atomic_add_f32(&dL_dcolor[3 * g + 0], v_cr);
-                atomic_add_f32(&dL_dcolor[3 * g + 1], v_cg);
-                atomic_add_f32(&dL_dcolor[3 * g + 2], v_cb);
-                atomic_add_f32(&dL_dmean2D[3 * g + 0], v_mx);
-                atomic_add_f32(&dL_dmean2D[3 * g + 1], v_my);
-                atomic_add_f32(&dL_dconic[4 * g + 0], v_ca);
-                atomic_add_f32(&dL_dconic[4 * g + 1], v_cb2);
-                atomic_add_f32(&dL_dconic[4 * g + 3], v_cc);
-                atomic_add_f32(&dL_dopacity[g], v_op);
-            }
+            const float c8 = reduce8(v_cr, v_cg, v_cb, v_r, v_rx, v_ry, v_rxx, v_rxy, hi8);
+            const float c1 = reduce1_to_lane63(v_ryy);
+            if ((lane & 7) == 0) tot[j * ACC_STRIDE + (lane >> 3)] = c8;
+            if (lane == 63) tot[j * ACC_STRIDE + 8] = c1;
+            touched |= 1ull << j;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // flush: lane = queued instance
+        if ((touched >> lane) & 1ull) {
+            const size_t g = __float_as_uint(q[lane].c.z);
+            float* dst = grad_acc + g * 12;
+#pragma unroll
+            for (int v = 0; v < 9; v++) atomic_add_f32(dst + v, tot[lane * ACC_STRIDE + v]);
         }
         __builtin_amdgcn_wave_barrier();
     }
 }
 
 void launch_blend_bwd(int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
-                      const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
-                      hipStream_t st)
+                      const float* dL_dpix, float* grad_acc, hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);
-    blend_bwd_kernel<<<t.T, 256, 0, st>>>(W, H, t.gx, im.ranges, b.point_list, g.g0, g.g1, feats, bg, im.final_T,
-                                          im.n_contrib, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
+    // Residency knob: extra dynamic LDS lowers the number of co-resident tiles per CU so that the
+    // longest-first tile order is dispatched dynamically (tuning: GSR_BWD_LDS_PAD bytes).
+    static const int pad = getenv("GSR_BWD_LDS_PAD") ? atoi(getenv("GSR_BWD_LDS_PAD")) : 0;
+    blend_bwd_kernel<<<t.T, 256, pad, st>>>(W, H, t.gx, im.ranges, im.order, b.point_list, g.g0, g.g1, feats, bg, im.final_T,
+                                          im.n_contrib, dL_dpix, grad_acc);
 }
 
 }  // namespace gsr

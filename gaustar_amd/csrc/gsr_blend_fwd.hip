@@ -6,10 +6,11 @@
 //  * One wave64 owns an 8x8 pixel block; a 16x16 tile is four independent waves (no workgroup
 //    barriers, each wave stops as soon as its own 64 pixels are saturated).
 //  * Each wave walks the tile's depth-sorted list 64 instances at a time: lane i fetches instance i
-//    (coalesced id load + two 16-byte record gathers), tests its alpha >= 1/255 bounding box against
-//    the wave's 8x8 block, and the survivors are compacted into a per-wave LDS queue with a
-//    ballot + prefix-popcount.  With surface splats of ~4 px radius this drops most of the
-//    (Gaussian, pixel) pairs the reference evaluates only to reject.
+//    (coalesced id load + two 16-byte record gathers + colour, issued one batch AHEAD so the gather
+//    latency hides behind the blend loop), tests exactly whether the splat can reach alpha >= 1/255
+//    anywhere in the wave's 8x8 block (block_min_half_quad), and the survivors are compacted into a
+//    per-wave LDS queue with a ballot + prefix-popcount.  With surface splats of ~4 px radius this drops
+//    most of the (Gaussian, pixel) pairs the reference evaluates only to reject.
 //  * The blend loop then reads one survivor per iteration from LDS at a wave-uniform address
 //    (broadcast ds_read_b128) -- position, conic, opacity AND colour come from LDS; the reference
 //    gathers colour from global memory per pixel (forward.cu:355).
@@ -25,14 +26,34 @@ struct __attribute__((aligned(16))) Slot {   // 48 B per queued instance
     float4 c;   // blue, list position + 1 (as uint bits), -, -
 };
 
+struct Fetched { float4 a, b; float fr, fg, fb; };
+
+__device__ __forceinline__ Fetched fetch_instance(uint32_t k, uint32_t n, const uint32_t* __restrict__ list,
+                                                  const float4* __restrict__ g0, const float4* __restrict__ g1,
+                                                  const float* __restrict__ feats)
+{
+    Fetched f;
+    f.a = make_float4(0.f, 0.f, 1.f, 0.f);
+    f.b = make_float4(1.f, 0.f, -1.f, 0.f);   // tau = -1: never kept
+    f.fr = f.fg = f.fb = 0.f;
+    if (k < n) {
+        const uint32_t gid = list[k];
+        f.a = g0[gid];
+        f.b = g1[gid];
+        f.fr = feats[3 * (size_t)gid]; f.fg = feats[3 * (size_t)gid + 1]; f.fb = feats[3 * (size_t)gid + 2];
+    }
+    return f;
+}
+
 __global__ void __launch_bounds__(256)
-blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ order,
+                 const uint32_t* __restrict__ point_list,
                  const float4* __restrict__ g0, const float4* __restrict__ g1, const float* __restrict__ feats,
                  const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ final_T,
                  uint32_t* __restrict__ n_contrib)
 {
     __shared__ Slot queue[4][64];
-    const int tile = blockIdx.x;
+    const int tile = (int)order[blockIdx.x];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tx = tile % gx, ty = tile / gx;
     const int sx = tx * TILE + (wave & 1) * SUB, sy = ty * TILE + (wave >> 1) * SUB;
@@ -43,35 +64,28 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
 
     const uint2 rg = ranges[tile];
     const uint32_t n = rg.y - rg.x;
+    const uint32_t* list = point_list + rg.x;
     Slot* q = queue[wave];
 
     float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f;
     uint32_t last = 0;
     bool done = !inside;
 
+    Fetched nxt = fetch_instance(lane, n, list, g0, g1, feats);
     for (uint32_t base = 0; base < n; base += 64) {
         if (__ballot(!done) == 0ull) break;
+        const Fetched cur = nxt;
+        nxt = fetch_instance(base + 64 + lane, n, list, g0, g1, feats);   // next batch in flight during the blend loop
         const uint32_t k = base + lane;
-        bool keep = false;
-        float4 ra, rb;
-        uint32_t gid = 0;
-        if (k < n) {
-            gid = point_list[rg.x + k];
-            ra = g0[gid];
-            rb = g1[gid];
-            // distance from the splat centre to the wave's pixel block, per axis
-            const float ddx = fmaxf(fmaxf(bx0 - ra.x, ra.x - bx1), 0.0f);
-            const float ddy = fmaxf(fmaxf(by0 - ra.y, ra.y - by1), 0.0f);
-            keep = ddx <= rb.z && ddy <= rb.w;
-        }
+        const bool keep = block_min_half_quad(cur.a.z, cur.a.w, cur.b.x, bx0 - cur.a.x, bx1 - cur.a.x, by0 - cur.a.y,
+                                              by1 - cur.a.y) <= cur.b.z;
         const unsigned long long m = __ballot(keep);
         const int cnt = __popcll(m);
         if (keep) {
             const int slot = __popcll(m & ((1ull << lane) - 1ull));
-            const float fr = feats[3 * (size_t)gid], fg = feats[3 * (size_t)gid + 1], fb = feats[3 * (size_t)gid + 2];
-            q[slot].a = ra;
-            q[slot].b = make_float4(rb.x, rb.y, fr, fg);
-            q[slot].c = make_float4(fb, __uint_as_float(k + 1), 0.f, 0.f);
+            q[slot].a = cur.a;
+            q[slot].b = make_float4(cur.b.x, cur.b.y, cur.fr, cur.fg);
+            q[slot].c = make_float4(cur.fb, __uint_as_float(k + 1), 0.f, 0.f);
         }
         __builtin_amdgcn_wave_barrier();
         for (int j = 0; j < cnt; j++) {
@@ -109,7 +123,7 @@ void launch_blend_fwd(int W, int H, const float* bg, const float* feats, GeomSta
                       float* out_color, hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);
-    blend_fwd_kernel<<<t.T, 256, 0, st>>>(W, H, t.gx, im.ranges, b.point_list, g.g0, g.g1, feats, bg, out_color,
+    blend_fwd_kernel<<<t.T, 256, 0, st>>>(W, H, t.gx, im.ranges, im.order, b.point_list, g.g0, g.g1, feats, bg, out_color,
                                           im.final_T, im.n_contrib);
 }
 

@@ -6,9 +6,12 @@
 // (DGR/rasterize_points.cu:151-159): each thread writes its Gaussian's dL_dmean3D / dL_dcov3D /
 // dL_dscale / dL_drot / dL_dsh outright -- zeros when the Gaussian was culled (radii == 0).
 //
-// Nothing is read back from the forward's geometry state: the 3D covariance, the EWA rows and the
-// SH basis are recomputed from the inputs (the reference re-reads cov3D and the `clamped` flags it
-// stored, 27 B/Gaussian of extra state traffic each way).
+// Input from the blend backward is the packed moment record grad_acc[P][12] (see gsr_blend_bwd.hip); this
+// kernel applies the per-Gaussian linear maps that turn the moments into dL_dmean2D (pixel->NDC scale
+// 0.5*W / 0.5*H, backward.cu:460-461), dL_dconic (the -0.5 factors, backward.cu:549-551), dL_dopacity and
+// dL_dcolor, and writes those outputs too.  From the forward's geometry state only the conic/opacity
+// record is read; the 3D covariance, the EWA rows and the SH basis are recomputed from the inputs (the
+// reference re-reads cov3D and the `clamped` flags it stored, 27 B/Gaussian of state traffic each way).
 #include "gsr_internal.h"
 
 namespace gsr {
@@ -18,16 +21,20 @@ geom_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const fl
                 const float* __restrict__ scales, float scale_modifier, const float* __restrict__ rotations,
                 const float* __restrict__ cov3D_precomp, const float* __restrict__ view,
                 const float* __restrict__ proj, const float* __restrict__ campos, float tan_fovx, float tan_fovy,
-                float focal_x, float focal_y, const int* __restrict__ radii, const float* __restrict__ dL_dmean2D,
-                const float* __restrict__ dL_dconic, float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D,
-                float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
-                float* __restrict__ dL_drot)
+                float focal_x, float focal_y, float half_w, float half_h, const int* __restrict__ radii,
+                const float4* __restrict__ g0, const float4* __restrict__ g1, const float4* __restrict__ grad_acc,
+                float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor,
+                float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
+                float* __restrict__ dL_dscale, float* __restrict__ dL_drot)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= P) return;
     const size_t i = (size_t)idx;
 
     if (!(radii[idx] > 0)) {
+        dL_dmean2D[3 * i] = 0.f; dL_dmean2D[3 * i + 1] = 0.f; dL_dmean2D[3 * i + 2] = 0.f;
+        dL_dcolor[3 * i] = 0.f; dL_dcolor[3 * i + 1] = 0.f; dL_dcolor[3 * i + 2] = 0.f;
+        dL_dopacity[i] = 0.f;
         dL_dmean3D[3 * i] = 0.f; dL_dmean3D[3 * i + 1] = 0.f; dL_dmean3D[3 * i + 2] = 0.f;
 #pragma unroll
         for (int k = 0; k < 6; k++) dL_dcov3D[6 * i + k] = 0.f;
@@ -39,6 +46,18 @@ geom_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const fl
     }
 
     const Vec3 mean = load3(means3D, i);
+
+    // ---------------- moments -> dL_dcolor, dL_dopacity, dL_dmean2D, dL_dconic
+    const float4 m0 = grad_acc[3 * i], m1 = grad_acc[3 * i + 1], m2 = grad_acc[3 * i + 2];
+    // m0 = {sum w*dpix_r, g, b, sum r}; m1 = {sum r dx, sum r dy, sum r dx^2, sum r dx dy}; m2.x = sum r dy^2
+    const float4 ga = g0[i], gb = g1[i];
+    const float con_a = ga.z, con_b = ga.w, con_c = gb.x, op = gb.y;
+    dL_dcolor[3 * i] = m0.x; dL_dcolor[3 * i + 1] = m0.y; dL_dcolor[3 * i + 2] = m0.z;
+    dL_dopacity[i] = m0.w;
+    const float gx2 = -op * (con_a * m1.x + con_b * m1.y) * half_w;
+    const float gy2 = -op * (con_c * m1.y + con_b * m1.x) * half_h;
+    dL_dmean2D[3 * i] = gx2; dL_dmean2D[3 * i + 1] = gy2; dL_dmean2D[3 * i + 2] = 0.f;
+    const float4 dcon = make_float4(-0.5f * op * m1.z, -0.5f * op * m1.w, 0.f, -0.5f * op * m2.x);   // (xx, xy, -, yy)
 
     // ---------------- conic -> cov2D -> {cov3D, view-space mean}  (backward.cu:144-274)
     float c3[6];
@@ -56,7 +75,6 @@ geom_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const fl
     float v0[3], v1[3], a, b, c;
     cov2d_from(e, c3, v0, v1, a, b, c);
 
-    const float4 dcon = reinterpret_cast<const float4*>(dL_dconic)[i];   // (xx, xy, -, yy)
     const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
     const float x_grad_mul = (e.txtz < -limx || e.txtz > limx) ? 0.f : 1.f;
     const float y_grad_mul = (e.tytz < -limy || e.tytz > limy) ? 0.f : 1.f;
@@ -105,7 +123,6 @@ geom_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const fl
         const float m_w = 1.0f / (xform4w(mean, proj) + 0.0000001f);
         const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
         const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
-        const float gx2 = dL_dmean2D[3 * i], gy2 = dL_dmean2D[3 * i + 1];
         gmx += (proj[0] * m_w - proj[3] * mul1) * gx2 + (proj[1] * m_w - proj[3] * mul2) * gy2;
         gmy += (proj[4] * m_w - proj[7] * mul1) * gx2 + (proj[5] * m_w - proj[7] * mul2) * gy2;
         gmz += (proj[8] * m_w - proj[11] * mul1) * gx2 + (proj[9] * m_w - proj[11] * mul2) * gy2;
@@ -124,8 +141,9 @@ geom_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const fl
         float col[3] = {0.f, 0.f, 0.f};
         for (int k = 0; k < nb; k++) { col[0] += basis[k] * sh[3 * k]; col[1] += basis[k] * sh[3 * k + 1]; col[2] += basis[k] * sh[3 * k + 2]; }
         float dRGB[3];
+        const float dcol[3] = {m0.x, m0.y, m0.z};
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++) dRGB[ch] = (col[ch] + 0.5f < 0.f) ? 0.f : dL_dcolor[3 * i + ch];
+        for (int ch = 0; ch < 3; ch++) dRGB[ch] = (col[ch] + 0.5f < 0.f) ? 0.f : dcol[ch];
         float* dsh = dL_dsh + i * M * 3;
         for (int k = 0; k < M; k++) {
             const float bk = k < nb ? basis[k] : 0.f;
@@ -207,15 +225,17 @@ geom_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const fl
 void launch_geom_bwd(int P, int D, int M, const float* means3D, const float* shs, const float* scales,
                      float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* view,
                      const float* proj, const float* campos, int W, int H, float tan_fovx, float tan_fovy,
-                     const int* radii, const float* dL_dmean2D, const float* dL_dconic, float* dL_dcolor,
-                     float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                     hipStream_t st)
+                     const int* radii, GeomState g, const float* grad_acc, float* dL_dmean2D, float* dL_dopacity,
+                     float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                     float* dL_drot, hipStream_t st)
 {
     const float focal_y = H / (2.0f * tan_fovy), focal_x = W / (2.0f * tan_fovx);   // rasterizer_impl.cu:381-382
     geom_bwd_kernel<<<(P + 255) / 256, 256, 0, st>>>(P, D, M, means3D, shs, scales, scale_modifier, rotations,
                                                      cov3D_precomp, view, proj, campos, tan_fovx, tan_fovy, focal_x,
-                                                     focal_y, radii, dL_dmean2D, dL_dconic, dL_dcolor, dL_dmean3D,
-                                                     dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+                                                     focal_y, 0.5f * W, 0.5f * H, radii, g.g0, g.g1,
+                                                     reinterpret_cast<const float4*>(grad_acc), dL_dmean2D,
+                                                     dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
+                                                     dL_drot);
 }
 
 }  // namespace gsr

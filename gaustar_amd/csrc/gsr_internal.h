@@ -28,7 +28,7 @@ __host__ __device__ inline size_t align_up(size_t x) { return (x + 255) & ~(size
 
 struct GeomState {           // per Gaussian
     float4* g0;              // {pix_x, pix_y, conic_a, conic_b}
-    float4* g1;              // {conic_c, opacity, cull_hx, cull_hy}
+    float4* g1;              // {conic_c, opacity, cull_tau = ln(255*opacity) + margin (< 0: never visible), 0}
     float* depth;            // view-space z (sort key)
     ushort4* rect;           // tile rect {min_x, min_y, max_x, max_y} actually binned (empty => no instances)
     float* rgb;              // SH-evaluated colours [P,3] (SH mode only, but always carved)
@@ -52,7 +52,10 @@ struct ImageState {          // per pixel / per tile
     uint2* ranges;           // [T] {start, end} into point_list
     uint32_t* tile_count;    // [T] instances per tile (atomics in preprocess)
     uint32_t* tile_cursor;   // [T] scatter cursors
-    uint32_t* totals;        // [4] {R, max tile count, 0, 0}
+    uint32_t* totals;        // [4] {R, max tile count, number of non-empty tiles, 0}
+    uint32_t* order;         // [T] tile ids, longest instance lists first (32-entry buckets), empty tiles last:
+                             // the blockIdx -> tile map of the per-tile kernels (longest-processing-time-first
+                             // dispatch evens out the very uneven per-tile work of a surface seen in perspective)
     size_t bytes;
 };
 inline ImageState carve_image(void* base, int W, int H)
@@ -65,6 +68,7 @@ inline ImageState carve_image(void* base, int W, int H)
     s.tile_count = (uint32_t*)(b + o); o = align_up(o + 4 * T);
     s.tile_cursor = (uint32_t*)(b + o); o = align_up(o + 4 * T);
     s.totals = (uint32_t*)(b + o); o = align_up(o + 16);
+    s.order = (uint32_t*)(b + o); o = align_up(o + 4 * T);
     s.bytes = o + 256;
     return s;
 }
@@ -103,14 +107,13 @@ void launch_tile_sort(int W, int H, uint32_t max_count, ImageState im, BinState 
 void launch_blend_fwd(int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
                       float* out_color, hipStream_t st);
 void launch_blend_bwd(int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
-                      const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                      float* dL_dcolor, hipStream_t st);
+                      const float* dL_dpix, float* grad_acc, hipStream_t st);
 void launch_geom_bwd(int P, int D, int M, const float* means3D, const float* shs, const float* scales,
                      float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* view,
                      const float* proj, const float* campos, int W, int H, float tan_fovx, float tan_fovy,
-                     const int* radii, const float* dL_dmean2D, const float* dL_dconic, float* dL_dcolor,
-                     float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                     hipStream_t st);
+                     const int* radii, GeomState g, const float* grad_acc, float* dL_dmean2D, float* dL_dopacity,
+                     float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                     float* dL_drot, hipStream_t st);
 void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t st);
 
 // ---------------------------------------------------------------- shared device math
@@ -250,6 +253,58 @@ __device__ __forceinline__ float pair_power(float ca, float cb, float cc, float 
 #pragma clang fp contract(off)
     const float q = __builtin_fmaf(cc * dy, dy, (ca * dx) * dx);
     return __builtin_fmaf(-(cb * dx), dy, -0.5f * q);
+}
+
+// Exact culling primitive: min over the rectangle [X0,X1]x[Y0,Y1] (coordinates relative to the splat
+// centre) of  f(x,y) = 0.5*(a x^2 + c y^2) + b x y  = -power.  A (splat, pixel block) pair can only reach
+// alpha >= 1/255 if this minimum is <= ln(255*opacity).  f is convex with its minimum (0) at the centre,
+// so the constrained minimum sits on one of the two edges facing the centre; both edge candidates are
+// points of the rectangle, hence min(fx, fy) is exact in every case (centre inside: both are 0).
+// Contraction is off: preprocess (tile counting) and scatter must take bit-identical decisions.
+__device__ __forceinline__ float block_min_half_quad(float a, float b, float c, float X0, float X1, float Y0,
+                                                     float Y1)
+{
+#pragma clang fp contract(off)
+    const float xc = fminf(fmaxf(0.0f, X0), X1);
+    const float yc = fminf(fmaxf(0.0f, Y0), Y1);
+    const float ys = fminf(fmaxf(-(b * xc) / c, Y0), Y1);
+    const float xs = fminf(fmaxf(-(b * yc) / a, X0), X1);
+    const float fx = 0.5f * ((a * xc) * xc + (c * ys) * ys) + (b * xc) * ys;
+    const float fy = 0.5f * ((a * xs) * xs + (c * yc) * yc) + (b * xs) * yc;
+    return fminf(fx, fy);
+}
+
+// Visit every tile of `rect` that the splat can reach (exact test above), with the visits of the 64 lanes of a
+// wave AGGREGATED by tile id: `f(tile, mask, leader)` is called once per distinct tile value per round, by
+// all lanes of the wave (converged), where `mask` = lanes visiting that tile and `leader` its lowest lane.
+// Mesh-ordered surface splats make neighbouring lanes hit the same few tiles, so a wave issues a handful
+// of atomics instead of one per (lane, tile).  Must be called by all 64 lanes (inactive ones pass an empty
+// rect).  The (rect, g0, g1) inputs are the stored ones in both callers => identical tile sets.
+template <class F>
+__device__ __forceinline__ void for_each_tile_aggregated(ushort4 rect, float px, float py, float ca, float cb,
+                                                         float cc, float tau, int gx, F f)
+{
+    int tx = rect.x, ty = rect.y;
+    bool more = rect.z > rect.x && rect.w > rect.y && tau >= 0.0f;
+    while (true) {
+        int cur = -1;
+        while (more) {   // advance this lane to its next reachable tile
+            const float X0 = (float)(tx * TILE) - px, Y0 = (float)(ty * TILE) - py;
+            const bool hit = block_min_half_quad(ca, cb, cc, X0, X0 + (float)(TILE - 1), Y0, Y0 + (float)(TILE - 1)) <= tau;
+            const int id = ty * gx + tx;
+            if (++tx == rect.z) { tx = rect.x; if (++ty == rect.w) more = false; }
+            if (hit) { cur = id; break; }
+        }
+        unsigned long long active = __ballot(cur >= 0);
+        if (active == 0ull) break;
+        while (active) {
+            const int leader = __ffsll((unsigned long long)active) - 1;
+            const int t = __shfl(cur, leader, 64);
+            const unsigned long long m = __ballot(cur == t);
+            f(t, m, leader);
+            active &= ~m;
+        }
+    }
 }
 
 // Pixel centre of an NDC coordinate; evaluated in double like auxiliary.h:41-44.

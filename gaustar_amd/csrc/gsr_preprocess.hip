@@ -2,15 +2,15 @@
 //
 // Computes what the reference's preprocessCUDA (DGR/cuda_rasterizer/forward.cu:155-256)
 // computes, with identical culling decisions and identical `radii`, but writes a different,
-// smaller geometry state (40 B/Gaussian, 52 in SH mode, vs the reference's 79) laid out for the
-// wave-per-8x8 blend kernels: two float4 records gathered per instance, plus the binned tile
-// rect so that the count pass (here) and the scatter pass agree on the instance set by
-// construction.
+// smaller geometry state (44 B/Gaussian, +12 in SH mode, vs the reference's 79) laid out for the
+// wave-per-8x8 blend kernels: two float4 records gathered per instance, plus the candidate tile
+// rect so that the count pass (here) and the scatter pass walk the same tiles.
 //
-// Tile set actually binned = reference rect (auxiliary.h:46-56, 3-sigma circle)  INTERSECT
-// a conservative bounding box of the region where alpha can reach 1/255.  Dropped tiles could
-// only hold pairs the reference skips at forward.cu:340-342, so results are unchanged while
-// num_rendered (library-internal) shrinks.
+// Tile set actually binned = tiles of the reference rect (auxiliary.h:46-56, 3-sigma circle) in which
+// the splat can reach alpha >= 1/255 at all (exact quadratic-vs-rectangle test, block_min_half_quad).
+// Dropped tiles could only hold pairs the reference skips at forward.cu:340-342, so results are
+// unchanged while num_rendered (library-internal) shrinks.  Per-tile counters are bumped with
+// wave-aggregated atomics (one per distinct tile per wave round instead of one per lane).
 #include "gsr_internal.h"
 
 namespace gsr {
@@ -26,100 +26,104 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
                   ushort4* __restrict__ rect, float* __restrict__ rgb, uint32_t* __restrict__ tile_count)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P) return;
+    const int lane = threadIdx.x & 63;
+    const bool valid = idx < P;
 
     int out_radius = 0;
     ushort4 out_rect = make_ushort4(0, 0, 0, 0);
+    float px = 0.f, py = 0.f, conic_a = 1.f, conic_b = 0.f, conic_c = 1.f, tau = -1.f;
 
-    const Vec3 p = load3(means3D, idx);
-    const float view_z = view_depth(p, view);
-    // Near-plane cull only (auxiliary.h:154; the NDC side test is dead code there).
-    if (view_z > NEAR_Z) {
-        const Vec3 ph = xform43(p, proj);
-        const float pw = 1.0f / (xform4w(p, proj) + 0.0000001f);
-        const float ndc_x = ph.x * pw, ndc_y = ph.y * pw;
+    if (valid) {
+        const Vec3 p = load3(means3D, idx);
+        const float view_z = view_depth(p, view);
+        // Near-plane cull only (auxiliary.h:154; the NDC side test is dead code there).
+        if (view_z > NEAR_Z) {
+            const Vec3 ph = xform43(p, proj);
+            const float pw = 1.0f / (xform4w(p, proj) + 0.0000001f);
+            const float ndc_x = ph.x * pw, ndc_y = ph.y * pw;
 
-        float c3[6];
-        if (cov3D_precomp) {
+            float c3[6];
+            if (cov3D_precomp) {
 #pragma unroll
-            for (int k = 0; k < 6; k++) c3[k] = cov3D_precomp[6 * (size_t)idx + k];
-        } else {
-            const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
-            cov3d_from_scale_rot(load3(scales, idx), scale_modifier, q, c3);
-        }
-        const Ewa e = ewa_rows(p, view, focal_x, focal_y, tan_fovx, tan_fovy);
-        float v0[3], v1[3], ca, cb, cc;
-        cov2d_from(e, c3, v0, v1, ca, cb, cc);
+                for (int k = 0; k < 6; k++) c3[k] = cov3D_precomp[6 * (size_t)idx + k];
+            } else {
+                const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+                cov3d_from_scale_rot(load3(scales, idx), scale_modifier, q, c3);
+            }
+            const Ewa e = ewa_rows(p, view, focal_x, focal_y, tan_fovx, tan_fovy);
+            float v0[3], v1[3], ca, cb, cc;
+            cov2d_from(e, c3, v0, v1, ca, cb, cc);
 
-        const float det = ca * cc - cb * cb;
-        if (det != 0.0f) {
-            const float det_inv = 1.f / det;
-            const float conic_a = cc * det_inv, conic_b = -cb * det_inv, conic_c = ca * det_inv;
-            const float mid = 0.5f * (ca + cc);
-            const float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
-            const float lambda1 = mid + disc, lambda2 = mid - disc;
-            const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
-            const float px = ndc2pix(ndc_x, W), py = ndc2pix(ndc_y, H);
-            const int r = (int)my_radius;
-            // Reference tile rect (C truncation toward zero, clamped to the grid).
-            int rx0 = min(gx, max(0, (int)((px - r) / TILE)));
-            int ry0 = min(gy, max(0, (int)((py - r) / TILE)));
-            int rx1 = min(gx, max(0, (int)((px + r + TILE - 1) / TILE)));
-            int ry1 = min(gy, max(0, (int)((py + r + TILE - 1) / TILE)));
-            if ((rx1 - rx0) * (ry1 - ry0) != 0) {
-                out_radius = r;
-                const float op = opacities[idx];
-                // alpha = min(0.99, op*exp(power)) >= 1/255  <=>  power >= -ln(255*op).
-                // tau carries an absolute safety margin far above any exp rounding error.
-                float hx = -1.f, hy = -1.f;
-                if (op * 255.0f * 1.0001f >= 1.0f) {
-                    const float tau = __logf(255.0f * op) + 0.02f;
-                    hx = sqrtf(2.0f * tau * ca) * 1.0005f + 0.01f;   // half extents of {d : d^T C d <= 2 tau}
-                    hy = sqrtf(2.0f * tau * cc) * 1.0005f + 0.01f;
-                    // Tiles holding an integer pixel coordinate within [p - h, p + h].
-                    const int ix0 = (int)ceilf(px - hx), ix1 = (int)floorf(px + hx);
-                    const int iy0 = (int)ceilf(py - hy), iy1 = (int)floorf(py + hy);
-                    if (ix1 < ix0 || iy1 < iy0 || ix1 < 0 || iy1 < 0) {
-                        rx1 = rx0; ry1 = ry0;
+            const float det = ca * cc - cb * cb;
+            if (det != 0.0f) {
+                const float det_inv = 1.f / det;
+                conic_a = cc * det_inv; conic_b = -cb * det_inv; conic_c = ca * det_inv;
+                const float mid = 0.5f * (ca + cc);
+                const float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
+                const float lambda1 = mid + disc, lambda2 = mid - disc;
+                const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+                px = ndc2pix(ndc_x, W); py = ndc2pix(ndc_y, H);
+                const int r = (int)my_radius;
+                // Reference tile rect (C truncation toward zero, clamped to the grid).
+                int rx0 = min(gx, max(0, (int)((px - r) / TILE)));
+                int ry0 = min(gy, max(0, (int)((py - r) / TILE)));
+                int rx1 = min(gx, max(0, (int)((px + r + TILE - 1) / TILE)));
+                int ry1 = min(gy, max(0, (int)((py + r + TILE - 1) / TILE)));
+                if ((rx1 - rx0) * (ry1 - ry0) != 0) {
+                    out_radius = r;
+                    const float op = opacities[idx];
+                    // alpha = min(0.99, op*exp(power)) >= 1/255  <=>  -power <= ln(255*op).  tau carries an
+                    // absolute safety margin far above any rounding in exp or in the quadratic form.
+                    if (op * 255.0f * 1.0001f >= 1.0f) {
+                        tau = fmaxf(__logf(255.0f * op), 0.0f) * 1.0005f + 0.02f;
+                        // shrink the candidate rect to the splat's alpha >= 1/255 bounding box first
+                        const float hx = sqrtf(2.0f * tau * ca) * 1.0005f + 0.01f;
+                        const float hy = sqrtf(2.0f * tau * cc) * 1.0005f + 0.01f;
+                        const int ix0 = (int)ceilf(px - hx), ix1 = (int)floorf(px + hx);
+                        const int iy0 = (int)ceilf(py - hy), iy1 = (int)floorf(py + hy);
+                        if (ix1 < ix0 || iy1 < iy0 || ix1 < 0 || iy1 < 0) {
+                            rx1 = rx0; ry1 = ry0;
+                        } else {
+                            rx0 = max(rx0, max(ix0, 0) / TILE);
+                            ry0 = max(ry0, max(iy0, 0) / TILE);
+                            rx1 = max(rx0, min(rx1, ix1 / TILE + 1));
+                            ry1 = max(ry0, min(ry1, iy1 / TILE + 1));
+                        }
                     } else {
-                        rx0 = max(rx0, max(ix0, 0) / TILE);
-                        ry0 = max(ry0, max(iy0, 0) / TILE);
-                        rx1 = min(rx1, ix1 / TILE + 1);
-                        ry1 = min(ry1, iy1 / TILE + 1);
-                        if (rx1 < rx0) rx1 = rx0;
-                        if (ry1 < ry0) ry1 = ry0;
+                        rx1 = rx0; ry1 = ry0;   // can never reach alpha >= 1/255 anywhere
                     }
-                } else {
-                    rx1 = rx0; ry1 = ry0;   // can never reach alpha >= 1/255 anywhere
-                }
-                if (colors_precomp == nullptr) {
-                    // SH -> RGB (forward.cu:20-71), +0.5 and clamp at 0.
-                    const float dx = p.x - campos[0], dy = p.y - campos[1], dz = p.z - campos[2];
-                    const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-                    float basis[16];
-                    sh_basis(D, dx * inv, dy * inv, dz * inv, basis);
-                    const int nb = (D + 1) * (D + 1);
-                    const float* sh = shs + (size_t)idx * M * 3;
-                    float cr = 0.f, cg = 0.f, cbb = 0.f;
-                    for (int k = 0; k < nb; k++) {
-                        cr += basis[k] * sh[3 * k]; cg += basis[k] * sh[3 * k + 1]; cbb += basis[k] * sh[3 * k + 2];
+                    if (colors_precomp == nullptr) {
+                        // SH -> RGB (forward.cu:20-71), +0.5 and clamp at 0.
+                        const float dx = p.x - campos[0], dy = p.y - campos[1], dz = p.z - campos[2];
+                        const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+                        float basis[16];
+                        sh_basis(D, dx * inv, dy * inv, dz * inv, basis);
+                        const int nb = (D + 1) * (D + 1);
+                        const float* sh = shs + (size_t)idx * M * 3;
+                        float cr = 0.f, cg = 0.f, cbb = 0.f;
+                        for (int k = 0; k < nb; k++) {
+                            cr += basis[k] * sh[3 * k]; cg += basis[k] * sh[3 * k + 1]; cbb += basis[k] * sh[3 * k + 2];
+                        }
+                        rgb[3 * (size_t)idx + 0] = fmaxf(cr + 0.5f, 0.0f);
+                        rgb[3 * (size_t)idx + 1] = fmaxf(cg + 0.5f, 0.0f);
+                        rgb[3 * (size_t)idx + 2] = fmaxf(cbb + 0.5f, 0.0f);
                     }
-                    rgb[3 * (size_t)idx + 0] = fmaxf(cr + 0.5f, 0.0f);
-                    rgb[3 * (size_t)idx + 1] = fmaxf(cg + 0.5f, 0.0f);
-                    rgb[3 * (size_t)idx + 2] = fmaxf(cbb + 0.5f, 0.0f);
+                    g0[idx] = make_float4(px, py, conic_a, conic_b);
+                    g1[idx] = make_float4(conic_c, op, tau, 0.0f);
+                    depth[idx] = view_z;
+                    out_rect = make_ushort4((unsigned short)rx0, (unsigned short)ry0, (unsigned short)rx1,
+                                            (unsigned short)ry1);
                 }
-                g0[idx] = make_float4(px, py, conic_a, conic_b);
-                g1[idx] = make_float4(conic_c, op, hx, hy);
-                depth[idx] = view_z;
-                out_rect = make_ushort4((unsigned short)rx0, (unsigned short)ry0, (unsigned short)rx1,
-                                        (unsigned short)ry1);
-                for (int y = ry0; y < ry1; y++)
-                    for (int x = rx0; x < rx1; x++) atomicAdd(&tile_count[y * gx + x], 1u);
             }
         }
+        radii[idx] = out_radius;
+        rect[idx] = out_rect;
     }
-    radii[idx] = out_radius;
-    rect[idx] = out_rect;
+    // All 64 lanes take part (lanes without work carry an empty rect).
+    for_each_tile_aggregated(out_rect, px, py, conic_a, conic_b, conic_c, tau, gx,
+                             [&](int tile, unsigned long long m, int leader) {
+                                 if (lane == leader) atomicAdd(&tile_count[tile], (uint32_t)__popcll(m));
+                             });
 }
 
 void launch_preprocess(int P, int D, int M, const float* means3D, const float* shs, const float* colors_precomp,

@@ -146,7 +146,7 @@ def rasterize_gaussians_backward_native(background, means3D, radii, colors, scal
         dL_dmeans3D = torch.empty(P, 3, **f32)
         dL_dmeans2D = torch.empty(P, 3, **f32)
         dL_dcolors = torch.empty(P, 3, **f32)
-        dL_dconic = torch.empty(P, 2, 2, **f32)
+        grad_scratch = torch.empty(lib.gsr_grad_scratch_bytes(P), dtype=torch.uint8, device=dev)
         dL_dopacity = torch.empty(P, 1, **f32)
         dL_dcov3D = torch.empty(P, 6, **f32)
         dL_dsh = torch.empty(P, M, 3, **f32)
@@ -156,7 +156,7 @@ def rasterize_gaussians_backward_native(background, means3D, radii, colors, scal
             P, int(degree), M, int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(scales),
             float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix),
             _ptr(campos), float(tan_fovx), float(tan_fovy), _ptr(radii), _ptr(geomBuffer), _ptr(binningBuffer),
-            _ptr(imageBuffer), _ptr(dL_dout_color), _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity),
+            _ptr(imageBuffer), _ptr(dL_dout_color), _ptr(grad_scratch), _ptr(dL_dmeans2D), _ptr(dL_dopacity),
             _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales),
             _ptr(dL_drotations), _stream()), "gsr_backward")
         if debug:

@@ -47,6 +47,9 @@ const char* gsr_last_error(void);
 size_t gsr_geom_bytes(int P);
 size_t gsr_image_bytes(int W, int H);
 size_t gsr_binning_bytes(int R);
+/* Backward-only scratch: one packed 48-byte accumulation record per Gaussian.  Takes the place of the
+ * dL_dconic [P,2,2] work tensor the reference binding allocates (DGR/rasterize_points.cu:154). */
+size_t gsr_grad_scratch_bytes(int P);
 
 /* Forward, first half: per-Gaussian projection/culling/covariance/SH->RGB, tile counting and
  * the tile-offset scan; reads back num_rendered (= Gaussian x tile instances this library will
@@ -85,15 +88,16 @@ int gsr_forward(gsr_alloc_fn geometry_buffer, gsr_alloc_fn binning_buffer, gsr_a
  * (DGR/cuda_rasterizer/rasterizer.h:57-83; rasterizer_impl.cu:340-434; backward.cu).
  * Output gradient arrays need NOT be zeroed by the caller (the reference requires zeroed
  * tensors, DGR/rasterize_points.cu:151-159; here the fill is part of the call):
- *   dL_dmean2D [P,3], dL_dconic [P,4] (xx, xy, -, yy), dL_dopacity [P], dL_dcolor [P,3],
- *   dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3] (NULL when M == 0), dL_dscale [P,3],
- *   dL_drot [P,4] (both NULL when cov3D_precomp is given). */
+ *   grad_scratch: gsr_grad_scratch_bytes(P) bytes of work space (contents undefined afterwards);
+ *   dL_dmean2D [P,3], dL_dopacity [P], dL_dcolor [P,3], dL_dmean3D [P,3], dL_dcov3D [P,6],
+ *   dL_dsh [P,M,3] (NULL when M == 0), dL_dscale [P,3], dL_drot [P,4] (both NULL when cov3D_precomp
+ *   is given). */
 int gsr_backward(int P, int D, int M, int R, const float* background, int W, int H, const float* means3D,
                  const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
                  const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
                  const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
                  const void* geom_buffer, const void* binning_buffer, const void* image_buffer, const float* dL_dpix,
-                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+                 void* grad_scratch, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                  float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, gsr_stream_t stream);
 
 /* Near-plane visibility test.  Replaces CudaRasterizer::Rasterizer::markVisible

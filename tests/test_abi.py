@@ -28,7 +28,7 @@ def _declared():
 def test_header_declares_the_expected_entry_points():
     d = _declared()
     for name in ("gsr_abi_version", "gsr_last_error", "gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes",
-                 "gsr_forward_stage1", "gsr_forward_stage2", "gsr_forward", "gsr_backward", "gsr_mark_visible",
+                 "gsr_grad_scratch_bytes", "gsr_forward_stage1", "gsr_forward_stage2", "gsr_forward", "gsr_backward", "gsr_mark_visible",
                  "gsr_debug_export"):
         assert name in d, name
     src = open(HEADER).read()
@@ -53,7 +53,7 @@ def test_ctypes_table_matches_header():
 def test_library_loads_and_exports_every_symbol(hip_lib):
     for name in _declared():
         assert hasattr(hip_lib, name), name
-    assert hip_lib.gsr_abi_version() == 1
+    assert hip_lib.gsr_abi_version() == 2
 
 
 def test_scratch_sizes(hip_lib):
