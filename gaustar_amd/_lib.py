@@ -10,7 +10,7 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
+LIB_PATH = os.environ.get("GSR_LIB_PATH", os.path.join(_HERE, "libgsr_hip.so"))   # override: experiment variants
 
 ABI_VERSION = 2
 ALLOC_FN = ctypes.CFUNCTYPE(c_void_p, c_void_p, c_size_t)

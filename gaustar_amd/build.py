@@ -32,15 +32,16 @@ def needs_build() -> bool:
     return any(os.path.getmtime(p) > t for p in _deps())
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = OUT) -> str:
+    """extra_flags/out: experiment variants (e.g. -DGSR_EXP_...) built next to the product library."""
+    if not force and not extra_flags and not needs_build():
         return OUT
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build", os.path.basename(out).replace(".so", ""))
     os.makedirs(objdir, exist_ok=True)
 
     def cc(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -52,12 +53,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(cc, SOURCES))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:   # python -m gaustar_amd.build --variant NAME -DFOO ...
+        i = sys.argv.index("--variant")
+        name, flags = sys.argv[i + 1], sys.argv[i + 2:]
+        print(build(force=True, extra_flags=flags, out=os.path.join(HERE, f"libgsr_hip_{name}.so")))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

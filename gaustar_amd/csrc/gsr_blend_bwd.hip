@@ -197,19 +197,30 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                 v_rx = v_r * dx; v_ry = v_r * dy;
                 v_rxx = v_rx * dx; v_rxy = v_rx * dy; v_ryy = v_ry * dy;
             }
+#ifdef GSR_EXP_NO_REDUCE
+            const float c8 = v_cr + v_cg + v_cb + v_r + v_rx + v_ry + v_rxx + v_rxy, c1 = v_ryy;
+#else
             const float c8 = reduce8(v_cr, v_cg, v_cb, v_r, v_rx, v_ry, v_rxx, v_rxy, hi8);
             const float c1 = reduce1_to_lane63(v_ryy);
+#endif
             if ((lane & 7) == 0) tot[j * ACC_STRIDE + (lane >> 3)] = c8;
             if (lane == 63) tot[j * ACC_STRIDE + 8] = c1;
             touched |= 1ull << j;
         }
         __builtin_amdgcn_wave_barrier();
-        // flush: lane = queued instance
-        if ((touched >> lane) & 1ull) {
-            const size_t g = __float_as_uint(q[lane].c.z);
-            float* dst = grad_acc + g * 12;
-#pragma unroll
-            for (int v = 0; v < 9; v++) atomic_add_f32(dst + v, tot[lane * ACC_STRIDE + v]);
+        // flush: lanes walk the (instance, moment) table row-major, so one atomic instruction covers the nine
+        // consecutive floats of ~7 packed records -- the memory pipeline merges lanes that share a cache line
+        // into one request instead of nine.
+        for (int idx = lane; idx < cnt * ACC_STRIDE; idx += 64) {
+            const int e = idx / ACC_STRIDE, v = idx - e * ACC_STRIDE;
+            if ((touched >> e) & 1ull) {
+                const size_t g = __float_as_uint(q[e].c.z);
+#ifdef GSR_EXP_NO_ATOMICS
+                if (tot[idx] == 123.456f) grad_acc[g * 12 + v] = tot[idx];
+#else
+                atomic_add_f32(grad_acc + g * 12 + v, tot[idx]);
+#endif
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
