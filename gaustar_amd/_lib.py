@@ -39,6 +39,7 @@ SIGNATURES = {
     "gsr_mark_visible": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsr_debug_export": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gsr_debug_set_trace": (c_int, [c_void_p]),
     "gsr_num_stages": (c_int, []),
     "gsr_stage_name": (c_char_p, [c_int]),
     "gsr_profile_enable": (c_int, [c_int]),

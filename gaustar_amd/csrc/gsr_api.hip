@@ -12,6 +12,8 @@
 
 using namespace gsr;
 
+namespace gsr { uint64_t* g_trace = nullptr; }
+
 namespace {
 thread_local std::string g_err;
 thread_local uint32_t* g_pinned = nullptr;   // 16-byte pinned landing pad for the stage-1 read-back
@@ -257,6 +259,12 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
     if (!means3D || !viewmatrix || !present) return fail_msg("gsr_mark_visible: required pointer is null");
     launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
     GSR_CHECK_LAUNCH("mark_visible_kernel");
+    return 0;
+}
+
+int gsr_debug_set_trace(void* device_buffer)
+{
+    gsr::g_trace = static_cast<uint64_t*>(device_buffer);
     return 0;
 }
 

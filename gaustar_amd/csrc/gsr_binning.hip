@@ -31,62 +31,95 @@ __device__ __forceinline__ int length_bucket(uint32_t c)
 {
     return c == 0 ? 65 : 64 - (int)min(64u, (c + 31u) >> 5);
 }
+// PER = tiles owned by each of the 1024 threads, held in registers (one round of 16-byte loads: the kernel is
+// a single workgroup, so its time is the sum of its dependent memory round trips).
+template <int PER>
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges,
                  uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ totals, uint32_t* __restrict__ order)
 {
     __shared__ uint32_t wave_sum[16];
     __shared__ uint32_t wave_max[16];
-    __shared__ uint32_t carry_s;
     __shared__ uint32_t bucket_n[NBUCKET];
-    if (threadIdx.x < NBUCKET) bucket_n[threadIdx.x] = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    uint32_t vmax = 0;
-    __syncthreads();
-    for (int base = 0; base < T; base += 1024) {
-        const int t = base + tid;
-        const uint32_t c = t < T ? tile_count[t] : 0u;
-        vmax = max(vmax, c);
-        if (t < T) atomicAdd(&bucket_n[length_bucket(c)], 1u);
-        const uint32_t incl = wave_incl_scan(c, lane);
-        if (lane == 63) wave_sum[wave] = incl;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (int w = 0; w < wave; w++) woff += wave_sum[w];
-        const uint32_t carry = carry_s;
-        const uint32_t start = carry + woff + incl - c;
-        if (t < T) {
-            ranges[t] = make_uint2(start, start + c);
-            tile_cursor[t] = start;
-        }
-        __syncthreads();
-        if (tid == 1023) carry_s = start + c;
-        __syncthreads();
+    if (tid < NBUCKET) bucket_n[tid] = 0;
+    const int t0 = tid * PER;
+    uint32_t c[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k += 4) {   // the scratch carve pads tile_count to 256 B, so the tail read stays in bounds
+        const uint4 v = (t0 + k < T) ? *reinterpret_cast<const uint4*>(tile_count + t0 + k) : make_uint4(0, 0, 0, 0);
+        c[k] = v.x; c[k + 1] = v.y; c[k + 2] = v.z; c[k + 3] = v.w;
     }
-    // max reduction
+    uint32_t sum = 0, vmax = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        if (t0 + k >= T) c[k] = 0;
+        sum += c[k];
+        vmax = max(vmax, c[k]);
+    }
+    const uint32_t incl = wave_incl_scan(sum, lane);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, d, 64));
+    if (lane == 63) wave_sum[wave] = incl;
     if (lane == 0) wave_max[wave] = vmax;
     __syncthreads();
+    uint32_t woff = 0, total = 0, gmax = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        const uint32_t s = wave_sum[w];
+        if (w < wave) woff += s;
+        total += s;
+        gmax = max(gmax, wave_max[w]);
+    }
+    uint32_t run = woff + incl - sum;
+    uint32_t n_empty = 0;   // empty tiles dominate: count them privately, one LDS atomic per thread
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int t = t0 + k;
+        if (t < T) {
+            ranges[t] = make_uint2(run, run + c[k]);
+            tile_cursor[t] = run;
+            run += c[k];
+            if (c[k] == 0) n_empty++;
+            else atomicAdd(&bucket_n[length_bucket(c[k])], 1u);
+        }
+    }
+    if (n_empty) atomicAdd(&bucket_n[NBUCKET - 1], n_empty);
+    __syncthreads();
     if (tid == 0) {
-        uint32_t m = 0;
-        for (int w = 0; w < 16; w++) m = max(m, wave_max[w]);
-        totals[0] = carry_s;
-        totals[1] = m;
+        totals[0] = total;
+        totals[1] = gmax;
         totals[2] = (uint32_t)T - bucket_n[NBUCKET - 1];
         totals[3] = 0;
-        // exclusive prefix over the buckets -> start offsets (in place)
-        uint32_t run = 0;
-        for (int b = 0; b < NBUCKET; b++) { const uint32_t c = bucket_n[b]; bucket_n[b] = run; run += c; }
+    }
+    if (wave == 1) {   // exclusive prefix over the 66 buckets -> start offsets (in place)
+        const uint32_t c0 = bucket_n[lane];
+        const uint32_t i0 = wave_incl_scan(c0, lane);
+        const uint32_t first64 = __shfl(i0, 63, 64);
+        const uint32_t c64 = bucket_n[64];
+        bucket_n[lane] = i0 - c0;
+        if (lane == 0) { bucket_n[64] = first64; bucket_n[65] = first64 + c64; }
     }
     __syncthreads();
-    for (int t = tid; t < T; t += 1024) order[atomicAdd(&bucket_n[length_bucket(tile_count[t])], 1u)] = (uint32_t)t;
+    uint32_t empty_at = n_empty ? atomicAdd(&bucket_n[NBUCKET - 1], n_empty) : 0u;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int t = t0 + k;
+        if (t < T) {
+            if (c[k] == 0) order[empty_at++] = (uint32_t)t;
+            else order[atomicAdd(&bucket_n[length_bucket(c[k])], 1u)] = (uint32_t)t;
+        }
+    }
 }
 
 void launch_tile_scan(ImageState im, int T, hipStream_t st)
 {
-    tile_scan_kernel<<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.tile_cursor, im.totals, im.order);
+    if (T <= 8 * 1024)          // up to 1920x1088
+        tile_scan_kernel<8><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.tile_cursor, im.totals, im.order);
+    else if (T <= 36 * 1024)    // up to 4096x2304
+        tile_scan_kernel<36><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.tile_cursor, im.totals, im.order);
+    else                        // up to ~8k x 8k
+        tile_scan_kernel<256><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.tile_cursor, im.totals, im.order);
 }
 
 // One thread per Gaussian: claim a slot in every reachable tile's bucket and store the sort key.  Walks exactly
@@ -103,21 +136,20 @@ scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __
     ushort4 r = make_ushort4(0, 0, 0, 0);
     float4 a = make_float4(0.f, 0.f, 1.f, 0.f), b = make_float4(1.f, 0.f, -1.f, 0.f);
     uint64_t key = 0;
-    if (idx < P) {
+    if (idx < P) {   // all four loads issue together; culled Gaussians carry an empty rect
         r = rect[idx];
-        if (r.z > r.x && r.w > r.y) {
-            a = g0[idx];
-            b = g1[idx];
-            key = ((uint64_t)__float_as_uint(depth[idx]) << 32) | (uint32_t)idx;
-        }
+        a = g0[idx];
+        b = g1[idx];
+        key = ((uint64_t)__float_as_uint(depth[idx]) << 32) | (uint32_t)idx;
+        if (!(r.z > r.x && r.w > r.y)) b.z = -1.f;
     }
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    for_each_tile_aggregated(r, a.x, a.y, a.z, a.w, b.x, b.z, gx, [&](int tile, unsigned long long m, int leader) {
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&tile_cursor[tile], (uint32_t)__popcll(m));
-        base = __shfl(base, leader, 64);
-        if ((m >> lane) & 1ull) keys[base + (uint32_t)__popcll(m & lt)] = key;
-    });
+    for_each_tile_aggregated(r, a.x, a.y, a.z, a.w, b.x, b.z, gx, lane,
+                             [&](int tile, bool is_leader, int group, int rank, int leader_lane) {
+                                 uint32_t base = 0;
+                                 if (is_leader) base = atomicAdd(&tile_cursor[tile], (uint32_t)group);
+                                 base = __shfl(base, leader_lane, 64);
+                                 if (tile >= 0) keys[base + (uint32_t)rank] = key;
+                             });
 }
 
 void launch_scatter(int P, int W, int H, GeomState g, ImageState im, BinState b, hipStream_t st)

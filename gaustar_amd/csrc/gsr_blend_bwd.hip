@@ -34,20 +34,23 @@ struct __attribute__((aligned(16))) SlotB {   // 48 B per queued instance
 
 struct FetchedB { float4 a, b; float fr, fg, fb; uint32_t gid; };
 
-__device__ __forceinline__ FetchedB fetch_instance_b(int k, const uint32_t* __restrict__ list,
-                                                     const float4* __restrict__ g0, const float4* __restrict__ g1,
-                                                     const float* __restrict__ feats)
+// Two-stage software pipeline over the dependent gather (list -> id -> records), see gsr_blend_fwd.hip.
+__device__ __forceinline__ uint32_t fetch_id_b(int k, const uint32_t* __restrict__ list)
+{
+    return k >= 0 ? list[k] : 0xffffffffu;
+}
+__device__ __forceinline__ FetchedB fetch_record_b(uint32_t gid, const float4* __restrict__ g0,
+                                                   const float4* __restrict__ g1, const float* __restrict__ feats)
 {
     FetchedB f;
     f.a = make_float4(0.f, 0.f, 1.f, 0.f);
     f.b = make_float4(1.f, 0.f, -1.f, 0.f);   // tau = -1: never kept
     f.fr = f.fg = f.fb = 0.f;
-    f.gid = 0;
-    if (k >= 0) {
-        f.gid = list[k];
-        f.a = g0[f.gid];
-        f.b = g1[f.gid];
-        f.fr = feats[3 * (size_t)f.gid]; f.fg = feats[3 * (size_t)f.gid + 1]; f.fb = feats[3 * (size_t)f.gid + 2];
+    f.gid = gid;
+    if (gid != 0xffffffffu) {
+        f.a = g0[gid];
+        f.b = g1[gid];
+        f.fr = feats[3 * (size_t)gid]; f.fg = feats[3 * (size_t)gid + 1]; f.fb = feats[3 * (size_t)gid + 2];
     }
     return f;
 }
@@ -114,8 +117,9 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                  const float4* __restrict__ g0, const float4* __restrict__ g1, const float* __restrict__ feats,
                  const float* __restrict__ bg, const float* __restrict__ final_T,
                  const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                 float* __restrict__ grad_acc)
+                 float* __restrict__ grad_acc, uint64_t* __restrict__ trace)
 {
+    const uint64_t t_start = trace ? wall_clock64() : 0;
     __shared__ SlotB queue[4][64];
     __shared__ float totals[4][64 * ACC_STRIDE];
     const int tile = (int)order[blockIdx.x];
@@ -151,11 +155,13 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, last_alpha = 0.f, last_r = 0.f, last_g = 0.f, last_b = 0.f;
 
     // lane l takes list position hi-1-l: queue order == back-to-front order
-    FetchedB nxt = fetch_instance_b((int)wave_last - 1 - lane, list, g0, g1, feats);
+    FetchedB nxt = fetch_record_b(fetch_id_b((int)wave_last - 1 - lane, list), g0, g1, feats);
+    uint32_t gid_nxt = fetch_id_b((int)wave_last - 65 - lane, list);
     for (int hi = (int)wave_last; hi > 0; hi -= 64) {
         const FetchedB cur = nxt;
         const int k = hi - 1 - lane;
-        nxt = fetch_instance_b(k - 64, list, g0, g1, feats);
+        nxt = fetch_record_b(gid_nxt, g0, g1, feats);   // records of the next batch (ids arrived during the last one)
+        gid_nxt = fetch_id_b(k - 128, list);            // ids two batches ahead
         const bool keep = block_min_half_quad(cur.a.z, cur.a.w, cur.b.x, bx0 - cur.a.x, bx1 - cur.a.x, by0 - cur.a.y,
                                               by1 - cur.a.y) <= cur.b.z;
         const unsigned long long m = __ballot(keep);
@@ -224,6 +230,10 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if (trace && lane == 0) {   // last wave to finish wins the end stamp (monotone clock, max via atomic)
+        if (wave == 0) trace[2 * blockIdx.x] = t_start;
+        atomicMax((unsigned long long*)&trace[2 * blockIdx.x + 1], (unsigned long long)wall_clock64());
+    }
 }
 
 void launch_blend_bwd(int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
@@ -234,7 +244,8 @@ void launch_blend_bwd(int W, int H, const float* bg, const float* feats, GeomSta
     // longest-first tile order is dispatched dynamically (tuning: GSR_BWD_LDS_PAD bytes).
     static const int pad = getenv("GSR_BWD_LDS_PAD") ? atoi(getenv("GSR_BWD_LDS_PAD")) : 0;
     blend_bwd_kernel<<<t.T, 256, pad, st>>>(W, H, t.gx, im.ranges, im.order, b.point_list, g.g0, g.g1, feats, bg, im.final_T,
-                                          im.n_contrib, dL_dpix, grad_acc);
+                                          im.n_contrib, dL_dpix, grad_acc,
+                                          g_trace ? g_trace + 2 * (size_t)t.T : nullptr);
 }
 
 }  // namespace gsr

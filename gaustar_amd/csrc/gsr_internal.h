@@ -87,6 +87,10 @@ inline BinState carve_bin(void* base, int R)
     return s;
 }
 
+// Optional per-workgroup timeline for tuning (gsr_debug_set_trace): when non-null, the blend kernels store
+// {start, end} of every workgroup (100 MHz wall clock) at trace[2*blockIdx] (forward) / trace[2*(T+blockIdx)].
+extern uint64_t* g_trace;
+
 // ---------------------------------------------------------------- kernel launchers (one per .hip file)
 struct Camera {              // passed by value to kernels (lands in SGPRs / kernarg)
     float view[16];
@@ -274,18 +278,21 @@ __device__ __forceinline__ float block_min_half_quad(float a, float b, float c, 
     return fminf(fx, fy);
 }
 
-// Visit every tile of `rect` that the splat can reach (exact test above), with the visits of the 64 lanes of a
-// wave AGGREGATED by tile id: `f(tile, mask, leader)` is called once per distinct tile value per round, by
-// all lanes of the wave (converged), where `mask` = lanes visiting that tile and `leader` its lowest lane.
-// Mesh-ordered surface splats make neighbouring lanes hit the same few tiles, so a wave issues a handful
-// of atomics instead of one per (lane, tile).  Must be called by all 64 lanes (inactive ones pass an empty
-// rect).  The (rect, g0, g1) inputs are the stored ones in both callers => identical tile sets.
+// Visit every tile of `rect` that the splat can reach (exact test above), one tile per lane per ROUND, with the
+// visits of the 64 lanes of a wave grouped by tile id.  Once per round, all lanes (converged) call
+//     f(tile, is_leader, group_size, rank, leader_lane)
+// tile < 0 for lanes with nothing left; among the lanes that present the same tile exactly one is the leader
+// and every lane knows its 0-based rank in the group.  Mesh-ordered surface splats make neighbouring lanes hit
+// the same few tiles, so a wave issues ONE atomic instruction per round whose active lanes are the group
+// leaders (count = group size) instead of one atomic per (lane, tile).  Must be called by all 64 lanes
+// (inactive ones pass an empty rect).  Both callers pass the stored (rect, g0, g1) => identical tile sets.
 template <class F>
 __device__ __forceinline__ void for_each_tile_aggregated(ushort4 rect, float px, float py, float ca, float cb,
-                                                         float cc, float tau, int gx, F f)
+                                                         float cc, float tau, int gx, int lane, F f)
 {
     int tx = rect.x, ty = rect.y;
     bool more = rect.z > rect.x && rect.w > rect.y && tau >= 0.0f;
+    const unsigned long long lt = (1ull << lane) - 1ull;
     while (true) {
         int cur = -1;
         while (more) {   // advance this lane to its next reachable tile
@@ -297,13 +304,15 @@ __device__ __forceinline__ void for_each_tile_aggregated(ushort4 rect, float px,
         }
         unsigned long long active = __ballot(cur >= 0);
         if (active == 0ull) break;
-        while (active) {
+        int leader_lane = lane, group = 0, rank = 0;
+        while (active) {   // group the lanes by tile value with ballots only (no memory traffic in here)
             const int leader = __ffsll((unsigned long long)active) - 1;
             const int t = __shfl(cur, leader, 64);
             const unsigned long long m = __ballot(cur == t);
-            f(t, m, leader);
+            if (cur == t) { leader_lane = leader; group = __popcll(m); rank = __popcll(m & lt); }
             active &= ~m;
         }
+        f(cur, cur >= 0 && lane == leader_lane, group, rank, leader_lane);
     }
 }
 

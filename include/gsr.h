@@ -116,6 +116,10 @@ int gsr_debug_export(int P, int R, int W, int H, const void* geom_buffer, const 
                      uint32_t* tile_ranges, uint32_t* point_list, float* final_T, uint32_t* n_contrib,
                      gsr_stream_t stream);
 
+/* Tuning aid: when device_buffer is non-NULL (4*T uint64), the two blend kernels record the start/end wall
+ * clock (100 MHz) of every workgroup: forward at [2*b], backward at [2*(T+b)], b = launch index.  NULL = off. */
+int gsr_debug_set_trace(void* device_buffer);
+
 /* Per-kernel timing for benchmarks (no reference counterpart; the reference has no profiling hooks,
  * SURVEY.md section 5).  While enabled, every stage this thread launches is bracketed by HIP events
  * recorded on the launch stream.  gsr_profile_read waits for the recorded events and returns, per
