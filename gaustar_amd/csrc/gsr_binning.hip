@@ -101,13 +101,19 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
         if (lane == 0) { bucket_n[64] = first64; bucket_n[65] = first64 + c64; }
     }
     __syncthreads();
+    // Launch positions follow a SNAKE over bands of 256 (one workgroup per CU per band under the observed
+    // round-robin dispatch): CU k gets ranks k, 511-k, 512+k, ... so per-CU sums of list lengths even out
+    // instead of CU 0 collecting the longest tile of every band.  Pure scheduling heuristic.
+    auto snake = [](uint32_t pos) { return (pos & 256u) ? (pos ^ 255u) : pos; };
     uint32_t empty_at = n_empty ? atomicAdd(&bucket_n[NBUCKET - 1], n_empty) : 0u;
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         const int t = t0 + k;
         if (t < T) {
-            if (c[k] == 0) order[empty_at++] = (uint32_t)t;
-            else order[atomicAdd(&bucket_n[length_bucket(c[k])], 1u)] = (uint32_t)t;
+            uint32_t pos = (c[k] == 0) ? empty_at++ : atomicAdd(&bucket_n[length_bucket(c[k])], 1u);
+            const uint32_t sp = snake(pos);
+            if (sp < (uint32_t)T && (pos | 255u) < (uint32_t)T) pos = sp;   // only inside complete bands
+            order[pos] = (uint32_t)t;
         }
     }
 }
@@ -184,8 +190,15 @@ tile_sort_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
     if (n <= (uint32_t)CAP) {
         for (uint32_t i = tid; i < np2; i += 256) s[i] = i < n ? gk[i] : ~0ull;
         __syncthreads();
+        // Compare-exchange index i touches the 2j-aligned block of elements around 2i: for j <= 64 the 64
+        // consecutive indices a wave owns (in each 256-stride pass) stay inside "its" 128 consecutive
+        // elements, stage after stage -- those stages need no workgroup barrier (LDS is in-order per wave).
+        // Only the stages with j >= 128 exchange data between waves: a 512-entry list sorts with 6
+        // barriers instead of 45.
         for (uint32_t k = 2; k <= np2; k <<= 1) {
             for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                const bool cross = j >= 128;
+                if (cross) __syncthreads();
                 for (uint32_t i = tid; i < (np2 >> 1); i += 256) {
                     // i-th compare-exchange of this stage: indices (lo, lo | j), lo has bit j clear.
                     const uint32_t lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
@@ -194,9 +207,11 @@ tile_sort_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
                     const uint64_t a = s[lo], b = s[hi];
                     if ((a > b) == asc) { s[lo] = b; s[hi] = a; }
                 }
-                __syncthreads();
+                if (cross) __syncthreads();
+                else __builtin_amdgcn_wave_barrier();
             }
         }
+        __syncthreads();
         for (uint32_t i = tid; i < n; i += 256) point_list[rg.x + i] = (uint32_t)s[i];
     } else {
         // Global-memory fallback on the NORMALISED bitonic network (every compare-exchange ascending;

@@ -5,25 +5,25 @@
 //
 //  * One wave64 owns an 8x8 pixel block; a 16x16 tile is four independent waves (no workgroup
 //    barriers, each wave stops as soon as its own 64 pixels are saturated).
+//  * Inside the wave each DPP ROW (16 lanes) owns a 4x4 pixel QUADRANT and consumes its OWN queue of
+//    splats: in one loop iteration the four rows blend four different Gaussians.  Surface splats
+//    (~4 px radius) cover a fraction of an 8x8 block, so feeding all 64 lanes the same splat leaves most
+//    lanes idle; per-quadrant queues keep them busy and shorten every wave's serial chain.
 //  * Each wave walks the tile's depth-sorted list 64 instances at a time: lane i fetches instance i
-//    (coalesced id load + two 16-byte record gathers + colour, issued one batch AHEAD so the gather
-//    latency hides behind the blend loop), tests exactly whether the splat can reach alpha >= 1/255
-//    anywhere in the wave's 8x8 block (block_min_half_quad), and the survivors are compacted into a
-//    per-wave LDS queue with a ballot + prefix-popcount.  With surface splats of ~4 px radius this drops
-//    most of the (Gaussian, pixel) pairs the reference evaluates only to reject.
-//  * The blend loop reads survivors from LDS at wave-uniform addresses (broadcast ds_read_b128) --
-//    position, conic, opacity AND colour come from LDS; the reference gathers colour from global memory
-//    per pixel (forward.cu:355).  It is unrolled four survivors deep and branch-free: the four Gaussian
-//    exponents/alphas are independent and evaluated together, only the short T-update chain is serial.
-//    A tile's list is a serial dependency per pixel, so the kernel's tail is the LATENCY of the longest
-//    list on a nearly empty chip; instruction-level parallelism, not occupancy, is what shortens it.
+//    (coalesced id load two batches ahead, two 16-byte record gathers + colour one batch ahead), parks
+//    it in LDS, and tests it exactly (block_min_half_quad) against each of the four quadrants that still
+//    has an unsaturated pixel; a ballot + prefix-popcount per quadrant appends the lane's index to that
+//    quadrant's byte queue -- depth order is preserved per quadrant, which is all a pixel needs.
+//  * The blend loop is four queue slots deep and branch-free: the four exponents/alphas are independent
+//    and evaluated together, only the short T-update chain is serial.  Position, conic, opacity AND
+//    colour come from LDS (the reference gathers colour from global memory per pixel, forward.cu:355).
 //
 // n_contrib stores the 1-based list position of the last blended instance, as the reference does.
 #include "gsr_internal.h"
 
 namespace gsr {
 
-struct __attribute__((aligned(16))) Slot {   // 48 B per queued instance
+struct __attribute__((aligned(16))) Slot {   // 48 B per fetched instance
     float4 a;   // x, y, conic_a, conic_b
     float4 b;   // conic_c, opacity, r, g
     float4 c;   // blue, list position + 1 (as uint bits), -, -
@@ -52,63 +52,83 @@ __device__ __forceinline__ Fetched fetch_record(uint32_t gid, const float4* __re
     return f;
 }
 
+constexpr int QCAP = 64 + 4;   // queue capacity per quadrant (+4: the 4-deep loop reads whole words)
+
 __global__ void __launch_bounds__(256)
 blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ order,
-                 const uint32_t* __restrict__ point_list,
-                 const float4* __restrict__ g0, const float4* __restrict__ g1, const float* __restrict__ feats,
-                 const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ final_T,
-                 uint32_t* __restrict__ n_contrib, uint64_t* __restrict__ trace)
+                 const uint32_t* __restrict__ point_list, const float4* __restrict__ g0,
+                 const float4* __restrict__ g1, const float* __restrict__ feats, const float* __restrict__ bg,
+                 float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                 uint64_t* __restrict__ trace)
 {
     const uint64_t t_start = trace ? wall_clock64() : 0;
-    __shared__ Slot queue[4][64 + 4];   // +4 neutral slots so the 4-deep loop needs no tail handling
+    __shared__ Slot entries[4][64 + 1];                               // [wave][batch lane]; slot 64 = neutral
+    __shared__ __attribute__((aligned(4))) uint8_t qidx[4][4][QCAP];  // [wave][quadrant][queue position]
     const int tile = (int)order[blockIdx.x];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = lane >> 4;                                        // DPP row = quadrant
     const int tx = tile % gx, ty = tile / gx;
     const int sx = tx * TILE + (wave & 1) * SUB, sy = ty * TILE + (wave >> 1) * SUB;
-    const int px = sx + (lane & 7), py = sy + (lane >> 3);
+    const int px = sx + (row & 1) * 4 + (lane & 3), py = sy + (row >> 1) * 4 + ((lane >> 2) & 3);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
-    const float bx0 = (float)sx, bx1 = (float)(sx + SUB - 1), by0 = (float)sy, by1 = (float)(sy + SUB - 1);
 
     const uint2 rg = ranges[tile];
     const uint32_t n = rg.y - rg.x;
     const uint32_t* list = point_list + rg.x;
-    Slot* q = queue[wave];
+    Slot* ent = entries[wave];
+    uint8_t (*qi)[QCAP] = qidx[wave];
+
+    if (lane == 0) {   // neutral instance: opacity 0 never passes the alpha test
+        ent[64].a = make_float4(0.f, 0.f, 0.f, 0.f);
+        ent[64].b = make_float4(0.f, 0.f, 0.f, 0.f);
+        ent[64].c = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 
     float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f;
     uint32_t last = 0;
     bool done = !inside;
+    const unsigned long long lt = (1ull << lane) - 1ull;
 
     Fetched nxt = fetch_record(fetch_id(lane, n, list), g0, g1, feats);
     uint32_t gid_nxt = fetch_id(64 + lane, n, list);
     for (uint32_t base = 0; base < n; base += 64) {
-        if (__ballot(!done) == 0ull) break;
+        const unsigned long long alive = __ballot(!done);
+        if (alive == 0ull) break;
         const Fetched cur = nxt;
         nxt = fetch_record(gid_nxt, g0, g1, feats);         // records of batch +1 (ids arrived during the last batch)
         gid_nxt = fetch_id(base + 128 + lane, n, list);     // ids of batch +2
         const uint32_t k = base + lane;
-        const bool keep = block_min_half_quad(cur.a.z, cur.a.w, cur.b.x, bx0 - cur.a.x, bx1 - cur.a.x, by0 - cur.a.y,
-                                              by1 - cur.a.y) <= cur.b.z;
-        const unsigned long long m = __ballot(keep);
-        const int cnt = __popcll(m);
-        if (keep) {
-            const int slot = __popcll(m & ((1ull << lane) - 1ull));
-            q[slot].a = cur.a;
-            q[slot].b = make_float4(cur.b.x, cur.b.y, cur.fr, cur.fg);
-            q[slot].c = make_float4(cur.fb, __uint_as_float(k + 1), 0.f, 0.f);
+        ent[lane].a = cur.a;
+        ent[lane].b = make_float4(cur.b.x, cur.b.y, cur.fr, cur.fg);
+        ent[lane].c = make_float4(cur.fb, __uint_as_float(k + 1), 0.f, 0.f);
+        // exact reachability test against each quadrant that still has an unsaturated pixel
+        int cnt[4];
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++) {
+            const float X0 = (float)(sx + (qd & 1) * 4) - cur.a.x, Y0 = (float)(sy + (qd >> 1) * 4) - cur.a.y;
+            const bool keep = ((alive >> (16 * qd)) & 0xffffull) != 0ull &&
+                              block_min_half_quad(cur.a.z, cur.a.w, cur.b.x, X0, X0 + 3.f, Y0, Y0 + 3.f) <= cur.b.z;
+            const unsigned long long m = __ballot(keep);
+            cnt[qd] = __popcll(m);
+            if (keep) qi[qd][__popcll(m & lt)] = (uint8_t)lane;
+            if (lane < 4) qi[qd][cnt[qd] + lane] = 64;   // pad to a multiple of 4 with the neutral instance
         }
-        if (lane < 4) {   // neutral padding behind the survivors: opacity 0 never passes the alpha test
-            q[cnt + lane].a = make_float4(0.f, 0.f, 0.f, 0.f);
-            q[cnt + lane].b = make_float4(0.f, 0.f, 0.f, 0.f);
-            q[cnt + lane].c = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        const int my_cnt = row == 0 ? cnt[0] : row == 1 ? cnt[1] : row == 2 ? cnt[2] : cnt[3];
+        const int max_cnt = max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3]));
         __builtin_amdgcn_wave_barrier();
-        for (int j = 0; j < cnt; j += 4) {
+        const uint8_t* myq = qi[row];
+        for (int j = 0; j < max_cnt; j += 4) {
+            // four queue positions at once; rows past their own queue end read the neutral instance
+            const uint32_t packed = j < my_cnt ? *reinterpret_cast<const uint32_t*>(myq + j) : 0x40404040u;
             float4 A[4], B[4], Cc[4];
             float alpha[4];
             bool ok[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { A[u] = q[j + u].a; B[u] = q[j + u].b; Cc[u] = q[j + u].c; }
+            for (int u = 0; u < 4; u++) {
+                const int e = (packed >> (8 * u)) & 0xff;
+                A[u] = ent[e].a; B[u] = ent[e].b; Cc[u] = ent[e].c;
+            }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const float dx = A[u].x - pxf, dy = A[u].y - pyf;

@@ -271,8 +271,10 @@ __device__ __forceinline__ float block_min_half_quad(float a, float b, float c, 
 #pragma clang fp contract(off)
     const float xc = fminf(fmaxf(0.0f, X0), X1);
     const float yc = fminf(fmaxf(0.0f, Y0), Y1);
-    const float ys = fminf(fmaxf(-(b * xc) / c, Y0), Y1);
-    const float xs = fminf(fmaxf(-(b * yc) / a, X0), X1);
+    // v_rcp_f32 instead of an IEEE division: any point of the rectangle is a valid (conservative) candidate,
+    // so the ulp of the quotient is irrelevant; what matters is that it is one deterministic instruction.
+    const float ys = fminf(fmaxf(-(b * xc) * __builtin_amdgcn_rcpf(c), Y0), Y1);
+    const float xs = fminf(fmaxf(-(b * yc) * __builtin_amdgcn_rcpf(a), X0), X1);
     const float fx = 0.5f * ((a * xc) * xc + (c * ys) * ys) + (b * xc) * ys;
     const float fy = 0.5f * ((a * xs) * xs + (c * yc) * yc) + (b * xs) * yc;
     return fminf(fx, fy);
