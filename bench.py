@@ -150,10 +150,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank, world, local = gdist.init_from_env("nccl")
+    # GSR_BENCH_BACKEND=gloo lets the multi-rank path be exercised on a box with fewer GPUs than ranks
+    # (ranks then share devices; RCCL itself refuses two ranks on one GPU).  Default: nccl (= RCCL).
+    backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and int(os.environ.get("WORLD_SIZE", "1")) > ndev:
+        raise SystemExit(f"WORLD_SIZE={os.environ.get('WORLD_SIZE')} ranks but only {ndev} GPUs visible")
+    local_env = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_env % max(ndev, 1))
+    rank, world, local = gdist.init_from_env(backend)
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    device = torch.device("cuda", local if world > 1 else 0)
+    device = torch.device("cuda", (local % max(ndev, 1)) if world > 1 else 0)
     torch.cuda.set_device(device)
     lib = _lib.load()
 
