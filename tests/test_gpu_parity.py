@@ -278,3 +278,77 @@ def test_long_tile_lists_use_the_big_lds_sort():
     assert (st["ranges"][:, 1] - st["ranges"][:, 0]).max() > 2048
     hip = parity.run_hip(kw, dpix)
     parity.compare_hip_to(hip, st["color"], st["radii"], g, what="long lists")
+
+
+# ------------------------------------------------------------------ robustness: sizes, streams, extremes
+def _compare_with_ref_or_oracle(kw, dpix, what, radii_slack=1):
+    from oracle import ref
+    hip = parity.run_hip(kw, dpix)
+    if ref.available():
+        rr = ref.RefRasterizer()
+        color, radii, _ = rr.forward(**kw)
+        g = {k: v.cpu().numpy() for k, v in rr.backward(dpix).items()}
+        color, radii = color.cpu().numpy(), radii.cpu().numpy()
+    else:
+        st, g = parity.run_oracle(kw, dpix)
+        color, radii = st["color"], st["radii"]
+    assert (hip["radii"] != radii).sum() <= radii_slack
+    hip["radii"] = radii
+    parity.compare_hip_to(hip, color, radii, g, what=what)
+
+
+def test_4k_image_many_tiles():
+    """3840x2160 = 32 400 tiles: exercises the wide tile-scan variant and 16-bit tile rects."""
+    from gaustar_amd import scene
+    rng = np.random.default_rng(21)
+    gs = scene.random_gaussians(60_000, rng, scale_range=(0.004, 0.05))
+    cam = scene.look_at_camera((0.2, 0.1, -4.0), (0, 0, 0), 3840, 2160, fovx=0.9, znear=0.01)
+    kw = _kw(gs, cam, np.array([0.1, 0.2, 0.3], np.float32))
+    dpix = rng.normal(size=(3, cam.H, cam.W)).astype(np.float32)
+    _compare_with_ref_or_oracle(kw, dpix, "4k")
+
+
+@pytest.mark.parametrize("W,H", [(1, 1), (17, 33), (16, 16), (250, 9)])
+def test_tiny_and_odd_image_sizes(W, H):
+    from gaustar_amd import scene
+    rng = np.random.default_rng(W * 100 + H)
+    gs = scene.random_gaussians(200, rng, scale_range=(0.05, 0.4))
+    cam = scene.look_at_camera((0, 0, -4.0), (0, 0, 0), W, H, fovx=0.8, znear=0.01)
+    kw = _kw(gs, cam, np.array([0.9, 0.1, 0.5], np.float32))
+    dpix = rng.normal(size=(3, H, W)).astype(np.float32)
+    _compare_with_ref_or_oracle(kw, dpix, f"{W}x{H}")
+
+
+def test_screen_filling_splats_and_giant_tile_lists():
+    """Splats that cover every tile (rect = whole grid) and > 16 384 instances per tile (the
+    global-memory sort network), at a size the reference build finishes quickly."""
+    from gaustar_amd import scene
+    rng = np.random.default_rng(33)
+    gs = scene.random_gaussians(18_000, rng, scale_range=(0.6, 1.5), box=((-0.3, 0.3), (-0.3, 0.3), (-0.5, 0.5)))
+    gs.opacities[:] = rng.uniform(0.004, 0.012, (gs.P, 1)).astype(np.float32)   # keep every pixel unsaturated: deep lists
+    cam = scene.look_at_camera((0, 0, -4.0), (0, 0, 0), 96, 64, fovx=0.6, znear=0.01)
+    kw = _kw(gs, cam, np.zeros(3, np.float32))
+    dpix = rng.normal(size=(3, cam.H, cam.W)).astype(np.float32)
+    _compare_with_ref_or_oracle(kw, dpix, "giant lists")
+
+
+def test_non_default_stream_and_degree_validation():
+    import torch
+    from gaustar_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib
+    kw, d = parity.load_golden("sh2_random")
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
+    mk = lambda deg: GaussianRasterizationSettings(kw["H"], kw["W"], kw["tanfovx"], kw["tanfovy"], t(kw["bg"]), 1.0,
+                                                   t(kw["view"]), t(kw["proj"]), deg, t(kw["campos"]), False, False)
+    args = dict(means3D=t(kw["means3D"]), means2D=torch.zeros(len(kw["means3D"]), 3, device=dev),
+                opacities=t(kw["opacities"]), shs=t(kw["shs"]), scales=t(kw["scales"]), rotations=t(kw["rotations"]))
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        color, radii = GaussianRasterizer(mk(2))(**args)
+    side.synchronize()
+    parity.check_image(color.cpu().numpy(), d["out_color"], "side stream")
+    with pytest.raises(_lib.GsrError, match="sh degree"):
+        GaussianRasterizer(mk(3))(**args)          # 9 coefficients cannot hold degree 3
+    with pytest.raises(_lib.GsrError, match="sh degree"):
+        GaussianRasterizer(mk(4))(**args)
