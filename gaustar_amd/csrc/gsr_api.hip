@@ -81,13 +81,16 @@ int fail_msg(const char* msg)
 
 extern "C" {
 
-int gsr_abi_version(void) { return 2; }
+int gsr_abi_version(void) { return 3; }
 
 const char* gsr_last_error(void) { return g_err.c_str(); }
 
 size_t gsr_geom_bytes(int P) { return carve_geom(nullptr, P > 0 ? P : 0).bytes; }
 size_t gsr_image_bytes(int W, int H) { return carve_image(nullptr, W, H).bytes; }
-size_t gsr_binning_bytes(int R) { return carve_bin(nullptr, R > 0 ? R : 0).bytes; }
+size_t gsr_binning_bytes(int R, int num_segments)
+{
+    return carve_bin(nullptr, R > 0 ? R : 0, num_segments > 0 ? num_segments : 0).bytes;
+}
 size_t gsr_grad_scratch_bytes(int P) { return (size_t)48 * (size_t)(P > 0 ? P : 0) + 256; }
 
 int gsr_forward_stage1(int P, int D, int M, const float* means3D, const float* shs, const float* colors_precomp,
@@ -95,13 +98,17 @@ int gsr_forward_stage1(int P, int D, int M, const float* means3D, const float* s
                        const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                        const float* campos, int W, int H, float tan_fovx, float tan_fovy, int prefiltered, int* radii,
                        void* geom_buffer, void* image_buffer, int* num_rendered, int* max_tile_instances,
-                       gsr_stream_t stream)
+                       int* num_segments, gsr_stream_t stream)
 {
     (void)prefiltered;   // the reference only uses it to trap on a culled point (auxiliary.h:156-160)
     g_err.clear();
-    if (!num_rendered || !max_tile_instances) return fail_msg("gsr_forward_stage1: null output pointer");
+    if (!num_rendered || !max_tile_instances || !num_segments)
+        return fail_msg("gsr_forward_stage1: null output pointer");
     *num_rendered = 0;
     *max_tile_instances = 0;
+    *num_segments = 0;
+    if ((long long)tiles_of(W > 0 ? W : 1, H > 0 ? H : 1).T > 256ll * 1024)
+        return fail_msg("gsr_forward_stage1: image too large (more than 262144 tiles)");
     if (W <= 0 || H <= 0) return fail_msg("gsr_forward_stage1: image size must be positive");
     if (P < 0) return fail_msg("gsr_forward_stage1: negative P");
     if (!image_buffer) return fail_msg("gsr_forward_stage1: image_buffer is null");
@@ -138,10 +145,11 @@ int gsr_forward_stage1(int P, int D, int M, const float* means3D, const float* s
     GSR_CHECK(hipStreamSynchronize(st));   // the forward's single host sync (cf. rasterizer_impl.cu:281)
     *num_rendered = (int)g_pinned[0];
     *max_tile_instances = (int)g_pinned[1];
+    *num_segments = (int)g_pinned[3];
     return 0;
 }
 
-int gsr_forward_stage2(int P, int R, int max_tile_instances, int W, int H, const float* background,
+int gsr_forward_stage2(int P, int R, int max_tile_instances, int num_segments, int W, int H, const float* background,
                        const float* colors_precomp, void* geom_buffer, void* binning_buffer, void* image_buffer,
                        float* out_color, gsr_stream_t stream)
 {
@@ -152,7 +160,7 @@ int gsr_forward_stage2(int P, int R, int max_tile_instances, int W, int H, const
     hipStream_t st = (hipStream_t)stream;
     ImageState im = carve_image(image_buffer, W, H);
     GeomState g = carve_geom(geom_buffer, P > 0 ? P : 0);
-    BinState b = carve_bin(binning_buffer, R > 0 ? R : 0);
+    BinState b = carve_bin(binning_buffer, R > 0 ? R : 0, num_segments > 0 ? num_segments : 0);
     if (R > 0) {
         {
             Scope sc(ST_SCATTER, st);
@@ -187,19 +195,20 @@ int gsr_forward(gsr_alloc_fn geometry_buffer, gsr_alloc_fn binning_buffer, gsr_a
     void* geom = geometry_buffer(alloc_ctx, gsr_geom_bytes(P));
     void* img = image_buffer(alloc_ctx, gsr_image_bytes(W, H));
     if (!geom || !img) return fail_msg("gsr_forward: allocator callback returned null");
-    int R = 0, maxc = 0;
+    int R = 0, maxc = 0, nseg = 0;
     int rc = gsr_forward_stage1(P, D, M, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
                                 cov3D_precomp, viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, prefiltered,
-                                radii, geom, img, &R, &maxc, stream);
+                                radii, geom, img, &R, &maxc, &nseg, stream);
     if (rc) return rc;
-    void* bin = binning_buffer(alloc_ctx, gsr_binning_bytes(R));
+    void* bin = binning_buffer(alloc_ctx, gsr_binning_bytes(R, nseg));
     if (!bin) return fail_msg("gsr_forward: allocator callback returned null");
-    rc = gsr_forward_stage2(P, R, maxc, W, H, background, colors_precomp, geom, bin, img, out_color, stream);
+    rc = gsr_forward_stage2(P, R, maxc, nseg, W, H, background, colors_precomp, geom, bin, img, out_color, stream);
     *num_rendered = R;
     return rc;
 }
 
-int gsr_backward(int P, int D, int M, int R, const float* background, int W, int H, const float* means3D,
+int gsr_backward(int P, int D, int M, int R, int num_segments, const float* background, int W, int H,
+                 const float* means3D,
                  const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
                  const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                  const float* campos, float tan_fovx, float tan_fovy, const int* radii, const void* geom_buffer,
@@ -222,7 +231,7 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int W, int
     hipStream_t st = (hipStream_t)stream;
     ImageState im = carve_image(const_cast<void*>(image_buffer), W, H);
     GeomState g = carve_geom(const_cast<void*>(geom_buffer), P);
-    BinState b = carve_bin(const_cast<void*>(binning_buffer), R > 0 ? R : 0);
+    BinState b = carve_bin(const_cast<void*>(binning_buffer), R > 0 ? R : 0, num_segments > 0 ? num_segments : 0);
     // Zero the packed moment records (the only atomic targets); every output tensor is written outright
     // by geom_bwd (cf. the nine zeroed tensors of rasterize_points.cu:151-159).
     float* grad_acc = static_cast<float*>(grad_scratch);
@@ -234,7 +243,7 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int W, int
     if (R > 0) {
         {
             Scope sc(ST_BLEND_BWD, st);
-            launch_blend_bwd(W, H, background, feats, g, im, b, dL_dpix, grad_acc, st);
+            launch_blend_bwd(W, H, num_segments, background, feats, g, im, b, dL_dpix, grad_acc, st);
         }
         GSR_CHECK_LAUNCH("blend_bwd_kernel");
     }
@@ -314,7 +323,7 @@ __global__ void export_geom_kernel(int P, const float4* g0, const float4* g1, co
     if (rgb) { rgb[3 * i] = rgb_in[3 * i]; rgb[3 * i + 1] = rgb_in[3 * i + 1]; rgb[3 * i + 2] = rgb_in[3 * i + 2]; }
 }
 
-int gsr_debug_export(int P, int R, int W, int H, const void* geom_buffer, const void* binning_buffer,
+int gsr_debug_export(int P, int R, int num_segments, int W, int H, const void* geom_buffer, const void* binning_buffer,
                      const void* image_buffer, float* means2D, float* conic_opacity, float* depths, float* rgb,
                      uint32_t* tile_ranges, uint32_t* point_list, float* final_T, uint32_t* n_contrib,
                      gsr_stream_t stream)
@@ -336,7 +345,7 @@ int gsr_debug_export(int P, int R, int W, int H, const void* geom_buffer, const 
         if (n_contrib) GSR_CHECK(hipMemcpyAsync(n_contrib, im.n_contrib, 4 * N, hipMemcpyDeviceToDevice, st));
     }
     if (R > 0 && binning_buffer && point_list) {
-        BinState b = carve_bin(const_cast<void*>(binning_buffer), R);
+        BinState b = carve_bin(const_cast<void*>(binning_buffer), R, num_segments > 0 ? num_segments : 0);
         GSR_CHECK(hipMemcpyAsync(point_list, b.point_list, 4 * (size_t)R, hipMemcpyDeviceToDevice, st));
     }
     return 0;

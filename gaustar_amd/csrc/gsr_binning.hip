@@ -36,9 +36,11 @@ __device__ __forceinline__ int length_bucket(uint32_t c)
 template <int PER>
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges,
-                 uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ totals, uint32_t* __restrict__ order)
+                 uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ totals, uint32_t* __restrict__ order,
+                 uint32_t* __restrict__ seg_off)
 {
     __shared__ uint32_t wave_sum[16];
+    __shared__ uint32_t wave_seg[16];
     __shared__ uint32_t wave_max[16];
     __shared__ uint32_t bucket_n[NBUCKET];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -50,28 +52,32 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
         const uint4 v = (t0 + k < T) ? *reinterpret_cast<const uint4*>(tile_count + t0 + k) : make_uint4(0, 0, 0, 0);
         c[k] = v.x; c[k + 1] = v.y; c[k + 2] = v.z; c[k + 3] = v.w;
     }
-    uint32_t sum = 0, vmax = 0;
+    uint32_t sum = 0, vmax = 0, segs = 0;
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         if (t0 + k >= T) c[k] = 0;
         sum += c[k];
+        segs += (c[k] + (uint32_t)SEG - 1u) / (uint32_t)SEG;
         vmax = max(vmax, c[k]);
     }
     const uint32_t incl = wave_incl_scan(sum, lane);
+    const uint32_t incl_seg = wave_incl_scan(segs, lane);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, d, 64));
-    if (lane == 63) wave_sum[wave] = incl;
+    if (lane == 63) { wave_sum[wave] = incl; wave_seg[wave] = incl_seg; }
     if (lane == 0) wave_max[wave] = vmax;
     __syncthreads();
-    uint32_t woff = 0, total = 0, gmax = 0;
+    uint32_t woff = 0, total = 0, gmax = 0, woff_seg = 0, total_seg = 0;
 #pragma unroll
     for (int w = 0; w < 16; w++) {
-        const uint32_t s = wave_sum[w];
-        if (w < wave) woff += s;
+        const uint32_t s = wave_sum[w], sg = wave_seg[w];
+        if (w < wave) { woff += s; woff_seg += sg; }
         total += s;
+        total_seg += sg;
         gmax = max(gmax, wave_max[w]);
     }
     uint32_t run = woff + incl - sum;
+    uint32_t run_seg = woff_seg + incl_seg - segs;
     uint32_t n_empty = 0;   // empty tiles dominate: count them privately, one LDS atomic per thread
 #pragma unroll
     for (int k = 0; k < PER; k++) {
@@ -79,7 +85,9 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
         if (t < T) {
             ranges[t] = make_uint2(run, run + c[k]);
             tile_cursor[t] = run;
+            seg_off[t] = run_seg;
             run += c[k];
+            run_seg += (c[k] + (uint32_t)SEG - 1u) / (uint32_t)SEG;
             if (c[k] == 0) n_empty++;
             else atomicAdd(&bucket_n[length_bucket(c[k])], 1u);
         }
@@ -90,7 +98,8 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
         totals[0] = total;
         totals[1] = gmax;
         totals[2] = (uint32_t)T - bucket_n[NBUCKET - 1];
-        totals[3] = 0;
+        totals[3] = total_seg;
+        seg_off[T] = total_seg;
     }
     if (wave == 1) {   // exclusive prefix over the 66 buckets -> start offsets (in place)
         const uint32_t c0 = bucket_n[lane];
@@ -121,11 +130,14 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
 void launch_tile_scan(ImageState im, int T, hipStream_t st)
 {
     if (T <= 8 * 1024)          // up to 1920x1088
-        tile_scan_kernel<8><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.tile_cursor, im.totals, im.order);
+        tile_scan_kernel<8><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.tile_cursor, im.totals, im.order,
+                                             im.seg_off);
     else if (T <= 36 * 1024)    // up to 4096x2304
-        tile_scan_kernel<36><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.tile_cursor, im.totals, im.order);
+        tile_scan_kernel<36><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.tile_cursor, im.totals, im.order,
+                                             im.seg_off);
     else                        // up to ~8k x 8k
-        tile_scan_kernel<256><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.tile_cursor, im.totals, im.order);
+        tile_scan_kernel<256><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.tile_cursor, im.totals, im.order,
+                                             im.seg_off);
 }
 
 // One thread per Gaussian: claim a slot in every reachable tile's bucket and store the sort key.  Walks exactly
@@ -135,10 +147,17 @@ void launch_tile_scan(ImageState im, int T, hipStream_t st)
 __global__ void __launch_bounds__(256)
 scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __restrict__ g0,
                const float4* __restrict__ g1, const float* __restrict__ depth, uint32_t* __restrict__ tile_cursor,
-               uint64_t* __restrict__ keys)
+               uint64_t* __restrict__ keys, int T, const uint32_t* __restrict__ seg_off,
+               uint32_t* __restrict__ unit_tile)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    // side job of the first T threads: expand the per-tile segment counts into the unit -> tile table
+    // (it lives in the binning buffer, which did not exist yet when the scan kernel ran)
+    if (idx < T) {
+        const uint32_t u0 = seg_off[idx], u1 = seg_off[idx + 1];
+        for (uint32_t u = u0; u < u1; u++) unit_tile[u] = (uint32_t)idx;
+    }
     ushort4 r = make_ushort4(0, 0, 0, 0);
     float4 a = make_float4(0.f, 0.f, 1.f, 0.f), b = make_float4(1.f, 0.f, -1.f, 0.f);
     uint64_t key = 0;
@@ -161,7 +180,9 @@ scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __
 void launch_scatter(int P, int W, int H, GeomState g, ImageState im, BinState b, hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);
-    scatter_kernel<<<(P + 255) / 256, 256, 0, st>>>(P, t.gx, g.rect, g.g0, g.g1, g.depth, im.tile_cursor, b.keys);
+    const int n = P > t.T ? P : t.T;
+    scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(P, t.gx, g.rect, g.g0, g.g1, g.depth, im.tile_cursor, b.keys, t.T,
+                                                    im.seg_off, b.unit_tile);
 }
 
 // ---- per-tile bitonic sort of 64-bit keys in LDS.

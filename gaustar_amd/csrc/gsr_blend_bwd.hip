@@ -4,23 +4,30 @@
 // SURVEY.md section 9 item 10): back-to-front replay, T recovered by division, accum_rec recurrence,
 // background term with T_final/(1-alpha), the 0.99 alpha clamp passing gradient as if unclamped.
 //
-// What differs is how the per-pair terms reach memory.  The reference issues 9 global float
-// atomicAdds per contributing (pixel, Gaussian) pair (backward.cu:523, :545-554).  Here
+// What differs is the decomposition and how the per-pair terms reach memory.  The reference runs one block
+// per tile over the whole list and issues 9 global float atomicAdds per contributing (pixel, Gaussian) pair
+// (backward.cu:523, :545-554).  Here
 //
-//  * a wave64 owns an 8x8 pixel block and walks the tile list back-to-front 64 instances at a time
-//    (next batch fetched one step ahead); instances that cannot reach alpha >= 1/255 inside the block
-//    (exact test, block_min_half_quad) never enter the per-wave LDS queue;
+//  * the work unit is a (tile, SEGMENT of SEG list positions) pair.  A pixel whose last contributor lies
+//    beyond the segment starts from the forward pass's snapshot at the segment's far boundary:
+//    T = T_snap, accum_rec = (C_final - C_snap) / T_snap -- exactly the state the reference's back-to-front
+//    recurrence has at that list position; a pixel that ends inside the segment starts from (T_final, 0)
+//    like the reference; a pixel that ended before it is idle.  Units have bounded size, so the dispatcher
+//    can balance them and no workgroup carries a 1 600-instance serial chain;
+//  * inside a unit a wave64 owns an 8x8 pixel block and walks the segment back-to-front 64 instances at a
+//    time (ids fetched two batches ahead, records one); instances that cannot reach alpha >= 1/255 inside the
+//    block (exact test, block_min_half_quad) never enter the per-wave LDS queue;
 //  * for a queued instance every lane evaluates its pixel; what is summed over pixels is reduced to
 //    NINE linear moments  {sum w*dL_dpix_rgb, sum r, sum r*dx, sum r*dy, sum r*dx^2, sum r*dx*dy, sum r*dy^2}
 //    (w = alpha*T, r = G*dL_dalpha): dL_dcolor, dL_dopacity, dL_dmean2D and dL_dconic are fixed linear
-//    maps of them with per-Gaussian coefficients, applied once per Gaussian in geom_bwd instead of once
-//    per pair here;
+//    maps of them with per-Gaussian coefficients, applied once per Gaussian in geom_bwd;
 //  * the nine values are reduced across the 64 lanes in registers by a TRANSPOSING reduction:
 //    v_permlane32_swap / v_permlane16_swap + add fold eight values into one register (8 lanes per
 //    value), three DPP steps finish it -- 18 VALU ops for 8 values instead of 8 x 6 shuffle-adds;
 //  * totals are parked in a per-wave LDS table (one row per queued instance) and flushed once per batch
-//    with lane = instance: nine wave-wide atomic instructions per 64 instances instead of nine
-//    single-lane atomics per instance.  Target = the packed 48-byte record grad_acc[gaussian][12].
+//    ROW-MAJOR: one atomic instruction covers the nine consecutive floats of ~7 packed 48-byte records
+//    grad_acc[gaussian][12], so the memory pipeline merges lanes per cache line (1.5 M atomic requests per
+//    1080p view instead of 8 M).
 #include "gsr_internal.h"
 #include <cstdlib>
 
@@ -35,9 +42,9 @@ struct __attribute__((aligned(16))) SlotB {   // 48 B per queued instance
 struct FetchedB { float4 a, b; float fr, fg, fb; uint32_t gid; };
 
 // Two-stage software pipeline over the dependent gather (list -> id -> records), see gsr_blend_fwd.hip.
-__device__ __forceinline__ uint32_t fetch_id_b(int k, const uint32_t* __restrict__ list)
+__device__ __forceinline__ uint32_t fetch_id_b(int k, int k_min, const uint32_t* __restrict__ list)
 {
-    return k >= 0 ? list[k] : 0xffffffffu;
+    return k >= k_min ? list[k] : 0xffffffffu;
 }
 __device__ __forceinline__ FetchedB fetch_record_b(uint32_t gid, const float4* __restrict__ g0,
                                                    const float4* __restrict__ g1, const float* __restrict__ feats)
@@ -109,21 +116,26 @@ __device__ __forceinline__ void atomic_add_f32(float* p, float v)
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-constexpr int ACC_STRIDE = 9;   // odd stride: conflict-free row-per-lane reads in the flush
+constexpr int ACC_STRIDE = 9;
 
-__global__ void __launch_bounds__(256)
-blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ order,
-                 const uint32_t* __restrict__ point_list,
-                 const float4* __restrict__ g0, const float4* __restrict__ g1, const float* __restrict__ feats,
-                 const float* __restrict__ bg, const float* __restrict__ final_T,
+__global__ void __launch_bounds__(64)
+blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ seg_off,
+                 const uint32_t* __restrict__ unit_tile, const float4* __restrict__ snap,
+                 const uint32_t* __restrict__ point_list, const float4* __restrict__ g0,
+                 const float4* __restrict__ g1, const float* __restrict__ feats, const float* __restrict__ bg,
+                 const float* __restrict__ final_T,
                  const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
                  float* __restrict__ grad_acc, uint64_t* __restrict__ trace)
 {
     const uint64_t t_start = trace ? wall_clock64() : 0;
-    __shared__ SlotB queue[4][64];
-    __shared__ float totals[4][64 * ACC_STRIDE];
-    const int tile = (int)order[blockIdx.x];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ SlotB queue[64];
+    __shared__ float totals[64 * ACC_STRIDE];
+    // one wave64 per workgroup: unit = (tile, segment), wave = 8x8 block of the tile
+    const uint32_t unit = blockIdx.x >> 2;
+    const int tile = (int)unit_tile[unit];
+    const uint32_t unit0 = seg_off[tile];
+    const int s0 = (int)(unit - unit0) * SEG;          // this unit covers list positions [s0, s1)
+    const int wave = blockIdx.x & 3, lane = threadIdx.x;
     const int tx = tile % gx, ty = tile / gx;
     const int sx = tx * TILE + (wave & 1) * SUB, sy = ty * TILE + (wave >> 1) * SUB;
     const int px = sx + (lane & 7), py = sy + (lane >> 3);
@@ -133,35 +145,51 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     const bool hi8 = (lane & 8) != 0;
 
     const uint2 rg = ranges[tile];
+    const int n = (int)(rg.y - rg.x);
+    const int s1 = min(s0 + SEG, n);
     const uint32_t* list = point_list + rg.x;
-    SlotB* q = queue[wave];
-    float* tot = totals[wave];
+    SlotB* q = queue;
+    float* tot = totals;
 
     const size_t pix = (size_t)W * py + px;
     const size_t HW = (size_t)H * W;
     const float T_final = inside ? final_T[pix] : 0.f;
-    const uint32_t my_last = inside ? n_contrib[pix] : 0u;   // 1-based position of the last contributor
+    const int my_last = inside ? (int)n_contrib[pix] : 0;   // 1-based position of the last contributor
     float dpr = 0.f, dpg = 0.f, dpb = 0.f;
     if (inside) { dpr = dL_dpix[pix]; dpg = dL_dpix[HW + pix]; dpb = dL_dpix[2 * HW + pix]; }
     const float bg_dot_dpixel = bg[0] * dpr + bg[1] * dpg + bg[2] * dpb;
 
-    // Nothing behind the deepest contributor of this wave can matter.
-    uint32_t wave_last = my_last;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, d, 64));
-    wave_last = __builtin_amdgcn_readfirstlane(wave_last);
-
+    // Per-pixel start state at the far end of the segment.
     float T = T_final;
     float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, last_alpha = 0.f, last_r = 0.f, last_g = 0.f, last_b = 0.f;
+    const int my_lim = min(my_last, s1);                 // this pixel replays positions [s0, my_lim)
+    if (my_last > s1) {
+        // the pixel blended instances beyond this segment: resume from the forward's snapshot taken before
+        // list position s1.  accum_rec at that point = colour composited behind s1, seen from s1.
+        const int pidx = 16 * (py - ty * TILE) + (px - tx * TILE);
+        const float4 sn = snap[(size_t)(unit + 1) * 256 + pidx];
+        const float4 fin = snap[(size_t)unit0 * 256 + pidx];   // {C_final rgb, T_final} kept in the tile's first slot
+        const float inv = __builtin_amdgcn_rcpf(sn.x);
+        T = sn.x;
+        acc_r = (fin.x - sn.y) * inv;
+        acc_g = (fin.y - sn.z) * inv;
+        acc_b = (fin.z - sn.w) * inv;
+    }
+
+    // Nothing behind the deepest position any pixel of this wave replays can matter.
+    int wave_hi = my_lim;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) wave_hi = max(wave_hi, __shfl_xor(wave_hi, d, 64));
+    wave_hi = __builtin_amdgcn_readfirstlane(wave_hi);
 
     // lane l takes list position hi-1-l: queue order == back-to-front order
-    FetchedB nxt = fetch_record_b(fetch_id_b((int)wave_last - 1 - lane, list), g0, g1, feats);
-    uint32_t gid_nxt = fetch_id_b((int)wave_last - 65 - lane, list);
-    for (int hi = (int)wave_last; hi > 0; hi -= 64) {
+    FetchedB nxt = fetch_record_b(fetch_id_b(wave_hi - 1 - lane, s0, list), g0, g1, feats);
+    uint32_t gid_nxt = fetch_id_b(wave_hi - 65 - lane, s0, list);
+    for (int hi = wave_hi; hi > s0; hi -= 64) {
         const FetchedB cur = nxt;
         const int k = hi - 1 - lane;
         nxt = fetch_record_b(gid_nxt, g0, g1, feats);   // records of the next batch (ids arrived during the last one)
-        gid_nxt = fetch_id_b(k - 128, list);            // ids two batches ahead
+        gid_nxt = fetch_id_b(k - 128, s0, list);        // ids two batches ahead
         const bool keep = block_min_half_quad(cur.a.z, cur.a.w, cur.b.x, bx0 - cur.a.x, bx1 - cur.a.x, by0 - cur.a.y,
                                               by1 - cur.a.y) <= cur.b.z;
         const unsigned long long m = __ballot(keep);
@@ -176,12 +204,12 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         unsigned long long touched = 0ull;
         for (int j = 0; j < cnt; j++) {
             const float4 A = q[j].a, B = q[j].b, Cc = q[j].c;
-            const uint32_t pos = __float_as_uint(Cc.y);
+            const int pos = (int)__float_as_uint(Cc.y);
             const float dx = A.x - pxf, dy = A.y - pyf;
             const float power = pair_power(A.z, A.w, B.x, dx, dy);
             const float G = __expf(power);
             const float alpha = fminf(ALPHA_MAX, B.y * G);
-            const bool live = pos < my_last && power <= 0.0f && alpha >= ALPHA_MIN;
+            const bool live = pos < my_lim && power <= 0.0f && alpha >= ALPHA_MIN;
             if (__ballot(live) == 0ull) continue;
 
             float v_cr = 0.f, v_cg = 0.f, v_cb = 0.f, v_r = 0.f, v_rx = 0.f, v_ry = 0.f, v_rxx = 0.f, v_rxy = 0.f,
@@ -231,20 +259,20 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         __builtin_amdgcn_wave_barrier();
     }
     if (trace && lane == 0) {   // last wave to finish wins the end stamp (monotone clock, max via atomic)
-        if (wave == 0) trace[2 * blockIdx.x] = t_start;
-        atomicMax((unsigned long long*)&trace[2 * blockIdx.x + 1], (unsigned long long)wall_clock64());
+        if (wave == 0) trace[2 * unit] = t_start;
+        atomicMax((unsigned long long*)&trace[2 * unit + 1], (unsigned long long)wall_clock64());
     }
 }
 
-void launch_blend_bwd(int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
+void launch_blend_bwd(int W, int H, int U, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
                       const float* dL_dpix, float* grad_acc, hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);
-    // Residency knob: extra dynamic LDS lowers the number of co-resident tiles per CU so that the
-    // longest-first tile order is dispatched dynamically (tuning: GSR_BWD_LDS_PAD bytes).
+    if (U <= 0) return;
+    // Residency knob: extra dynamic LDS lowers the number of co-resident units per CU (tuning only).
     static const int pad = getenv("GSR_BWD_LDS_PAD") ? atoi(getenv("GSR_BWD_LDS_PAD")) : 0;
-    blend_bwd_kernel<<<t.T, 256, pad, st>>>(W, H, t.gx, im.ranges, im.order, b.point_list, g.g0, g.g1, feats, bg, im.final_T,
-                                          im.n_contrib, dL_dpix, grad_acc,
+    blend_bwd_kernel<<<4 * U, 64, pad, st>>>(W, H, t.gx, im.ranges, im.seg_off, b.unit_tile, b.snap, b.point_list, g.g0,
+                                          g.g1, feats, bg, im.final_T, im.n_contrib, dL_dpix, grad_acc,
                                           g_trace ? g_trace + 2 * (size_t)t.T : nullptr);
 }
 

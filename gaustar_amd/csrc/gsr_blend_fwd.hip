@@ -19,6 +19,8 @@
 //    colour come from LDS (the reference gathers colour from global memory per pixel, forward.cu:355).
 //
 // n_contrib stores the 1-based list position of the last blended instance, as the reference does.
+// At every SEG-th list position the running (T, C) of the pixels still alive is snapshotted for the
+// segment-parallel backward pass (gsr_blend_bwd.hip).
 #include "gsr_internal.h"
 
 namespace gsr {
@@ -59,7 +61,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                  const uint32_t* __restrict__ point_list, const float4* __restrict__ g0,
                  const float4* __restrict__ g1, const float* __restrict__ feats, const float* __restrict__ bg,
                  float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                 uint64_t* __restrict__ trace)
+                 const uint32_t* __restrict__ seg_off, float4* __restrict__ snap, uint64_t* __restrict__ trace)
 {
     const uint64_t t_start = trace ? wall_clock64() : 0;
     __shared__ Slot entries[4][64 + 1];                               // [wave][batch lane]; slot 64 = neutral
@@ -72,9 +74,11 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     const int px = sx + (row & 1) * 4 + (lane & 3), py = sy + (row >> 1) * 4 + ((lane >> 2) & 3);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
+    const int pix_in_tile = 16 * (py - ty * TILE) + (px - tx * TILE);
 
     const uint2 rg = ranges[tile];
     const uint32_t n = rg.y - rg.x;
+    const uint32_t unit0 = seg_off[tile];
     const uint32_t* list = point_list + rg.x;
     Slot* ent = entries[wave];
     uint8_t (*qi)[QCAP] = qidx[wave];
@@ -95,6 +99,10 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     for (uint32_t base = 0; base < n; base += 64) {
         const unsigned long long alive = __ballot(!done);
         if (alive == 0ull) break;
+        // segment boundary: snapshot the running state of every pixel still alive (the backward blend
+        // starts its segments from these instead of replaying the whole list)
+        if (base != 0 && (base % SEG) == 0 && !done)
+            snap[(size_t)(unit0 + base / SEG) * 256 + pix_in_tile] = make_float4(T, Cr, Cg, Cb);
         const Fetched cur = nxt;
         nxt = fetch_record(gid_nxt, g0, g1, feats);         // records of batch +1 (ids arrived during the last batch)
         gid_nxt = fetch_id(base + 128 + lane, n, list);     // ids of batch +2
@@ -159,6 +167,9 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         out_color[pix] = Cr + T * bg[0];
         out_color[HW + pix] = Cg + T * bg[1];
         out_color[2 * HW + pix] = Cb + T * bg[2];
+        // a tile with more than one segment: the first unit's snapshot slot (never used as a boundary) keeps the
+        // final composited colour, from which the backward derives "colour behind a boundary" = C_final - C_snap
+        if (n > (uint32_t)SEG) snap[(size_t)unit0 * 256 + pix_in_tile] = make_float4(Cr, Cg, Cb, T);
     }
     if (trace && lane == 0) {   // last wave to finish wins the end stamp
         if (wave == 0) trace[2 * blockIdx.x] = t_start;
@@ -171,7 +182,7 @@ void launch_blend_fwd(int W, int H, const float* bg, const float* feats, GeomSta
 {
     const Tiles t = tiles_of(W, H);
     blend_fwd_kernel<<<t.T, 256, 0, st>>>(W, H, t.gx, im.ranges, im.order, b.point_list, g.g0, g.g1, feats, bg, out_color,
-                                          im.final_T, im.n_contrib, g_trace);
+                                          im.final_T, im.n_contrib, im.seg_off, b.snap, g_trace);
 }
 
 }  // namespace gsr

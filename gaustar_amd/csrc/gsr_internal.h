@@ -52,10 +52,11 @@ struct ImageState {          // per pixel / per tile
     uint2* ranges;           // [T] {start, end} into point_list
     uint32_t* tile_count;    // [T] instances per tile (atomics in preprocess)
     uint32_t* tile_cursor;   // [T] scatter cursors
-    uint32_t* totals;        // [4] {R, max tile count, number of non-empty tiles, 0}
+    uint32_t* totals;        // [4] {R, max tile count, number of non-empty tiles, U = number of list segments}
     uint32_t* order;         // [T] tile ids, longest instance lists first (32-entry buckets), empty tiles last:
                              // the blockIdx -> tile map of the per-tile kernels (longest-processing-time-first
                              // dispatch evens out the very uneven per-tile work of a surface seen in perspective)
+    uint32_t* seg_off;       // [T+1] exclusive prefix of ceil(list length / SEG): first segment (unit) id of a tile
     size_t bytes;
 };
 inline ImageState carve_image(void* base, int W, int H)
@@ -69,20 +70,34 @@ inline ImageState carve_image(void* base, int W, int H)
     s.tile_cursor = (uint32_t*)(b + o); o = align_up(o + 4 * T);
     s.totals = (uint32_t*)(b + o); o = align_up(o + 16);
     s.order = (uint32_t*)(b + o); o = align_up(o + 4 * T);
+    s.seg_off = (uint32_t*)(b + o); o = align_up(o + 4 * (T + 1));
     s.bytes = o + 256;
     return s;
 }
 
-struct BinState {            // per instance
+// A tile's depth-sorted list is cut into SEGMENTS of SEG instances.  The forward blend snapshots every
+// pixel's running (T, C) at the segment boundaries it crosses; the backward blend then treats each
+// (tile, segment) as an independent workgroup-sized unit.  Per-tile work ranges over three orders of
+// magnitude for a surface seen in perspective; segments bound the unit size, which is what lets the
+// hardware dispatcher balance the backward pass and cuts its serial chain.
+constexpr int SEG = 64;
+
+struct BinState {            // per instance / per segment
     uint64_t* keys;          // [R] (depth_bits << 32) | gaussian, bucketed by tile, unsorted within the bucket
     uint32_t* point_list;    // [R] gaussian ids, tile-major, depth-ascending, ties by ascending id
+    uint32_t* unit_tile;     // [U] tile of segment (unit) u; its segment index is u - seg_off[tile]
+    float4* snap;            // [U][256] per-pixel {T, Cr, Cg, Cb} BEFORE the first instance of segment u (u not the
+                             // first segment of its tile; that slot holds {C_final rgb, T_final} when the tile has
+                             // more than one segment); pixel index = 16*(y - tile_y0) + (x - tile_x0)
     size_t bytes;
 };
-inline BinState carve_bin(void* base, int R)
+inline BinState carve_bin(void* base, int R, int U)
 {
     BinState s; size_t o = 0; char* b = (char*)base;
     s.keys = (uint64_t*)(b + o); o = align_up(o + 8 * (size_t)R);
     s.point_list = (uint32_t*)(b + o); o = align_up(o + 4 * (size_t)R);
+    s.unit_tile = (uint32_t*)(b + o); o = align_up(o + 4 * (size_t)U);
+    s.snap = (float4*)(b + o); o = align_up(o + sizeof(float4) * 256 * (size_t)U);
     s.bytes = o + 256;
     return s;
 }
@@ -110,7 +125,7 @@ void launch_scatter(int P, int W, int H, GeomState g, ImageState im, BinState b,
 void launch_tile_sort(int W, int H, uint32_t max_count, ImageState im, BinState b, hipStream_t st);
 void launch_blend_fwd(int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
                       float* out_color, hipStream_t st);
-void launch_blend_bwd(int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
+void launch_blend_bwd(int W, int H, int U, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
                       const float* dL_dpix, float* grad_acc, hipStream_t st);
 void launch_geom_bwd(int P, int D, int M, const float* means3D, const float* shs, const float* scales,
                      float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* view,

@@ -82,8 +82,8 @@ def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rot
                                cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
                                image_width, sh, degree, campos, prefiltered, debug):
     """-> (num_rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer), like
-    RasterizeGaussiansCUDA (DGR/rasterize_points.cu:35-115), plus a 7th element: the longest
-    per-tile instance list (informational)."""
+    RasterizeGaussiansCUDA (DGR/rasterize_points.cu:35-115), plus two more elements: the longest
+    per-tile instance list (informational) and the number of list segments (backward work units)."""
     lib = _lib.load()
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")   # rasterize_points.cu:57-59
@@ -96,7 +96,7 @@ def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rot
             # rasterize_points.cu:68-81: zero-filled image, no rasterization at all
             return (0, torch.zeros(3, H, W, dtype=torch.float32, device=dev),
                     torch.zeros(0, dtype=torch.int32, device=dev), torch.empty(0, **byte_opts),
-                    torch.empty(0, **byte_opts), torch.empty(0, **byte_opts), 0)
+                    torch.empty(0, **byte_opts), torch.empty(0, **byte_opts), 0, 0)
         means3D = _dev_f32(means3D, dev)
         background, viewmatrix, projmatrix, campos = (_dev_f32(x, dev) for x in (background, viewmatrix, projmatrix, campos))
         colors, opacity, scales, rotations, cov3D_precomp, sh = (
@@ -106,25 +106,26 @@ def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rot
         radii = torch.empty(P, dtype=torch.int32, device=dev)
         geom = torch.empty(lib.gsr_geom_bytes(P), **byte_opts)
         img = torch.empty(lib.gsr_image_bytes(W, H), **byte_opts)
-        R, maxc = ctypes.c_int(0), ctypes.c_int(0)
+        R, maxc, nseg = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         st = _stream()
         _lib.check(lib.gsr_forward_stage1(
             P, int(degree), M, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales),
             float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix),
             _ptr(campos), W, H, float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(radii), _ptr(geom),
-            _ptr(img), ctypes.byref(R), ctypes.byref(maxc), st), "gsr_forward_stage1")
-        binning = torch.empty(lib.gsr_binning_bytes(R.value), **byte_opts)
+            _ptr(img), ctypes.byref(R), ctypes.byref(maxc), ctypes.byref(nseg), st), "gsr_forward_stage1")
+        binning = torch.empty(lib.gsr_binning_bytes(R.value, nseg.value), **byte_opts)
         _lib.check(lib.gsr_forward_stage2(
-            P, R.value, maxc.value, W, H, _ptr(background), _ptr(colors), _ptr(geom), _ptr(binning), _ptr(img),
+            P, R.value, maxc.value, nseg.value, W, H, _ptr(background), _ptr(colors), _ptr(geom), _ptr(binning), _ptr(img),
             _ptr(out_color), st), "gsr_forward_stage2")
         if debug:
             torch.cuda.synchronize(dev)   # surface asynchronous faults here, like CHECK_CUDA(..., debug)
-    return R.value, out_color, radii, geom, binning, img, maxc.value
+    return R.value, out_color, radii, geom, binning, img, maxc.value, nseg.value
 
 
 def rasterize_gaussians_backward_native(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                         cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
-                                        sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+                                        sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug,
+                                        num_segments=0):
     """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
     dL_drotations), like RasterizeGaussiansBackwardCUDA (DGR/rasterize_points.cu:117-196)."""
     lib = _lib.load()
@@ -153,7 +154,7 @@ def rasterize_gaussians_backward_native(background, means3D, radii, colors, scal
         dL_dscales = torch.zeros(P, 3, **f32) if has_cov else torch.empty(P, 3, **f32)
         dL_drotations = torch.zeros(P, 4, **f32) if has_cov else torch.empty(P, 4, **f32)
         _lib.check(lib.gsr_backward(
-            P, int(degree), M, int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(scales),
+            P, int(degree), M, int(R), int(num_segments), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(scales),
             float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix),
             _ptr(campos), float(tan_fovx), float(tan_fovy), _ptr(radii), _ptr(geomBuffer), _ptr(binningBuffer),
             _ptr(imageBuffer), _ptr(dL_dout_color), _ptr(grad_scratch), _ptr(dL_dmeans2D), _ptr(dL_dopacity),
@@ -208,9 +209,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raise ex
         else:
             out = rasterize_gaussians_native(*args)
-        num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, _max_tile = out
+        num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, _max_tile, num_segments = out
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
+        ctx.num_segments = num_segments
         ctx.opacity_shape = opacities.shape
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                               binningBuffer, imgBuffer)
@@ -231,13 +233,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         if raster_settings.debug:
             cpu_args = cpu_deep_copy_tuple(args)
             try:
-                grads_native = rasterize_gaussians_backward_native(*args)
+                grads_native = rasterize_gaussians_backward_native(*args, num_segments=ctx.num_segments)
             except Exception as ex:
                 torch.save(cpu_args, "snapshot_bw.dump")
                 print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise ex
         else:
-            grads_native = rasterize_gaussians_backward_native(*args)
+            grads_native = rasterize_gaussians_backward_native(*args, num_segments=ctx.num_segments)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = grads_native
 

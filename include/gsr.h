@@ -46,7 +46,7 @@ const char* gsr_last_error(void);
  * BinningState>() (DGR/cuda_rasterizer/rasterizer_impl.h:66-72). */
 size_t gsr_geom_bytes(int P);
 size_t gsr_image_bytes(int W, int H);
-size_t gsr_binning_bytes(int R);
+size_t gsr_binning_bytes(int R, int num_segments);
 /* Backward-only scratch: one packed 48-byte accumulation record per Gaussian.  Takes the place of the
  * dL_dconic [P,2,2] work tensor the reference binding allocates (DGR/rasterize_points.cu:154). */
 size_t gsr_grad_scratch_bytes(int P);
@@ -58,19 +58,21 @@ size_t gsr_grad_scratch_bytes(int P);
  * (FORWARD::preprocess, forward.cu:155-256, + InclusiveSum).
  *   radii [P] int32 out (same values as the reference's), geom/image scratch sized by
  *   gsr_geom_bytes / gsr_image_bytes.  *num_rendered [host] out; *max_tile_instances [host] out =
- *   the longest per-tile list (lets stage 2 pick its LDS sort capacity without a second sync). */
+ *   the longest per-tile list (lets stage 2 pick its LDS sort capacity without a second sync);
+ *   *num_segments [host] out = number of (tile, list segment) work units of the backward pass, which
+ *   also sizes the per-segment snapshot area of the binning buffer. */
 int gsr_forward_stage1(int P, int D, int M, const float* means3D, const float* shs, const float* colors_precomp,
                        const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                        const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                        const float* campos, int W, int H, float tan_fovx, float tan_fovy, int prefiltered,
                        int* radii, void* geom_buffer, void* image_buffer, int* num_rendered,
-                       int* max_tile_instances, gsr_stream_t stream);
+                       int* max_tile_instances, int* num_segments, gsr_stream_t stream);
 
 /* Forward, second half: instance scatter into per-tile buckets, per-tile depth sort, alpha
  * blend.  Replaces rasterizer_impl.cu:283-335 (duplicateWithKeys, SortPairs,
  * identifyTileRanges, FORWARD::render = forward.cu:261-374).
- *   out_color [3,H,W] planar; binning scratch sized by gsr_binning_bytes(R). */
-int gsr_forward_stage2(int P, int R, int max_tile_instances, int W, int H, const float* background,
+ *   out_color [3,H,W] planar; binning scratch sized by gsr_binning_bytes(R, num_segments). */
+int gsr_forward_stage2(int P, int R, int max_tile_instances, int num_segments, int W, int H, const float* background,
                        const float* colors_precomp, void* geom_buffer, void* binning_buffer, void* image_buffer,
                        float* out_color, gsr_stream_t stream);
 
@@ -92,8 +94,8 @@ int gsr_forward(gsr_alloc_fn geometry_buffer, gsr_alloc_fn binning_buffer, gsr_a
  *   dL_dmean2D [P,3], dL_dopacity [P], dL_dcolor [P,3], dL_dmean3D [P,3], dL_dcov3D [P,6],
  *   dL_dsh [P,M,3] (NULL when M == 0), dL_dscale [P,3], dL_drot [P,4] (both NULL when cov3D_precomp
  *   is given). */
-int gsr_backward(int P, int D, int M, int R, const float* background, int W, int H, const float* means3D,
-                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+int gsr_backward(int P, int D, int M, int R, int num_segments, const float* background, int W, int H,
+                 const float* means3D, const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
                  const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
                  const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
                  const void* geom_buffer, const void* binning_buffer, const void* image_buffer, const float* dL_dpix,
@@ -111,7 +113,7 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
  *   means2D [P,2], conic_opacity [P,4], depths [P], rgb [P,3] (SH mode only),
  *   tile_ranges [T,2] uint32, point_list [R] uint32, final_T [H*W], n_contrib [H*W] uint32.
  * No reference counterpart (the reference exposes its scratch only as opaque bytes). */
-int gsr_debug_export(int P, int R, int W, int H, const void* geom_buffer, const void* binning_buffer,
+int gsr_debug_export(int P, int R, int num_segments, int W, int H, const void* geom_buffer, const void* binning_buffer,
                      const void* image_buffer, float* means2D, float* conic_opacity, float* depths, float* rgb,
                      uint32_t* tile_ranges, uint32_t* point_list, float* final_T, uint32_t* n_contrib,
                      gsr_stream_t stream);

@@ -36,7 +36,7 @@ P, W, H = gs.P, cam.W, cam.H
 out = R.rasterize_gaussians_native(t(bg), t(gs.means3D), t(gs.colors_precomp), t(gs.opacities), t(gs.scales),
                                    t(gs.rotations), 1.0, e, t(cam.viewmatrix), t(cam.projmatrix), cam.tanfovx,
                                    cam.tanfovy, H, W, e, 0, t(cam.campos), False, False)
-Rn, c2, r2, geom, binning, img, maxc = out
+Rn, c2, r2, geom, binning, img, maxc, nseg = out
 print("R ref", Rr, "R ours", Rn, "max tile", maxc, "radii mismatch", (r2.cpu().numpy() != radii).sum())
 T = ((W + 15) // 16) * ((H + 15) // 16)
 gx = (W + 15) // 16
@@ -47,7 +47,7 @@ nc = torch.zeros(H, W, dtype=torch.int32, device=dev)
 co = torch.zeros(P, 4, device=dev)
 m2 = torch.zeros(P, 2, device=dev)
 p = lambda x: ctypes.c_void_p(x.data_ptr())
-lib.gsr_debug_export(P, Rn, W, H, p(geom), p(binning), p(img), p(m2), p(co), None, None, p(rng_), p(pl), p(fT), p(nc), None)
+lib.gsr_debug_export(P, Rn, nseg, W, H, p(geom), p(binning), p(img), p(m2), p(co), None, None, p(rng_), p(pl), p(fT), p(nc), None)
 torch.cuda.synchronize()
 c2 = c2.cpu().numpy()
 err = np.abs(c2 - color).max(0)
@@ -116,7 +116,7 @@ for tile in tiles[:3]:
         print("  ref keys", [hex(int(kb[p_])) for p_ in pos])
 
 dp = torch.zeros(P, device=dev)
-lib.gsr_debug_export(P, Rn, W, H, p(geom), p(binning), p(img), None, None, p(dp), None, None, None, None, None, None)
+lib.gsr_debug_export(P, Rn, nseg, W, H, p(geom), p(binning), p(img), None, None, p(dp), None, None, None, None, None, None)
 torch.cuda.synchronize()
 mine = dp.cpu().numpy()
 vis = radii > 0

@@ -53,7 +53,7 @@ def test_ctypes_table_matches_header():
 def test_library_loads_and_exports_every_symbol(hip_lib):
     for name in _declared():
         assert hasattr(hip_lib, name), name
-    assert hip_lib.gsr_abi_version() == 2
+    assert hip_lib.gsr_abi_version() == 3
 
 
 def test_scratch_sizes(hip_lib):
@@ -61,24 +61,25 @@ def test_scratch_sizes(hip_lib):
     g = hip_lib.gsr_geom_bytes(500_000)
     assert 56 * 500_000 <= g <= 56 * 500_000 + 4096
     i = hip_lib.gsr_image_bytes(1920, 1080)
-    assert 8 * 1920 * 1080 <= i <= 8 * 1920 * 1080 + 20 * 8160 + 8192   # + ranges, counts, cursors, order per tile
+    assert 8 * 1920 * 1080 <= i <= 8 * 1920 * 1080 + 24 * 8160 + 8192   # + ranges, counts, cursors, order, seg_off
     assert hip_lib.gsr_grad_scratch_bytes(500_000) == 48 * 500_000 + 256
-    b = hip_lib.gsr_binning_bytes(1_000_000)
+    b = hip_lib.gsr_binning_bytes(1_000_000, 0)
     assert 12_000_000 <= b <= 12_000_000 + 2048
-    assert hip_lib.gsr_geom_bytes(0) > 0 and hip_lib.gsr_binning_bytes(0) > 0
+    assert hip_lib.gsr_binning_bytes(1_000_000, 1000) - b == 1000 * (4 + 256 * 16) + 96   # unit table + snapshots
+    assert hip_lib.gsr_geom_bytes(0) > 0 and hip_lib.gsr_binning_bytes(0, 0) > 0
 
 
 def test_validation_errors_without_gpu(hip_lib):
-    R, mx = ctypes.c_int(7), ctypes.c_int(7)
+    R, mx, ns = ctypes.c_int(7), ctypes.c_int(7), ctypes.c_int(7)
     null = None
     rc = hip_lib.gsr_forward_stage1(10, 0, 0, null, null, null, null, null, 1.0, null, null, null, null, null, 64, 64,
-                                    0.5, 0.5, 0, null, null, null, ctypes.byref(R), ctypes.byref(mx), null)
+                                    0.5, 0.5, 0, null, null, null, ctypes.byref(R), ctypes.byref(mx), ctypes.byref(ns), null)
     assert rc != 0 and b"null" in hip_lib.gsr_last_error()
     rc = hip_lib.gsr_forward_stage1(10, 0, 0, null, null, null, null, null, 1.0, null, null, null, null, null, 0, 64,
-                                    0.5, 0.5, 0, null, null, null, ctypes.byref(R), ctypes.byref(mx), null)
+                                    0.5, 0.5, 0, null, null, null, ctypes.byref(R), ctypes.byref(mx), ctypes.byref(ns), null)
     assert rc != 0 and b"positive" in hip_lib.gsr_last_error()
     assert R.value == 0
-    rc = hip_lib.gsr_backward(5, 0, 0, 0, null, 8, 8, *([null] * 4), 1.0, *([null] * 5), 0.5, 0.5, *([null] * 15))
+    rc = hip_lib.gsr_backward(5, 0, 0, 0, 0, null, 8, 8, *([null] * 4), 1.0, *([null] * 5), 0.5, 0.5, *([null] * 15))
     assert rc != 0 and hip_lib.gsr_last_error()
     # P == 0 backward is a no-op success (rasterize_points.cu:161)
-    assert hip_lib.gsr_backward(0, 0, 0, 0, null, 8, 8, *([null] * 4), 1.0, *([null] * 5), 0.5, 0.5, *([null] * 15)) == 0
+    assert hip_lib.gsr_backward(0, 0, 0, 0, 0, null, 8, 8, *([null] * 4), 1.0, *([null] * 5), 0.5, 0.5, *([null] * 15)) == 0

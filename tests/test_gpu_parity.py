@@ -57,7 +57,7 @@ def test_hip_internal_state_matches_reference(name, hip_lib):
                                        opt("scales"), opt("rotations"), kw["scale_modifier"], opt("cov3D_precomp"),
                                        t(kw["view"]), t(kw["proj"]), kw["tanfovx"], kw["tanfovy"], H, W, opt("shs"),
                                        kw["sh_degree"], t(kw["campos"]), False, False)
-    Rn, color, radii, geom, binning, img, maxc = out
+    Rn, color, radii, geom, binning, img, maxc, nseg = out
     assert 0 < Rn <= int(d["out_num_rendered"]) and 0 < maxc <= Rn
     T = ((W + 15) // 16) * ((H + 15) // 16)
     m2 = torch.zeros(P, 2, device=dev); co = torch.zeros(P, 4, device=dev); dp = torch.zeros(P, device=dev)
@@ -65,7 +65,7 @@ def test_hip_internal_state_matches_reference(name, hip_lib):
     rng_ = torch.zeros(T, 2, dtype=torch.int32, device=dev); pl = torch.zeros(max(Rn, 1), dtype=torch.int32, device=dev)
     fT = torch.zeros(H, W, device=dev); nc = torch.zeros(H, W, dtype=torch.int32, device=dev)
     p = lambda x: ctypes.c_void_p(x.data_ptr())
-    rc = hip_lib.gsr_debug_export(P, Rn, W, H, p(geom), p(binning), p(img), p(m2), p(co), p(dp),
+    rc = hip_lib.gsr_debug_export(P, Rn, nseg, W, H, p(geom), p(binning), p(img), p(m2), p(co), p(dp),
                                   p(rgb) if kw["shs"] is not None else None, p(rng_), p(pl), p(fT), p(nc), None)
     assert rc == 0, hip_lib.gsr_last_error()
     torch.cuda.synchronize()
