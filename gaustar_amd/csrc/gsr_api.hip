@@ -125,7 +125,9 @@ int gsr_forward_stage1(int P, int D, int M, const float* means3D, const float* s
     hipStream_t st = (hipStream_t)stream;
     const Tiles t = tiles_of(W, H);
     ImageState im = carve_image(image_buffer, W, H);
-    GSR_CHECK(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * (size_t)t.T, st));
+    // counters and cursors are adjacent in the image buffer: one fill covers both
+    GSR_CHECK(hipMemsetAsync(im.tile_count, 0,
+                             (size_t)((char*)(im.tile_cursor + (size_t)t.T * NSHARD) - (char*)im.tile_count), st));
     if (P > 0) {
         GeomState g = carve_geom(geom_buffer, P);
         {

@@ -48,7 +48,7 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
     const int t0 = tid * PER;
     uint32_t c[PER];
 #pragma unroll
-    for (int k = 0; k < PER; k += 4) {   // the scratch carve pads tile_count to 256 B, so the tail read stays in bounds
+    for (int k = 0; k < PER; k += 4) {   // the scratch carve pads tile_total to 256 B, so the tail read stays in bounds
         const uint4 v = (t0 + k < T) ? *reinterpret_cast<const uint4*>(tile_count + t0 + k) : make_uint4(0, 0, 0, 0);
         c[k] = v.x; c[k + 1] = v.y; c[k + 2] = v.z; c[k + 3] = v.w;
     }
@@ -84,7 +84,7 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
         const int t = t0 + k;
         if (t < T) {
             ranges[t] = make_uint2(run, run + c[k]);
-            tile_cursor[t] = run;
+
             seg_off[t] = run_seg;
             run += c[k];
             run_seg += (c[k] + (uint32_t)SEG - 1u) / (uint32_t)SEG;
@@ -127,16 +127,30 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
     }
 }
 
+// A tile's list length = sum of its eight shard counters; done chip-wide so that the single-workgroup scan
+// below reads T values instead of 8 T.
+__global__ void __launch_bounds__(256)
+tile_total_kernel(int T, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_total)
+{
+    static_assert(NSHARD == 8, "two 16-byte loads per tile");
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const uint4* pc = reinterpret_cast<const uint4*>(tile_count + (size_t)t * NSHARD);
+    const uint4 v0 = pc[0], v1 = pc[1];
+    tile_total[t] = (v0.x + v0.y + v0.z + v0.w) + (v1.x + v1.y + v1.z + v1.w);
+}
+
 void launch_tile_scan(ImageState im, int T, hipStream_t st)
 {
+    tile_total_kernel<<<(T + 255) / 256, 256, 0, st>>>(T, im.tile_count, im.tile_total);
     if (T <= 8 * 1024)          // up to 1920x1088
-        tile_scan_kernel<8><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.tile_cursor, im.totals, im.order,
+        tile_scan_kernel<8><<<1, 1024, 0, st>>>(T, im.tile_total, im.ranges, im.tile_cursor, im.totals, im.order,
                                              im.seg_off);
     else if (T <= 36 * 1024)    // up to 4096x2304
-        tile_scan_kernel<36><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.tile_cursor, im.totals, im.order,
+        tile_scan_kernel<36><<<1, 1024, 0, st>>>(T, im.tile_total, im.ranges, im.tile_cursor, im.totals, im.order,
                                              im.seg_off);
     else                        // up to ~8k x 8k
-        tile_scan_kernel<256><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.tile_cursor, im.totals, im.order,
+        tile_scan_kernel<256><<<1, 1024, 0, st>>>(T, im.tile_total, im.ranges, im.tile_cursor, im.totals, im.order,
                                              im.seg_off);
 }
 
@@ -148,10 +162,12 @@ __global__ void __launch_bounds__(256)
 scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __restrict__ g0,
                const float4* __restrict__ g1, const float* __restrict__ depth, uint32_t* __restrict__ tile_cursor,
                uint64_t* __restrict__ keys, int T, const uint32_t* __restrict__ seg_off,
-               uint32_t* __restrict__ unit_tile)
+               uint32_t* __restrict__ unit_tile, const uint32_t* __restrict__ tile_count,
+               const uint2* __restrict__ ranges)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    const int shard = (int)(blockIdx.x & (NSHARD - 1));
     // side job of the first T threads: expand the per-tile segment counts into the unit -> tile table
     // (it lives in the binning buffer, which did not exist yet when the scan kernel ran)
     if (idx < T) {
@@ -171,7 +187,17 @@ scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __
     for_each_tile_aggregated(r, a.x, a.y, a.z, a.w, b.x, b.z, gx, lane,
                              [&](int tile, bool is_leader, int group, int rank, int leader_lane) {
                                  uint32_t base = 0;
-                                 if (is_leader) base = atomicAdd(&tile_cursor[tile], (uint32_t)group);
+                                 if (is_leader) {
+                                     // slot = tile start + counts of the lower shards + position inside this shard
+                                     // (shard cursors start at zero; the scan kernel does not expand them)
+                                     const uint4* pc = reinterpret_cast<const uint4*>(tile_count + (size_t)tile * NSHARD);
+                                     const uint4 v0 = pc[0], v1 = pc[1];
+                                     const uint32_t cs[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                                     uint32_t below = ranges[tile].x;
+#pragma unroll
+                                     for (int s_ = 0; s_ < NSHARD; s_++) below += s_ < shard ? cs[s_] : 0u;
+                                     base = below + atomicAdd(&tile_cursor[tile * NSHARD + shard], (uint32_t)group);
+                                 }
                                  base = __shfl(base, leader_lane, 64);
                                  if (tile >= 0) keys[base + (uint32_t)rank] = key;
                              });
@@ -182,7 +208,7 @@ void launch_scatter(int P, int W, int H, GeomState g, ImageState im, BinState b,
     const Tiles t = tiles_of(W, H);
     const int n = P > t.T ? P : t.T;
     scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(P, t.gx, g.rect, g.g0, g.g1, g.depth, im.tile_cursor, b.keys, t.T,
-                                                    im.seg_off, b.unit_tile);
+                                                    im.seg_off, b.unit_tile, im.tile_count, im.ranges);
 }
 
 // ---- per-tile bitonic sort of 64-bit keys in LDS.

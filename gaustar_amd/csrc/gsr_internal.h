@@ -46,17 +46,24 @@ inline GeomState carve_geom(void* base, int P)
     return s;
 }
 
+// Per-tile counters are SHARDED: workgroup b updates shard b % NSHARD.  Device-scope atomics on one address are
+// serialised at the memory side (~0.1 us each); a long tile list means hundreds of updates of its counter even
+// after wave aggregation, which was what bounded preprocess and scatter.  Eight shards cut each chain by eight;
+// the shard is a function of the Gaussian index only (same in both kernels), never of where a block runs.
+constexpr int NSHARD = 8;
+
 struct ImageState {          // per pixel / per tile
     float* final_T;          // [H*W]
     uint32_t* n_contrib;     // [H*W] 1-based position in the tile list of the last blended instance
     uint2* ranges;           // [T] {start, end} into point_list
-    uint32_t* tile_count;    // [T] instances per tile (atomics in preprocess)
-    uint32_t* tile_cursor;   // [T] scatter cursors
+    uint32_t* tile_count;    // [T][NSHARD] instances per (tile, shard) (atomics in preprocess)
+    uint32_t* tile_cursor;   // [T][NSHARD] scatter cursors: a tile's bucket is the concatenation of its shards
     uint32_t* totals;        // [4] {R, max tile count, number of non-empty tiles, U = number of list segments}
     uint32_t* order;         // [T] tile ids, longest instance lists first (32-entry buckets), empty tiles last:
                              // the blockIdx -> tile map of the per-tile kernels (longest-processing-time-first
                              // dispatch evens out the very uneven per-tile work of a surface seen in perspective)
     uint32_t* seg_off;       // [T+1] exclusive prefix of ceil(list length / SEG): first segment (unit) id of a tile
+    uint32_t* tile_total;    // [T] list length per tile = sum of its shard counters
     size_t bytes;
 };
 inline ImageState carve_image(void* base, int W, int H)
@@ -66,11 +73,12 @@ inline ImageState carve_image(void* base, int W, int H)
     s.final_T = (float*)(b + o); o = align_up(o + 4 * N);
     s.n_contrib = (uint32_t*)(b + o); o = align_up(o + 4 * N);
     s.ranges = (uint2*)(b + o); o = align_up(o + 8 * T);
-    s.tile_count = (uint32_t*)(b + o); o = align_up(o + 4 * T);
-    s.tile_cursor = (uint32_t*)(b + o); o = align_up(o + 4 * T);
+    s.tile_count = (uint32_t*)(b + o); o = align_up(o + 4 * T * NSHARD);
+    s.tile_cursor = (uint32_t*)(b + o); o = align_up(o + 4 * T * NSHARD);
     s.totals = (uint32_t*)(b + o); o = align_up(o + 16);
     s.order = (uint32_t*)(b + o); o = align_up(o + 4 * T);
     s.seg_off = (uint32_t*)(b + o); o = align_up(o + 4 * (T + 1));
+    s.tile_total = (uint32_t*)(b + o); o = align_up(o + 4 * T);
     s.bytes = o + 256;
     return s;
 }
@@ -303,16 +311,19 @@ __device__ __forceinline__ float block_min_half_quad(float a, float b, float c, 
 // the same few tiles, so a wave issues ONE atomic instruction per round whose active lanes are the group
 // leaders (count = group size) instead of one atomic per (lane, tile).  Must be called by all 64 lanes
 // (inactive ones pass an empty rect).  Both callers pass the stored (rect, g0, g1) => identical tile sets.
-template <class F>
-__device__ __forceinline__ void for_each_tile_aggregated(ushort4 rect, float px, float py, float ca, float cb,
-                                                         float cc, float tau, int gx, int lane, F f)
-{
-    int tx = rect.x, ty = rect.y;
-    bool more = rect.z > rect.x && rect.w > rect.y && tau >= 0.0f;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    while (true) {
+struct TileVisit { int tile; bool is_leader; int group, rank, leader_lane; };
+struct TileWalker {
+    ushort4 rect; float px, py, ca, cb, cc, tau; int gx, lane, tx, ty; bool more;
+    __device__ __forceinline__ TileWalker(ushort4 r, float px_, float py_, float ca_, float cb_, float cc_, float tau_,
+                                          int gx_, int lane_)
+        : rect(r), px(px_), py(py_), ca(ca_), cb(cb_), cc(cc_), tau(tau_), gx(gx_), lane(lane_), tx(r.x), ty(r.y),
+          more(r.z > r.x && r.w > r.y && tau_ >= 0.0f) {}
+    // One round: every lane advances to its next reachable tile (or none), lanes are grouped by tile id.
+    // Returns false (wave-uniformly) when no lane has a tile left; v.tile < 0 for lanes without one.
+    __device__ __forceinline__ bool next_round(TileVisit& v)
+    {
         int cur = -1;
-        while (more) {   // advance this lane to its next reachable tile
+        while (more) {
             const float X0 = (float)(tx * TILE) - px, Y0 = (float)(ty * TILE) - py;
             const bool hit = block_min_half_quad(ca, cb, cc, X0, X0 + (float)(TILE - 1), Y0, Y0 + (float)(TILE - 1)) <= tau;
             const int id = ty * gx + tx;
@@ -320,17 +331,27 @@ __device__ __forceinline__ void for_each_tile_aggregated(ushort4 rect, float px,
             if (hit) { cur = id; break; }
         }
         unsigned long long active = __ballot(cur >= 0);
-        if (active == 0ull) break;
-        int leader_lane = lane, group = 0, rank = 0;
+        v.tile = cur; v.is_leader = false; v.group = 0; v.rank = 0; v.leader_lane = lane;
+        if (active == 0ull) return false;
+        const unsigned long long lt = (1ull << lane) - 1ull;
         while (active) {   // group the lanes by tile value with ballots only (no memory traffic in here)
             const int leader = __ffsll((unsigned long long)active) - 1;
             const int t = __shfl(cur, leader, 64);
             const unsigned long long m = __ballot(cur == t);
-            if (cur == t) { leader_lane = leader; group = __popcll(m); rank = __popcll(m & lt); }
+            if (cur == t) { v.leader_lane = leader; v.group = __popcll(m); v.rank = __popcll(m & lt); }
             active &= ~m;
         }
-        f(cur, cur >= 0 && lane == leader_lane, group, rank, leader_lane);
+        v.is_leader = cur >= 0 && lane == v.leader_lane;
+        return true;
     }
+};
+template <class F>
+__device__ __forceinline__ void for_each_tile_aggregated(ushort4 rect, float px, float py, float ca, float cb,
+                                                         float cc, float tau, int gx, int lane, F f)
+{
+    TileWalker w(rect, px, py, ca, cb, cc, tau, gx, lane);
+    TileVisit v;
+    while (w.next_round(v)) f(v.tile, v.is_leader, v.group, v.rank, v.leader_lane);
 }
 
 // Pixel centre of an NDC coordinate; evaluated in double like auxiliary.h:41-44.

@@ -122,7 +122,8 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
     // All 64 lanes take part (lanes without work carry an empty rect).
     for_each_tile_aggregated(out_rect, px, py, conic_a, conic_b, conic_c, tau, gx, lane,
                              [&](int tile, bool is_leader, int group, int, int) {
-                                 if (is_leader) atomicAdd(&tile_count[tile], (uint32_t)group);
+                                 if (is_leader)
+                                     atomicAdd(&tile_count[tile * NSHARD + (int)(blockIdx.x & (NSHARD - 1))], (uint32_t)group);
                              });
 }
 

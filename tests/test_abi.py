@@ -61,7 +61,7 @@ def test_scratch_sizes(hip_lib):
     g = hip_lib.gsr_geom_bytes(500_000)
     assert 56 * 500_000 <= g <= 56 * 500_000 + 4096
     i = hip_lib.gsr_image_bytes(1920, 1080)
-    assert 8 * 1920 * 1080 <= i <= 8 * 1920 * 1080 + 24 * 8160 + 8192   # + ranges, counts, cursors, order, seg_off
+    assert 8 * 1920 * 1080 <= i <= 8 * 1920 * 1080 + (8 + 64 + 12) * 8160 + 8192   # ranges, 2x8 shard counters, order, seg_off, totals
     assert hip_lib.gsr_grad_scratch_bytes(500_000) == 48 * 500_000 + 256
     b = hip_lib.gsr_binning_bytes(1_000_000, 0)
     assert 12_000_000 <= b <= 12_000_000 + 2048
