@@ -70,7 +70,10 @@ __device__ __forceinline__ void atomic_add_f32(float* p, float v)
 
 constexpr int GRP = 8;          // instances per MFMA group: A-operand rows 0..7 carry their r, rows 8..15 their w
 constexpr int RSTRIDE = 68;     // floats per row of the r|w table: 64 pixels + 4 (16-byte aligned, spreads banks)
-constexpr int RAW_STRIDE = 9;   // floats per instance in the moment table (odd: conflict-free lane-per-row access)
+// Once an instance's w and r are out, its queue slot only needs to keep x, y and the gaussian id: the nine
+// moments overwrite the other nine floats of the 48-byte slot (no separate moment table -> more resident waves).
+constexpr int SLOT_FLOATS = 12;
+__device__ __forceinline__ int moment_off(int m) { return m < 8 ? 2 + m : 11; }   // skips x, y (0, 1) and the id (10)
 
 static_assert(SEG == 64, "one fetch batch per unit");
 
@@ -86,7 +89,6 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     __shared__ SlotB queue[64];
     __shared__ __attribute__((aligned(16))) float Rm[2 * GRP * RSTRIDE];   // rows 0..7: r, rows 8..15: w, [row][pixel lane]
     float* const Wm = Rm + GRP * RSTRIDE;
-    __shared__ float raw[64 * RAW_STRIDE];                             // per queued instance: 9 moments
     // one wave64 per workgroup: unit = (tile, segment), wave = 8x8 block of the tile
     const uint32_t unit = blockIdx.x >> 2;
     const int tile = (int)unit_tile[unit];
@@ -105,6 +107,7 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     const int s1 = min(s0 + SEG, n);
     const uint32_t* list = point_list + rg.x;
     SlotB* q = queue;
+    float* const qf = reinterpret_cast<float*>(queue);
 
     const size_t pix = (size_t)W * py + px;
     const size_t HW = (size_t)H * W;
@@ -251,7 +254,7 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         for (int i = 0; i < 4; i++) {
             const int row = 4 * kap + i, inst = g0i + (row & 7);
             const bool take = row < GRP ? col < 6 : (col >= 6 && col < 9);
-            if (take && inst < cnt) raw[inst * RAW_STRIDE + col] = acc0[i] + acc1[i];
+            if (take && inst < cnt) qf[inst * SLOT_FLOATS + moment_off(col)] = acc0[i] + acc1[i];
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -259,17 +262,18 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     // ---- lane = queued instance: re-centre the spatial sums on the splat (dx = x_splat - x_pixel) and lay the
     // nine moments out in grad_acc order {c_r, c_g, c_b, sum r, sum r dx, sum r dy, sum r dx^2, sum r dx dy, sum r dy^2}
     if (lane < cnt && ((touched >> lane) & 1ull)) {
-        float* rw = &raw[lane * RAW_STRIDE];
-        const float m0 = rw[0], mx = rw[1], my = rw[2], mxx = rw[3], mxy = rw[4], myy = rw[5];
-        const float c0 = rw[6], c1 = rw[7], c2 = rw[8];
-        const float X = q[lane].a.x - (bx0 + 3.5f), Y = q[lane].a.y - (by0 + 3.5f);
-        rw[0] = c0; rw[1] = c1; rw[2] = c2;
-        rw[3] = m0;
-        rw[4] = X * m0 - mx;
-        rw[5] = Y * m0 - my;
-        rw[6] = (X * X) * m0 - 2.f * X * mx + mxx;
-        rw[7] = (X * Y) * m0 - X * my - Y * mx + mxy;
-        rw[8] = (Y * Y) * m0 - 2.f * Y * my + myy;
+        float* rw = &qf[lane * SLOT_FLOATS];
+        const float m0 = rw[moment_off(0)], mx = rw[moment_off(1)], my = rw[moment_off(2)], mxx = rw[moment_off(3)],
+                    mxy = rw[moment_off(4)], myy = rw[moment_off(5)];
+        const float c0 = rw[moment_off(6)], c1 = rw[moment_off(7)], c2 = rw[moment_off(8)];
+        const float X = rw[0] - (bx0 + 3.5f), Y = rw[1] - (by0 + 3.5f);
+        rw[moment_off(0)] = c0; rw[moment_off(1)] = c1; rw[moment_off(2)] = c2;
+        rw[moment_off(3)] = m0;
+        rw[moment_off(4)] = X * m0 - mx;
+        rw[moment_off(5)] = Y * m0 - my;
+        rw[moment_off(6)] = (X * X) * m0 - 2.f * X * mx + mxx;
+        rw[moment_off(7)] = (X * Y) * m0 - X * my - Y * mx + mxy;
+        rw[moment_off(8)] = (Y * Y) * m0 - 2.f * Y * my + myy;
     }
     __builtin_amdgcn_wave_barrier();
     // flush: lanes walk the (instance, moment) table row-major, so one atomic instruction covers the nine
@@ -278,8 +282,8 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     for (int idx = lane; idx < cnt * 9; idx += 64) {
         const int e = idx / 9, v = idx - e * 9;
         if ((touched >> e) & 1ull) {
-            const size_t g = __float_as_uint(q[e].c.z);
-            atomic_add_f32(grad_acc + g * 12 + v, raw[e * RAW_STRIDE + v]);
+            const size_t g = __float_as_uint(qf[e * SLOT_FLOATS + 10]);
+            atomic_add_f32(grad_acc + g * 12 + v, qf[e * SLOT_FLOATS + moment_off(v)]);
         }
     }
     if (trace && lane == 0) {   // last wave to finish wins the end stamp (monotone clock, max via atomic)
