@@ -31,31 +31,43 @@ __device__ __forceinline__ int length_bucket(uint32_t c)
 {
     return c == 0 ? 65 : 64 - (int)min(64u, (c + 31u) >> 5);
 }
-// PER = tiles owned by each of the 1024 threads, held in registers (one round of 16-byte loads: the kernel is
-// a single workgroup, so its time is the sum of its dependent memory round trips).
+// PER = tiles owned by each of the 1024 threads, held in registers (the kernel is a single workgroup, so its
+// time is the sum of its dependent memory round trips: the eight shard counters of every tile are summed
+// here, straight from the preprocess counters, instead of by a separate launch).
+// The histogram over length buckets is privatised NCOPY ways by lane: almost all tiles of a view fall into a
+// few buckets, and same-address LDS atomics serialise per lane.
+constexpr int NCOPY = 16;
+constexpr int NHIST = NBUCKET * NCOPY;
+static_assert(NHIST <= 2048 && NHIST % 2 == 0, "two histogram entries per thread in the prefix pass");
+
 template <int PER>
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges,
-                 uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ totals, uint32_t* __restrict__ order,
-                 uint32_t* __restrict__ seg_off)
+                 uint32_t* __restrict__ totals, uint32_t* __restrict__ order, uint32_t* __restrict__ seg_off)
 {
+    static_assert(NSHARD == 8, "two 16-byte loads per tile");
     __shared__ uint32_t wave_sum[16];
     __shared__ uint32_t wave_seg[16];
     __shared__ uint32_t wave_max[16];
-    __shared__ uint32_t bucket_n[NBUCKET];
+    __shared__ uint32_t wave_hist[16];
+    __shared__ uint32_t hist[NHIST];   // [bucket][copy]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < NBUCKET) bucket_n[tid] = 0;
+    const int copy = lane & (NCOPY - 1);
+    for (int i = tid; i < NHIST; i += 1024) hist[i] = 0;
     const int t0 = tid * PER;
     uint32_t c[PER];
 #pragma unroll
-    for (int k = 0; k < PER; k += 4) {   // the scratch carve pads tile_total to 256 B, so the tail read stays in bounds
-        const uint4 v = (t0 + k < T) ? *reinterpret_cast<const uint4*>(tile_count + t0 + k) : make_uint4(0, 0, 0, 0);
-        c[k] = v.x; c[k + 1] = v.y; c[k + 2] = v.z; c[k + 3] = v.w;
+    for (int k = 0; k < PER; k++) {
+        c[k] = 0;
+        if (t0 + k < T) {
+            const uint4* pc = reinterpret_cast<const uint4*>(tile_count + (size_t)(t0 + k) * NSHARD);
+            const uint4 v0 = pc[0], v1 = pc[1];
+            c[k] = (v0.x + v0.y + v0.z + v0.w) + (v1.x + v1.y + v1.z + v1.w);
+        }
     }
     uint32_t sum = 0, vmax = 0, segs = 0;
 #pragma unroll
     for (int k = 0; k < PER; k++) {
-        if (t0 + k >= T) c[k] = 0;
         sum += c[k];
         segs += (c[k] + (uint32_t)SEG - 1u) / (uint32_t)SEG;
         vmax = max(vmax, c[k]);
@@ -70,9 +82,9 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
     uint32_t woff = 0, total = 0, gmax = 0, woff_seg = 0, total_seg = 0;
 #pragma unroll
     for (int w = 0; w < 16; w++) {
-        const uint32_t s = wave_sum[w], sg = wave_seg[w];
-        if (w < wave) { woff += s; woff_seg += sg; }
-        total += s;
+        const uint32_t s_ = wave_sum[w], sg = wave_seg[w];
+        if (w < wave) { woff += s_; woff_seg += sg; }
+        total += s_;
         total_seg += sg;
         gmax = max(gmax, wave_max[w]);
     }
@@ -84,42 +96,50 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
         const int t = t0 + k;
         if (t < T) {
             ranges[t] = make_uint2(run, run + c[k]);
-
             seg_off[t] = run_seg;
             run += c[k];
             run_seg += (c[k] + (uint32_t)SEG - 1u) / (uint32_t)SEG;
             if (c[k] == 0) n_empty++;
-            else atomicAdd(&bucket_n[length_bucket(c[k])], 1u);
+            else atomicAdd(&hist[length_bucket(c[k]) * NCOPY + copy], 1u);
         }
     }
-    if (n_empty) atomicAdd(&bucket_n[NBUCKET - 1], n_empty);
+    if (n_empty) atomicAdd(&hist[(NBUCKET - 1) * NCOPY + copy], n_empty);
     __syncthreads();
     if (tid == 0) {
+        uint32_t empty = 0;
+        for (int i = 0; i < NCOPY; i++) empty += hist[(NBUCKET - 1) * NCOPY + i];
         totals[0] = total;
         totals[1] = gmax;
-        totals[2] = (uint32_t)T - bucket_n[NBUCKET - 1];
+        totals[2] = (uint32_t)T - empty;
         totals[3] = total_seg;
         seg_off[T] = total_seg;
     }
-    if (wave == 1) {   // exclusive prefix over the 66 buckets -> start offsets (in place)
-        const uint32_t c0 = bucket_n[lane];
-        const uint32_t i0 = wave_incl_scan(c0, lane);
-        const uint32_t first64 = __shfl(i0, 63, 64);
-        const uint32_t c64 = bucket_n[64];
-        bucket_n[lane] = i0 - c0;
-        if (lane == 0) { bucket_n[64] = first64; bucket_n[65] = first64 + c64; }
+    // exclusive prefix over the flattened [bucket][copy] histogram (in place): two entries per thread
+    uint32_t e0 = 0, e1 = 0;
+    if (2 * tid < NHIST) { e0 = hist[2 * tid]; e1 = hist[2 * tid + 1]; }
+    const uint32_t hs = e0 + e1;
+    const uint32_t hincl = wave_incl_scan(hs, lane);
+    if (lane == 63) wave_hist[wave] = hincl;
+    __syncthreads();   // also orders thread 0's reads of the empty bucket before the overwrite below
+    uint32_t hoff = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) hoff += w < wave ? wave_hist[w] : 0u;
+    if (2 * tid < NHIST) {
+        const uint32_t excl = hoff + hincl - hs;
+        hist[2 * tid] = excl;
+        hist[2 * tid + 1] = excl + e0;
     }
     __syncthreads();
     // Launch positions follow a SNAKE over bands of 256 (one workgroup per CU per band under the observed
     // round-robin dispatch): CU k gets ranks k, 511-k, 512+k, ... so per-CU sums of list lengths even out
     // instead of CU 0 collecting the longest tile of every band.  Pure scheduling heuristic.
     auto snake = [](uint32_t pos) { return (pos & 256u) ? (pos ^ 255u) : pos; };
-    uint32_t empty_at = n_empty ? atomicAdd(&bucket_n[NBUCKET - 1], n_empty) : 0u;
+    uint32_t empty_at = n_empty ? atomicAdd(&hist[(NBUCKET - 1) * NCOPY + copy], n_empty) : 0u;
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         const int t = t0 + k;
         if (t < T) {
-            uint32_t pos = (c[k] == 0) ? empty_at++ : atomicAdd(&bucket_n[length_bucket(c[k])], 1u);
+            uint32_t pos = (c[k] == 0) ? empty_at++ : atomicAdd(&hist[length_bucket(c[k]) * NCOPY + copy], 1u);
             const uint32_t sp = snake(pos);
             if (sp < (uint32_t)T && (pos | 255u) < (uint32_t)T) pos = sp;   // only inside complete bands
             order[pos] = (uint32_t)t;
@@ -127,31 +147,14 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
     }
 }
 
-// A tile's list length = sum of its eight shard counters; done chip-wide so that the single-workgroup scan
-// below reads T values instead of 8 T.
-__global__ void __launch_bounds__(256)
-tile_total_kernel(int T, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_total)
-{
-    static_assert(NSHARD == 8, "two 16-byte loads per tile");
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= T) return;
-    const uint4* pc = reinterpret_cast<const uint4*>(tile_count + (size_t)t * NSHARD);
-    const uint4 v0 = pc[0], v1 = pc[1];
-    tile_total[t] = (v0.x + v0.y + v0.z + v0.w) + (v1.x + v1.y + v1.z + v1.w);
-}
-
 void launch_tile_scan(ImageState im, int T, hipStream_t st)
 {
-    tile_total_kernel<<<(T + 255) / 256, 256, 0, st>>>(T, im.tile_count, im.tile_total);
     if (T <= 8 * 1024)          // up to 1920x1088
-        tile_scan_kernel<8><<<1, 1024, 0, st>>>(T, im.tile_total, im.ranges, im.tile_cursor, im.totals, im.order,
-                                             im.seg_off);
+        tile_scan_kernel<8><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.totals, im.order, im.seg_off);
     else if (T <= 36 * 1024)    // up to 4096x2304
-        tile_scan_kernel<36><<<1, 1024, 0, st>>>(T, im.tile_total, im.ranges, im.tile_cursor, im.totals, im.order,
-                                             im.seg_off);
+        tile_scan_kernel<36><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.totals, im.order, im.seg_off);
     else                        // up to ~8k x 8k
-        tile_scan_kernel<256><<<1, 1024, 0, st>>>(T, im.tile_total, im.ranges, im.tile_cursor, im.totals, im.order,
-                                             im.seg_off);
+        tile_scan_kernel<256><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.totals, im.order, im.seg_off);
 }
 
 // One thread per Gaussian: claim a slot in every reachable tile's bucket and store the sort key.  Walks exactly

@@ -63,7 +63,6 @@ struct ImageState {          // per pixel / per tile
                              // the blockIdx -> tile map of the per-tile kernels (longest-processing-time-first
                              // dispatch evens out the very uneven per-tile work of a surface seen in perspective)
     uint32_t* seg_off;       // [T+1] exclusive prefix of ceil(list length / SEG): first segment (unit) id of a tile
-    uint32_t* tile_total;    // [T] list length per tile = sum of its shard counters
     size_t bytes;
 };
 inline ImageState carve_image(void* base, int W, int H)
@@ -78,7 +77,6 @@ inline ImageState carve_image(void* base, int W, int H)
     s.totals = (uint32_t*)(b + o); o = align_up(o + 16);
     s.order = (uint32_t*)(b + o); o = align_up(o + 4 * T);
     s.seg_off = (uint32_t*)(b + o); o = align_up(o + 4 * (T + 1));
-    s.tile_total = (uint32_t*)(b + o); o = align_up(o + 4 * T);
     s.bytes = o + 256;
     return s;
 }

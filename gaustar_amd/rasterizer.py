@@ -217,12 +217,15 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                               binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)   # no P-element zero fill for the integer output's "gradient" per backward
         return color, radii
 
     @staticmethod
     def backward(ctx, grad_out_color, _):
         num_rendered = ctx.num_rendered
         raster_settings = ctx.raster_settings
+        if grad_out_color is None:   # the colour image did not take part in the loss
+            return (None,) * 9
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
          imgBuffer) = ctx.saved_tensors
         args = (raster_settings.bg, means3D, radii, colors_precomp, scales, rotations,
