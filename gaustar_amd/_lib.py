@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSR_LIB_PATH", os.path.join(_HERE, "libgsr_hip.so"))   # override: experiment variants
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 ALLOC_FN = ctypes.CFUNCTYPE(c_void_p, c_void_p, c_size_t)
 
 # name -> (restype, argtypes); mirrors include/gsr.h one to one (tests check both directions).
@@ -22,6 +22,7 @@ SIGNATURES = {
     "gsr_geom_bytes": (c_size_t, [c_int]),
     "gsr_image_bytes": (c_size_t, [c_int, c_int]),
     "gsr_binning_bytes": (c_size_t, [c_int, c_int]),
+    "gsr_binning_bytes_mt": (c_size_t, [c_int, c_int, c_int]),
     "gsr_grad_scratch_bytes": (c_size_t, [c_int]),
     "gsr_forward_stage1": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float,
@@ -29,6 +30,8 @@ SIGNATURES = {
                                    c_void_p]),
     "gsr_forward_stage2": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p]),
+    "gsr_forward_stage2_mt": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsr_forward": (c_int, [ALLOC_FN, ALLOC_FN, ALLOC_FN, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int,
                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, POINTER(c_int),
@@ -37,6 +40,10 @@ SIGNATURES = {
                              c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gsr_backward_mt": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsr_mark_visible": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsr_debug_export": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -81,16 +81,18 @@ int fail_msg(const char* msg)
 
 extern "C" {
 
-int gsr_abi_version(void) { return 3; }
+int gsr_abi_version(void) { return 4; }
 
 const char* gsr_last_error(void) { return g_err.c_str(); }
 
 size_t gsr_geom_bytes(int P) { return carve_geom(nullptr, P > 0 ? P : 0).bytes; }
 size_t gsr_image_bytes(int W, int H) { return carve_image(nullptr, W, H).bytes; }
-size_t gsr_binning_bytes(int R, int num_segments)
+size_t gsr_binning_bytes_mt(int R, int num_segments, int num_channels)
 {
-    return carve_bin(nullptr, R > 0 ? R : 0, num_segments > 0 ? num_segments : 0).bytes;
+    return carve_bin(nullptr, R > 0 ? R : 0, num_segments > 0 ? num_segments : 0,
+                     channels_ok(num_channels) ? num_channels : 3).bytes;
 }
+size_t gsr_binning_bytes(int R, int num_segments) { return gsr_binning_bytes_mt(R, num_segments, 3); }
 size_t gsr_grad_scratch_bytes(int P) { return (size_t)48 * (size_t)(P > 0 ? P : 0) + 256; }
 
 int gsr_forward_stage1(int P, int D, int M, const float* means3D, const float* shs, const float* colors_precomp,
@@ -155,14 +157,26 @@ int gsr_forward_stage2(int P, int R, int max_tile_instances, int num_segments, i
                        const float* colors_precomp, void* geom_buffer, void* binning_buffer, void* image_buffer,
                        float* out_color, gsr_stream_t stream)
 {
+    return gsr_forward_stage2_mt(P, R, max_tile_instances, num_segments, 3, W, H, background, colors_precomp,
+                                 geom_buffer, binning_buffer, image_buffer, out_color, stream);
+}
+
+int gsr_forward_stage2_mt(int P, int R, int max_tile_instances, int num_segments, int num_channels, int W, int H,
+                          const float* background, const float* colors_precomp, void* geom_buffer, void* binning_buffer,
+                          void* image_buffer, float* out_color, gsr_stream_t stream)
+{
     g_err.clear();
     if (W <= 0 || H <= 0) return fail_msg("gsr_forward_stage2: image size must be positive");
     if (!background || !out_color || !image_buffer) return fail_msg("gsr_forward_stage2: required pointer is null");
     if (R > 0 && (!binning_buffer || !geom_buffer)) return fail_msg("gsr_forward_stage2: scratch buffer is null");
+    if (!channels_ok(num_channels)) return fail_msg("gsr_forward_stage2: num_channels must be 3 or 6");
+    if (num_channels != 3 && !colors_precomp)
+        return fail_msg("gsr_forward_stage2: multi-target renders need precomputed colours [P, num_channels]");
+    const int C = num_channels;
     hipStream_t st = (hipStream_t)stream;
     ImageState im = carve_image(image_buffer, W, H);
     GeomState g = carve_geom(geom_buffer, P > 0 ? P : 0);
-    BinState b = carve_bin(binning_buffer, R > 0 ? R : 0, num_segments > 0 ? num_segments : 0);
+    BinState b = carve_bin(binning_buffer, R > 0 ? R : 0, num_segments > 0 ? num_segments : 0, C);
     if (R > 0) {
         {
             Scope sc(ST_SCATTER, st);
@@ -178,7 +192,7 @@ int gsr_forward_stage2(int P, int R, int max_tile_instances, int num_segments, i
     const float* feats = colors_precomp ? colors_precomp : g.rgb;
     {
         Scope sc(ST_BLEND_FWD, st);
-        launch_blend_fwd(W, H, background, feats, g, im, b, out_color, st);
+        launch_blend_fwd(C, W, H, background, feats, g, im, b, out_color, st);
     }
     GSR_CHECK_LAUNCH("blend_fwd_kernel");
     return 0;
@@ -210,7 +224,21 @@ int gsr_forward(gsr_alloc_fn geometry_buffer, gsr_alloc_fn binning_buffer, gsr_a
 }
 
 int gsr_backward(int P, int D, int M, int R, int num_segments, const float* background, int W, int H,
-                 const float* means3D,
+                 const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                 float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                 const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                 const void* geom_buffer, const void* binning_buffer, const void* image_buffer, const float* dL_dpix,
+                 void* grad_scratch, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, gsr_stream_t stream)
+{
+    return gsr_backward_mt(P, D, M, R, num_segments, 3, background, W, H, means3D, shs, colors_precomp, scales,
+                           scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy,
+                           radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, grad_scratch, dL_dmean2D,
+                           dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, stream);
+}
+
+int gsr_backward_mt(int P, int D, int M, int R, int num_segments, int num_channels, const float* background, int W,
+                    int H, const float* means3D,
                  const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
                  const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                  const float* campos, float tan_fovx, float tan_fovy, const int* radii, const void* geom_buffer,
@@ -230,10 +258,14 @@ int gsr_backward(int P, int D, int M, int R, int num_segments, const float* back
     if (!cov3D_precomp && (!scales || !rotations || !dL_dscale || !dL_drot))
         return fail_msg("gsr_backward: scales/rotations and their gradients are required without cov3D_precomp");
     if (R > 0 && !binning_buffer) return fail_msg("gsr_backward: binning_buffer is null");
+    if (!channels_ok(num_channels)) return fail_msg("gsr_backward: num_channels must be 3 or 6");
+    if (num_channels != 3 && !colors_precomp)
+        return fail_msg("gsr_backward: multi-target renders need precomputed colours [P, num_channels]");
+    const int C = num_channels;
     hipStream_t st = (hipStream_t)stream;
     ImageState im = carve_image(const_cast<void*>(image_buffer), W, H);
     GeomState g = carve_geom(const_cast<void*>(geom_buffer), P);
-    BinState b = carve_bin(const_cast<void*>(binning_buffer), R > 0 ? R : 0, num_segments > 0 ? num_segments : 0);
+    BinState b = carve_bin(const_cast<void*>(binning_buffer), R > 0 ? R : 0, num_segments > 0 ? num_segments : 0, C);
     // Zero the packed moment records (the only atomic targets); every output tensor is written outright
     // by geom_bwd (cf. the nine zeroed tensors of rasterize_points.cu:151-159).
     float* grad_acc = static_cast<float*>(grad_scratch);
@@ -245,7 +277,7 @@ int gsr_backward(int P, int D, int M, int R, int num_segments, const float* back
     if (R > 0) {
         {
             Scope sc(ST_BLEND_BWD, st);
-            launch_blend_bwd(W, H, num_segments, background, feats, g, im, b, dL_dpix, grad_acc, st);
+            launch_blend_bwd(C, W, H, num_segments, background, feats, g, im, b, dL_dpix, grad_acc, st);
         }
         GSR_CHECK_LAUNCH("blend_bwd_kernel");
     }
@@ -253,7 +285,7 @@ int gsr_backward(int P, int D, int M, int R, int num_segments, const float* back
         Scope sc(ST_GEOM_BWD, st);
         launch_geom_bwd(P, D, M, means3D, shs, cov3D_precomp ? nullptr : scales, scale_modifier,
                         cov3D_precomp ? nullptr : rotations, cov3D_precomp, viewmatrix, projmatrix, campos, W, H,
-                        tan_fovx, tan_fovy, radii, g, grad_acc, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D,
+                        tan_fovx, tan_fovy, radii, g, C, grad_acc, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D,
                         dL_dcov3D, shs ? dL_dsh : nullptr, cov3D_precomp ? nullptr : dL_dscale, cov3D_precomp ? nullptr : dL_drot,
                         st);
     }

@@ -25,11 +25,17 @@
 //    reduced by v_mfma_f32_16x16x4_f32 (exact f32 multiply-add, 16 issues cover 64 pixels) while the vector
 //    ALU already works on the next instances.  This is the one place on the path that IS a contraction; it
 //    replaces a 26-instruction cross-lane VALU reduction per instance (30 % of the kernel before);
+//    The moments land in the fields of the instance's LDS queue slot that are dead by then;
 //  * one lane per instance then re-centres the six spatial sums on the splat (dx = x_splat - x_pixel) --
 //    dL_dcolor, dL_dopacity, dL_dmean2D and dL_dconic are fixed per-Gaussian linear maps of the nine moments,
 //    applied once per Gaussian in geom_bwd -- and the table is flushed ROW-MAJOR: one atomic instruction covers
 //    the nine consecutive floats of ~7 packed 48-byte records grad_acc[gaussian][12], so the memory pipeline
 //    merges lanes per cache line (1.5 M atomic requests per 1080p view instead of 8 M).
+//
+// Template over the channel count C (3 = the reference's NUM_CHANNELS; 6 = two targets sharing geometry blended
+// in one walk, see gsr_blend_fwd.hip): w is shared by all channels, r sums dL_dalpha over them, so a 6-channel
+// unit costs ~20 % more than a 3-channel one instead of 2x.  Record of the accumulation table:
+// grad_acc[gaussian][GRAD_RS] = {sum r, sum r dx, sum r dy, sum r dx^2, sum r dx dy, sum r dy^2, c_0 .. c_{C-1}}.
 #include "gsr_internal.h"
 #include <cstdlib>
 
@@ -37,28 +43,44 @@ namespace gsr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct __attribute__((aligned(16))) SlotB {   // 48 B per queued instance
-    float4 a;   // x, y, conic_a, conic_b
-    float4 b;   // conic_c, opacity, r, g
-    float4 c;   // blue, list position (0-based, uint bits), gaussian id (uint bits), -
+// LDS queue slot of one fetched instance, as floats:
+//   [0] x  [1] y  [2] gaussian id (uint bits)  [3] conic_a  [4] conic_b  [5] conic_c  [6] opacity
+//   [7] list position (uint bits)  [8 ..] colour channels            -> 12 floats (C = 3), 16 floats (C = 6)
+// Once the instance's w and r are out only x, y and the id are still needed: the 6 + C moments overwrite
+// floats [3 .. 8 + C] (no separate moment table -> more resident waves).
+template <int C> struct SlotLayout {
+    static constexpr int FLOATS = (8 + C + 3) / 4 * 4;
+    static constexpr int VECS = FLOATS / 4;
+    static constexpr int NM = 6 + C;        // moments per instance
+    static constexpr int MOM0 = 3;          // first overwritten float
+    static_assert(MOM0 + NM <= FLOATS, "moments must fit the slot");
 };
 
-struct FetchedB { float4 a, b; float fr, fg, fb; uint32_t gid; };
+template <int C> struct FetchedB { float4 a, b; float col[C]; uint32_t gid; };
 
-__device__ __forceinline__ FetchedB fetch_instance_b(int k, int k_min, const uint32_t* __restrict__ list,
-                                                     const float4* __restrict__ g0, const float4* __restrict__ g1,
-                                                     const float* __restrict__ feats)
+template <int C>
+__device__ __forceinline__ FetchedB<C> fetch_instance_b(int k, int k_min, const uint32_t* __restrict__ list,
+                                                        const float4* __restrict__ g0, const float4* __restrict__ g1,
+                                                        const float* __restrict__ feats)
 {
-    FetchedB f;
+    FetchedB<C> f;
     f.a = make_float4(0.f, 0.f, 1.f, 0.f);
     f.b = make_float4(1.f, 0.f, -1.f, 0.f);   // tau = -1: never kept
-    f.fr = f.fg = f.fb = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) f.col[ch] = 0.f;
     f.gid = 0;
     if (k >= k_min) {
         f.gid = list[k];
         f.a = g0[f.gid];
         f.b = g1[f.gid];
-        f.fr = feats[3 * (size_t)f.gid]; f.fg = feats[3 * (size_t)f.gid + 1]; f.fb = feats[3 * (size_t)f.gid + 2];
+        if constexpr (C % 2 == 0) {
+            const float2* pf = reinterpret_cast<const float2*>(feats + (size_t)C * f.gid);
+#pragma unroll
+            for (int ch = 0; ch < C; ch += 2) { const float2 v = pf[ch / 2]; f.col[ch] = v.x; f.col[ch + 1] = v.y; }
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) f.col[ch] = feats[(size_t)C * f.gid + ch];
+        }
     }
     return f;
 }
@@ -70,13 +92,10 @@ __device__ __forceinline__ void atomic_add_f32(float* p, float v)
 
 constexpr int GRP = 8;          // instances per MFMA group: A-operand rows 0..7 carry their r, rows 8..15 their w
 constexpr int RSTRIDE = 68;     // floats per row of the r|w table: 64 pixels + 4 (16-byte aligned, spreads banks)
-// Once an instance's w and r are out, its queue slot only needs to keep x, y and the gaussian id: the nine
-// moments overwrite the other nine floats of the 48-byte slot (no separate moment table -> more resident waves).
-constexpr int SLOT_FLOATS = 12;
-__device__ __forceinline__ int moment_off(int m) { return m < 8 ? 2 + m : 11; }   // skips x, y (0, 1) and the id (10)
 
 static_assert(SEG == 64, "one fetch batch per unit");
 
+template <int C>
 __global__ void __launch_bounds__(64)
 blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ seg_off,
                  const uint32_t* __restrict__ unit_tile, const float4* __restrict__ snap,
@@ -85,8 +104,12 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                  const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
                  const float* __restrict__ dL_dpix, float* __restrict__ grad_acc, uint64_t* __restrict__ trace)
 {
+    using L = SlotLayout<C>;
+    constexpr int SF = L::FLOATS, NM = L::NM, MOM0 = L::MOM0, SV = snap_vecs(C);
+    static_assert(NM <= 16 && NM <= GRAD_RS, "moment columns must fit one MFMA tile and one record");
+    static_assert((C + 1) * 64 <= 2 * GRP * RSTRIDE, "dL_dpix staging must fit the r|w table");
     const uint64_t t_start = trace ? wall_clock64() : 0;
-    __shared__ SlotB queue[64];
+    __shared__ __attribute__((aligned(16))) float qf[64 * SF];             // queue slots (see SlotLayout)
     __shared__ __attribute__((aligned(16))) float Rm[2 * GRP * RSTRIDE];   // rows 0..7: r, rows 8..15: w, [row][pixel lane]
     float* const Wm = Rm + GRP * RSTRIDE;
     // one wave64 per workgroup: unit = (tile, segment), wave = 8x8 block of the tile
@@ -106,53 +129,69 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     const int n = (int)(rg.y - rg.x);
     const int s1 = min(s0 + SEG, n);
     const uint32_t* list = point_list + rg.x;
-    SlotB* q = queue;
-    float* const qf = reinterpret_cast<float*>(queue);
 
     const size_t pix = (size_t)W * py + px;
     const size_t HW = (size_t)H * W;
     const float T_final = inside ? final_T[pix] : 0.f;
     const int my_last = inside ? (int)n_contrib[pix] : 0;   // 1-based position of the last contributor
-    float dpr = 0.f, dpg = 0.f, dpb = 0.f;
-    if (inside) { dpr = dL_dpix[pix]; dpg = dL_dpix[HW + pix]; dpb = dL_dpix[2 * HW + pix]; }
-    const float bg_dot_dpixel = bg[0] * dpr + bg[1] * dpg + bg[2] * dpb;
+    float dp[C];
+    float bg_dot_dpixel = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) {
+        dp[ch] = inside ? dL_dpix[ch * HW + pix] : 0.f;
+        bg_dot_dpixel += bg[ch] * dp[ch];
+    }
 
     // Per-pixel start state at the far end of the segment.
     float T = T_final;
-    float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, last_alpha = 0.f, last_r = 0.f, last_g = 0.f, last_b = 0.f;
+    float acc[C], last_c[C];
+    float last_alpha = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) { acc[ch] = 0.f; last_c[ch] = 0.f; }
     const int my_lim = min(my_last, s1);                 // this pixel replays positions [s0, my_lim)
     if (my_last > s1) {
         // the pixel blended instances beyond this segment: resume from the forward's snapshot taken before
         // list position s1.  accum_rec at that point = colour composited behind s1, seen from s1.
         const int pidx = 16 * (py - ty * TILE) + (px - tx * TILE);
-        const float4 sn = snap[(size_t)(unit + 1) * 256 + pidx];
-        const float4 fin = snap[(size_t)unit0 * 256 + pidx];   // {C_final rgb, T_final} kept in the tile's first slot
-        const float inv = __builtin_amdgcn_rcpf(sn.x);
-        T = sn.x;
-        acc_r = (fin.x - sn.y) * inv;
-        acc_g = (fin.y - sn.z) * inv;
-        acc_b = (fin.z - sn.w) * inv;
+        float Ts, Tf, cs[C], cf[C];
+        load_snapshot<C>(snap + ((size_t)(unit + 1) * 256 + pidx) * SV, Ts, cs);
+        load_snapshot<C>(snap + ((size_t)unit0 * 256 + pidx) * SV, Tf, cf);   // final (T, C) kept in the tile's first slot
+        const float inv = __builtin_amdgcn_rcpf(Ts);
+        T = Ts;
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) acc[ch] = (cf[ch] - cs[ch]) * inv;
     }
 
-    // Nothing behind the deepest position any pixel of this wave replays can matter.
-    int wave_hi = my_lim;
+    // Nothing behind the deepest position any pixel of this wave replays can matter.  In every segment but a
+    // pixel's last one that is simply the segment end (one ballot); only otherwise reduce.
+    int wave_hi;
+#ifndef GSR_NO_HI_SHORTCUT
+    if (__ballot(my_last >= s1) != 0ull) {
+        wave_hi = s1;
+    } else
+#endif
+    {
+        wave_hi = my_lim;
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) wave_hi = max(wave_hi, __shfl_xor(wave_hi, d, 64));
-    wave_hi = __builtin_amdgcn_readfirstlane(wave_hi);
+        for (int d = 32; d > 0; d >>= 1) wave_hi = max(wave_hi, __shfl_xor(wave_hi, d, 64));
+        wave_hi = __builtin_amdgcn_readfirstlane(wave_hi);
+    }
     if (wave_hi <= s0) return;
 
     // lane l takes list position wave_hi-1-l: queue order == back-to-front order
     const int k = wave_hi - 1 - lane;
-    const FetchedB cur = fetch_instance_b(k, s0, list, g0, g1, feats);
+    const FetchedB<C> cur = fetch_instance_b<C>(k, s0, list, g0, g1, feats);
 
-    // B operands of the contraction, constant over the unit.  MFMA step t (0..15) consumes the four pixels
+    // B operand of the contraction, constant over the unit.  MFMA step t (0..15) consumes the four pixels
     // p = 16*kap + t, kap = 0..3; in the B operand lane l carries row kap = l >> 4, column col = l & 15.
-    // Columns 0..5 of the spatial operand: {1, x, y, x^2, xy, y^2} of pixel p relative to the block centre;
-    // columns 0..2 of the colour operand: dL_dpix_{r,g,b} of pixel p (staged through LDS once).
+    // Columns 0..5: {1, x, y, x^2, xy, y^2} of pixel p relative to the block centre (used by the r rows);
+    // columns 6..6+C-1: dL_dpix of pixel p per channel (used by the w rows; staged through LDS once).
     const int kap = lane >> 4, col = lane & 15;
-    Rm[lane] = dpr; Rm[64 + lane] = dpg; Rm[128 + lane] = dpb; Rm[192 + lane] = 0.f;   // [channel][pixel], 4th = 0
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) Rm[ch * 64 + lane] = dp[ch];   // [channel][pixel]
+    Rm[C * 64 + lane] = 0.f;                                      // extra all-zero channel for the unused columns
     __builtin_amdgcn_wave_barrier();
-    float Bf[16];   // columns 0..5 spatial (used by the r rows), 6..8 dL_dpix (used by the w rows), 9..15 zero
+    float Bf[16];
     {
         // spatial monomial of this lane's column as  base(y) + x*slope(y) + x^2*quad : x is a compile-time constant
         // per step, y takes two values per lane; all products are exact (small half-integers), one term non-zero
@@ -162,7 +201,7 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         const float base_b = col == 0 ? 1.0f : col == 2 ? yb : col == 5 ? yb * yb : 0.0f;
         const float slope_a = col == 1 ? 1.0f : col == 4 ? ya : 0.0f;
         const float slope_b = col == 1 ? 1.0f : col == 4 ? yb : 0.0f;
-        const int ch = (col >= 6 && col < 9) ? col - 6 : 3;
+        const int ch = (col >= 6 && col < 6 + C) ? col - 6 : C;
         const float4* pd = reinterpret_cast<const float4*>(&Rm[ch * 64 + 16 * kap]);
         const bool spatial = col < 6;
 #pragma unroll
@@ -186,9 +225,16 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     const int cnt = __popcll(m);
     if (keep) {
         const int slot = __popcll(m & ((1ull << lane) - 1ull));
-        q[slot].a = cur.a;
-        q[slot].b = make_float4(cur.b.x, cur.b.y, cur.fr, cur.fg);
-        q[slot].c = make_float4(cur.fb, __uint_as_float((uint32_t)k), __uint_as_float(cur.gid), 0.f);
+        float4* qs = reinterpret_cast<float4*>(&qf[slot * SF]);
+        qs[0] = make_float4(cur.a.x, cur.a.y, __uint_as_float(cur.gid), cur.a.z);
+        qs[1] = make_float4(cur.a.w, cur.b.x, cur.b.y, __uint_as_float((uint32_t)k));
+#pragma unroll
+        for (int v = 2; v < L::VECS; v++) {
+            const int c0 = 4 * (v - 2);
+            qs[v] = make_float4(c0 < C ? cur.col[c0 < C ? c0 : 0] : 0.f, c0 + 1 < C ? cur.col[c0 + 1 < C ? c0 + 1 : 0] : 0.f,
+                                c0 + 2 < C ? cur.col[c0 + 2 < C ? c0 + 2 : 0] : 0.f,
+                                c0 + 3 < C ? cur.col[c0 + 3 < C ? c0 + 3 : 0] : 0.f);
+        }
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -200,12 +246,23 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             const int j = g0i + jj;
             float r = 0.f, w = 0.f;
             if (j < cnt) {
-                const float4 A = q[j].a, B = q[j].b, Cc = q[j].c;
-                const int pos = (int)__float_as_uint(Cc.y);
+                const float4* qs = reinterpret_cast<const float4*>(&qf[j * SF]);
+                const float4 A = qs[0], B = qs[1];
+                float cc[C];
+#pragma unroll
+                for (int v = 2; v < L::VECS; v++) {
+                    const float4 kv = qs[v];
+                    const int c0 = 4 * (v - 2);
+                    if (c0 < C) cc[c0 < C ? c0 : 0] = kv.x;
+                    if (c0 + 1 < C) cc[c0 + 1 < C ? c0 + 1 : 0] = kv.y;
+                    if (c0 + 2 < C) cc[c0 + 2 < C ? c0 + 2 : 0] = kv.z;
+                    if (c0 + 3 < C) cc[c0 + 3 < C ? c0 + 3 : 0] = kv.w;
+                }
+                const int pos = (int)__float_as_uint(B.w);
                 const float dx = A.x - pxf, dy = A.y - pyf;
-                const float power = pair_power(A.z, A.w, B.x, dx, dy);
+                const float power = pair_power(A.w, B.x, B.y, dx, dy);
                 const float G = __expf(power);
-                const float alpha = fminf(ALPHA_MAX, B.y * G);
+                const float alpha = fminf(ALPHA_MAX, B.z * G);
                 const bool live = pos < my_lim && power <= 0.0f && alpha >= ALPHA_MIN;
                 if (__ballot(live) != 0ull) {
                     touched |= 1ull << j;
@@ -213,11 +270,13 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                         const float rinv = __builtin_amdgcn_rcpf(1.f - alpha);
                         T = T * rinv;
                         w = alpha * T;
-                        acc_r = last_alpha * last_r + (1.f - last_alpha) * acc_r;
-                        acc_g = last_alpha * last_g + (1.f - last_alpha) * acc_g;
-                        acc_b = last_alpha * last_b + (1.f - last_alpha) * acc_b;
-                        last_r = B.z; last_g = B.w; last_b = Cc.x;
-                        float dL_dalpha = (B.z - acc_r) * dpr + (B.w - acc_g) * dpg + (Cc.x - acc_b) * dpb;
+                        float dL_dalpha = 0.f;
+#pragma unroll
+                        for (int ch = 0; ch < C; ch++) {
+                            acc[ch] = last_alpha * last_c[ch] + (1.f - last_alpha) * acc[ch];
+                            last_c[ch] = cc[ch];
+                            dL_dalpha += (cc[ch] - acc[ch]) * dp[ch];
+                        }
                         dL_dalpha *= T;
                         last_alpha = alpha;
                         dL_dalpha -= (T_final * rinv) * bg_dot_dpixel;
@@ -229,14 +288,14 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             Wm[jj * RSTRIDE + lane] = w;
         }
         __builtin_amdgcn_wave_barrier();
-        // ---- matrix pipe: [GRP instances x 64 pixels] . [64 pixels x 16] for r (6 columns used) and w (3 used).
-        // A operand: lane l carries instance row (l & 15) and, for step t, pixel 16*kap + t -> its 16 steps are
-        // 16 consecutive floats of the row (four ds_read_b128).
-        // two interleaved accumulators (even / odd steps) halve the dependent-accumulator chain
+        // ---- matrix pipe: [16 rows = r and w of GRP instances] x [64 pixels] . [64 pixels x 16 columns].
+        // A operand: lane l carries table row (l & 15) and, for step t, pixel 16*kap + t -> its 16 steps are
+        // 16 consecutive floats of the row (four ds_read_b128).  Two interleaved accumulators (even / odd steps)
+        // halve the dependent-accumulator chain.
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         float ra[16];
         {
-            const float4* pr = reinterpret_cast<const float4*>(&Rm[col * RSTRIDE + 16 * kap]);   // row col of r|w
+            const float4* pr = reinterpret_cast<const float4*>(&Rm[col * RSTRIDE + 16 * kap]);
 #pragma unroll
             for (int qd = 0; qd < 4; qd++) {
                 const float4 v = pr[qd];
@@ -249,41 +308,38 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[t + 1], Bf[t + 1], acc1, 0, 0, 0);
         }
         // D layout: lane l, register i -> operand row 4*(l >> 4) + i, column l & 15.
-        // rows 0..7: r of instance row, columns 0..5 = spatial sums; rows 8..15: w of instance row-8, columns 6..8.
+        // rows 0..7: r of instance row, columns 0..5 = spatial sums; rows 8..15: w of instance row-8, columns 6..6+C-1.
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int row = 4 * kap + i, inst = g0i + (row & 7);
-            const bool take = row < GRP ? col < 6 : (col >= 6 && col < 9);
-            if (take && inst < cnt) qf[inst * SLOT_FLOATS + moment_off(col)] = acc0[i] + acc1[i];
+            const bool take = row < GRP ? col < 6 : (col >= 6 && col < NM);
+            if (take && inst < cnt) qf[inst * SF + MOM0 + col] = acc0[i] + acc1[i];
         }
         __builtin_amdgcn_wave_barrier();
     }
 
-    // ---- lane = queued instance: re-centre the spatial sums on the splat (dx = x_splat - x_pixel) and lay the
-    // nine moments out in grad_acc order {c_r, c_g, c_b, sum r, sum r dx, sum r dy, sum r dx^2, sum r dx dy, sum r dy^2}
+    // ---- lane = queued instance: re-centre the spatial sums on the splat (dx = x_splat - x_pixel), in place:
+    // {sum r, sum r dx, sum r dy, sum r dx^2, sum r dx dy, sum r dy^2}; the colour moments stay as they are.
     if (lane < cnt && ((touched >> lane) & 1ull)) {
-        float* rw = &qf[lane * SLOT_FLOATS];
-        const float m0 = rw[moment_off(0)], mx = rw[moment_off(1)], my = rw[moment_off(2)], mxx = rw[moment_off(3)],
-                    mxy = rw[moment_off(4)], myy = rw[moment_off(5)];
-        const float c0 = rw[moment_off(6)], c1 = rw[moment_off(7)], c2 = rw[moment_off(8)];
+        float* rw = &qf[lane * SF];
+        const float m0 = rw[MOM0], mx = rw[MOM0 + 1], my = rw[MOM0 + 2], mxx = rw[MOM0 + 3], mxy = rw[MOM0 + 4],
+                    myy = rw[MOM0 + 5];
         const float X = rw[0] - (bx0 + 3.5f), Y = rw[1] - (by0 + 3.5f);
-        rw[moment_off(0)] = c0; rw[moment_off(1)] = c1; rw[moment_off(2)] = c2;
-        rw[moment_off(3)] = m0;
-        rw[moment_off(4)] = X * m0 - mx;
-        rw[moment_off(5)] = Y * m0 - my;
-        rw[moment_off(6)] = (X * X) * m0 - 2.f * X * mx + mxx;
-        rw[moment_off(7)] = (X * Y) * m0 - X * my - Y * mx + mxy;
-        rw[moment_off(8)] = (Y * Y) * m0 - 2.f * Y * my + myy;
+        rw[MOM0 + 1] = X * m0 - mx;
+        rw[MOM0 + 2] = Y * m0 - my;
+        rw[MOM0 + 3] = (X * X) * m0 - 2.f * X * mx + mxx;
+        rw[MOM0 + 4] = (X * Y) * m0 - X * my - Y * mx + mxy;
+        rw[MOM0 + 5] = (Y * Y) * m0 - 2.f * Y * my + myy;
     }
     __builtin_amdgcn_wave_barrier();
-    // flush: lanes walk the (instance, moment) table row-major, so one atomic instruction covers the nine
-    // consecutive floats of ~7 packed records -- the memory pipeline merges lanes that share a cache line
-    // into one request instead of nine.
-    for (int idx = lane; idx < cnt * 9; idx += 64) {
-        const int e = idx / 9, v = idx - e * 9;
+    // flush: lanes walk the (instance, moment) table row-major, so one atomic instruction covers the consecutive
+    // floats of several packed records -- the memory pipeline merges lanes that share a cache line into one
+    // request instead of one per float.
+    for (int idx = lane; idx < cnt * NM; idx += 64) {
+        const int e = idx / NM, v = idx - e * NM;
         if ((touched >> e) & 1ull) {
-            const size_t g = __float_as_uint(qf[e * SLOT_FLOATS + 10]);
-            atomic_add_f32(grad_acc + g * 12 + v, qf[e * SLOT_FLOATS + moment_off(v)]);
+            const size_t g = __float_as_uint(qf[e * SF + 2]);
+            atomic_add_f32(grad_acc + g * GRAD_RS + v, qf[e * SF + MOM0 + v]);
         }
     }
     if (trace && lane == 0) {   // last wave to finish wins the end stamp (monotone clock, max via atomic)
@@ -292,16 +348,20 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     }
 }
 
-void launch_blend_bwd(int W, int H, int U, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
-                      const float* dL_dpix, float* grad_acc, hipStream_t st)
+void launch_blend_bwd(int C, int W, int H, int U, const float* bg, const float* feats, GeomState g, ImageState im,
+                      BinState b, const float* dL_dpix, float* grad_acc, hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);
     if (U <= 0) return;
     // Residency knob: extra dynamic LDS lowers the number of co-resident units per CU (tuning only).
     static const int pad = getenv("GSR_BWD_LDS_PAD") ? atoi(getenv("GSR_BWD_LDS_PAD")) : 0;
-    blend_bwd_kernel<<<4 * U, 64, pad, st>>>(W, H, t.gx, im.ranges, im.seg_off, b.unit_tile, b.snap, b.point_list,
-                                             g.g0, g.g1, feats, bg, im.final_T, im.n_contrib, dL_dpix, grad_acc,
-                                             g_trace ? g_trace + 2 * (size_t)t.T : nullptr);
+    uint64_t* tr = g_trace ? g_trace + 2 * (size_t)t.T : nullptr;
+    if (C == 6)
+        blend_bwd_kernel<6><<<4 * U, 64, pad, st>>>(W, H, t.gx, im.ranges, im.seg_off, b.unit_tile, b.snap, b.point_list,
+                                                    g.g0, g.g1, feats, bg, im.final_T, im.n_contrib, dL_dpix, grad_acc, tr);
+    else
+        blend_bwd_kernel<3><<<4 * U, 64, pad, st>>>(W, H, t.gx, im.ranges, im.seg_off, b.unit_tile, b.snap, b.point_list,
+                                                    g.g0, g.g1, feats, bg, im.final_T, im.n_contrib, dL_dpix, grad_acc, tr);
 }
 
 }  // namespace gsr

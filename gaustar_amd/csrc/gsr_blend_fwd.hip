@@ -21,17 +21,24 @@
 // n_contrib stores the 1-based list position of the last blended instance, as the reference does.
 // At every SEG-th list position the running (T, C) of the pixels still alive is snapshotted for the
 // segment-parallel backward pass (gsr_blend_bwd.hip).
+//
+// The kernel is a template over the number of colour channels C: 3 is the reference's NUM_CHANNELS
+// (cuda_rasterizer/config.h:15); 6 renders TWO targets that share geometry (GauSTAR's RGB + depth-as-colour
+// passes, refine.py:552 and :607) in one walk -- alpha, T, termination and n_contrib do not depend on colour,
+// so channels 0-2 / 3-5 are bit-identical to two separate 3-channel renders.
 #include "gsr_internal.h"
 
 namespace gsr {
 
-struct __attribute__((aligned(16))) Slot {   // 48 B per fetched instance
-    float4 a;   // x, y, conic_a, conic_b
-    float4 b;   // conic_c, opacity, r, g
-    float4 c;   // blue, list position + 1 (as uint bits), -, -
+template <int C>
+struct __attribute__((aligned(16))) Slot {   // 48 B (C = 3) / 64 B (C = 6) per fetched instance
+    float4 a;                        // x, y, conic_a, conic_b
+    float4 b;                        // conic_c, opacity, list position + 1 (as uint bits), -
+    float col[(C + 3) / 4 * 4];      // colour channels
 };
 
-struct Fetched { float4 a, b; float fr, fg, fb; };
+template <int C>
+struct Fetched { float4 a, b; float col[C]; };
 
 // Two-stage software pipeline over the dependent gather (list -> id -> records): ids are fetched two batches
 // ahead, records one batch ahead, so neither load latency sits on the per-batch critical path.
@@ -39,23 +46,33 @@ __device__ __forceinline__ uint32_t fetch_id(uint32_t k, uint32_t n, const uint3
 {
     return k < n ? list[k] : 0xffffffffu;
 }
-__device__ __forceinline__ Fetched fetch_record(uint32_t gid, const float4* __restrict__ g0,
-                                                const float4* __restrict__ g1, const float* __restrict__ feats)
+template <int C>
+__device__ __forceinline__ Fetched<C> fetch_record(uint32_t gid, const float4* __restrict__ g0,
+                                                   const float4* __restrict__ g1, const float* __restrict__ feats)
 {
-    Fetched f;
+    Fetched<C> f;
     f.a = make_float4(0.f, 0.f, 1.f, 0.f);
     f.b = make_float4(1.f, 0.f, -1.f, 0.f);   // tau = -1: never kept
-    f.fr = f.fg = f.fb = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) f.col[ch] = 0.f;
     if (gid != 0xffffffffu) {
         f.a = g0[gid];
         f.b = g1[gid];
-        f.fr = feats[3 * (size_t)gid]; f.fg = feats[3 * (size_t)gid + 1]; f.fb = feats[3 * (size_t)gid + 2];
+        if constexpr (C % 2 == 0) {   // rows of an even channel count are 8-byte aligned
+            const float2* pf = reinterpret_cast<const float2*>(feats + (size_t)C * gid);
+#pragma unroll
+            for (int ch = 0; ch < C; ch += 2) { const float2 v = pf[ch / 2]; f.col[ch] = v.x; f.col[ch + 1] = v.y; }
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) f.col[ch] = feats[(size_t)C * gid + ch];
+        }
     }
     return f;
 }
 
 constexpr int QCAP = 64 + 4;   // queue capacity per quadrant (+4: the 4-deep loop reads whole words)
 
+template <int C>
 __global__ void __launch_bounds__(256)
 blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ order,
                  const uint32_t* __restrict__ point_list, const float4* __restrict__ g0,
@@ -64,7 +81,9 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                  const uint32_t* __restrict__ seg_off, float4* __restrict__ snap, uint64_t* __restrict__ trace)
 {
     const uint64_t t_start = trace ? wall_clock64() : 0;
-    __shared__ Slot entries[4][64 + 1];                               // [wave][batch lane]; slot 64 = neutral
+    constexpr int SV = snap_vecs(C);
+    constexpr int CV = (C + 3) / 4;                                   // float4s of colour per slot
+    __shared__ Slot<C> entries[4][64 + 1];                            // [wave][batch lane]; slot 64 = neutral
     __shared__ __attribute__((aligned(4))) uint8_t qidx[4][4][QCAP];  // [wave][quadrant][queue position]
     const int tile = (int)order[blockIdx.x];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -80,21 +99,25 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     const uint32_t n = rg.y - rg.x;
     const uint32_t unit0 = seg_off[tile];
     const uint32_t* list = point_list + rg.x;
-    Slot* ent = entries[wave];
+    Slot<C>* ent = entries[wave];
     uint8_t (*qi)[QCAP] = qidx[wave];
 
     if (lane == 0) {   // neutral instance: opacity 0 never passes the alpha test
         ent[64].a = make_float4(0.f, 0.f, 0.f, 0.f);
         ent[64].b = make_float4(0.f, 0.f, 0.f, 0.f);
-        ent[64].c = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ch = 0; ch < CV * 4; ch++) ent[64].col[ch] = 0.f;
     }
 
-    float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f;
+    float T = 1.0f;
+    float Cc[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) Cc[ch] = 0.f;
     uint32_t last = 0;
     bool done = !inside;
     const unsigned long long lt = (1ull << lane) - 1ull;
 
-    Fetched nxt = fetch_record(fetch_id(lane, n, list), g0, g1, feats);
+    Fetched<C> nxt = fetch_record<C>(fetch_id(lane, n, list), g0, g1, feats);
     uint32_t gid_nxt = fetch_id(64 + lane, n, list);
     for (uint32_t base = 0; base < n; base += 64) {
         const unsigned long long alive = __ballot(!done);
@@ -102,14 +125,18 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         // segment boundary: snapshot the running state of every pixel still alive (the backward blend
         // starts its segments from these instead of replaying the whole list)
         if (base != 0 && (base % SEG) == 0 && !done)
-            snap[(size_t)(unit0 + base / SEG) * 256 + pix_in_tile] = make_float4(T, Cr, Cg, Cb);
-        const Fetched cur = nxt;
-        nxt = fetch_record(gid_nxt, g0, g1, feats);         // records of batch +1 (ids arrived during the last batch)
+            store_snapshot<C>(snap + ((size_t)(unit0 + base / SEG) * 256 + pix_in_tile) * SV, T, Cc);
+        const Fetched<C> cur = nxt;
+        nxt = fetch_record<C>(gid_nxt, g0, g1, feats);      // records of batch +1 (ids arrived during the last batch)
         gid_nxt = fetch_id(base + 128 + lane, n, list);     // ids of batch +2
         const uint32_t k = base + lane;
         ent[lane].a = cur.a;
-        ent[lane].b = make_float4(cur.b.x, cur.b.y, cur.fr, cur.fg);
-        ent[lane].c = make_float4(cur.fb, __uint_as_float(k + 1), 0.f, 0.f);
+        ent[lane].b = make_float4(cur.b.x, cur.b.y, __uint_as_float(k + 1), 0.f);
+#pragma unroll
+        for (int v = 0; v < CV; v++)
+            reinterpret_cast<float4*>(ent[lane].col)[v] =
+                make_float4(cur.col[4 * v], 4 * v + 1 < C ? cur.col[4 * v + 1] : 0.f, 4 * v + 2 < C ? cur.col[4 * v + 2] : 0.f,
+                            4 * v + 3 < C ? cur.col[4 * v + 3] : 0.f);
         // exact reachability test against each quadrant that still has an unsaturated pixel
         int cnt[4];
 #pragma unroll
@@ -129,13 +156,15 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         for (int j = 0; j < max_cnt; j += 4) {
             // four queue positions at once; rows past their own queue end read the neutral instance
             const uint32_t packed = j < my_cnt ? *reinterpret_cast<const uint32_t*>(myq + j) : 0x40404040u;
-            float4 A[4], B[4], Cc[4];
+            float4 A[4], B[4], K[4][CV];
             float alpha[4];
             bool ok[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int e = (packed >> (8 * u)) & 0xff;
-                A[u] = ent[e].a; B[u] = ent[e].b; Cc[u] = ent[e].c;
+                A[u] = ent[e].a; B[u] = ent[e].b;
+#pragma unroll
+                for (int v = 0; v < CV; v++) K[u][v] = reinterpret_cast<const float4*>(ent[e].col)[v];
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -152,9 +181,13 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                 const bool upd = live && !stop;
                 done = done || stop;
                 const float w = upd ? alpha[u] * T : 0.0f;
-                Cr += B[u].z * w; Cg += B[u].w * w; Cb += Cc[u].x * w;
+#pragma unroll
+                for (int ch = 0; ch < C; ch++) {
+                    const float4 kv = K[u][ch / 4];
+                    Cc[ch] += (ch % 4 == 0 ? kv.x : ch % 4 == 1 ? kv.y : ch % 4 == 2 ? kv.z : kv.w) * w;
+                }
                 T = upd ? test_T : T;
-                last = upd ? __float_as_uint(Cc[u].y) : last;
+                last = upd ? __float_as_uint(B[u].z) : last;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -164,12 +197,11 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         const size_t HW = (size_t)H * W;
         final_T[pix] = T;
         n_contrib[pix] = last;
-        out_color[pix] = Cr + T * bg[0];
-        out_color[HW + pix] = Cg + T * bg[1];
-        out_color[2 * HW + pix] = Cb + T * bg[2];
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) out_color[ch * HW + pix] = Cc[ch] + T * bg[ch];
         // a tile with more than one segment: the first unit's snapshot slot (never used as a boundary) keeps the
-        // final composited colour, from which the backward derives "colour behind a boundary" = C_final - C_snap
-        if (n > (uint32_t)SEG) snap[(size_t)unit0 * 256 + pix_in_tile] = make_float4(Cr, Cg, Cb, T);
+        // final (T, C), from which the backward derives "colour behind a boundary" = C_final - C_snap
+        if (n > (uint32_t)SEG) store_snapshot<C>(snap + ((size_t)unit0 * 256 + pix_in_tile) * SV, T, Cc);
     }
     if (trace && lane == 0) {   // last wave to finish wins the end stamp
         if (wave == 0) trace[2 * blockIdx.x] = t_start;
@@ -177,12 +209,16 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     }
 }
 
-void launch_blend_fwd(int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
+void launch_blend_fwd(int C, int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
                       float* out_color, hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);
-    blend_fwd_kernel<<<t.T, 256, 0, st>>>(W, H, t.gx, im.ranges, im.order, b.point_list, g.g0, g.g1, feats, bg, out_color,
-                                          im.final_T, im.n_contrib, im.seg_off, b.snap, g_trace);
+    if (C == 6)
+        blend_fwd_kernel<6><<<t.T, 256, 0, st>>>(W, H, t.gx, im.ranges, im.order, b.point_list, g.g0, g.g1, feats, bg,
+                                                 out_color, im.final_T, im.n_contrib, im.seg_off, b.snap, g_trace);
+    else
+        blend_fwd_kernel<3><<<t.T, 256, 0, st>>>(W, H, t.gx, im.ranges, im.order, b.point_list, g.g0, g.g1, feats, bg,
+                                                 out_color, im.final_T, im.n_contrib, im.seg_off, b.snap, g_trace);
 }
 
 }  // namespace gsr

@@ -17,7 +17,7 @@
 namespace gsr {
 
 __global__ void __launch_bounds__(256)
-geom_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
+geom_bwd_kernel(int P, int D, int M, int C, const float* __restrict__ means3D, const float* __restrict__ shs,
                 const float* __restrict__ scales, float scale_modifier, const float* __restrict__ rotations,
                 const float* __restrict__ cov3D_precomp, const float* __restrict__ view,
                 const float* __restrict__ proj, const float* __restrict__ campos, float tan_fovx, float tan_fovy,
@@ -33,7 +33,7 @@ geom_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const fl
 
     if (!(radii[idx] > 0)) {
         dL_dmean2D[3 * i] = 0.f; dL_dmean2D[3 * i + 1] = 0.f; dL_dmean2D[3 * i + 2] = 0.f;
-        dL_dcolor[3 * i] = 0.f; dL_dcolor[3 * i + 1] = 0.f; dL_dcolor[3 * i + 2] = 0.f;
+        for (int ch = 0; ch < C; ch++) dL_dcolor[(size_t)C * i + ch] = 0.f;
         dL_dopacity[i] = 0.f;
         dL_dmean3D[3 * i] = 0.f; dL_dmean3D[3 * i + 1] = 0.f; dL_dmean3D[3 * i + 2] = 0.f;
 #pragma unroll
@@ -48,16 +48,24 @@ geom_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const fl
     const Vec3 mean = load3(means3D, i);
 
     // ---------------- moments -> dL_dcolor, dL_dopacity, dL_dmean2D, dL_dconic
-    const float4 m0 = grad_acc[3 * i], m1 = grad_acc[3 * i + 1], m2 = grad_acc[3 * i + 2];
-    // m0 = {sum w*dpix_r, g, b, sum r}; m1 = {sum r dx, sum r dy, sum r dx^2, sum r dx dy}; m2.x = sum r dy^2
+    static_assert(GRAD_RS == 12, "three float4 per record");
+    const float4 f0 = grad_acc[3 * i], f1 = grad_acc[3 * i + 1], f2 = grad_acc[3 * i + 2];
+    // record = {sum r, sum r dx, sum r dy, sum r dx^2 | sum r dx dy, sum r dy^2, c0, c1 | c2, c3, c4, c5},
+    // c_k = sum w*dL_dpix_k (gsr_blend_bwd.hip)
+    const float s_r = f0.x, s_x = f0.y, s_y = f0.z, s_xx = f0.w, s_xy = f1.x, s_yy = f1.y;
+    const float cm[6] = {f1.z, f1.w, f2.x, f2.y, f2.z, f2.w};
     const float4 ga = g0[i], gb = g1[i];
     const float con_a = ga.z, con_b = ga.w, con_c = gb.x, op = gb.y;
-    dL_dcolor[3 * i] = m0.x; dL_dcolor[3 * i + 1] = m0.y; dL_dcolor[3 * i + 2] = m0.z;
-    dL_dopacity[i] = m0.w;
-    const float gx2 = -op * (con_a * m1.x + con_b * m1.y) * half_w;
-    const float gy2 = -op * (con_c * m1.y + con_b * m1.x) * half_h;
+    if (C == 3) { dL_dcolor[3 * i] = cm[0]; dL_dcolor[3 * i + 1] = cm[1]; dL_dcolor[3 * i + 2] = cm[2]; }
+    else {
+#pragma unroll
+        for (int ch = 0; ch < 6; ch++) if (ch < C) dL_dcolor[(size_t)C * i + ch] = cm[ch];
+    }
+    dL_dopacity[i] = s_r;
+    const float gx2 = -op * (con_a * s_x + con_b * s_y) * half_w;
+    const float gy2 = -op * (con_c * s_y + con_b * s_x) * half_h;
     dL_dmean2D[3 * i] = gx2; dL_dmean2D[3 * i + 1] = gy2; dL_dmean2D[3 * i + 2] = 0.f;
-    const float4 dcon = make_float4(-0.5f * op * m1.z, -0.5f * op * m1.w, 0.f, -0.5f * op * m2.x);   // (xx, xy, -, yy)
+    const float4 dcon = make_float4(-0.5f * op * s_xx, -0.5f * op * s_xy, 0.f, -0.5f * op * s_yy);   // (xx, xy, -, yy)
 
     // ---------------- conic -> cov2D -> {cov3D, view-space mean}  (backward.cu:144-274)
     float c3[6];
@@ -141,7 +149,7 @@ geom_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const fl
         float col[3] = {0.f, 0.f, 0.f};
         for (int k = 0; k < nb; k++) { col[0] += basis[k] * sh[3 * k]; col[1] += basis[k] * sh[3 * k + 1]; col[2] += basis[k] * sh[3 * k + 2]; }
         float dRGB[3];
-        const float dcol[3] = {m0.x, m0.y, m0.z};
+        const float dcol[3] = {cm[0], cm[1], cm[2]};
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) dRGB[ch] = (col[ch] + 0.5f < 0.f) ? 0.f : dcol[ch];
         float* dsh = dL_dsh + i * M * 3;
@@ -225,12 +233,12 @@ geom_bwd_kernel(int P, int D, int M, const float* __restrict__ means3D, const fl
 void launch_geom_bwd(int P, int D, int M, const float* means3D, const float* shs, const float* scales,
                      float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* view,
                      const float* proj, const float* campos, int W, int H, float tan_fovx, float tan_fovy,
-                     const int* radii, GeomState g, const float* grad_acc, float* dL_dmean2D, float* dL_dopacity,
+                     const int* radii, GeomState g, int C, const float* grad_acc, float* dL_dmean2D, float* dL_dopacity,
                      float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
                      float* dL_drot, hipStream_t st)
 {
     const float focal_y = H / (2.0f * tan_fovy), focal_x = W / (2.0f * tan_fovx);   // rasterizer_impl.cu:381-382
-    geom_bwd_kernel<<<(P + 255) / 256, 256, 0, st>>>(P, D, M, means3D, shs, scales, scale_modifier, rotations,
+    geom_bwd_kernel<<<(P + 255) / 256, 256, 0, st>>>(P, D, M, C, means3D, shs, scales, scale_modifier, rotations,
                                                      cov3D_precomp, view, proj, campos, tan_fovx, tan_fovy, focal_x,
                                                      focal_y, 0.5f * W, 0.5f * H, radii, g.g0, g.g1,
                                                      reinterpret_cast<const float4*>(grad_acc), dL_dmean2D,

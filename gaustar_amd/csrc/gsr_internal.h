@@ -88,22 +88,28 @@ inline ImageState carve_image(void* base, int W, int H)
 // hardware dispatcher balance the backward pass and cuts its serial chain.
 constexpr int SEG = 64;
 
+// Channel count of a render: 3 = the reference's NUM_CHANNELS (cuda_rasterizer/config.h:15); 6 = two targets
+// sharing geometry, blended in one walk.  A snapshot is (T, C[0..C-1]) padded to whole float4s.
+__host__ __device__ constexpr int snap_vecs(int C) { return (C + 4) / 4; }
+__host__ __device__ constexpr bool channels_ok(int C) { return C == 3 || C == 6; }
+constexpr int GRAD_RS = 12;  // floats per record of the backward accumulation table: 6 geometric moments + C <= 6 colours
+
 struct BinState {            // per instance / per segment
     uint64_t* keys;          // [R] (depth_bits << 32) | gaussian, bucketed by tile, unsorted within the bucket
     uint32_t* point_list;    // [R] gaussian ids, tile-major, depth-ascending, ties by ascending id
     uint32_t* unit_tile;     // [U] tile of segment (unit) u; its segment index is u - seg_off[tile]
-    float4* snap;            // [U][256] per-pixel {T, Cr, Cg, Cb} BEFORE the first instance of segment u (u not the
-                             // first segment of its tile; that slot holds {C_final rgb, T_final} when the tile has
-                             // more than one segment); pixel index = 16*(y - tile_y0) + (x - tile_x0)
+    float4* snap;            // [U][256][snap_vecs(C)] per-pixel {T, C0, C1, ...} BEFORE the first instance of segment
+                             // u (u not the first segment of its tile; that slot holds the FINAL {T, C...} when the
+                             // tile has more than one segment); pixel index = 16*(y - tile_y0) + (x - tile_x0)
     size_t bytes;
 };
-inline BinState carve_bin(void* base, int R, int U)
+inline BinState carve_bin(void* base, int R, int U, int C = 3)
 {
     BinState s; size_t o = 0; char* b = (char*)base;
     s.keys = (uint64_t*)(b + o); o = align_up(o + 8 * (size_t)R);
     s.point_list = (uint32_t*)(b + o); o = align_up(o + 4 * (size_t)R);
     s.unit_tile = (uint32_t*)(b + o); o = align_up(o + 4 * (size_t)U);
-    s.snap = (float4*)(b + o); o = align_up(o + sizeof(float4) * 256 * (size_t)U);
+    s.snap = (float4*)(b + o); o = align_up(o + sizeof(float4) * 256 * (size_t)snap_vecs(C) * (size_t)U);
     s.bytes = o + 256;
     return s;
 }
@@ -129,14 +135,14 @@ void launch_preprocess(int P, int D, int M, const float* means3D, const float* s
 void launch_tile_scan(ImageState im, int T, hipStream_t st);
 void launch_scatter(int P, int W, int H, GeomState g, ImageState im, BinState b, hipStream_t st);
 void launch_tile_sort(int W, int H, uint32_t max_count, ImageState im, BinState b, hipStream_t st);
-void launch_blend_fwd(int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
+void launch_blend_fwd(int C, int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
                       float* out_color, hipStream_t st);
-void launch_blend_bwd(int W, int H, int U, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
+void launch_blend_bwd(int C, int W, int H, int U, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
                       const float* dL_dpix, float* grad_acc, hipStream_t st);
 void launch_geom_bwd(int P, int D, int M, const float* means3D, const float* shs, const float* scales,
                      float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* view,
                      const float* proj, const float* campos, int W, int H, float tan_fovx, float tan_fovy,
-                     const int* radii, GeomState g, const float* grad_acc, float* dL_dmean2D, float* dL_dopacity,
+                     const int* radii, GeomState g, int C, const float* grad_acc, float* dL_dmean2D, float* dL_dopacity,
                      float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
                      float* dL_drot, hipStream_t st);
 void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t st);
@@ -353,6 +359,31 @@ __device__ __forceinline__ void for_each_tile_aggregated(ushort4 rect, float px,
 }
 
 // Pixel centre of an NDC coordinate; evaluated in double like auxiliary.h:41-44.
+// Snapshot record of one pixel: float4s {T, C0, C1, C2}, {C3, C4, C5, 0}, ...
+template <int C>
+__device__ __forceinline__ void store_snapshot(float4* dst, float T, const float (&c)[C])
+{
+    float v[4 * snap_vecs(C)];
+    v[0] = T;
+#pragma unroll
+    for (int k = 1; k < 4 * snap_vecs(C); k++) v[k] = k - 1 < C ? c[k - 1 < C ? k - 1 : 0] : 0.f;
+#pragma unroll
+    for (int k = 0; k < snap_vecs(C); k++) dst[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+}
+template <int C>
+__device__ __forceinline__ void load_snapshot(const float4* src, float& T, float (&c)[C])
+{
+    float v[4 * snap_vecs(C)];
+#pragma unroll
+    for (int k = 0; k < snap_vecs(C); k++) {
+        const float4 q = src[k];
+        v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+    }
+    T = v[0];
+#pragma unroll
+    for (int k = 0; k < C; k++) c[k] = v[k + 1];
+}
+
 __device__ __forceinline__ float ndc2pix(float v, int S) { return (float)((((double)v + 1.0) * S - 1.0) * 0.5); }
 #endif  // __HIPCC__
 

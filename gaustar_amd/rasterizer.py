@@ -69,6 +69,20 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _num_channels(colors, background) -> int:
+    """3 (the reference's NUM_CHANNELS) unless precomputed colours carry 6 columns: two targets that share
+    geometry (GauSTAR's RGB + depth-as-colour renders, refine.py:552 / :607) blended in one pass -- an extension,
+    see include/gsr.h::gsr_forward_stage2_mt."""
+    C = 3
+    if colors is not None and colors.numel() != 0:
+        if colors.ndimension() != 2 or int(colors.size(1)) not in (3, 6):
+            raise RuntimeError("colors_precomp must have dimensions (num_points, 3) or (num_points, 6)")
+        C = int(colors.size(1))
+    if background.numel() != C:
+        raise RuntimeError(f"bg must have {C} elements (one per colour channel), got {background.numel()}")
+    return C
+
+
 def _require_gpu(t: torch.Tensor, what: str):
     if not t.is_cuda:
         raise RuntimeError(f"gaustar_amd: {what} must live on a HIP (cuda) device -- there is no CPU path")
@@ -94,7 +108,7 @@ def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rot
         byte_opts = dict(dtype=torch.uint8, device=dev)
         if P == 0:
             # rasterize_points.cu:68-81: zero-filled image, no rasterization at all
-            return (0, torch.zeros(3, H, W, dtype=torch.float32, device=dev),
+            return (0, torch.zeros(_num_channels(colors, background), H, W, dtype=torch.float32, device=dev),
                     torch.zeros(0, dtype=torch.int32, device=dev), torch.empty(0, **byte_opts),
                     torch.empty(0, **byte_opts), torch.empty(0, **byte_opts), 0, 0)
         means3D = _dev_f32(means3D, dev)
@@ -102,7 +116,8 @@ def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rot
         colors, opacity, scales, rotations, cov3D_precomp, sh = (
             _dev_f32(x, dev) for x in (colors, opacity, scales, rotations, cov3D_precomp, sh))
         M = int(sh.size(1)) if sh is not None and sh.numel() != 0 else 0
-        out_color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+        C = _num_channels(colors, background)
+        out_color = torch.empty(C, H, W, dtype=torch.float32, device=dev)
         radii = torch.empty(P, dtype=torch.int32, device=dev)
         geom = torch.empty(lib.gsr_geom_bytes(P), **byte_opts)
         img = torch.empty(lib.gsr_image_bytes(W, H), **byte_opts)
@@ -113,10 +128,16 @@ def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rot
             float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix),
             _ptr(campos), W, H, float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(radii), _ptr(geom),
             _ptr(img), ctypes.byref(R), ctypes.byref(maxc), ctypes.byref(nseg), st), "gsr_forward_stage1")
-        binning = torch.empty(lib.gsr_binning_bytes(R.value, nseg.value), **byte_opts)
-        _lib.check(lib.gsr_forward_stage2(
-            P, R.value, maxc.value, nseg.value, W, H, _ptr(background), _ptr(colors), _ptr(geom), _ptr(binning), _ptr(img),
-            _ptr(out_color), st), "gsr_forward_stage2")
+        if C == 3:
+            binning = torch.empty(lib.gsr_binning_bytes(R.value, nseg.value), **byte_opts)
+            _lib.check(lib.gsr_forward_stage2(
+                P, R.value, maxc.value, nseg.value, W, H, _ptr(background), _ptr(colors), _ptr(geom), _ptr(binning),
+                _ptr(img), _ptr(out_color), st), "gsr_forward_stage2")
+        else:
+            binning = torch.empty(lib.gsr_binning_bytes_mt(R.value, nseg.value, C), **byte_opts)
+            _lib.check(lib.gsr_forward_stage2_mt(
+                P, R.value, maxc.value, nseg.value, C, W, H, _ptr(background), _ptr(colors), _ptr(geom), _ptr(binning),
+                _ptr(img), _ptr(out_color), st), "gsr_forward_stage2_mt")
         if debug:
             torch.cuda.synchronize(dev)   # surface asynchronous faults here, like CHECK_CUDA(..., debug)
     return R.value, out_color, radii, geom, binning, img, maxc.value, nseg.value
@@ -137,29 +158,36 @@ def rasterize_gaussians_backward_native(background, means3D, radii, colors, scal
     with torch.cuda.device(dev):
         if P == 0:
             z = lambda *s: torch.zeros(*s, **f32)
-            return z(0, 3), z(0, 3), z(0, 1), z(0, 3), z(0, 6), z(0, M, 3), z(0, 3), z(0, 4)
+            return z(0, 3), z(0, int(dL_dout_color.size(0))), z(0, 1), z(0, 3), z(0, 6), z(0, M, 3), z(0, 3), z(0, 4)
         means3D = _dev_f32(means3D, dev)
         background, viewmatrix, projmatrix, campos = (_dev_f32(x, dev) for x in (background, viewmatrix, projmatrix, campos))
         colors, scales, rotations, cov3D_precomp, sh = (_dev_f32(x, dev) for x in (colors, scales, rotations, cov3D_precomp, sh))
         dL_dout_color = _dev_f32(dL_dout_color, dev)
         has_cov = cov3D_precomp is not None and cov3D_precomp.numel() != 0
+        C = _num_channels(colors, background)
+        if int(dL_dout_color.size(0)) != C:
+            raise RuntimeError(f"dL_dout_color must have {C} channels, got {int(dL_dout_color.size(0))}")
         # torch.empty: the library fills whatever it needs zeroed (rasterize_points.cu:151-159 uses zeros).
         dL_dmeans3D = torch.empty(P, 3, **f32)
         dL_dmeans2D = torch.empty(P, 3, **f32)
-        dL_dcolors = torch.empty(P, 3, **f32)
+        dL_dcolors = torch.empty(P, C, **f32)
         grad_scratch = torch.empty(lib.gsr_grad_scratch_bytes(P), dtype=torch.uint8, device=dev)
         dL_dopacity = torch.empty(P, 1, **f32)
         dL_dcov3D = torch.empty(P, 6, **f32)
         dL_dsh = torch.empty(P, M, 3, **f32)
         dL_dscales = torch.zeros(P, 3, **f32) if has_cov else torch.empty(P, 3, **f32)
         dL_drotations = torch.zeros(P, 4, **f32) if has_cov else torch.empty(P, 4, **f32)
-        _lib.check(lib.gsr_backward(
-            P, int(degree), M, int(R), int(num_segments), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(scales),
-            float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix),
-            _ptr(campos), float(tan_fovx), float(tan_fovy), _ptr(radii), _ptr(geomBuffer), _ptr(binningBuffer),
-            _ptr(imageBuffer), _ptr(dL_dout_color), _ptr(grad_scratch), _ptr(dL_dmeans2D), _ptr(dL_dopacity),
-            _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales),
-            _ptr(dL_drotations), _stream()), "gsr_backward")
+        head = (P, int(degree), M, int(R), int(num_segments))
+        tail = (_ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(scales),
+                float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix),
+                _ptr(campos), float(tan_fovx), float(tan_fovy), _ptr(radii), _ptr(geomBuffer), _ptr(binningBuffer),
+                _ptr(imageBuffer), _ptr(dL_dout_color), _ptr(grad_scratch), _ptr(dL_dmeans2D), _ptr(dL_dopacity),
+                _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales),
+                _ptr(dL_drotations), _stream())
+        if C == 3:
+            _lib.check(lib.gsr_backward(*head, *tail), "gsr_backward")
+        else:
+            _lib.check(lib.gsr_backward_mt(*head, C, *tail), "gsr_backward_mt")
         if debug:
             torch.cuda.synchronize(dev)
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations

@@ -47,6 +47,8 @@ const char* gsr_last_error(void);
 size_t gsr_geom_bytes(int P);
 size_t gsr_image_bytes(int W, int H);
 size_t gsr_binning_bytes(int R, int num_segments);
+/* Same for a render with num_channels colour channels (3 or 6, see gsr_forward_stage2_mt). */
+size_t gsr_binning_bytes_mt(int R, int num_segments, int num_channels);
 /* Backward-only scratch: one packed 48-byte accumulation record per Gaussian.  Takes the place of the
  * dL_dconic [P,2,2] work tensor the reference binding allocates (DGR/rasterize_points.cu:154). */
 size_t gsr_grad_scratch_bytes(int P);
@@ -76,6 +78,16 @@ int gsr_forward_stage2(int P, int R, int max_tile_instances, int num_segments, i
                        const float* colors_precomp, void* geom_buffer, void* binning_buffer, void* image_buffer,
                        float* out_color, gsr_stream_t stream);
 
+/* Multi-target extension (no reference counterpart: the reference fixes
+ * NUM_CHANNELS = 3 at compile time, DGR/cuda_rasterizer/config.h:15, and GauSTAR renders RGB and
+ * depth-as-colour in two full passes over identical geometry, gaustar_trainers/refine.py:552 and :607).
+ * num_channels = 6 blends two 3-channel targets in ONE walk after ONE stage 1: colors_precomp is [P,6]
+ * (required: no in-kernel SH for the extra channels), background [6], out_color [6,H,W] planar.  Channels 0-2
+ * and 3-5 equal two separate 3-channel renders bit for bit.  num_channels = 3 is gsr_forward_stage2. */
+int gsr_forward_stage2_mt(int P, int R, int max_tile_instances, int num_segments, int num_channels, int W, int H,
+                          const float* background, const float* colors_precomp, void* geom_buffer, void* binning_buffer,
+                          void* image_buffer, float* out_color, gsr_stream_t stream);
+
 /* One-call forward with the reference's allocator-callback shape.  Replaces
  * CudaRasterizer::Rasterizer::forward (DGR/cuda_rasterizer/rasterizer.h:31-55).
  * Returns num_rendered through *num_rendered [host]. */
@@ -101,6 +113,18 @@ int gsr_backward(int P, int D, int M, int R, int num_segments, const float* back
                  const void* geom_buffer, const void* binning_buffer, const void* image_buffer, const float* dL_dpix,
                  void* grad_scratch, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
                  float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, gsr_stream_t stream);
+
+/* Backward of a num_channels render (see gsr_forward_stage2_mt): dL_dpix [num_channels,H,W], dL_dcolor
+ * [P,num_channels]; every other gradient is the sum over the targets, i.e. what autograd would accumulate from
+ * the separate backward passes of the reference.  num_channels = 3 is gsr_backward. */
+int gsr_backward_mt(int P, int D, int M, int R, int num_segments, int num_channels, const float* background, int W,
+                    int H, const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                    float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                    const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                    const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
+                    const float* dL_dpix, void* grad_scratch, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
+                    float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                    gsr_stream_t stream);
 
 /* Near-plane visibility test.  Replaces CudaRasterizer::Rasterizer::markVisible
  * (DGR/cuda_rasterizer/rasterizer.h:24-29; rasterizer_impl.cu:54-66, :141-153).

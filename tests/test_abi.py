@@ -29,7 +29,7 @@ def test_header_declares_the_expected_entry_points():
     d = _declared()
     for name in ("gsr_abi_version", "gsr_last_error", "gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes",
                  "gsr_grad_scratch_bytes", "gsr_forward_stage1", "gsr_forward_stage2", "gsr_forward", "gsr_backward", "gsr_mark_visible",
-                 "gsr_debug_export"):
+                 "gsr_debug_export", "gsr_binning_bytes_mt", "gsr_forward_stage2_mt", "gsr_backward_mt"):
         assert name in d, name
     src = open(HEADER).read()
     # every entry point cites the reference interface it replaces
@@ -53,7 +53,7 @@ def test_ctypes_table_matches_header():
 def test_library_loads_and_exports_every_symbol(hip_lib):
     for name in _declared():
         assert hasattr(hip_lib, name), name
-    assert hip_lib.gsr_abi_version() == 3
+    assert hip_lib.gsr_abi_version() == 4
 
 
 def test_scratch_sizes(hip_lib):
@@ -67,6 +67,9 @@ def test_scratch_sizes(hip_lib):
     assert 12_000_000 <= b <= 12_000_000 + 2048
     assert hip_lib.gsr_binning_bytes(1_000_000, 1000) - b == 1000 * (4 + 256 * 16) + 96   # unit table + snapshots
     assert hip_lib.gsr_geom_bytes(0) > 0 and hip_lib.gsr_binning_bytes(0, 0) > 0
+    # multi-target: 3 channels = the plain size; 6 channels double the per-pixel snapshot (two float4 instead of one)
+    assert hip_lib.gsr_binning_bytes_mt(1_000_000, 1000, 3) == hip_lib.gsr_binning_bytes(1_000_000, 1000)
+    assert hip_lib.gsr_binning_bytes_mt(1_000_000, 1000, 6) - hip_lib.gsr_binning_bytes(1_000_000, 1000) == 1000 * 256 * 16
 
 
 def test_validation_errors_without_gpu(hip_lib):

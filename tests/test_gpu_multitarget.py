@@ -1,0 +1,143 @@
+"""Multi-target render: colours [P,6] = two 3-channel targets that share geometry,
+blended in ONE pass (gsr_forward_stage2_mt / gsr_backward_mt).
+
+The reference has no such entry point -- GauSTAR issues two full renders per iteration (RGB, then depth-as-colour
+with bg = 10; gaustar_trainers/refine.py:552 and :607).  The contract is therefore stated against those two
+renders: channels 0-2 / 3-5 of the 6-channel image equal the two 3-channel images BIT FOR BIT (alpha, T,
+termination and n_contrib do not depend on colour), dL_dcolor splits per target, and every other gradient is
+the sum autograd would accumulate from the two separate backward passes.  Checked against this library's own
+3-channel path, the CPU oracle and, at full size, the reference's own kernels (oracle/_ref)."""
+import numpy as np
+import pytest
+
+import parity
+
+pytestmark = pytest.mark.gpu
+
+SUMMED = ["dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dscales", "dL_drotations"]
+
+
+def _kw(gs, cam, bg, colors):
+    return dict(means3D=gs.means3D, opacities=gs.opacities, view=cam.viewmatrix, proj=cam.projmatrix,
+                campos=cam.campos, W=cam.W, H=cam.H, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg, shs=None,
+                colors_precomp=colors, scales=gs.scales, rotations=gs.rotations, cov3D_precomp=None, sh_degree=0,
+                scale_modifier=1.0)
+
+
+def _two_targets(gs, cam, rng):
+    from gaustar_amd import scene
+    rgb = rng.uniform(0, 1, (gs.P, 3)).astype(np.float32)
+    dep = scene.view_depth_colors(gs, cam)
+    bg_rgb, bg_dep = np.array([0.2, 0.7, 0.1], np.float32), np.full(3, 10.0, np.float32)   # refine.py:607 uses bg = max_depth
+    d_rgb = rng.normal(size=(3, cam.H, cam.W)).astype(np.float32)
+    d_dep = rng.normal(size=(3, cam.H, cam.W)).astype(np.float32)
+    d_dep[1:] = 0.0   # the trainer only looks at channel 0 of the depth render ([..., 0], refine.py:616)
+    return (_kw(gs, cam, bg_rgb, rgb), d_rgb), (_kw(gs, cam, bg_dep, dep), d_dep), \
+           (_kw(gs, cam, np.concatenate([bg_rgb, bg_dep]), np.concatenate([rgb, dep], 1)), np.concatenate([d_rgb, d_dep]))
+
+
+def _check_against_pair(six, a, b, what, exact_images):
+    """six = 6-channel result; a, b = dicts of the two 3-channel results (color, radii, gradients)."""
+    assert np.array_equal(six["radii"], a["radii"]) and np.array_equal(six["radii"], b["radii"])
+    if exact_images:
+        assert np.array_equal(six["color"][:3], a["color"]), f"{what}: RGB channels are not bit-identical"
+        assert np.array_equal(six["color"][3:], b["color"]), f"{what}: depth channels are not bit-identical"
+    else:
+        parity.check_image(six["color"][:3], a["color"], f"{what} rgb")
+        parity.check_image(six["color"][3:], b["color"], f"{what} depth")
+    parity.check_grad(six["dL_dcolors"][:, :3], a["dL_dcolors"], f"{what} dL_dcolors[rgb]")
+    parity.check_grad(six["dL_dcolors"][:, 3:], b["dL_dcolors"], f"{what} dL_dcolors[depth]")
+    for k in SUMMED:
+        parity.check_grad(six[k], np.asarray(a[k], np.float64).reshape(six[k].shape) + np.asarray(b[k], np.float64).reshape(six[k].shape),
+                          f"{what} {k} (sum of the two passes)")
+
+
+def _scenes():
+    from gaustar_amd import scene
+    rng = np.random.default_rng(77)
+    gs = scene.random_gaussians(4000, rng, scale_range=(0.01, 0.12))
+    yield "random 4k, 203x117", gs, scene.look_at_camera((0.3, 0.2, -4.0), (0, 0, 0), 203, 117, fovx=0.9, znear=0.01), rng
+    verts, faces = scene.uv_sphere(24, 16, radius=0.9, center=(0, 1.2, 0))
+    gm = scene.mesh_bound_gaussians(verts, faces, rng, thickness=3.0e-6)
+    yield "mesh sphere, 256x192", gm, scene.look_at_camera((0, 1.2, -3.0), (0, 1.2, 0), 256, 192, fovx=0.8, znear=0.01), rng
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_six_channels_equal_two_renders(idx):
+    name, gs, cam, rng = list(_scenes())[idx]
+    (kw_a, d_a), (kw_b, d_b), (kw6, d6) = _two_targets(gs, cam, rng)
+    a, b, six = parity.run_hip(kw_a, d_a), parity.run_hip(kw_b, d_b), parity.run_hip(kw6, d6)
+    assert six["color"].shape == (6, cam.H, cam.W) and six["dL_dcolors"].shape == (gs.P, 6)
+    _check_against_pair(six, a, b, name + " vs own 3-channel path", exact_images=True)
+    # and against the CPU restatement of the reference, run once per target
+    (st_a, g_a), (st_b, g_b) = parity.run_oracle(kw_a, d_a), parity.run_oracle(kw_b, d_b)
+    oa = dict(color=st_a["color"], radii=st_a["radii"], **g_a)
+    ob = dict(color=st_b["color"], radii=st_b["radii"], **g_b)
+    _check_against_pair(six, oa, ob, name + " vs oracle", exact_images=False)
+
+
+def test_long_lists_cross_segment_boundaries():
+    """Lists far longer than one 64-entry segment with low opacity: every backward unit resumes from a
+    6-channel snapshot (two float4 per pixel)."""
+    from gaustar_amd import scene
+    rng = np.random.default_rng(5)
+    gs = scene.random_gaussians(2500, rng, scale_range=(0.03, 0.08), box=((-0.2, 0.2), (-0.2, 0.2), (-0.5, 0.5)))
+    gs.opacities[:] = rng.uniform(0.01, 0.05, (gs.P, 1)).astype(np.float32)
+    cam = scene.look_at_camera((0, 0, -4.0), (0, 0, 0), 80, 48, fovx=0.5, znear=0.01)
+    (kw_a, d_a), (kw_b, d_b), (kw6, d6) = _two_targets(gs, cam, rng)
+    d_b[1:] = rng.normal(size=(2, cam.H, cam.W)).astype(np.float32)   # all six channels carry gradient here
+    d6 = np.concatenate([d_a, d_b])
+    (st_a, g_a), (st_b, g_b) = parity.run_oracle(kw_a, d_a), parity.run_oracle(kw_b, d_b)
+    assert (st_a["ranges"][:, 1] - st_a["ranges"][:, 0]).max() > 1000
+    six = parity.run_hip(kw6, d6)
+    _check_against_pair(six, dict(color=st_a["color"], radii=st_a["radii"], **g_a),
+                        dict(color=st_b["color"], radii=st_b["radii"], **g_b), "long lists vs oracle", exact_images=False)
+
+
+def test_full_size_config_c_against_reference_kernels():
+    """Config C (491 520 Gaussians, 1080p), one view: 6-channel render vs the reference's own kernels run twice."""
+    from oracle import ref
+    from gaustar_amd import scene
+    if not ref.available():
+        pytest.skip("oracle/_ref/libgsr_ref.so not built")
+    gs, cams, bg = scene.config_C()
+    cam = cams[11]
+    rng = np.random.default_rng(11)
+    (kw_a, d_a), (kw_b, d_b), (kw6, d6) = _two_targets(gs, cam, rng)
+    kw_a["colors_precomp"] = gs.colors_precomp
+    kw6["colors_precomp"] = np.concatenate([gs.colors_precomp, kw_b["colors_precomp"]], 1)
+    res = []
+    for kw, d in ((kw_a, d_a), (kw_b, d_b)):
+        rr = ref.RefRasterizer()
+        color, radii, _ = rr.forward(**kw)
+        g = {k: v.cpu().numpy() for k, v in rr.backward(d).items()}
+        res.append(dict(color=color.cpu().numpy(), radii=radii.cpu().numpy(), **g))
+    six = parity.run_hip(kw6, d6)
+    assert (six["radii"] != res[0]["radii"]).sum() <= 1
+    six["radii"] = res[0]["radii"]
+    _check_against_pair(six, res[0], res[1], "config C vs reference kernels", exact_images=False)
+
+
+def test_argument_validation():
+    import torch
+    from gaustar_amd import GaussianRasterizationSettings, GaussianRasterizer, scene
+    rng = np.random.default_rng(0)
+    gs = scene.random_gaussians(50, rng)
+    cam = scene.look_at_camera((0, 0, -4.0), (0, 0, 0), 32, 32, fovx=0.8, znear=0.01)
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
+
+    def render(colors, bg):
+        s = GaussianRasterizationSettings(32, 32, cam.tanfovx, cam.tanfovy, t(bg), 1.0, t(cam.viewmatrix), t(cam.projmatrix),
+                                          0, t(cam.campos), False, False)
+        return GaussianRasterizer(s)(means3D=t(gs.means3D), means2D=torch.zeros(50, 3, device=dev), opacities=t(gs.opacities),
+                                     colors_precomp=t(colors), scales=t(gs.scales), rotations=t(gs.rotations))
+
+    img, _ = render(rng.uniform(0, 1, (50, 6)), np.zeros(6))
+    assert tuple(img.shape) == (6, 32, 32)
+    with pytest.raises(RuntimeError, match="bg must have 6"):
+        render(rng.uniform(0, 1, (50, 6)), np.zeros(3))
+    with pytest.raises(RuntimeError, match="bg must have 3"):
+        render(rng.uniform(0, 1, (50, 3)), np.zeros(6))
+    with pytest.raises(RuntimeError, match=r"\(num_points, 3\) or \(num_points, 6\)"):
+        render(rng.uniform(0, 1, (50, 4)), np.zeros(4))
