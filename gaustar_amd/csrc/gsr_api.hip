@@ -20,10 +20,10 @@ thread_local uint32_t* g_pinned = nullptr;   // 16-byte pinned landing pad for t
 
 // ---- optional per-kernel timing (gsr_profile_*): HIP events on the launch stream around every stage.
 enum Stage { ST_PREPROCESS = 0, ST_TILE_SCAN, ST_SCATTER, ST_TILE_SORT, ST_BLEND_FWD, ST_ZERO_FILL, ST_BLEND_BWD,
-             ST_GEOM_BWD, ST_COUNT };
+             ST_GEOM_BWD, ST_LOSS, ST_COUNT };
 const char* const kStageNames[ST_COUNT] = {"preprocess_kernel", "tile_scan_kernel", "scatter_kernel",
                                            "tile_sort_kernel", "blend_fwd_kernel", "zero_fill", "blend_bwd_kernel",
-                                           "geom_bwd_kernel"};
+                                           "geom_bwd_kernel", "loss_kernels"};
 struct Rec { int stage; hipEvent_t a, b; };
 // Process-wide (PyTorch runs backward on its own autograd thread), guarded by a mutex.
 struct Profiler {
@@ -81,7 +81,7 @@ int fail_msg(const char* msg)
 
 extern "C" {
 
-int gsr_abi_version(void) { return 4; }
+int gsr_abi_version(void) { return 5; }
 
 const char* gsr_last_error(void) { return g_err.c_str(); }
 
@@ -290,6 +290,51 @@ int gsr_backward_mt(int P, int D, int M, int R, int num_segments, int num_channe
                         st);
     }
     GSR_CHECK_LAUNCH("geom_bwd_kernel");
+    return 0;
+}
+
+size_t gsr_l1_ssim_workspace_bytes(int C, int H, int W)
+{
+    return l1_ssim_workspace_bytes(C > 0 ? C : 0, H > 0 ? H : 0, W > 0 ? W : 0);
+}
+
+int gsr_l1_ssim(int C, int H, int W, const float* pred, long long pred_sc, long long pred_sy, long long pred_sx,
+                const float* gt, long long gt_sc, long long gt_sy, long long gt_sx, float dssim_factor,
+                void* workspace, float* loss_out, float* dL_dpred, long long grad_sc, long long grad_sy,
+                long long grad_sx, gsr_stream_t stream)
+{
+    g_err.clear();
+    if (C <= 0 || H <= 0 || W <= 0) return fail_msg("gsr_l1_ssim: image size must be positive");
+    if (C > 65535) return fail_msg("gsr_l1_ssim: too many channels");
+    if (!pred || !gt || !workspace || !loss_out) return fail_msg("gsr_l1_ssim: required pointer is null");
+    const long long ps[3] = {pred_sc, pred_sy, pred_sx}, gs_[3] = {gt_sc, gt_sy, gt_sx},
+                    qs[3] = {grad_sc, grad_sy, grad_sx};
+    hipStream_t st = (hipStream_t)stream;
+    {
+        Scope sc(ST_LOSS, st);
+        launch_l1_ssim(C, H, W, pred, ps, gt, gs_, dssim_factor, workspace, loss_out, dL_dpred, qs, st);
+    }
+    GSR_CHECK_LAUNCH("l1_ssim kernels");
+    return 0;
+}
+
+size_t gsr_depth_l1_workspace_bytes(void) { return depth_l1_workspace_bytes(); }
+
+int gsr_depth_l1(int H, int W, const float* pred, long long pred_sy, long long pred_sx, const float* gt,
+                 long long gt_sy, long long gt_sx, float max_depth, float depth_factor, float mask_factor,
+                 void* workspace, float* loss_out, float* dL_dpred, long long grad_sy, long long grad_sx,
+                 gsr_stream_t stream)
+{
+    g_err.clear();
+    if (H <= 0 || W <= 0) return fail_msg("gsr_depth_l1: image size must be positive");
+    if (!pred || !gt || !workspace || !loss_out) return fail_msg("gsr_depth_l1: required pointer is null");
+    const long long ps[2] = {pred_sy, pred_sx}, gs_[2] = {gt_sy, gt_sx}, qs[2] = {grad_sy, grad_sx};
+    hipStream_t st = (hipStream_t)stream;
+    {
+        Scope sc(ST_LOSS, st);
+        launch_depth_l1(H, W, pred, ps, gt, gs_, max_depth, depth_factor, mask_factor, workspace, loss_out, dL_dpred, qs, st);
+    }
+    GSR_CHECK_LAUNCH("depth_l1 kernels");
     return 0;
 }
 

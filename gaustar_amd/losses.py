@@ -1,0 +1,149 @@
+"""Image-space losses of the GauSTAR refinement loop as fused HIP ops.
+
+Host-side mirror of gaustar_utils/loss_utils.py (`l1_loss`, `ssim`) and of the loss assembly in
+gaustar_trainers/refine.py:451-453 (`(1 - f) * l1 + f * (1 - ssim)`, on the margin-cropped view of
+:584-594) and :634-660 (masked depth + silhouette L1).  Each op is ONE call into libgsr_hip.so that returns
+the loss value AND d loss / d pred; autograd just scales that gradient by the incoming scalar.  The gradient
+w.r.t. the ground-truth image is not provided (the trainer never needs it).
+
+There is no CPU path: CPU tensors raise, like the rasterizer (gaustar_amd/rasterizer.py).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chw_view(t: torch.Tensor, what: str) -> torch.Tensor:
+    """[C,H,W] or [1,C,H,W] float32 HIP tensor, any strides (views are used as they are, never copied)."""
+    if not t.is_cuda:
+        raise RuntimeError(f"gaustar_amd.losses: {what} must live on a HIP (cuda) device -- there is no CPU path")
+    if t.dim() == 4 and t.size(0) == 1:
+        t = t[0]
+    if t.dim() != 3:
+        raise RuntimeError(f"{what} must have dimensions (C, H, W) or (1, C, H, W), got {tuple(t.shape)}")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t
+
+
+def _crop(t: torch.Tensor, margin: Optional[Sequence[int]]) -> torch.Tensor:
+    """refine.py:587: pred[..., m2:-m3, m0:-m1] with margin = (left, right, top, bottom)."""
+    if margin is None:
+        return t
+    m0, m1, m2, m3 = (int(v) for v in margin)
+    return t[..., m2:(-m3 if m3 else None), m0:(-m1 if m1 else None)]
+
+
+class _L1DSSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, gt, dssim_factor, margin):
+        lib = _lib.load()
+        p_full = _chw_view(pred, "pred")
+        g_full = _chw_view(gt, "gt")
+        if p_full.shape != g_full.shape:
+            raise RuntimeError(f"pred {tuple(p_full.shape)} and gt {tuple(g_full.shape)} differ in shape")
+        p, g = _crop(p_full, margin), _crop(g_full, margin)
+        C, H, W = (int(v) for v in p.shape)
+        if H <= 0 or W <= 0:
+            raise RuntimeError("the margin leaves an empty image")
+        dev = p.device
+        need_grad = ctx.needs_input_grad[0]
+        with torch.cuda.device(dev):
+            ws = torch.empty(lib.gsr_l1_ssim_workspace_bytes(C, H, W), dtype=torch.uint8, device=dev)
+            out = torch.empty(3, dtype=torch.float32, device=dev)
+            grad_full = gv = None
+            if need_grad:
+                # planar [C,H,W] -- the layout the backward blend reads; zero outside the crop
+                grad_full = (torch.zeros if margin is not None else torch.empty)(p_full.shape, dtype=torch.float32, device=dev)
+                gv = _crop(grad_full, margin)
+            _lib.check(lib.gsr_l1_ssim(
+                C, H, W, ctypes.c_void_p(p.data_ptr()), p.stride(0), p.stride(1), p.stride(2),
+                ctypes.c_void_p(g.data_ptr()), g.stride(0), g.stride(1), g.stride(2), float(dssim_factor),
+                ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                ctypes.c_void_p(gv.data_ptr()) if need_grad else None,
+                gv.stride(0) if need_grad else 0, gv.stride(1) if need_grad else 0, gv.stride(2) if need_grad else 0,
+                _stream()), "gsr_l1_ssim")
+        ctx.grad_full = grad_full
+        ctx.pred_shape = pred.shape
+        ctx.mark_non_differentiable(out)
+        return out[0], out
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_parts):
+        if ctx.grad_full is None or g_loss is None:
+            return None, None, None, None
+        return (ctx.grad_full * g_loss).reshape(ctx.pred_shape), None, None, None
+
+
+def l1_dssim_loss(pred: torch.Tensor, gt: torch.Tensor, dssim_factor: float = 0.2,
+                  margin: Optional[Sequence[int]] = None, return_parts: bool = False):
+    """(1 - f) * l1_loss(pred, gt) + f * (1 - ssim(pred, gt)) on pred[..., m2:-m3, m0:-m1] (refine.py:451-453,
+    :584-594).  pred/gt: [C,H,W] or [1,C,H,W], any strides.  With return_parts also returns the device vector
+    {loss, l1 mean, ssim mean} (no host sync anywhere)."""
+    if gt.requires_grad:
+        raise NotImplementedError("gaustar_amd.losses: no gradient w.r.t. the ground-truth image")
+    loss, parts = _L1DSSIM.apply(pred, gt, float(dssim_factor), None if margin is None else tuple(margin))
+    return (loss, parts) if return_parts else loss
+
+
+def l1_loss(network_output: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
+    """loss_utils.py:17-18."""
+    return l1_dssim_loss(network_output, gt, 0.0)
+
+
+def ssim(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11, size_average: bool = True) -> torch.Tensor:
+    """loss_utils.py:33-43 with the defaults the trainer uses (window 11, mean over everything)."""
+    if window_size != 11 or not size_average:
+        raise NotImplementedError("gaustar_amd.losses.ssim: only window_size=11, size_average=True (the trainer's use)")
+    return 1.0 - l1_dssim_loss(img1, img2, 1.0)
+
+
+class _DepthL1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, gt, max_depth, depth_factor, mask_factor):
+        lib = _lib.load()
+        if not pred.is_cuda:
+            raise RuntimeError("gaustar_amd.losses: pred must live on a HIP (cuda) device -- there is no CPU path")
+        if pred.dim() != 2 or pred.shape != gt.shape:
+            raise RuntimeError(f"pred and gt must both be (H, W), got {tuple(pred.shape)} and {tuple(gt.shape)}")
+        p = pred if pred.dtype == torch.float32 else pred.float()
+        g = gt if gt.dtype == torch.float32 else gt.float()
+        H, W = (int(v) for v in p.shape)
+        dev = p.device
+        need_grad = ctx.needs_input_grad[0]
+        with torch.cuda.device(dev):
+            ws = torch.empty(lib.gsr_depth_l1_workspace_bytes(), dtype=torch.uint8, device=dev)
+            out = torch.empty(4, dtype=torch.float32, device=dev)
+            grad = torch.empty(H, W, dtype=torch.float32, device=dev) if need_grad else None
+            _lib.check(lib.gsr_depth_l1(
+                H, W, ctypes.c_void_p(p.data_ptr()), p.stride(0), p.stride(1), ctypes.c_void_p(g.data_ptr()),
+                g.stride(0), g.stride(1), float(max_depth), float(depth_factor), float(mask_factor),
+                ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                ctypes.c_void_p(grad.data_ptr()) if need_grad else None, W if need_grad else 0, 1 if need_grad else 0,
+                _stream()), "gsr_depth_l1")
+        ctx.grad = grad
+        ctx.mark_non_differentiable(out)
+        return out[0] + out[1], out
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_parts):
+        if ctx.grad is None or g_loss is None:
+            return None, None, None, None, None
+        return ctx.grad * g_loss, None, None, None, None
+
+
+def depth_mask_l1_loss(pred_depth: torch.Tensor, gt_depth: torch.Tensor, max_depth: float, depth_factor: float = 1.0,
+                       mask_factor: float = 1.0, return_parts: bool = False):
+    """depth_factor * |pred - gt|.mean over {gt < max_depth} + mask_factor * |pred - max_depth|.mean over
+    {gt > max_depth} (refine.py:634-660, depth_alpha = False).  parts = {depth term, mask term, #fg, #bg}."""
+    loss, parts = _DepthL1.apply(pred_depth, gt_depth, float(max_depth), float(depth_factor), float(mask_factor))
+    return (loss, parts) if return_parts else loss

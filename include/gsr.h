@@ -142,6 +142,31 @@ int gsr_debug_export(int P, int R, int num_segments, int W, int H, const void* g
                      uint32_t* tile_ranges, uint32_t* point_list, float* final_T, uint32_t* n_contrib,
                      gsr_stream_t stream);
 
+/* ---- Image-space losses either side of the rasterizer.
+ * gsr_l1_ssim replaces  (1 - f) * l1_loss(pred, gt) + f * (1 - ssim(pred, gt))  (gaustar_trainers/refine.py:451-453
+ * over gaustar_utils/loss_utils.py:17-62: 11x11 Gaussian window, sigma 1.5, zero padding, mean over all
+ * elements) AND its autograd backward w.r.t. pred, in two tiled passes.  Images are indexed [C,H,W] through
+ * element strides (channel, row, column), so the reference's transposed views of [H,W,3] storage and its
+ * margin crop (refine.py:584-594: pass pointers to the crop origin and the cropped H, W) need no copy.
+ *   loss_out [3] device floats: {loss, l1 mean, ssim mean};  dL_dpred may be NULL (value only), else it receives
+ *   d loss / d pred for the H x W region through its own strides (planar [C,H,W] is what gsr_backward reads).
+ *   workspace: gsr_l1_ssim_workspace_bytes(C, H, W) bytes.  No host synchronisation. */
+size_t gsr_l1_ssim_workspace_bytes(int C, int H, int W);
+int gsr_l1_ssim(int C, int H, int W, const float* pred, long long pred_sc, long long pred_sy, long long pred_sx,
+                const float* gt, long long gt_sc, long long gt_sy, long long gt_sx, float dssim_factor,
+                void* workspace, float* loss_out, float* dL_dpred, long long grad_sc, long long grad_sy,
+                long long grad_sx, gsr_stream_t stream);
+
+/* Masked depth + silhouette L1 of gaustar_trainers/refine.py:634-660 (depth_alpha = False branch):
+ *   depth_factor * mean_{gt < max_depth} |pred - gt|  +  mask_factor * mean_{gt > max_depth} |pred - max_depth|
+ * on one [H,W] depth image (strided), with the gradient w.r.t. pred.
+ *   loss_out [4] device floats: {depth term, mask term, #foreground, #background}. */
+size_t gsr_depth_l1_workspace_bytes(void);
+int gsr_depth_l1(int H, int W, const float* pred, long long pred_sy, long long pred_sx, const float* gt,
+                 long long gt_sy, long long gt_sx, float max_depth, float depth_factor, float mask_factor,
+                 void* workspace, float* loss_out, float* dL_dpred, long long grad_sy, long long grad_sx,
+                 gsr_stream_t stream);
+
 /* Tuning aid: when device_buffer is non-NULL (4*T uint64), the two blend kernels record the start/end wall
  * clock (100 MHz) of every workgroup: forward at [2*b], backward at [2*(T+b)], b = launch index.  NULL = off. */
 int gsr_debug_set_trace(void* device_buffer);
