@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_longlong, c_size_t, c_vo
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSR_LIB_PATH", os.path.join(_HERE, "libgsr_hip.so"))   # override: experiment variants
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 ALLOC_FN = ctypes.CFUNCTYPE(c_void_p, c_void_p, c_size_t)
 
 # name -> (restype, argtypes); mirrors include/gsr.h one to one (tests check both directions).
@@ -47,6 +47,9 @@ SIGNATURES = {
     "gsr_mark_visible": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsr_debug_export": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gsr_sh_to_rgb": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gsr_sh_to_rgb_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p]),
     "gsr_l1_ssim_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gsr_l1_ssim": (c_int, [c_int, c_int, c_int, c_void_p, c_longlong, c_longlong, c_longlong, c_void_p, c_longlong,
                             c_longlong, c_longlong, c_float, c_void_p, c_void_p, c_void_p, c_longlong, c_longlong,

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libgsr_hip.so")
 SOURCES = ["gsr_api.hip", "gsr_preprocess.hip", "gsr_binning.hip", "gsr_blend_fwd.hip", "gsr_blend_bwd.hip",
-           "gsr_geom_bwd.hip", "gsr_loss.hip"]
+           "gsr_geom_bwd.hip", "gsr_loss.hip", "gsr_producers.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 

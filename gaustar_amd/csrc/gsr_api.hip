@@ -20,10 +20,10 @@ thread_local uint32_t* g_pinned = nullptr;   // 16-byte pinned landing pad for t
 
 // ---- optional per-kernel timing (gsr_profile_*): HIP events on the launch stream around every stage.
 enum Stage { ST_PREPROCESS = 0, ST_TILE_SCAN, ST_SCATTER, ST_TILE_SORT, ST_BLEND_FWD, ST_ZERO_FILL, ST_BLEND_BWD,
-             ST_GEOM_BWD, ST_LOSS, ST_COUNT };
+             ST_GEOM_BWD, ST_LOSS, ST_PRODUCERS, ST_COUNT };
 const char* const kStageNames[ST_COUNT] = {"preprocess_kernel", "tile_scan_kernel", "scatter_kernel",
                                            "tile_sort_kernel", "blend_fwd_kernel", "zero_fill", "blend_bwd_kernel",
-                                           "geom_bwd_kernel", "loss_kernels"};
+                                           "geom_bwd_kernel", "loss_kernels", "producer_kernels"};
 struct Rec { int stage; hipEvent_t a, b; };
 // Process-wide (PyTorch runs backward on its own autograd thread), guarded by a mutex.
 struct Profiler {
@@ -81,7 +81,7 @@ int fail_msg(const char* msg)
 
 extern "C" {
 
-int gsr_abi_version(void) { return 5; }
+int gsr_abi_version(void) { return 6; }
 
 const char* gsr_last_error(void) { return g_err.c_str(); }
 
@@ -290,6 +290,40 @@ int gsr_backward_mt(int P, int D, int M, int R, int num_segments, int num_channe
                         st);
     }
     GSR_CHECK_LAUNCH("geom_bwd_kernel");
+    return 0;
+}
+
+int gsr_sh_to_rgb(int P, int D, int M, const float* positions, const float* campos, const float* shs, float* rgb,
+                  gsr_stream_t stream)
+{
+    g_err.clear();
+    if (P <= 0) return 0;
+    if (!positions || !campos || !shs || !rgb) return fail_msg("gsr_sh_to_rgb: required pointer is null");
+    if (D < 0 || D > 3 || (D + 1) * (D + 1) > M) return fail_msg("gsr_sh_to_rgb: sh degree must be 0..3 and fit in M coefficients");
+    hipStream_t st = (hipStream_t)stream;
+    {
+        Scope sc(ST_PRODUCERS, st);
+        launch_sh_to_rgb(P, D, M, positions, campos, shs, rgb, st);
+    }
+    GSR_CHECK_LAUNCH("sh_to_rgb_kernel");
+    return 0;
+}
+
+int gsr_sh_to_rgb_backward(int P, int D, int M, const float* positions, const float* campos, const float* shs,
+                           const float* dL_drgb, float* dL_dsh, float* dL_dpos, gsr_stream_t stream)
+{
+    g_err.clear();
+    if (P <= 0) return 0;
+    if (!positions || !campos || !shs || !dL_drgb || !dL_dsh || !dL_dpos)
+        return fail_msg("gsr_sh_to_rgb_backward: required pointer is null");
+    if (D < 0 || D > 3 || (D + 1) * (D + 1) > M)
+        return fail_msg("gsr_sh_to_rgb_backward: sh degree must be 0..3 and fit in M coefficients");
+    hipStream_t st = (hipStream_t)stream;
+    {
+        Scope sc(ST_PRODUCERS, st);
+        launch_sh_to_rgb_bwd(P, D, M, positions, campos, shs, dL_drgb, dL_dsh, dL_dpos, st);
+    }
+    GSR_CHECK_LAUNCH("sh_to_rgb_bwd_kernel");
     return 0;
 }
 

@@ -114,6 +114,12 @@ inline BinState carve_bin(void* base, int R, int U, int C = 3)
     return s;
 }
 
+// producers of rasterizer inputs (gsr_producers.hip)
+void launch_sh_to_rgb(int P, int D, int M, const float* positions, const float* campos, const float* shs, float* rgb,
+                      hipStream_t st);
+void launch_sh_to_rgb_bwd(int P, int D, int M, const float* positions, const float* campos, const float* shs,
+                          const float* dL_drgb, float* dL_dsh, float* dL_dpos, hipStream_t st);
+
 // image-space losses (gsr_loss.hip)
 size_t l1_ssim_workspace_bytes(int C, int H, int W);
 void launch_l1_ssim(int C, int H, int W, const float* pred, const long long* pred_strides, const float* gt,
@@ -284,6 +290,63 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
             }
         }
     }
+}
+
+// Backward of colour = clamp_min(sum_k basis_k(dir) * sh_k + 0.5, 0), dir = normalize(mean - campos)
+// (computeColorFromSH backward, backward.cu:20-139; dnormvdv, auxiliary.h:107-117): writes dL_dsh for all M
+// coefficients (zero above the active degree) and ADDS the view-direction term to the mean's gradient.
+__device__ __forceinline__ void sh_colour_backward(int D, int M, Vec3 mean, const float* __restrict__ campos,
+                                                   const float* __restrict__ sh, const float (&dcol)[3],
+                                                   float* __restrict__ dsh, float& gmx, float& gmy, float& gmz)
+{
+    const float ox = mean.x - campos[0], oy = mean.y - campos[1], oz = mean.z - campos[2];
+    const float inv = 1.0f / sqrtf(ox * ox + oy * oy + oz * oz);
+    const float x = ox * inv, y = oy * inv, z = oz * inv;
+    float basis[16];
+    sh_basis(D, x, y, z, basis);
+    const int nb = (D + 1) * (D + 1);
+    // recompute the clamp decision of the forward (forward.cu:63-70)
+    float col[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < nb; k++) { col[0] += basis[k] * sh[3 * k]; col[1] += basis[k] * sh[3 * k + 1]; col[2] += basis[k] * sh[3 * k + 2]; }
+    float dRGB[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) dRGB[ch] = (col[ch] + 0.5f < 0.f) ? 0.f : dcol[ch];
+    for (int k = 0; k < M; k++) {
+        const float bk = k < nb ? basis[k] : 0.f;
+        dsh[3 * k] = bk * dRGB[0]; dsh[3 * k + 1] = bk * dRGB[1]; dsh[3 * k + 2] = bk * dRGB[2];
+    }
+    // d(colour)/d(direction)
+    float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+#define SHD(k) (sh[3 * (k)] * dRGB[0] + sh[3 * (k) + 1] * dRGB[1] + sh[3 * (k) + 2] * dRGB[2])
+    if (D > 0) {
+        ddx = -kSH1 * SHD(3); ddy = -kSH1 * SHD(1); ddz = kSH1 * SHD(2);
+        if (D > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            const float s4 = SHD(4), s5 = SHD(5), s6 = SHD(6), s7 = SHD(7), s8 = SHD(8);
+            ddx += kSH2[0] * y * s4 + kSH2[2] * 2.f * -x * s6 + kSH2[3] * z * s7 + kSH2[4] * 2.f * x * s8;
+            ddy += kSH2[0] * x * s4 + kSH2[1] * z * s5 + kSH2[2] * 2.f * -y * s6 + kSH2[4] * 2.f * -y * s8;
+            ddz += kSH2[1] * y * s5 + kSH2[2] * 2.f * 2.f * z * s6 + kSH2[3] * x * s7;
+            if (D > 2) {
+                const float s9 = SHD(9), s10 = SHD(10), s11 = SHD(11), s12 = SHD(12), s13 = SHD(13), s14 = SHD(14),
+                            s15 = SHD(15);
+                ddx += kSH3[0] * s9 * 3.f * 2.f * xy + kSH3[1] * s10 * yz + kSH3[2] * s11 * -2.f * xy +
+                       kSH3[3] * s12 * -3.f * 2.f * xz + kSH3[4] * s13 * (-3.f * xx + 4.f * zz - yy) +
+                       kSH3[5] * s14 * 2.f * xz + kSH3[6] * s15 * 3.f * (xx - yy);
+                ddy += kSH3[0] * s9 * 3.f * (xx - yy) + kSH3[1] * s10 * xz + kSH3[2] * s11 * (-3.f * yy + 4.f * zz - xx) +
+                       kSH3[3] * s12 * -3.f * 2.f * yz + kSH3[4] * s13 * -2.f * xy + kSH3[5] * s14 * -2.f * yz +
+                       kSH3[6] * s15 * -3.f * 2.f * xy;
+                ddz += kSH3[1] * s10 * xy + kSH3[2] * s11 * 4.f * 2.f * yz + kSH3[3] * s12 * 3.f * (2.f * zz - xx - yy) +
+                       kSH3[4] * s13 * 4.f * 2.f * xz + kSH3[5] * s14 * (xx - yy);
+            }
+        }
+    }
+#undef SHD
+    // through the normalisation of the view direction (auxiliary.h:107-117)
+    const float sum2 = ox * ox + oy * oy + oz * oz;
+    const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    gmx += ((sum2 - ox * ox) * ddx - oy * ox * ddy - oz * ox * ddz) * invsum32;
+    gmy += (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * invsum32;
+    gmz += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
 }
 
 // Gaussian exponent of one (pixel, splat) pair: -0.5*(a dx^2 + c dy^2) - b dx dy (forward.cu:334).

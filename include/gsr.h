@@ -142,6 +142,17 @@ int gsr_debug_export(int P, int R, int num_segments, int W, int H, const void* g
                      uint32_t* tile_ranges, uint32_t* point_list, float* final_T, uint32_t* n_contrib,
                      gsr_stream_t stream);
 
+/* ---- Producers of rasterizer inputs.
+ * gsr_sh_to_rgb replaces SuGaR.get_points_rgb (gaustar_scene/sugar_model.py:674-718):
+ *   rgb = clamp_min(eval_sh(D, sh[:, :(D+1)^2], normalize(positions - campos)) + 0.5, 0)
+ * (eval_sh: gaustar_utils/spherical_harmonics.py:117-172); gsr_sh_to_rgb_backward is its autograd backward.
+ *   positions [P,3], campos [3], shs [P,M,3] with (D+1)^2 <= M, D in 0..3; rgb / dL_drgb [P,3];
+ *   dL_dsh [P,M,3] (zero above the active degree), dL_dpos [P,3] -- both written outright. */
+int gsr_sh_to_rgb(int P, int D, int M, const float* positions, const float* campos, const float* shs, float* rgb,
+                  gsr_stream_t stream);
+int gsr_sh_to_rgb_backward(int P, int D, int M, const float* positions, const float* campos, const float* shs,
+                           const float* dL_drgb, float* dL_dsh, float* dL_dpos, gsr_stream_t stream);
+
 /* ---- Image-space losses either side of the rasterizer.
  * gsr_l1_ssim replaces  (1 - f) * l1_loss(pred, gt) + f * (1 - ssim(pred, gt))  (gaustar_trainers/refine.py:451-453
  * over gaustar_utils/loss_utils.py:17-62: 11x11 Gaussian window, sigma 1.5, zero padding, mean over all

@@ -48,3 +48,19 @@ def test_losses_module_has_no_cpu_path():
         losses.l1_dssim_loss(a, a.clone())
     with pytest.raises(RuntimeError, match="no CPU path"):
         losses.depth_mask_l1_loss(a[0], a[1], 10.0)
+
+
+def test_points_rgb_oracle_matches_reference_vectors():
+    """oracle/producers_oracle.py against vectors made with the reference's own eval_sh (producers_kat.npz)."""
+    from oracle import producers_oracle
+    z = np.load(os.path.join(ROOT, "tests", "golden", "producers_kat.npz"))
+    for lv in (1, 2, 3, 4):
+        k = f"l{lv}"
+        pos = torch.from_numpy(z[f"{k}_pos"]).requires_grad_(True)
+        sh = torch.from_numpy(z[f"{k}_sh"]).requires_grad_(True)
+        col = producers_oracle.points_rgb(pos, torch.from_numpy(z[f"{k}_cam"]), sh, lv)
+        col.backward(torch.from_numpy(z[f"{k}_dL"]))
+        np.testing.assert_allclose(col.detach().numpy(), z[f"{k}_colors"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(sh.grad.numpy(), z[f"{k}_dsh"], rtol=1e-6, atol=1e-7)
+        dpos = pos.grad.numpy() if pos.grad is not None else np.zeros_like(z[f"{k}_dpos"])
+        np.testing.assert_allclose(dpos, z[f"{k}_dpos"], rtol=1e-5, atol=1e-6)
