@@ -81,7 +81,7 @@ int fail_msg(const char* msg)
 
 extern "C" {
 
-int gsr_abi_version(void) { return 6; }
+int gsr_abi_version(void) { return 7; }
 
 const char* gsr_last_error(void) { return g_err.c_str(); }
 
@@ -324,6 +324,53 @@ int gsr_sh_to_rgb_backward(int P, int D, int M, const float* positions, const fl
         launch_sh_to_rgb_bwd(P, D, M, positions, campos, shs, dL_drgb, dL_dsh, dL_dpos, st);
     }
     GSR_CHECK_LAUNCH("sh_to_rgb_bwd_kernel");
+    return 0;
+}
+
+int gsr_mesh_gaussians(int F, int G, const float* verts, const long long* faces, const float* bary,
+                       const float* raw_scales, const float* raw_complex, float thickness, float min_scale,
+                       float max_scale, const float* delta_t, const float* delta_r, float* points, float* scaling,
+                       float* quaternions, gsr_stream_t stream)
+{
+    g_err.clear();
+    if (F <= 0) return 0;
+    if (G <= 0 || G > 64) return fail_msg("gsr_mesh_gaussians: Gaussians per face must be 1..64");
+    if (!verts || !faces || !bary || !raw_scales || !raw_complex || !points || !scaling || !quaternions)
+        return fail_msg("gsr_mesh_gaussians: required pointer is null");
+    hipStream_t st = (hipStream_t)stream;
+    {
+        Scope sc(ST_PRODUCERS, st);
+        launch_mesh_gaussians(F, G, verts, faces, bary, raw_scales, raw_complex, thickness, min_scale, max_scale, delta_t,
+                              delta_r, points, scaling, quaternions, st);
+    }
+    GSR_CHECK_LAUNCH("mesh_gaussians_fwd_kernel");
+    return 0;
+}
+
+int gsr_mesh_gaussians_backward(int F, int G, int V, const float* verts, const long long* faces, const float* bary,
+                                const float* raw_scales, const float* raw_complex, float min_scale, float max_scale,
+                                const float* delta_r, const float* dL_dpoints, const float* dL_dscaling,
+                                const float* dL_dquaternions, float* dL_dverts, float* dL_draw_scales,
+                                float* dL_draw_complex, float* dL_ddelta_t, float* dL_ddelta_r, gsr_stream_t stream)
+{
+    g_err.clear();
+    if (V < 0) return fail_msg("gsr_mesh_gaussians_backward: negative V");
+    if (V > 0 && !dL_dverts) return fail_msg("gsr_mesh_gaussians_backward: dL_dverts is null");
+    hipStream_t st = (hipStream_t)stream;
+    if (V > 0) GSR_CHECK(hipMemsetAsync(dL_dverts, 0, sizeof(float) * 3 * (size_t)V, st));
+    if (F <= 0) return 0;
+    if (G <= 0 || G > 64) return fail_msg("gsr_mesh_gaussians_backward: Gaussians per face must be 1..64");
+    if (!verts || !faces || !bary || !raw_scales || !raw_complex || !dL_draw_scales || !dL_draw_complex)
+        return fail_msg("gsr_mesh_gaussians_backward: required pointer is null");
+    if (delta_r == nullptr && dL_ddelta_r != nullptr)
+        return fail_msg("gsr_mesh_gaussians_backward: dL_ddelta_r given without delta_r");
+    {
+        Scope sc(ST_PRODUCERS, st);
+        launch_mesh_gaussians_bwd(F, G, verts, faces, bary, raw_scales, raw_complex, min_scale, max_scale, delta_r,
+                                  dL_dpoints, dL_dscaling, dL_dquaternions, dL_dverts, dL_draw_scales, dL_draw_complex,
+                                  dL_ddelta_t, dL_ddelta_r, st);
+    }
+    GSR_CHECK_LAUNCH("mesh_gaussians_bwd_kernel");
     return 0;
 }
 

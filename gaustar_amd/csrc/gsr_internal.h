@@ -120,6 +120,16 @@ void launch_sh_to_rgb(int P, int D, int M, const float* positions, const float* 
 void launch_sh_to_rgb_bwd(int P, int D, int M, const float* positions, const float* campos, const float* shs,
                           const float* dL_drgb, float* dL_dsh, float* dL_dpos, hipStream_t st);
 
+void launch_mesh_gaussians(int F, int G, const float* verts, const long long* faces, const float* bary,
+                           const float* raw_scales, const float* raw_complex, float thickness, float min_scale,
+                           float max_scale, const float* delta_t, const float* delta_r, float* points, float* scaling,
+                           float* quats, hipStream_t st);
+void launch_mesh_gaussians_bwd(int F, int G, const float* verts, const long long* faces, const float* bary,
+                               const float* raw_scales, const float* raw_complex, float min_scale, float max_scale,
+                               const float* delta_r, const float* dL_dpoints, const float* dL_dscaling,
+                               const float* dL_dquats, float* dL_dverts, float* dL_draw_scales, float* dL_draw_complex,
+                               float* dL_ddelta_t, float* dL_ddelta_r, hipStream_t st);
+
 // image-space losses (gsr_loss.hip)
 size_t l1_ssim_workspace_bytes(int C, int H, int W);
 void launch_l1_ssim(int C, int H, int W, const float* pred, const long long* pred_strides, const float* gt,

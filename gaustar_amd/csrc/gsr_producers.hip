@@ -48,6 +48,245 @@ sh_to_rgb_bwd_kernel(int P, int D, int M, const float* __restrict__ positions, c
     dL_dpos[3 * i] = gx; dL_dpos[3 * i + 1] = gy; dL_dpos[3 * i + 2] = gz;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Mesh-bound Gaussians: SuGaR.points / .scaling / .quaternions (gaustar_scene/sugar_model.py:417-435, :457-476,
+// :478-508) -- the per-call rebuild of means, scales and rotations of the 6 Gaussians bound to every triangle,
+// ~50 PyTorch kernels forward (gathers, normalisations, cross products, a batched matrix product and
+// pytorch3d's matrix_to_quaternion) and their autograd mirror, run before EACH render.
+//
+// One thread per FACE, looping over its G Gaussians: the face frame (normal R0, first edge bR1, bR2 = R0 x bR1) is
+// built once, each Gaussian turns (bR1, bR2) by its learned unit complex number, optionally pre-multiplies the
+// loose-bind rotation delta_r, and converts the matrix to a quaternion (best-conditioned candidate, as pytorch3d).
+//
+// Backward: the rasterizer returns dL/dq for the unit quaternion q it was given.  Every parameter upstream moves
+// R = R(q) inside SO(3), so only the tangential part of dL/dq matters: for R' = exp([w]x) R, dq = 1/2 (0, w) (x) q,
+//     G = dL/dw = 1/2 ( -g_w v + w g_v + v x g_v ),   q = (w, v), dL/dq = (g_w, g_v),
+// and the gradient w.r.t. the matrix that reproduces G along every rotation direction is  dL/dR = 1/2 [G]x R
+// (< 1/2 [G]x R, [dw]x R > = G . dw).  From there it is plain chain rule through the frame (no derivative of
+// matrix_to_quaternion is ever needed); a face's three vertex gradients are summed over its G Gaussians in
+// registers and leave as 9 atomics.
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ float norm(V3 a) { return sqrtf(dot(a, a)); }
+__device__ __forceinline__ V3 ld3(const float* p, size_t i) { return V3{p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
+__device__ __forceinline__ void st3(float* p, size_t i, V3 v) { p[3 * i] = v.x; p[3 * i + 1] = v.y; p[3 * i + 2] = v.z; }
+// d/dx of x / max(|x|, eps) applied to g (the eps branch, reached only by degenerate input, is treated as a constant scale)
+__device__ __forceinline__ V3 normalize_bwd(V3 unit, float len, float eps, V3 g)
+{
+    const float inv = 1.0f / fmaxf(len, eps);
+    return len > eps ? inv * (g - dot(g, unit) * unit) : inv * g;
+}
+
+struct FaceFrame { V3 v0, v1, v2, e1, e2, nrm, R0, a, bR1, cr, bR2; float len, la, lc; };
+__device__ __forceinline__ FaceFrame face_frame(const float* __restrict__ verts, const long long* __restrict__ faces, size_t f)
+{
+    FaceFrame F;
+    F.v0 = ld3(verts, (size_t)faces[3 * f]); F.v1 = ld3(verts, (size_t)faces[3 * f + 1]); F.v2 = ld3(verts, (size_t)faces[3 * f + 2]);
+    F.e1 = F.v1 - F.v0; F.e2 = F.v2 - F.v0;
+    F.nrm = cross(F.e1, F.e2);
+    F.len = norm(F.nrm);
+    const V3 n0 = (1.0f / fmaxf(F.len, 1e-6f)) * F.nrm;              // pytorch3d face normal
+    F.R0 = (1.0f / fmaxf(norm(n0), 1e-12f)) * n0;                    // F.normalize, sugar_model.py:483
+    F.a = F.v0 - F.v1; F.la = norm(F.a);
+    F.bR1 = (1.0f / fmaxf(F.la, 1e-12f)) * F.a;                      // :487
+    F.cr = cross(F.R0, F.bR1); F.lc = norm(F.cr);
+    F.bR2 = (1.0f / fmaxf(F.lc, 1e-12f)) * F.cr;                     // :490
+    return F;
+}
+
+// R (row-major r[i][j]) of one Gaussian; also returns the unit complex number and, if present, D = R(delta_r).
+struct GaussFrame { float R[3][3]; float D[3][3]; float qc, qs, lq; float dw; V3 dv; float ld; bool loose; };
+__device__ __forceinline__ GaussFrame gauss_frame(const FaceFrame& F, const float* __restrict__ raw_complex,
+                                                  const float* __restrict__ delta_r, size_t n)
+{
+    GaussFrame Gf;
+    const float cx = raw_complex[2 * n], cy = raw_complex[2 * n + 1];
+    Gf.lq = sqrtf(cx * cx + cy * cy);
+    const float iq = 1.0f / fmaxf(Gf.lq, 1e-12f);
+    Gf.qc = cx * iq; Gf.qs = cy * iq;                                                   // :493
+    const V3 R1 = Gf.qc * F.bR1 + Gf.qs * F.bR2, R2 = (-Gf.qs) * F.bR1 + Gf.qc * F.bR2;   // :494-495
+    const float B[3][3] = {{F.R0.x, R1.x, R2.x}, {F.R0.y, R1.y, R2.y}, {F.R0.z, R1.z, R2.z}};   // columns R0 | R1 | R2
+    Gf.loose = delta_r != nullptr;
+    if (Gf.loose) {
+        const float r = delta_r[4 * n], i = delta_r[4 * n + 1], j = delta_r[4 * n + 2], k = delta_r[4 * n + 3];
+        const float ss = r * r + i * i + j * j + k * k;
+        const float two_s = 2.0f / ss;                                                  // quaternion_to_matrix
+        Gf.ld = sqrtf(ss);
+        Gf.dw = r / Gf.ld; Gf.dv = v3(i / Gf.ld, j / Gf.ld, k / Gf.ld);
+        const float D[3][3] = {{1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r)},
+                               {two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r)},
+                               {two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)}};
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                Gf.D[a][b] = D[a][b];
+                Gf.R[a][b] = D[a][0] * B[0][b] + D[a][1] * B[1][b] + D[a][2] * B[2][b];   // bmm(delta_r_mat, R), :505
+            }
+    } else {
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) Gf.R[a][b] = B[a][b];
+    }
+    return Gf;
+}
+
+// pytorch3d matrix_to_quaternion (best-conditioned candidate) followed by F.normalize (:506-508)
+__device__ __forceinline__ void matrix_to_unit_quaternion(const float (&m)[3][3], float (&q)[4])
+{
+    const float t0 = 1.0f + m[0][0] + m[1][1] + m[2][2], t1 = 1.0f + m[0][0] - m[1][1] - m[2][2],
+                t2 = 1.0f - m[0][0] + m[1][1] - m[2][2], t3 = 1.0f - m[0][0] - m[1][1] + m[2][2];
+    const float qa[4] = {t0 > 0.f ? sqrtf(t0) : 0.f, t1 > 0.f ? sqrtf(t1) : 0.f, t2 > 0.f ? sqrtf(t2) : 0.f,
+                         t3 > 0.f ? sqrtf(t3) : 0.f};
+    int best = 0;
+#pragma unroll
+    for (int c = 1; c < 4; c++) if (qa[c] > qa[best]) best = c;   // first maximum, like argmax
+    float cand[4];
+    if (best == 0) { cand[0] = qa[0] * qa[0]; cand[1] = m[2][1] - m[1][2]; cand[2] = m[0][2] - m[2][0]; cand[3] = m[1][0] - m[0][1]; }
+    else if (best == 1) { cand[0] = m[2][1] - m[1][2]; cand[1] = qa[1] * qa[1]; cand[2] = m[1][0] + m[0][1]; cand[3] = m[0][2] + m[2][0]; }
+    else if (best == 2) { cand[0] = m[0][2] - m[2][0]; cand[1] = m[1][0] + m[0][1]; cand[2] = qa[2] * qa[2]; cand[3] = m[1][2] + m[2][1]; }
+    else { cand[0] = m[1][0] - m[0][1]; cand[1] = m[2][0] + m[0][2]; cand[2] = m[2][1] + m[1][2]; cand[3] = qa[3] * qa[3]; }
+    const float d = 1.0f / (2.0f * fmaxf(qa[best], 0.1f));
+    float n2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; c++) { cand[c] *= d; n2 += cand[c] * cand[c]; }
+    const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+#pragma unroll
+    for (int c = 0; c < 4; c++) q[c] = cand[c] * inv;
+}
+
+__global__ void __launch_bounds__(128)
+mesh_gaussians_fwd_kernel(int F, int G, const float* __restrict__ verts, const long long* __restrict__ faces,
+                          const float* __restrict__ bary, const float* __restrict__ raw_scales,
+                          const float* __restrict__ raw_complex, float thickness, float min_scale, float max_scale,
+                          const float* __restrict__ delta_t, const float* __restrict__ delta_r,
+                          float* __restrict__ points, float* __restrict__ scaling, float* __restrict__ quats)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const FaceFrame Ff = face_frame(verts, faces, (size_t)f);
+    for (int g = 0; g < G; g++) {
+        const size_t n = (size_t)f * G + g;
+        V3 p = (bary[3 * g] * Ff.v0 + bary[3 * g + 1] * Ff.v1) + bary[3 * g + 2] * Ff.v2;   // :428-429
+        if (delta_t) p = p + ld3(delta_t, n);                                                 // :432
+        st3(points, n, p);
+        const float s0 = fmaxf(fminf(__expf(raw_scales[2 * n]), max_scale), min_scale);       // :461-465
+        const float s1 = fmaxf(fminf(__expf(raw_scales[2 * n + 1]), max_scale), min_scale);
+        st3(scaling, n, v3(thickness, s0, s1));                                               // :472-475
+        const GaussFrame Gf = gauss_frame(Ff, raw_complex, delta_r, n);
+        float q[4];
+        matrix_to_unit_quaternion(Gf.R, q);
+        reinterpret_cast<float4*>(quats)[n] = make_float4(q[0], q[1], q[2], q[3]);
+    }
+}
+
+__global__ void __launch_bounds__(128)
+mesh_gaussians_bwd_kernel(int F, int G, const float* __restrict__ verts, const long long* __restrict__ faces,
+                          const float* __restrict__ bary, const float* __restrict__ raw_scales,
+                          const float* __restrict__ raw_complex, float min_scale, float max_scale,
+                          const float* __restrict__ delta_r, const float* __restrict__ dL_dpoints,
+                          const float* __restrict__ dL_dscaling, const float* __restrict__ dL_dquats,
+                          float* __restrict__ dL_dverts, float* __restrict__ dL_draw_scales,
+                          float* __restrict__ dL_draw_complex, float* __restrict__ dL_ddelta_t,
+                          float* __restrict__ dL_ddelta_r)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const FaceFrame Ff = face_frame(verts, faces, (size_t)f);
+    V3 gv0 = v3(0, 0, 0), gv1 = gv0, gv2 = gv0, gR0 = gv0, gbR1 = gv0, gbR2 = gv0;
+    for (int g = 0; g < G; g++) {
+        const size_t n = (size_t)f * G + g;
+        // means
+        const V3 gm = dL_dpoints ? ld3(dL_dpoints, n) : v3(0, 0, 0);
+        gv0 = gv0 + bary[3 * g] * gm; gv1 = gv1 + bary[3 * g + 1] * gm; gv2 = gv2 + bary[3 * g + 2] * gm;
+        if (dL_ddelta_t) st3(dL_ddelta_t, n, gm);
+        // scales: exp, then clamp_max, clamp_min masks (x <= max, y >= min)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const float e = __expf(raw_scales[2 * n + j]);
+            const bool pass = e <= max_scale && fminf(e, max_scale) >= min_scale;
+            dL_draw_scales[2 * n + j] = (dL_dscaling && pass) ? dL_dscaling[3 * n + 1 + j] * e : 0.f;
+        }
+        // rotation
+        const GaussFrame Gf = gauss_frame(Ff, raw_complex, delta_r, n);
+        float q[4];
+        matrix_to_unit_quaternion(Gf.R, q);
+        const float4 gq = dL_dquats ? reinterpret_cast<const float4*>(dL_dquats)[n] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const V3 qv = v3(q[1], q[2], q[3]), gqv = v3(gq.y, gq.z, gq.w);
+        const V3 Gw = 0.5f * (((-gq.x) * qv + q[0] * gqv) + cross(qv, gqv));           // dL/d(rotation vector)
+        // dL/dR = 1/2 [G]x R, column by column
+        V3 A[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) A[c] = 0.5f * cross(Gw, v3(Gf.R[0][c], Gf.R[1][c], Gf.R[2][c]));
+        V3 gB[3];
+        if (Gf.loose) {
+            // delta_r: dphi = 2 vec(dd^ (x) conj(d^)), dd^ = (I - d^ d^T) dd / |d|
+            const float hw = -2.0f * dot(Gw, Gf.dv);
+            const V3 hv = 2.0f * (Gf.dw * Gw - cross(Gf.dv, Gw));
+            const float il = 1.0f / Gf.ld;
+            if (dL_ddelta_r) reinterpret_cast<float4*>(dL_ddelta_r)[n] = make_float4(hw * il, hv.x * il, hv.y * il, hv.z * il);
+#pragma unroll
+            for (int c = 0; c < 3; c++)   // dL/dB = D^T dL/dR
+                gB[c] = v3(Gf.D[0][0] * A[c].x + Gf.D[1][0] * A[c].y + Gf.D[2][0] * A[c].z,
+                           Gf.D[0][1] * A[c].x + Gf.D[1][1] * A[c].y + Gf.D[2][1] * A[c].z,
+                           Gf.D[0][2] * A[c].x + Gf.D[1][2] * A[c].y + Gf.D[2][2] * A[c].z);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; c++) gB[c] = A[c];
+        }
+        gR0 = gR0 + gB[0];
+        const float g_qc = dot(gB[1], Ff.bR1) + dot(gB[2], Ff.bR2), g_qs = dot(gB[1], Ff.bR2) - dot(gB[2], Ff.bR1);
+        gbR1 = gbR1 + (Gf.qc * gB[1] - Gf.qs * gB[2]);
+        gbR2 = gbR2 + (Gf.qs * gB[1] + Gf.qc * gB[2]);
+        {   // through the normalisation of the raw complex number (:493)
+            const float inv = 1.0f / fmaxf(Gf.lq, 1e-12f);
+            const float d = g_qc * Gf.qc + g_qs * Gf.qs;
+            const bool reg = Gf.lq > 1e-12f;
+            dL_draw_complex[2 * n] = reg ? inv * (g_qc - d * Gf.qc) : inv * g_qc;
+            dL_draw_complex[2 * n + 1] = reg ? inv * (g_qs - d * Gf.qs) : inv * g_qs;
+        }
+    }
+    // face frame -> vertices
+    const V3 gcr = normalize_bwd(Ff.bR2, Ff.lc, 1e-12f, gbR2);       // bR2 = normalize(R0 x bR1)
+    gR0 = gR0 + cross(Ff.bR1, gcr);
+    gbR1 = gbR1 + cross(gcr, Ff.R0);
+    const V3 ga = normalize_bwd(Ff.bR1, Ff.la, 1e-12f, gbR1);        // bR1 = normalize(v0 - v1)
+    gv0 = gv0 + ga; gv1 = gv1 - ga;
+    const V3 gn = normalize_bwd(Ff.R0, Ff.len, 1e-6f, gR0);          // R0 = normalize((e1 x e2) / max(|.|, 1e-6))
+    const V3 ge1 = cross(Ff.e2, gn), ge2 = cross(gn, Ff.e1);
+    gv1 = gv1 + ge1; gv2 = gv2 + ge2; gv0 = gv0 - (ge1 + ge2);
+    const size_t i0 = (size_t)faces[3 * (size_t)f], i1 = (size_t)faces[3 * (size_t)f + 1], i2 = (size_t)faces[3 * (size_t)f + 2];
+    atomicAdd(dL_dverts + 3 * i0, gv0.x); atomicAdd(dL_dverts + 3 * i0 + 1, gv0.y); atomicAdd(dL_dverts + 3 * i0 + 2, gv0.z);
+    atomicAdd(dL_dverts + 3 * i1, gv1.x); atomicAdd(dL_dverts + 3 * i1 + 1, gv1.y); atomicAdd(dL_dverts + 3 * i1 + 2, gv1.z);
+    atomicAdd(dL_dverts + 3 * i2, gv2.x); atomicAdd(dL_dverts + 3 * i2 + 1, gv2.y); atomicAdd(dL_dverts + 3 * i2 + 2, gv2.z);
+}
+
+void launch_mesh_gaussians(int F, int G, const float* verts, const long long* faces, const float* bary,
+                           const float* raw_scales, const float* raw_complex, float thickness, float min_scale,
+                           float max_scale, const float* delta_t, const float* delta_r, float* points, float* scaling,
+                           float* quats, hipStream_t st)
+{
+    mesh_gaussians_fwd_kernel<<<(F + 127) / 128, 128, 0, st>>>(F, G, verts, faces, bary, raw_scales, raw_complex, thickness,
+                                                              min_scale, max_scale, delta_t, delta_r, points, scaling, quats);
+}
+
+void launch_mesh_gaussians_bwd(int F, int G, const float* verts, const long long* faces, const float* bary,
+                               const float* raw_scales, const float* raw_complex, float min_scale, float max_scale,
+                               const float* delta_r, const float* dL_dpoints, const float* dL_dscaling,
+                               const float* dL_dquats, float* dL_dverts, float* dL_draw_scales, float* dL_draw_complex,
+                               float* dL_ddelta_t, float* dL_ddelta_r, hipStream_t st)
+{
+    mesh_gaussians_bwd_kernel<<<(F + 127) / 128, 128, 0, st>>>(F, G, verts, faces, bary, raw_scales, raw_complex, min_scale,
+                                                              max_scale, delta_r, dL_dpoints, dL_dscaling, dL_dquats, dL_dverts,
+                                                              dL_draw_scales, dL_draw_complex, dL_ddelta_t, dL_ddelta_r);
+}
+
 void launch_sh_to_rgb(int P, int D, int M, const float* positions, const float* campos, const float* shs, float* rgb,
                       hipStream_t st)
 {

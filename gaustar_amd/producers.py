@@ -69,3 +69,67 @@ def points_rgb(positions: torch.Tensor, camera_centers: torch.Tensor, sh_coordin
     camera_centers)) + 0.5, 0), sugar_model.py:698-716 with one camera centre ((3,) or (1,3)), sh_coordinates
     [P, n_coeffs, 3] as SuGaR stores them (sugar_model.py:449-450)."""
     return _PointsRGB.apply(positions, camera_centers, sh_coordinates, int(sh_levels))
+
+
+class _MeshGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, verts, faces, bary, raw_scales, raw_complex, thickness, min_scale, max_scale, delta_t, delta_r):
+        lib = _lib.load()
+        if not verts.is_cuda:
+            raise RuntimeError("gaustar_amd.producers: verts must live on a HIP (cuda) device -- there is no CPU path")
+        dev = verts.device
+        f32 = lambda t: None if t is None else t.detach().to(dev, torch.float32).contiguous()
+        v, rs, rc, dt, dr = f32(verts), f32(raw_scales), f32(raw_complex), f32(delta_t), f32(delta_r)
+        fc = faces.detach().to(dev, torch.int64).contiguous()
+        bc = f32(bary).reshape(-1, 3)
+        F, G, V = int(fc.size(0)), int(bc.size(0)), int(v.size(0))
+        N = F * G
+        if v.dim() != 2 or v.size(1) != 3 or fc.dim() != 2 or fc.size(1) != 3:
+            raise RuntimeError("verts must be (V, 3) and faces (F, 3)")
+        if tuple(rs.shape) != (N, 2) or tuple(rc.shape) != (N, 2):
+            raise RuntimeError(f"raw scales and raw 2-D rotations must both be ({N}, 2)")
+        if (dt is not None and tuple(dt.shape) != (N, 3)) or (dr is not None and tuple(dr.shape) != (N, 4)):
+            raise RuntimeError(f"delta_t must be ({N}, 3) and delta_r ({N}, 4)")
+        lo = float("-inf") if min_scale is None else float(min_scale)
+        hi = float("inf") if max_scale is None else float(max_scale)
+        points = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        scaling = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        quats = torch.empty(N, 4, dtype=torch.float32, device=dev)
+        op = lambda t: None if t is None else _p(t)
+        with torch.cuda.device(dev):
+            _lib.check(lib.gsr_mesh_gaussians(F, G, _p(v), _p(fc), _p(bc), _p(rs), _p(rc), float(thickness), lo, hi, op(dt),
+                                              op(dr), _p(points), _p(scaling), _p(quats), _stream()), "gsr_mesh_gaussians")
+        ctx.save_for_backward(v, fc, bc, rs, rc, dr)
+        ctx.dims = (F, G, V, lo, hi, dt is not None)
+        return points, scaling, quats
+
+    @staticmethod
+    def backward(ctx, g_points, g_scaling, g_quats):
+        lib = _lib.load()
+        v, fc, bc, rs, rc, dr = ctx.saved_tensors
+        F, G, V, lo, hi, has_dt = ctx.dims
+        dev = v.device
+        c = lambda t: None if t is None else t.to(torch.float32).contiguous()
+        g_points, g_scaling, g_quats = c(g_points), c(g_scaling), c(g_quats)
+        d_verts = torch.empty_like(v)
+        d_rs, d_rc = torch.empty_like(rs), torch.empty_like(rc)
+        d_dt = torch.empty(F * G, 3, dtype=torch.float32, device=dev) if has_dt else None
+        d_dr = torch.empty_like(dr) if dr is not None else None
+        op = lambda t: None if t is None else _p(t)
+        with torch.cuda.device(dev):
+            _lib.check(lib.gsr_mesh_gaussians_backward(
+                F, G, V, _p(v), _p(fc), _p(bc), _p(rs), _p(rc), lo, hi, op(dr), op(g_points), op(g_scaling), op(g_quats),
+                _p(d_verts), _p(d_rs), _p(d_rc), op(d_dt), op(d_dr), _stream()), "gsr_mesh_gaussians_backward")
+        return d_verts, None, None, d_rs, d_rc, None, None, None, d_dt, d_dr
+
+
+def mesh_bound_gaussians(verts: torch.Tensor, faces: torch.Tensor, bary_coords: torch.Tensor, raw_scales: torch.Tensor,
+                         raw_complex: torch.Tensor, thickness: float, min_scale=None, max_scale=None,
+                         delta_t: torch.Tensor = None, delta_r: torch.Tensor = None):
+    """-> (points [N,3], scaling [N,3], quaternions [N,4]) of the N = F*G Gaussians bound to a triangle mesh:
+    SuGaR.points / .scaling / .quaternions (sugar_model.py:417-435, :457-476, :478-508) in one kernel, one more
+    for the backward.  Arguments are the model's `_points`, `_surface_mesh_faces`,
+    `surface_triangle_bary_coords` ([G,3] or [G,3,1]), `_scales`, `_quaternions` (the 2-D rotation),
+    `surface_mesh_thickness`, `min_gaussian_scale`, `max_gaussian_scale`, and the loose-bind `_delta_t`, `_delta_r`."""
+    return _MeshGaussians.apply(verts, faces, bary_coords, raw_scales, raw_complex, float(thickness), min_scale,
+                                max_scale, delta_t, delta_r)

@@ -153,6 +153,28 @@ int gsr_sh_to_rgb(int P, int D, int M, const float* positions, const float* camp
 int gsr_sh_to_rgb_backward(int P, int D, int M, const float* positions, const float* campos, const float* shs,
                            const float* dL_drgb, float* dL_dsh, float* dL_dpos, gsr_stream_t stream);
 
+/* gsr_mesh_gaussians replaces the properties SuGaR.points / .scaling / .quaternions for Gaussians bound to a
+ * triangle mesh (gaustar_scene/sugar_model.py:417-435, :457-476, :478-508; pytorch3d 0.7.4 face normals,
+ * quaternion_to_matrix, matrix_to_quaternion): Gaussian n = f*G + g of face f gets
+ *   points[n]  = sum_k bary[g][k] * verts[faces[f][k]]  (+ delta_t[n]),
+ *   scaling[n] = {thickness, clamp(exp(raw_scales[n]), min_scale, max_scale)},
+ *   quaternions[n] = normalize(matrix_to_quaternion(R(delta_r[n]) * [n_f | R1 | R2])),  (w, x, y, z),
+ * with [R1 R2] the face's (first edge, normal x edge) basis turned by normalize(raw_complex[n]).
+ *   verts [V,3] f32, faces [F,3] int64, bary [G,3], raw_scales / raw_complex [F*G,2]; delta_t [F*G,3] and
+ *   delta_r [F*G,4] are the loose-bind offsets and may be NULL; min_scale / max_scale: -inf / +inf for "none".
+ * gsr_mesh_gaussians_backward is its autograd backward: dL_dverts [V,3] is zeroed and accumulated inside;
+ * dL_draw_scales, dL_draw_complex (and dL_ddelta_t, dL_ddelta_r when non-NULL) are written outright; any of
+ * the three incoming gradients may be NULL (= zero). */
+int gsr_mesh_gaussians(int F, int G, const float* verts, const long long* faces, const float* bary,
+                       const float* raw_scales, const float* raw_complex, float thickness, float min_scale,
+                       float max_scale, const float* delta_t, const float* delta_r, float* points, float* scaling,
+                       float* quaternions, gsr_stream_t stream);
+int gsr_mesh_gaussians_backward(int F, int G, int V, const float* verts, const long long* faces, const float* bary,
+                                const float* raw_scales, const float* raw_complex, float min_scale, float max_scale,
+                                const float* delta_r, const float* dL_dpoints, const float* dL_dscaling,
+                                const float* dL_dquaternions, float* dL_dverts, float* dL_draw_scales,
+                                float* dL_draw_complex, float* dL_ddelta_t, float* dL_ddelta_r, gsr_stream_t stream);
+
 /* ---- Image-space losses either side of the rasterizer.
  * gsr_l1_ssim replaces  (1 - f) * l1_loss(pred, gt) + f * (1 - ssim(pred, gt))  (gaustar_trainers/refine.py:451-453
  * over gaustar_utils/loss_utils.py:17-62: 11x11 Gaussian window, sigma 1.5, zero padding, mean over all

@@ -36,3 +36,80 @@ def points_rgb(positions, camera_centers, sh_coordinates, sh_levels):
     sh = sh_coordinates[:, :sh_levels ** 2]                                           # :711
     shs_view = sh.transpose(-1, -2).view(-1, 3, sh_levels ** 2)                       # :713
     return torch.clamp_min(eval_sh(sh_levels - 1, shs_view, dirs) + 0.5, 0.0).view(-1, 3)   # :714-716
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Mesh-bound Gaussians: SuGaR.points / .scaling / .quaternions (gaustar_scene/sugar_model.py:417-435, :457-476,
+# :478-508).  Two third-party pieces are absent from /root/reference and restated from their published algorithms
+# (pytorch3d 0.7.4, pinned in the reference's environment.yml:161):
+#   * Meshes.faces_normals_list(): n = (v1 - v0) x (v2 - v0), divided by max(|n|, 1e-6)
+#     (pytorch3d/csrc/face_areas_normals);
+#   * transforms.quaternion_to_matrix / matrix_to_quaternion (pytorch3d/transforms/rotation_conversions.py):
+#     real-first quaternions; matrix_to_quaternion picks the best-conditioned of the four candidates.
+# sugar_model.py itself cannot be imported here (open3d, pytorch3d), so this part of the oracle is pinned by
+# closed-form properties in tests/ (the rotation's first axis is the face normal, means lie in the face plane,
+# R(q) is orthonormal, finite differences) rather than by reference outputs: PARITY UNPINNED for these functions.
+def face_normals(verts, faces):
+    v0, v1, v2 = verts[faces[:, 0]], verts[faces[:, 1]], verts[faces[:, 2]]
+    n = torch.cross(v1 - v0, v2 - v0, dim=-1)
+    return n / n.norm(dim=-1, keepdim=True).clamp(min=1e-6)
+
+
+def quaternion_to_matrix(q):
+    r, i, j, k = torch.unbind(q, -1)
+    two_s = 2.0 / (q * q).sum(-1)
+    o = torch.stack((1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
+                     two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
+                     two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)), -1)
+    return o.reshape(q.shape[:-1] + (3, 3))
+
+
+def _sqrt_positive_part(x):
+    ret = torch.zeros_like(x)
+    m = x > 0
+    ret[m] = torch.sqrt(x[m])
+    return ret
+
+
+def matrix_to_quaternion(matrix):
+    batch_dim = matrix.shape[:-2]
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = torch.unbind(matrix.reshape(batch_dim + (9,)), dim=-1)
+    q_abs = _sqrt_positive_part(torch.stack([1.0 + m00 + m11 + m22, 1.0 + m00 - m11 - m22, 1.0 - m00 + m11 - m22,
+                                             1.0 - m00 - m11 + m22], dim=-1))
+    quat_by_rijk = torch.stack([
+        torch.stack([q_abs[..., 0] ** 2, m21 - m12, m02 - m20, m10 - m01], dim=-1),
+        torch.stack([m21 - m12, q_abs[..., 1] ** 2, m10 + m01, m02 + m20], dim=-1),
+        torch.stack([m02 - m20, m10 + m01, q_abs[..., 2] ** 2, m12 + m21], dim=-1),
+        torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[..., 3] ** 2], dim=-1)], dim=-2)
+    flr = torch.tensor(0.1).to(dtype=q_abs.dtype, device=q_abs.device)
+    quat_candidates = quat_by_rijk / (2.0 * q_abs[..., None].max(flr))
+    return quat_candidates[torch.nn.functional.one_hot(q_abs.argmax(dim=-1), num_classes=4) > 0.5, :].reshape(batch_dim + (4,))
+
+
+def mesh_bound_gaussians(verts, faces, bary, raw_scales, raw_complex, thickness, min_scale=None, max_scale=None,
+                         delta_t=None, delta_r=None):
+    """-> (points [N,3], scaling [N,3], quaternions [N,4]), N = F * G, Gaussian n = f * G + g.
+    verts [V,3], faces [F,3] long, bary [G,3], raw_scales [N,2] (log), raw_complex [N,2]."""
+    F_, G = faces.shape[0], bary.shape[0]
+    fv = verts[faces]                                                        # sugar_model.py:425
+    points = (fv[:, None] * bary[None, :, :, None]).sum(dim=-2).reshape(F_ * G, 3)   # :428-429
+    if delta_t is not None:
+        points = points + delta_t                                            # :432
+    plane = torch.exp(raw_scales)                                            # :461 (scale_activation = exp)
+    if max_scale is not None:
+        plane = torch.clamp_max(plane, max_scale)                            # :463
+    if min_scale is not None:
+        plane = torch.clamp_min(plane, min_scale)                            # :465
+    scaling = torch.cat([thickness * torch.ones(len(raw_scales), 1, dtype=plane.dtype, device=plane.device), plane], dim=-1)   # :472-475
+    nf = torch.nn.functional.normalize
+    R_0 = nf(face_normals(verts, faces), dim=-1)                             # :483
+    base_R_1 = nf(fv[:, 0] - fv[:, 1], dim=-1)                               # :487
+    base_R_2 = nf(torch.cross(R_0, base_R_1, dim=-1))                        # :490
+    cplx = nf(raw_complex, dim=-1).view(F_, G, 2)                            # :493
+    R_1 = cplx[..., 0:1] * base_R_1[:, None] + cplx[..., 1:2] * base_R_2[:, None]    # :494
+    R_2 = -cplx[..., 1:2] * base_R_1[:, None] + cplx[..., 0:1] * base_R_2[:, None]   # :495
+    R = torch.cat([R_0[:, None, ..., None].expand(-1, G, -1, -1).clone(), R_1[..., None], R_2[..., None]],
+                  dim=-1).view(-1, 3, 3)                                     # :498-502
+    if delta_r is not None:
+        R = torch.bmm(quaternion_to_matrix(delta_r), R)                      # :504-505
+    return points, scaling, nf(matrix_to_quaternion(R), dim=-1)              # :506-508

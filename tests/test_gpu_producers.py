@@ -85,3 +85,85 @@ def test_validation(hip_lib):
         producers.points_rgb(pos, torch.zeros(3).cuda(), torch.rand(10, 4, 3).cuda(), 3)
     with pytest.raises(RuntimeError, match="no CPU path"):
         producers.points_rgb(pos.cpu(), torch.zeros(3), torch.rand(10, 4, 3), 2)
+
+
+# ------------------------------------------------------------------ mesh-bound Gaussians
+BARY6 = [[2 / 3, 1 / 6, 1 / 6], [1 / 6, 2 / 3, 1 / 6], [1 / 6, 1 / 6, 2 / 3], [1 / 6, 5 / 12, 5 / 12], [5 / 12, 1 / 6, 5 / 12],
+         [5 / 12, 5 / 12, 1 / 6]]   # sugar_model.py:217-226
+
+
+def _mesh_case(level, loose, seed, clamp):
+    from gaustar_amd import scene
+    v, f = scene.icosphere(level, radius=0.9, center=(0.0, 1.2, 0.0))
+    g = torch.Generator().manual_seed(seed)
+    v = torch.from_numpy(v).float() + 0.01 * torch.randn(v.shape[0], 3, generator=g)
+    f = torch.from_numpy(f).long()
+    N = f.shape[0] * 6
+    d = dict(verts=v, faces=f, bary=torch.tensor(BARY6), raw_scales=torch.randn(N, 2, generator=g) * 0.4 - 4.0,
+             raw_complex=torch.randn(N, 2, generator=g), thickness=3e-6,
+             min_scale=(0.012 if clamp else None), max_scale=(0.03 if clamp else None),
+             delta_t=(0.01 * torch.randn(N, 3, generator=g) if loose else None),
+             delta_r=(torch.randn(N, 4, generator=g) * 0.3 + torch.tensor([1.0, 0, 0, 0]) if loose else None))
+    w = dict(points=torch.randn(N, 3, generator=g), scaling=torch.randn(N, 3, generator=g), quats=torch.randn(N, 4, generator=g))
+    return d, w
+
+
+def _quat_R(q):
+    from oracle import producers_oracle
+    return producers_oracle.quaternion_to_matrix(q)
+
+
+@pytest.mark.parametrize("loose,clamp,level", [(False, False, 2), (True, True, 2), (True, False, 4)])
+def test_mesh_bound_gaussians_against_oracle(loose, clamp, level, hip_lib):
+    """Forward (quaternions compared through R(q): q and -q are the same rotation) and every gradient against
+    autograd of the torch restatement of sugar_model.py:417-508, with a loss that only depends on R(q) -- the
+    way the rasterizer consumes the quaternion."""
+    from gaustar_amd import producers
+    from oracle import producers_oracle
+    d, w = _mesh_case(level, loose, 100 + level, clamp)
+    names = ["verts", "raw_scales", "raw_complex"] + (["delta_t", "delta_r"] if loose else [])
+
+    def run(fn, dev):
+        args = {k: (v.clone().to(dev).requires_grad_(k in names) if torch.is_tensor(v) else v) for k, v in d.items()}
+        p, s, q = fn(args["verts"], args["faces"], args["bary"], args["raw_scales"], args["raw_complex"], args["thickness"],
+                     args["min_scale"], args["max_scale"], args["delta_t"], args["delta_r"])
+        W3 = torch.randn(3, 3, generator=torch.Generator().manual_seed(1)).to(dev)
+        # the rasterizer sees q only through R(q) (polynomial in q, no normalisation inside)
+        r, i, j, k = q.unbind(-1)
+        R = torch.stack((1 - 2 * (j * j + k * k), 2 * (i * j - k * r), 2 * (i * k + j * r), 2 * (i * j + k * r),
+                         1 - 2 * (i * i + k * k), 2 * (j * k - i * r), 2 * (i * k - j * r), 2 * (j * k + i * r),
+                         1 - 2 * (i * i + j * j)), -1).reshape(-1, 3, 3)
+        loss = (p * w["points"].to(dev)).sum() + (s * w["scaling"].to(dev)).sum() + ((R @ W3) * w["quats"].to(dev)[:, :3, None]).sum()
+        loss.backward()
+        return p.detach().cpu(), s.detach().cpu(), q.detach().cpu(), {k: args[k].grad.cpu() for k in names}
+
+    p0, s0, q0, g0 = run(producers_oracle.mesh_bound_gaussians, "cpu")
+    p1, s1, q1, g1 = run(producers.mesh_bound_gaussians, "cuda")
+    np.testing.assert_allclose(p1.numpy(), p0.numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(s1.numpy(), s0.numpy(), rtol=2e-6, atol=0)
+    assert np.abs(q1.norm(dim=-1).numpy() - 1).max() < 1e-6
+    np.testing.assert_allclose(_quat_R(q1).numpy(), _quat_R(q0).numpy(), rtol=0, atol=3e-6)
+    assert (np.abs((q1 * q0).sum(-1).numpy()) > 1 - 1e-5).all()
+    for k in names:
+        a, b = g1[k].numpy().astype(np.float64), g0[k].numpy().astype(np.float64)
+        err = np.abs(a - b).max() / np.abs(b).max()
+        assert err < 2e-4, f"{k}: normalised max error {err:.3e}"
+
+
+def test_mesh_bound_closed_form_properties(hip_lib):
+    """What SURVEY.md 8c asks of this producer: the rotation's first axis is the face normal, the other two span
+    the face plane, means lie in the face plane (strict binding), thickness is the first scale."""
+    from gaustar_amd import producers
+    d, _ = _mesh_case(3, False, 7, False)
+    dev = "cuda"
+    p, s, q = producers.mesh_bound_gaussians(d["verts"].to(dev), d["faces"].to(dev), d["bary"].to(dev), d["raw_scales"].to(dev),
+                                             d["raw_complex"].to(dev), d["thickness"])
+    R = _quat_R(q.cpu())
+    fv = d["verts"][d["faces"]]
+    n = torch.cross(fv[:, 1] - fv[:, 0], fv[:, 2] - fv[:, 0], dim=-1)
+    n = (n / n.norm(dim=-1, keepdim=True)).repeat_interleave(6, 0)
+    assert (R[:, :, 0] - n).abs().max() < 1e-5
+    assert (R[:, :, 1] * n).sum(-1).abs().max() < 1e-5 and (R[:, :, 2] * n).sum(-1).abs().max() < 1e-5
+    assert (R.transpose(1, 2) @ R - torch.eye(3)).abs().max() < 1e-5 and (torch.det(R) - 1).abs().max() < 1e-5
+    assert (((p.cpu() - fv[:, 0].repeat_interleave(6, 0)) * n).sum(-1)).abs().max() < 1e-6
+    assert (s[:, 0].cpu() == torch.tensor(3e-6)).all() and (s[:, 1:].cpu() > 0).all()
