@@ -51,6 +51,8 @@ class Camera:
     viewmatrix: np.ndarray   # [4,4] float32, TRANSPOSED world->view (row-vector convention)
     projmatrix: np.ndarray   # [4,4] float32, TRANSPOSED full projection (view * proj)
     campos: np.ndarray       # [3]
+    name: str = ""           # img_name of cameras.json
+    uid: int = 0
 
 
 def focal2fov(focal: float, pixels: float) -> float:
@@ -83,6 +85,20 @@ def get_projection_matrix(znear: float, zfar: float, fovX: float, fovY: float) -
     P[2, 2] = zfar / (zfar - znear)
     P[2, 3] = -(zfar * znear) / (zfar - znear)
     return P
+
+
+def camera_from_RT(R: np.ndarray, T: np.ndarray, W: int, H: int, fovx: float, fovy: float, znear: float = 0.01,
+                   zfar: float = 100.0) -> Camera:
+    """The matrices a GSCamera carries (gaustar_scene/cameras.py:206-220) from a 3DGS-convention pose: R = camera-to-world
+    rotation ("stored transposed"), T = world-to-camera translation.  world_view = getWorld2View2(R, T)^T,
+    full_proj = world_view @ getProjectionMatrix(...)^T, camera centre = inverse(world_view)[3, :3]."""
+    view_t = get_world2view(np.asarray(R, dtype=np.float64), np.asarray(T, dtype=np.float64)).transpose()
+    proj_t = get_projection_matrix(znear, zfar, fovx, fovy).transpose()
+    full_t = (view_t @ proj_t).astype(F32)
+    campos = np.linalg.inv(view_t.astype(np.float64))[3, :3]
+    return Camera(W=int(W), H=int(H), tanfovx=math.tan(fovx * 0.5), tanfovy=math.tan(fovy * 0.5),
+                  viewmatrix=np.ascontiguousarray(view_t, dtype=F32), projmatrix=np.ascontiguousarray(full_t),
+                  campos=campos.astype(F32))
 
 
 def look_at_camera(eye, target, W: int, H: int, focal_px: Optional[float] = None, fovx: Optional[float] = None,

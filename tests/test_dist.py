@@ -67,3 +67,41 @@ def test_single_process_is_a_noop():
     p.grad = torch.ones(4)
     gd.GradAllReducer([p])()
     assert torch.equal(p.grad, torch.ones(4)) and gd.world_size() == 1 and gd.rank() == 0
+
+
+def _sweep_worker(rank, world, port, n, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gaustar_amd import sweep
+    mine = sweep.camera_shard(n)
+    local = torch.tensor([[float(i), float(i * i)] for i in mine]).reshape(len(mine), 2)
+    full = sweep.gather_rows(local, n)
+    q.put((rank, mine, full.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sweep_sharding_and_gather_world_size_2():
+    """Camera sweeps (gaustar_amd/sweep.py): strided shards cover every camera exactly once and the gathered table
+    has row i = camera i on every rank (gloo, world size 2, odd camera count)."""
+    import torch.multiprocessing as mp
+    from gaustar_amd import sweep
+    n = 7
+    assert sorted(sweep.camera_shard(n, 0, 2) + sweep.camera_shard(n, 1, 2)) == list(range(n))
+    assert sweep.camera_shard(5, 0, 1) == [0, 1, 2, 3, 4] and sweep.camera_shard(2, 1, 4) == [1] and sweep.camera_shard(2, 3, 4) == []
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650
+    ps = [ctx.Process(target=_sweep_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    expect = [[float(i), float(i * i)] for i in range(n)]
+    for rank, mine, full in res:
+        assert mine == list(range(rank, n, 2)) and full == expect
