@@ -54,23 +54,32 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int copy = lane & (NCOPY - 1);
     for (int i = tid; i < NHIST; i += 1024) hist[i] = 0;
-    const int t0 = tid * PER;
-    uint32_t c[PER];
+    // PER > 0: this thread's PER tiles live in registers.  PER == 0 (images above 8 192 tiles): the thread owns
+    // ceil(T / 1024) consecutive tiles and re-reads their counters (L2-resident) in each of the three passes.
+    constexpr bool IN_REGS = PER > 0;
+    const int per = IN_REGS ? PER : (T + 1023) / 1024;
+    const int t0 = tid * per;
+    uint32_t c[IN_REGS ? PER : 1];
+    auto count_of = [&](int t) -> uint32_t {
+        if (t >= T) return 0u;
+        const uint4* pc = reinterpret_cast<const uint4*>(tile_count + (size_t)t * NSHARD);
+        const uint4 v0 = pc[0], v1 = pc[1];
+        return (v0.x + v0.y + v0.z + v0.w) + (v1.x + v1.y + v1.z + v1.w);
+    };
+    if constexpr (IN_REGS) {
 #pragma unroll
-    for (int k = 0; k < PER; k++) {
-        c[k] = 0;
-        if (t0 + k < T) {
-            const uint4* pc = reinterpret_cast<const uint4*>(tile_count + (size_t)(t0 + k) * NSHARD);
-            const uint4 v0 = pc[0], v1 = pc[1];
-            c[k] = (v0.x + v0.y + v0.z + v0.w) + (v1.x + v1.y + v1.z + v1.w);
-        }
+        for (int k = 0; k < PER; k++) c[k] = count_of(t0 + k);
     }
+    auto cnt = [&](int k) -> uint32_t {
+        if constexpr (IN_REGS) return c[k]; else return count_of(t0 + k);
+    };
     uint32_t sum = 0, vmax = 0, segs = 0;
 #pragma unroll
-    for (int k = 0; k < PER; k++) {
-        sum += c[k];
-        segs += (c[k] + (uint32_t)SEG - 1u) / (uint32_t)SEG;
-        vmax = max(vmax, c[k]);
+    for (int k = 0; k < per; k++) {
+        const uint32_t ck = cnt(k);
+        sum += ck;
+        segs += (ck + (uint32_t)SEG - 1u) / (uint32_t)SEG;
+        vmax = max(vmax, ck);
     }
     const uint32_t incl = wave_incl_scan(sum, lane);
     const uint32_t incl_seg = wave_incl_scan(segs, lane);
@@ -92,15 +101,16 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
     uint32_t run_seg = woff_seg + incl_seg - segs;
     uint32_t n_empty = 0;   // empty tiles dominate: count them privately, one LDS atomic per thread
 #pragma unroll
-    for (int k = 0; k < PER; k++) {
+    for (int k = 0; k < per; k++) {
         const int t = t0 + k;
         if (t < T) {
-            ranges[t] = make_uint2(run, run + c[k]);
+            const uint32_t ck = cnt(k);
+            ranges[t] = make_uint2(run, run + ck);
             seg_off[t] = run_seg;
-            run += c[k];
-            run_seg += (c[k] + (uint32_t)SEG - 1u) / (uint32_t)SEG;
-            if (c[k] == 0) n_empty++;
-            else atomicAdd(&hist[length_bucket(c[k]) * NCOPY + copy], 1u);
+            run += ck;
+            run_seg += (ck + (uint32_t)SEG - 1u) / (uint32_t)SEG;
+            if (ck == 0) n_empty++;
+            else atomicAdd(&hist[length_bucket(ck) * NCOPY + copy], 1u);
         }
     }
     if (n_empty) atomicAdd(&hist[(NBUCKET - 1) * NCOPY + copy], n_empty);
@@ -136,10 +146,11 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
     auto snake = [](uint32_t pos) { return (pos & 256u) ? (pos ^ 255u) : pos; };
     uint32_t empty_at = n_empty ? atomicAdd(&hist[(NBUCKET - 1) * NCOPY + copy], n_empty) : 0u;
 #pragma unroll
-    for (int k = 0; k < PER; k++) {
+    for (int k = 0; k < per; k++) {
         const int t = t0 + k;
         if (t < T) {
-            uint32_t pos = (c[k] == 0) ? empty_at++ : atomicAdd(&hist[length_bucket(c[k]) * NCOPY + copy], 1u);
+            const uint32_t ck = cnt(k);
+            uint32_t pos = (ck == 0) ? empty_at++ : atomicAdd(&hist[length_bucket(ck) * NCOPY + copy], 1u);
             const uint32_t sp = snake(pos);
             if (sp < (uint32_t)T && (pos | 255u) < (uint32_t)T) pos = sp;   // only inside complete bands
             order[pos] = (uint32_t)t;
@@ -149,12 +160,10 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
 
 void launch_tile_scan(ImageState im, int T, hipStream_t st)
 {
-    if (T <= 8 * 1024)          // up to 1920x1088
+    if (T <= 8 * 1024)          // up to 1920x1088: counts stay in registers
         tile_scan_kernel<8><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.totals, im.order, im.seg_off);
-    else if (T <= 36 * 1024)    // up to 4096x2304
-        tile_scan_kernel<36><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.totals, im.order, im.seg_off);
-    else                        // up to ~8k x 8k
-        tile_scan_kernel<256><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.totals, im.order, im.seg_off);
+    else                        // any larger grid (gsr_forward_stage1 caps T at 262 144 = 8k x 8k)
+        tile_scan_kernel<0><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.totals, im.order, im.seg_off);
 }
 
 // One thread per Gaussian: claim a slot in every reachable tile's bucket and store the sort key.  Walks exactly
