@@ -144,10 +144,13 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
 
     // Per-pixel start state at the far end of the segment.
     float T = T_final;
-    float acc[C], last_c[C];
-    float last_alpha = 0.f;
+    // acc = colour composited BEHIND the current list position as seen from it (the reference's accum_rec).  The
+    // reference folds contributor i into accum_rec lazily, when it reaches contributor i-1 (last_alpha / last_color,
+    // backward.cu:505-520); folding it right after use is the same arithmetic on the same operands one step earlier
+    // and needs no "last" registers.
+    float acc[C];
 #pragma unroll
-    for (int ch = 0; ch < C; ch++) { acc[ch] = 0.f; last_c[ch] = 0.f; }
+    for (int ch = 0; ch < C; ch++) acc[ch] = 0.f;
     const int my_lim = min(my_last, s1);                 // this pixel replays positions [s0, my_lim)
     if (my_last > s1) {
         // the pixel blended instances beyond this segment: resume from the forward's snapshot taken before
@@ -270,15 +273,14 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                         const float rinv = __builtin_amdgcn_rcpf(1.f - alpha);
                         T = T * rinv;
                         w = alpha * T;
+                        const float one_minus = 1.f - alpha;
                         float dL_dalpha = 0.f;
 #pragma unroll
                         for (int ch = 0; ch < C; ch++) {
-                            acc[ch] = last_alpha * last_c[ch] + (1.f - last_alpha) * acc[ch];
-                            last_c[ch] = cc[ch];
                             dL_dalpha += (cc[ch] - acc[ch]) * dp[ch];
+                            acc[ch] = alpha * cc[ch] + one_minus * acc[ch];
                         }
                         dL_dalpha *= T;
-                        last_alpha = alpha;
                         dL_dalpha -= (T_final * rinv) * bg_dot_dpixel;
                         r = G * dL_dalpha;
                     }
