@@ -66,7 +66,32 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
         const uint4 v0 = pc[0], v1 = pc[1];
         return (v0.x + v0.y + v0.z + v0.w) + (v1.x + v1.y + v1.z + v1.w);
     };
-    if constexpr (IN_REGS) {
+    if constexpr (PER == 8) {
+        // A thread's 8 tiles x 8 shards are 256 contiguous bytes, so per-thread loads touch 64 cache lines per
+        // instruction (6.7 of this kernel's 16 us).  Instead each wave streams its 16 KB in 16 fully coalesced
+        // 16-byte loads (lane L, load i -> half of tile 32 i + L / 2), adds the two halves with a DPP swap and
+        // transposes through LDS to the tile-per-thread layout the scan wants.
+        static_assert(NSHARD == 8, "two 16-byte halves per tile");
+        __shared__ __attribute__((aligned(16))) uint32_t tot[16][512];
+        const uint4* wbase = reinterpret_cast<const uint4*>(tile_count) + (size_t)wave * 1024;
+        const size_t n16 = (size_t)T * 2;                 // number of 16-byte halves in the counter array
+        uint32_t half[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const size_t h = (size_t)wave * 1024 + (size_t)i * 64 + lane;
+            const uint4 v = h < n16 ? wbase[i * 64 + lane] : make_uint4(0, 0, 0, 0);
+            half[i] = (v.x + v.y) + (v.z + v.w);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)half[i], 0xB1, 0xf, 0xf, true);   // lane ^ 1
+            if ((lane & 1) == 0) tot[wave][i * 32 + (lane >> 1)] = half[i] + other;
+        }
+        __builtin_amdgcn_wave_barrier();   // own wave's rows only: LDS is in-order per wave
+        const uint4 a = *reinterpret_cast<const uint4*>(&tot[wave][lane * 8]);
+        const uint4 b = *reinterpret_cast<const uint4*>(&tot[wave][lane * 8 + 4]);
+        c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+    } else if constexpr (IN_REGS) {
 #pragma unroll
         for (int k = 0; k < PER; k++) c[k] = count_of(t0 + k);
     }
@@ -100,6 +125,35 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
     uint32_t run = woff + incl - sum;
     uint32_t run_seg = woff_seg + incl_seg - segs;
     uint32_t n_empty = 0;   // empty tiles dominate: count them privately, one LDS atomic per thread
+    if constexpr (PER == 8) {
+        // the 8 ranges (64 B) and 8 segment offsets (32 B) of a thread leave as 16-byte stores; the image-state carve
+        // pads both arrays, and tiles >= T carry empty ranges that nobody reads
+        uint32_t rs[9], sg[8];
+        rs[0] = run;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            sg[k] = run_seg;
+            rs[k + 1] = rs[k] + c[k];
+            run_seg += (c[k] + (uint32_t)SEG - 1u) / (uint32_t)SEG;
+            if (t0 + k < T) {
+                if (c[k] == 0) n_empty++;
+                else atomicAdd(&hist[length_bucket(c[k]) * NCOPY + copy], 1u);
+            }
+        }
+        run = rs[8];
+        if (t0 + 7 < T) {
+            uint4* pr = reinterpret_cast<uint4*>(ranges + t0);
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) pr[k / 2] = make_uint4(rs[k], rs[k + 1], rs[k + 1], rs[k + 2]);
+            uint4* ps = reinterpret_cast<uint4*>(seg_off + t0);
+            ps[0] = make_uint4(sg[0], sg[1], sg[2], sg[3]);
+            ps[1] = make_uint4(sg[4], sg[5], sg[6], sg[7]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (t0 + k < T) { ranges[t0 + k] = make_uint2(rs[k], rs[k + 1]); seg_off[t0 + k] = sg[k]; }
+        }
+    } else {
 #pragma unroll
     for (int k = 0; k < per; k++) {
         const int t = t0 + k;
@@ -112,6 +166,7 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
             if (ck == 0) n_empty++;
             else atomicAdd(&hist[length_bucket(ck) * NCOPY + copy], 1u);
         }
+    }
     }
     if (n_empty) atomicAdd(&hist[(NBUCKET - 1) * NCOPY + copy], n_empty);
     __syncthreads();
