@@ -441,7 +441,6 @@ __device__ __forceinline__ void for_each_tile_aggregated(ushort4 rect, float px,
     while (w.next_round(v)) f(v.tile, v.is_leader, v.group, v.rank, v.leader_lane);
 }
 
-// Pixel centre of an NDC coordinate; evaluated in double like auxiliary.h:41-44.
 // Snapshot record of one pixel: float4s {T, C0, C1, C2}, {C3, C4, C5, 0}, ...
 template <int C>
 __device__ __forceinline__ void store_snapshot(float4* dst, float T, const float (&c)[C])
@@ -467,6 +466,7 @@ __device__ __forceinline__ void load_snapshot(const float4* src, float& T, float
     for (int k = 0; k < C; k++) c[k] = v[k + 1];
 }
 
+// Pixel centre of an NDC coordinate; evaluated in double like auxiliary.h:41-44.
 __device__ __forceinline__ float ndc2pix(float v, int S) { return (float)((((double)v + 1.0) * S - 1.0) * 0.5); }
 #endif  // __HIPCC__
 
