@@ -129,7 +129,7 @@ int gsr_forward_stage1(int P, int D, int M, const float* means3D, const float* s
     ImageState im = carve_image(image_buffer, W, H);
     // counters and cursors are adjacent in the image buffer: one fill covers both
     GSR_CHECK(hipMemsetAsync(im.tile_count, 0,
-                             (size_t)((char*)(im.tile_cursor + (size_t)t.T * NSHARD) - (char*)im.tile_count), st));
+                             (size_t)((char*)(im.tile_cursor + shard_stride(t.T) * NSHARD) - (char*)im.tile_count), st));
     if (P > 0) {
         GeomState g = carve_geom(geom_buffer, P);
         {

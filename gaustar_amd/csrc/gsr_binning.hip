@@ -60,37 +60,29 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
     const int per = IN_REGS ? PER : (T + 1023) / 1024;
     const int t0 = tid * per;
     uint32_t c[IN_REGS ? PER : 1];
+    const size_t Tp = shard_stride(T);
     auto count_of = [&](int t) -> uint32_t {
         if (t >= T) return 0u;
-        const uint4* pc = reinterpret_cast<const uint4*>(tile_count + (size_t)t * NSHARD);
-        const uint4 v0 = pc[0], v1 = pc[1];
-        return (v0.x + v0.y + v0.z + v0.w) + (v1.x + v1.y + v1.z + v1.w);
+        uint32_t v = 0;
+#pragma unroll
+        for (int sh = 0; sh < NSHARD; sh++) v += tile_count[sh * Tp + t];
+        return v;
     };
     if constexpr (PER == 8) {
-        // A thread's 8 tiles x 8 shards are 256 contiguous bytes, so per-thread loads touch 64 cache lines per
-        // instruction (6.7 of this kernel's 16 us).  Instead each wave streams its 16 KB in 16 fully coalesced
-        // 16-byte loads (lane L, load i -> half of tile 32 i + L / 2), adds the two halves with a DPP swap and
-        // transposes through LDS to the tile-per-thread layout the scan wants.
-        static_assert(NSHARD == 8, "two 16-byte halves per tile");
-        __shared__ __attribute__((aligned(16))) uint32_t tot[16][512];
-        const uint4* wbase = reinterpret_cast<const uint4*>(tile_count) + (size_t)wave * 1024;
-        const size_t n16 = (size_t)T * 2;                 // number of 16-byte halves in the counter array
-        uint32_t half[16];
+        // shard-major rows: a thread's 8 tiles are 32 contiguous bytes in each of the 8 rows, lanes are contiguous
+        // -> 16 fully coalesced 16-byte loads per thread (rows are padded, so the tail stays inside the row)
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const size_t h = (size_t)wave * 1024 + (size_t)i * 64 + lane;
-            const uint4 v = h < n16 ? wbase[i * 64 + lane] : make_uint4(0, 0, 0, 0);
-            half[i] = (v.x + v.y) + (v.z + v.w);
+        for (int k = 0; k < 8; k++) c[k] = 0;
+        if ((size_t)t0 < Tp) {
+#pragma unroll
+            for (int sh = 0; sh < NSHARD; sh++) {
+                const uint4* pr = reinterpret_cast<const uint4*>(tile_count + sh * Tp + t0);
+                const uint4 a = pr[0], b = pr[1];
+                c[0] += a.x; c[1] += a.y; c[2] += a.z; c[3] += a.w; c[4] += b.x; c[5] += b.y; c[6] += b.z; c[7] += b.w;
+            }
         }
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)half[i], 0xB1, 0xf, 0xf, true);   // lane ^ 1
-            if ((lane & 1) == 0) tot[wave][i * 32 + (lane >> 1)] = half[i] + other;
-        }
-        __builtin_amdgcn_wave_barrier();   // own wave's rows only: LDS is in-order per wave
-        const uint4 a = *reinterpret_cast<const uint4*>(&tot[wave][lane * 8]);
-        const uint4 b = *reinterpret_cast<const uint4*>(&tot[wave][lane * 8 + 4]);
-        c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+        for (int k = 0; k < 8; k++) if (t0 + k >= T) c[k] = 0;
     } else if constexpr (IN_REGS) {
 #pragma unroll
         for (int k = 0; k < PER; k++) c[k] = count_of(t0 + k);
@@ -235,6 +227,7 @@ scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int shard = (int)(blockIdx.x & (NSHARD - 1));
+    const size_t Tp = shard_stride(T);
     // side job of the first T threads: expand the per-tile segment counts into the unit -> tile table
     // (it lives in the binning buffer, which did not exist yet when the scan kernel ran)
     if (idx < T) {
@@ -257,13 +250,11 @@ scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __
                                  if (is_leader) {
                                      // slot = tile start + counts of the lower shards + position inside this shard
                                      // (shard cursors start at zero; the scan kernel does not expand them)
-                                     const uint4* pc = reinterpret_cast<const uint4*>(tile_count + (size_t)tile * NSHARD);
-                                     const uint4 v0 = pc[0], v1 = pc[1];
-                                     const uint32_t cs[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                                      uint32_t below = ranges[tile].x;
 #pragma unroll
-                                     for (int s_ = 0; s_ < NSHARD; s_++) below += s_ < shard ? cs[s_] : 0u;
-                                     base = below + atomicAdd(&tile_cursor[tile * NSHARD + shard], (uint32_t)group);
+                                     for (int s_ = 0; s_ < NSHARD - 1; s_++)
+                                         if (s_ < shard) below += tile_count[s_ * Tp + tile];
+                                     base = below + atomicAdd(&tile_cursor[shard * Tp + tile], (uint32_t)group);
                                  }
                                  base = __shfl(base, leader_lane, 64);
                                  if (tile >= 0) keys[base + (uint32_t)rank] = key;

@@ -341,7 +341,11 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         const int e = idx / NM, v = idx - e * NM;
         if ((touched >> e) & 1ull) {
             const size_t g = __float_as_uint(qf[e * SF + 2]);
+#ifdef GSR_BWD_NO_FLUSH   // timing ablation only (results are wrong): keep the address math, drop the memory operation
+            if (qf[e * SF + MOM0 + v] == 1.2345e33f) atomic_add_f32(grad_acc + g * GRAD_RS + v, 1.f);
+#else
             atomic_add_f32(grad_acc + g * GRAD_RS + v, qf[e * SF + MOM0 + v]);
+#endif
         }
     }
     if (trace && lane == 0) {   // last wave to finish wins the end stamp (monotone clock, max via atomic)

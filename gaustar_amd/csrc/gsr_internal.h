@@ -51,13 +51,18 @@ inline GeomState carve_geom(void* base, int P)
 // after wave aggregation, which was what bounded preprocess and scatter.  Eight shards cut each chain by eight;
 // the shard is a function of the Gaussian index only (same in both kernels), never of where a block runs.
 constexpr int NSHARD = 8;
+// Counters are stored SHARD-MAJOR, [shard][tile]: the eight shards of one tile used to share 32 bytes, so eight
+// workgroups on eight XCDs bounced one cache line between them (the atomics alone were half of preprocess: 31.6 us
+// with, 15.3 us without); shard-major keeps a line to one shard -- and a shard to one XCD under round-robin dispatch.
+// The per-shard row is padded to a multiple of 64 tiles so that rows stay 256-byte aligned.
+__host__ __device__ inline size_t shard_stride(int T) { return ((size_t)T + 63) & ~(size_t)63; }
 
 struct ImageState {          // per pixel / per tile
     float* final_T;          // [H*W]
     uint32_t* n_contrib;     // [H*W] 1-based position in the tile list of the last blended instance
     uint2* ranges;           // [T] {start, end} into point_list
-    uint32_t* tile_count;    // [T][NSHARD] instances per (tile, shard) (atomics in preprocess)
-    uint32_t* tile_cursor;   // [T][NSHARD] scatter cursors: a tile's bucket is the concatenation of its shards
+    uint32_t* tile_count;    // [NSHARD][Tp] instances per (shard, tile) (atomics in preprocess), Tp = shard_stride(T)
+    uint32_t* tile_cursor;   // [NSHARD][Tp] scatter cursors: a tile's bucket is the concatenation of its shards
     uint32_t* totals;        // [4] {R, max tile count, number of non-empty tiles, U = number of list segments}
     uint32_t* order;         // [T] tile ids, longest instance lists first (32-entry buckets), empty tiles last:
                              // the blockIdx -> tile map of the per-tile kernels (longest-processing-time-first
@@ -72,8 +77,8 @@ inline ImageState carve_image(void* base, int W, int H)
     s.final_T = (float*)(b + o); o = align_up(o + 4 * N);
     s.n_contrib = (uint32_t*)(b + o); o = align_up(o + 4 * N);
     s.ranges = (uint2*)(b + o); o = align_up(o + 8 * T);
-    s.tile_count = (uint32_t*)(b + o); o = align_up(o + 4 * T * NSHARD);
-    s.tile_cursor = (uint32_t*)(b + o); o = align_up(o + 4 * T * NSHARD);
+    s.tile_count = (uint32_t*)(b + o); o = align_up(o + 4 * shard_stride((int)T) * NSHARD);
+    s.tile_cursor = (uint32_t*)(b + o); o = align_up(o + 4 * shard_stride((int)T) * NSHARD);
     s.totals = (uint32_t*)(b + o); o = align_up(o + 16);
     s.order = (uint32_t*)(b + o); o = align_up(o + 4 * T);
     s.seg_off = (uint32_t*)(b + o); o = align_up(o + 4 * (T + 1));

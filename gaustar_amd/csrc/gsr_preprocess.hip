@@ -123,7 +123,7 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
     for_each_tile_aggregated(out_rect, px, py, conic_a, conic_b, conic_c, tau, gx, lane,
                              [&](int tile, bool is_leader, int group, int, int) {
                                  if (is_leader)
-                                     atomicAdd(&tile_count[tile * NSHARD + (int)(blockIdx.x & (NSHARD - 1))], (uint32_t)group);
+                                     atomicAdd(&tile_count[(size_t)(blockIdx.x & (NSHARD - 1)) * shard_stride(gx * gy) + tile], (uint32_t)group);
                              });
 }
 
