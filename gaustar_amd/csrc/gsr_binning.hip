@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(1024)
 tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges,
                  uint32_t* __restrict__ totals, uint32_t* __restrict__ order, uint32_t* __restrict__ seg_off)
 {
-    static_assert(NSHARD == 8, "two 16-byte loads per tile");
+    static_assert((NSHARD & (NSHARD - 1)) == 0, "shard = workgroup index & (NSHARD - 1)");
     __shared__ uint32_t wave_sum[16];
     __shared__ uint32_t wave_seg[16];
     __shared__ uint32_t wave_max[16];
