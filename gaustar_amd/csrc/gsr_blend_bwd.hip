@@ -112,12 +112,28 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     __shared__ __attribute__((aligned(16))) float qf[64 * SF];             // queue slots (see SlotLayout)
     __shared__ __attribute__((aligned(16))) float Rm[2 * GRP * RSTRIDE];   // rows 0..7: r, rows 8..15: w, [row][pixel lane]
     float* const Wm = Rm + GRP * RSTRIDE;
-    // one wave64 per workgroup: unit = (tile, segment), wave = 8x8 block of the tile
+    // one wave64 per workgroup: unit = (tile, segment), wave = 8x8 block of the tile.
+    // XCD-aware placement: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the
+    // naive map (unit = id / 4) would put the four blocks of a unit -- which gather the SAME instance records -- on
+    // four different L2s.  Instead the four blocks of a unit take four consecutive slots of ONE XCD.
+#ifndef GSR_BWD_NAIVE_MAP
+    // Units of one tile are consecutive and also share their pixels' dL_dpix / T / n_contrib and the tile's final
+    // snapshot, so an XCD takes RUNS of 8 consecutive units: of every 64 units, XCD x owns [8x, 8x + 8).
+    const uint32_t n_units = gridDim.x >> 2;
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t grp = slot >> 2;                       // index of this (unit) among the XCD's units
+    uint32_t unit = (grp >> 3) * 64u + xcd * 8u + (grp & 7u);
+    uint32_t wave_sel = slot & 3u;
+    const uint32_t full = (n_units >> 6) << 6;            // units covered by complete groups of 64
+    if (blockIdx.x >= full * 4u) { unit = blockIdx.x >> 2; wave_sel = blockIdx.x & 3u; }   // ragged tail: plain map
+#else
     const uint32_t unit = blockIdx.x >> 2;
+    const uint32_t wave_sel = blockIdx.x & 3u;
+#endif
     const int tile = (int)unit_tile[unit];
     const uint32_t unit0 = seg_off[tile];
     const int s0 = (int)(unit - unit0) * SEG;          // this unit covers list positions [s0, s1)
-    const int wave = blockIdx.x & 3, lane = threadIdx.x;
+    const int wave = (int)wave_sel, lane = threadIdx.x;
     const int tx = tile % gx, ty = tile / gx;
     const int sx = tx * TILE + (wave & 1) * SUB, sy = ty * TILE + (wave >> 1) * SUB;
     const int px = sx + (lane & 7), py = sy + (lane >> 3);
