@@ -93,7 +93,7 @@ __device__ __forceinline__ void atomic_add_f32(float* p, float v)
 constexpr int GRP = 8;          // instances per MFMA group: A-operand rows 0..7 carry their r, rows 8..15 their w
 constexpr int RSTRIDE = 68;     // floats per row of the r|w table: 64 pixels + 4 (16-byte aligned, spreads banks)
 
-static_assert(SEG == 64, "one fetch batch per unit");
+static_assert(SEG % 64 == 0, "a unit is a whole number of 64-instance fetch batches");
 
 template <int C>
 __global__ void __launch_bounds__(64)
@@ -197,9 +197,11 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     }
     if (wave_hi <= s0) return;
 
-    // lane l takes list position wave_hi-1-l: queue order == back-to-front order
-    const int k = wave_hi - 1 - lane;
-    const FetchedB<C> cur = fetch_instance_b<C>(k, s0, list, g0, g1, feats);
+    // The unit is walked back to front in batches of 64 list positions; lane l of a batch takes position hi-1-l
+    // (queue order == back-to-front order).
+#ifdef GSR_BWD_PREFETCH
+    FetchedB<C> nxt = fetch_instance_b<C>(wave_hi - 1 - lane, s0, list, g0, g1, feats);
+#endif
 
     // B operand of the contraction, constant over the unit.  MFMA step t (0..15) consumes the four pixels
     // p = 16*kap + t, kap = 0..3; in the B operand lane l carries row kap = l >> 4, column col = l & 15.
@@ -238,6 +240,14 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     }
     __builtin_amdgcn_wave_barrier();
 
+    for (int hi = wave_hi; hi > s0; hi -= 64) {
+    const int k = hi - 1 - lane;
+#ifdef GSR_BWD_PREFETCH
+    const FetchedB<C> cur = nxt;
+    if (hi - 64 > s0) nxt = fetch_instance_b<C>(hi - 65 - lane, s0, list, g0, g1, feats);
+#else
+    const FetchedB<C> cur = fetch_instance_b<C>(k, s0, list, g0, g1, feats);
+#endif
     const bool keep = block_min_half_quad(cur.a.z, cur.a.w, cur.b.x, bx0 - cur.a.x, bx1 - cur.a.x, by0 - cur.a.y,
                                           by1 - cur.a.y) <= cur.b.z;
     const unsigned long long m = __ballot(keep);
@@ -357,13 +367,11 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         const int e = idx / NM, v = idx - e * NM;
         if ((touched >> e) & 1ull) {
             const size_t g = __float_as_uint(qf[e * SF + 2]);
-#ifdef GSR_BWD_NO_FLUSH   // timing ablation only (results are wrong): keep the address math, drop the memory operation
-            if (qf[e * SF + MOM0 + v] == 1.2345e33f) atomic_add_f32(grad_acc + g * GRAD_RS + v, 1.f);
-#else
             atomic_add_f32(grad_acc + g * GRAD_RS + v, qf[e * SF + MOM0 + v]);
-#endif
         }
     }
+    __builtin_amdgcn_wave_barrier();   // the queue is rewritten by the next batch
+    }   // batches of the unit
     if (trace && lane == 0) {   // last wave to finish wins the end stamp (monotone clock, max via atomic)
         if (wave == 0) trace[2 * unit] = t_start;
         atomicMax((unsigned long long*)&trace[2 * unit + 1], (unsigned long long)wall_clock64());
