@@ -90,7 +90,10 @@ __device__ __forceinline__ void atomic_add_f32(float* p, float v)
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-constexpr int GRP = 8;          // instances per MFMA group: A-operand rows 0..7 carry their r, rows 8..15 their w
+#ifndef GSR_BWD_GRP
+#define GSR_BWD_GRP 8
+#endif
+constexpr int GRP = GSR_BWD_GRP;   // instances per MFMA group: A-operand rows 0..GRP-1 carry their r, the next GRP rows their w
 constexpr int RSTRIDE = 68;     // floats per row of the r|w table: 64 pixels + 4 (16-byte aligned, spreads banks)
 
 static_assert(SEG % 64 == 0, "a unit is a whole number of 64-instance fetch batches");
@@ -323,10 +326,10 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         float ra[16];
         {
-            const float4* pr = reinterpret_cast<const float4*>(&Rm[col * RSTRIDE + 16 * kap]);
+            const float4* pr = reinterpret_cast<const float4*>(&Rm[(col < 2 * GRP ? col : 0) * RSTRIDE + 16 * kap]);
 #pragma unroll
             for (int qd = 0; qd < 4; qd++) {
-                const float4 v = pr[qd];
+                const float4 v = (2 * GRP == 16 || col < 2 * GRP) ? pr[qd] : make_float4(0.f, 0.f, 0.f, 0.f);
                 ra[4 * qd] = v.x; ra[4 * qd + 1] = v.y; ra[4 * qd + 2] = v.z; ra[4 * qd + 3] = v.w;
             }
         }
@@ -339,8 +342,8 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         // rows 0..7: r of instance row, columns 0..5 = spatial sums; rows 8..15: w of instance row-8, columns 6..6+C-1.
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int row = 4 * kap + i, inst = g0i + (row & 7);
-            const bool take = row < GRP ? col < 6 : (col >= 6 && col < NM);
+            const int row = 4 * kap + i, inst = g0i + (row & (GRP - 1));
+            const bool take = row < GRP ? col < 6 : (row < 2 * GRP && col >= 6 && col < NM);
             if (take && inst < cnt) qf[inst * SF + MOM0 + col] = acc0[i] + acc1[i];
         }
         __builtin_amdgcn_wave_barrier();
