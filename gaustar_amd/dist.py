@@ -90,39 +90,55 @@ class GradAllReducer:
 
     @torch.no_grad()
     def __call__(self) -> None:
+        """After this call every p.grad holds the mean (or sum) over ranks.  Fast path (all grads present): ONE
+        torch.cat per bucket into a persistent flat buffer, an in-place all-reduce, one divide, and p.grad re-pointed at views of the flat buffer -- no copy back.  The views stay valid until the
+        next call; callers that keep gradients across steps must clone them."""
         ws = world_size()
         if ws == 1:
             return
+        # SUM + one divide kernel on every backend: gloo has no AVG, and the RCCL AVG path cannot be exercised on the
+        # single-GPU boxes this is developed on -- a 12 us kernel is not worth an untested collective.
+        use_avg = False
         works = []
+        fast = []
         for bi, bucket in enumerate(self.buckets):
             n = sum(p.numel() for p in bucket)
-            if bi >= len(self._flat) or self._flat[bi].numel() != n or self._flat[bi].device != bucket[0].device:
-                flat = torch.empty(n, dtype=torch.float32, device=bucket[0].device)
+            dev = bucket[0].device
+            if bi >= len(self._flat) or self._flat[bi].numel() != n or self._flat[bi].device != dev:
+                flat = torch.empty(n, dtype=torch.float32, device=dev)
                 if bi < len(self._flat):
                     self._flat[bi] = flat
                 else:
                     self._flat.append(flat)
             flat = self._flat[bi]
-            off = 0
-            for p in bucket:
-                k = p.numel()
-                if p.grad is None:
-                    flat[off:off + k].zero_()
-                else:
-                    flat[off:off + k].copy_(p.grad.reshape(-1))
-                off += k
-            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+            all_there = all(p.grad is not None and p.grad.dtype == torch.float32 for p in bucket)
+            fast.append(all_there)
+            if all_there:
+                # a gradient that already is a view of this buffer (kept from the last call) must not alias the output
+                parts = [(p.grad.clone() if p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() else p.grad).reshape(-1)
+                         for p in bucket]
+                torch.cat(parts, out=flat)
+            else:
+                off = 0
+                for p in bucket:
+                    k = p.numel()
+                    if p.grad is None:
+                        flat[off:off + k].zero_()
+                    else:
+                        flat[off:off + k].copy_(p.grad.reshape(-1))
+                    off += k
+            works.append(dist.all_reduce(flat, op=dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM, async_op=True))
         for bi, bucket in enumerate(self.buckets):
             works[bi].wait()
             flat = self._flat[bi]
-            if self.average:
+            if self.average and not use_avg:
                 flat.div_(ws)
             off = 0
             for p in bucket:
                 k = p.numel()
                 g = flat[off:off + k].view_as(p)
-                if p.grad is None:
-                    p.grad = g.clone()
+                if fast[bi] or p.grad is None:
+                    p.grad = g if fast[bi] else g.clone()
                 else:
                     p.grad.copy_(g)
                 off += k
