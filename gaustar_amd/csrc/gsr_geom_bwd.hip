@@ -16,18 +16,17 @@
 
 namespace gsr {
 
-__global__ void __launch_bounds__(256)
-geom_bwd_kernel(int P, int D, int M, int C, const float* __restrict__ means3D, const float* __restrict__ shs,
+__device__ __forceinline__ void
+geom_bwd_body(int idx, int P, int D, int M, int C, const float* __restrict__ means3D, float* __restrict__ my_sh,
                 const float* __restrict__ scales, float scale_modifier, const float* __restrict__ rotations,
                 const float* __restrict__ cov3D_precomp, const float* __restrict__ view,
                 const float* __restrict__ proj, const float* __restrict__ campos, float tan_fovx, float tan_fovy,
                 float focal_x, float focal_y, float half_w, float half_h, const int* __restrict__ radii,
                 const float4* __restrict__ g0, const float4* __restrict__ g1, const float4* __restrict__ grad_acc,
                 float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor,
-                float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
-                float* __restrict__ dL_dscale, float* __restrict__ dL_drot)
+                float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscale,
+              float* __restrict__ dL_drot)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= P) return;
     const size_t i = (size_t)idx;
 
@@ -40,8 +39,8 @@ geom_bwd_kernel(int P, int D, int M, int C, const float* __restrict__ means3D, c
         for (int k = 0; k < 6; k++) dL_dcov3D[6 * i + k] = 0.f;
         if (dL_dscale) { dL_dscale[3 * i] = 0.f; dL_dscale[3 * i + 1] = 0.f; dL_dscale[3 * i + 2] = 0.f; }
         if (dL_drot) reinterpret_cast<float4*>(dL_drot)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (dL_dsh)
-            for (int k = 0; k < 3 * M; k++) dL_dsh[i * 3 * M + k] = 0.f;
+        if (my_sh)
+            for (int k = 0; k < 3 * M; k++) my_sh[k] = 0.f;
         return;
     }
 
@@ -137,9 +136,9 @@ geom_bwd_kernel(int P, int D, int M, int C, const float* __restrict__ means3D, c
     }
 
     // ---------------- colour -> SH coefficients and view direction (backward.cu:20-139)
-    if (shs) {
+    if (my_sh) {
         const float dcol[3] = {cm[0], cm[1], cm[2]};
-        sh_colour_backward(D, M, mean, campos, shs + i * M * 3, dcol, dL_dsh + i * M * 3, gmx, gmy, gmz);
+        sh_colour_backward(D, M, mean, campos, my_sh, dcol, my_sh, gmx, gmy, gmz);
     }
     dL_dmean3D[3 * i] = gmx; dL_dmean3D[3 * i + 1] = gmy; dL_dmean3D[3 * i + 2] = gmz;
 
@@ -181,6 +180,40 @@ geom_bwd_kernel(int P, int D, int M, int C, const float* __restrict__ means3D, c
     }
 }
 
+
+__global__ void __launch_bounds__(256)
+geom_bwd_kernel(int P, int D, int M, int C, const float* __restrict__ means3D, const float* __restrict__ shs,
+                const float* __restrict__ scales, float scale_modifier, const float* __restrict__ rotations,
+                const float* __restrict__ cov3D_precomp, const float* __restrict__ view,
+                const float* __restrict__ proj, const float* __restrict__ campos, float tan_fovx, float tan_fovy,
+                float focal_x, float focal_y, float half_w, float half_h, const int* __restrict__ radii,
+                const float4* __restrict__ g0, const float4* __restrict__ g1, const float4* __restrict__ grad_acc,
+                float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor,
+                float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
+                float* __restrict__ dL_dscale, float* __restrict__ dL_drot)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    // SH mode: coefficient rows come in, and their gradients leave, through LDS (coalesced; see sh_stage_load).  The
+    // gradient row overwrites the coefficient row in place, so no lane may leave before the wave's final store.
+    extern __shared__ float sh_lds[];
+    float* wave_rows = nullptr;
+    float* my_sh = nullptr;
+    if (shs) {
+        wave_rows = sh_lds + (size_t)(threadIdx.x >> 6) * 64 * sh_row_stride(M);
+        sh_stage_load(wave_rows, shs, (size_t)(idx - lane), P, M, lane);
+        __builtin_amdgcn_wave_barrier();
+        my_sh = wave_rows + lane * sh_row_stride(M);
+    }
+    geom_bwd_body(idx, P, D, M, C, means3D, my_sh, scales, scale_modifier, rotations, cov3D_precomp, view, proj, campos, tan_fovx,
+                  tan_fovy, focal_x, focal_y, half_w, half_h, radii, g0, g1, grad_acc, dL_dmean2D, dL_dopacity, dL_dcolor,
+                  dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot);
+    if (shs) {
+        __builtin_amdgcn_wave_barrier();
+        sh_stage_store(wave_rows, dL_dsh, (size_t)(idx - lane), P, M, lane);
+    }
+}
+
 void launch_geom_bwd(int P, int D, int M, const float* means3D, const float* shs, const float* scales,
                      float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* view,
                      const float* proj, const float* campos, int W, int H, float tan_fovx, float tan_fovy,
@@ -189,7 +222,8 @@ void launch_geom_bwd(int P, int D, int M, const float* means3D, const float* shs
                      float* dL_drot, hipStream_t st)
 {
     const float focal_y = H / (2.0f * tan_fovy), focal_x = W / (2.0f * tan_fovx);   // rasterizer_impl.cu:381-382
-    geom_bwd_kernel<<<(P + 255) / 256, 256, 0, st>>>(P, D, M, C, means3D, shs, scales, scale_modifier, rotations,
+    const size_t lds = shs ? sh_stage_bytes(M, 4) : 0;
+    geom_bwd_kernel<<<(P + 255) / 256, 256, lds, st>>>(P, D, M, C, means3D, shs, scales, scale_modifier, rotations,
                                                      cov3D_precomp, view, proj, campos, tan_fovx, tan_fovy, focal_x,
                                                      focal_y, 0.5f * W, 0.5f * H, radii, g.g0, g.g1,
                                                      reinterpret_cast<const float4*>(grad_acc), dL_dmean2D,

@@ -28,6 +28,15 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool valid = idx < P;
+    // SH mode: the wave's 64 coefficient rows come in through LDS (coalesced), see sh_stage_load
+    extern __shared__ float sh_lds[];
+    float* my_sh = nullptr;
+    if (colors_precomp == nullptr) {
+        float* wave_rows = sh_lds + (size_t)(threadIdx.x >> 6) * 64 * sh_row_stride(M);
+        sh_stage_load(wave_rows, shs, (size_t)(idx - lane), P, M, lane);
+        __builtin_amdgcn_wave_barrier();
+        my_sh = wave_rows + lane * sh_row_stride(M);
+    }
 
     int out_radius = 0;
     ushort4 out_rect = make_ushort4(0, 0, 0, 0);
@@ -99,7 +108,7 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
                         float basis[16];
                         sh_basis(D, dx * inv, dy * inv, dz * inv, basis);
                         const int nb = (D + 1) * (D + 1);
-                        const float* sh = shs + (size_t)idx * M * 3;
+                        const float* sh = my_sh;
                         float cr = 0.f, cg = 0.f, cbb = 0.f;
                         for (int k = 0; k < nb; k++) {
                             cr += basis[k] * sh[3 * k]; cg += basis[k] * sh[3 * k + 1]; cbb += basis[k] * sh[3 * k + 2];
@@ -134,7 +143,8 @@ void launch_preprocess(int P, int D, int M, const float* means3D, const float* s
 {
     const Tiles t = tiles_of(W, H);
     const float focal_y = H / (2.0f * tan_fovy), focal_x = W / (2.0f * tan_fovx);   // rasterizer_impl.cu:222-223
-    preprocess_kernel<<<(P + 255) / 256, 256, 0, st>>>(P, D, M, means3D, shs, colors_precomp, opacities, scales,
+    const size_t lds = colors_precomp ? 0 : sh_stage_bytes(M, 4);
+    preprocess_kernel<<<(P + 255) / 256, 256, lds, st>>>(P, D, M, means3D, shs, colors_precomp, opacities, scales,
                                                        scale_modifier, rotations, cov3D_precomp, view, proj, campos, W,
                                                        H, tan_fovx, tan_fovy, focal_x, focal_y, t.gx, t.gy, radii,
                                                        g.g0, g.g1, g.depth, g.rect, g.rgb, im.tile_count);

@@ -16,7 +16,12 @@ __global__ void __launch_bounds__(256)
 sh_to_rgb_kernel(int P, int D, int M, const float* __restrict__ positions, const float* __restrict__ campos,
                  const float* __restrict__ shs, float* __restrict__ rgb)
 {
+    extern __shared__ float sh_lds[];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    float* wave_rows = sh_lds + (size_t)(threadIdx.x >> 6) * 64 * sh_row_stride(M);
+    sh_stage_load(wave_rows, shs, (size_t)(idx - lane), P, M, lane);   // coalesced, see gsr_internal.h
+    __builtin_amdgcn_wave_barrier();
     if (idx >= P) return;
     const size_t i = (size_t)idx;
     const Vec3 p = load3(positions, i);
@@ -25,7 +30,7 @@ sh_to_rgb_kernel(int P, int D, int M, const float* __restrict__ positions, const
     float basis[16];
     sh_basis(D, dx * inv, dy * inv, dz * inv, basis);
     const int nb = (D + 1) * (D + 1);
-    const float* sh = shs + i * M * 3;
+    const float* sh = wave_rows + lane * sh_row_stride(M);
     float cr = 0.f, cg = 0.f, cb = 0.f;
     for (int k = 0; k < nb; k++) { cr += basis[k] * sh[3 * k]; cg += basis[k] * sh[3 * k + 1]; cb += basis[k] * sh[3 * k + 2]; }
     rgb[3 * i] = fmaxf(cr + 0.5f, 0.0f);
@@ -38,14 +43,23 @@ sh_to_rgb_bwd_kernel(int P, int D, int M, const float* __restrict__ positions, c
                      const float* __restrict__ shs, const float* __restrict__ dL_drgb, float* __restrict__ dL_dsh,
                      float* __restrict__ dL_dpos)
 {
+    extern __shared__ float sh_lds[];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P) return;
-    const size_t i = (size_t)idx;
-    const Vec3 p = load3(positions, i);
-    const float dcol[3] = {dL_drgb[3 * i], dL_drgb[3 * i + 1], dL_drgb[3 * i + 2]};
-    float gx = 0.f, gy = 0.f, gz = 0.f;
-    sh_colour_backward(D, M, p, campos, shs + i * M * 3, dcol, dL_dsh + i * M * 3, gx, gy, gz);
-    dL_dpos[3 * i] = gx; dL_dpos[3 * i + 1] = gy; dL_dpos[3 * i + 2] = gz;
+    const int lane = threadIdx.x & 63;
+    float* wave_rows = sh_lds + (size_t)(threadIdx.x >> 6) * 64 * sh_row_stride(M);
+    sh_stage_load(wave_rows, shs, (size_t)(idx - lane), P, M, lane);
+    __builtin_amdgcn_wave_barrier();
+    if (idx < P) {
+        const size_t i = (size_t)idx;
+        const Vec3 p = load3(positions, i);
+        const float dcol[3] = {dL_drgb[3 * i], dL_drgb[3 * i + 1], dL_drgb[3 * i + 2]};
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        float* row = wave_rows + lane * sh_row_stride(M);
+        sh_colour_backward(D, M, p, campos, row, dcol, row, gx, gy, gz);   // gradient row replaces the coefficient row
+        dL_dpos[3 * i] = gx; dL_dpos[3 * i + 1] = gy; dL_dpos[3 * i + 2] = gz;
+    }
+    __builtin_amdgcn_wave_barrier();
+    sh_stage_store(wave_rows, dL_dsh, (size_t)(idx - lane), P, M, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -290,13 +304,13 @@ void launch_mesh_gaussians_bwd(int F, int G, const float* verts, const long long
 void launch_sh_to_rgb(int P, int D, int M, const float* positions, const float* campos, const float* shs, float* rgb,
                       hipStream_t st)
 {
-    sh_to_rgb_kernel<<<(P + 255) / 256, 256, 0, st>>>(P, D, M, positions, campos, shs, rgb);
+    sh_to_rgb_kernel<<<(P + 255) / 256, 256, sh_stage_bytes(M, 4), st>>>(P, D, M, positions, campos, shs, rgb);
 }
 
 void launch_sh_to_rgb_bwd(int P, int D, int M, const float* positions, const float* campos, const float* shs,
                           const float* dL_drgb, float* dL_dsh, float* dL_dpos, hipStream_t st)
 {
-    sh_to_rgb_bwd_kernel<<<(P + 255) / 256, 256, 0, st>>>(P, D, M, positions, campos, shs, dL_drgb, dL_dsh, dL_dpos);
+    sh_to_rgb_bwd_kernel<<<(P + 255) / 256, 256, sh_stage_bytes(M, 4), st>>>(P, D, M, positions, campos, shs, dL_drgb, dL_dsh, dL_dpos);
 }
 
 }  // namespace gsr
