@@ -464,6 +464,24 @@ tile_sort_reg_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
     else sort_tile_in_registers<8>(s, gk, out, n, np2);
 }
 
+// Lists of 2 049 .. 16 384 entries (close-up views: a few dozen tiles of a 1 M-Gaussian model): the same register network
+// with 1 024 threads per tile, E = 4 / 8 / 16 keys per thread; the 10 cross-wave stages go through np2 * 8 bytes of LDS.
+__global__ void __launch_bounds__(1024)
+tile_sort_big_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ order, const uint64_t* __restrict__ keys,
+                     uint32_t* __restrict__ point_list)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
+    const uint2 rg = ranges[order[blockIdx.x]];
+    const uint32_t n = rg.y - rg.x;
+    if (n <= 2048u || n > 16384u) return;
+    const uint64_t* gk = keys + rg.x;
+    uint32_t* out = point_list + rg.x;
+    if (n <= 4096u) sort_tile_in_registers<4>(s, gk, out, n, 4096u);
+    else if (n <= 8192u) sort_tile_in_registers<8>(s, gk, out, n, 8192u);
+    else sort_tile_in_registers<16>(s, gk, out, n, 16384u);
+}
+
 void launch_tile_sort(int W, int H, uint32_t max_count, ImageState im, BinState b, hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);
@@ -476,14 +494,30 @@ void launch_tile_sort(int W, int H, uint32_t max_count, ImageState im, BinState 
     static const bool lds_sort = getenv("GSR_SORT_LDS") != nullptr;   // A/B switch: the LDS network for every tile
     if (lds_sort) tile_sort_kernel<2048, 0, false><<<t.T, 256, 2048 * 8, st>>>(im.ranges, im.order, b.keys, b.point_list);
     else tile_sort_reg_kernel<<<t.T, 256, 0, st>>>(im.ranges, im.order, b.keys, b.point_list);
-    if (max_count > 2048) {
+    if (max_count > 2048 && !lds_sort) {
+        // the longest lists sit at the front of `order` (32-entry length classes, snake within bands of 256): every tile
+        // above 2 048 entries is within the first few bands, but the kernel checks each tile's length itself anyway
+        static bool attr_big = false;
+        if (!attr_big) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_big_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
+            attr_big = true;
+        }
+        const uint32_t cap = max_count > 16384u ? 16384u : max_count;
+        uint32_t np2 = 4096; while (np2 < cap) np2 <<= 1;
+        tile_sort_big_kernel<<<t.T, 1024, (size_t)np2 * 8, st>>>(im.ranges, im.order, b.keys, b.point_list);
+    }
+    if (max_count > 16384 || (lds_sort && max_count > 2048)) {
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_kernel<16384, 2048, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
             attr_set = true;
         }
-        tile_sort_kernel<16384, 2048, true><<<t.T, 256, 16384 * 8, st>>>(im.ranges, im.order, b.keys, b.point_list);
+        if (lds_sort)
+            tile_sort_kernel<16384, 2048, true><<<t.T, 256, 16384 * 8, st>>>(im.ranges, im.order, b.keys, b.point_list);
+        else   // only the lists the register kernels do not take: the global-memory network
+            tile_sort_kernel<16384, 16384, true><<<t.T, 256, 16384 * 8, st>>>(im.ranges, im.order, b.keys, b.point_list);
     }
 }
 
