@@ -192,7 +192,8 @@ int gsr_forward_stage2_mt(int P, int R, int max_tile_instances, int num_segments
     const float* feats = colors_precomp ? colors_precomp : g.rgb;
     {
         Scope sc(ST_BLEND_FWD, st);
-        launch_blend_fwd(C, W, H, background, feats, g, im, b, out_color, st);
+        launch_blend_fwd(C, W, H, num_segments, (uint32_t)(max_tile_instances > 0 ? max_tile_instances : 0), background, feats, g, im, b,
+                         out_color, st);
     }
     GSR_CHECK_LAUNCH("blend_fwd_kernel");
     return 0;

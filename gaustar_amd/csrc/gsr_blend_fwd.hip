@@ -22,13 +22,54 @@
 // At every SEG-th list position the running (T, C) of the pixels still alive is snapshotted for the
 // segment-parallel backward pass (gsr_blend_bwd.hip).
 //
+// LONG TILES.  A tile's walk is serial per pixel, so the kernel's span used to be its longest tile (a 1 600-entry tile
+// takes 95 us while the whole image needs 68 us of machine time; close-up views with 10 000-entry tiles were entirely
+// critical-path-bound).  For tiles above GSR_FWD_LONG entries (default 4 096) blend_fwd_partial_kernel first reduces
+// every 64-entry segment INDEPENDENTLY (one wave per segment and 8x8 block, like the backward's units) to the
+// per-pixel pair  P_s = prod (1 - alpha),  C_s = sum c alpha T_local  (T_local starts at 1) and the last contributing
+// position; the main kernel then steps through a long tile's segments in O(1) each:  C += T * C_s,  T *= P_s.
+// Termination stays exact: T can only fall below 1e-4 inside segment s if T * P_s < 1e-4, and then that one batch is
+// walked the ordinary way for the whole wave.  Pixels of the skipped segments see the same products in a different
+// association (T * (a * b) instead of (T * a) * b): ulp-level, far inside the 1e-4 parity bound.
+// Measured: the walk is needed in every segment in which ANY of a wave's 64 pixels terminates, and on an opaque surface
+// those are many -- with the threshold at 512..1 024 the path costs more than it saves on config C (0.166 vs 0.096 ms) and
+// B; it pays for close-up views with lists of thousands of entries (config D: 0.55 -> 0.40 ms), hence the default.  The
+// long tiles run on a helper stream, concurrently with the main kernel.
+//
 // The kernel is a template over the number of colour channels C: 3 is the reference's NUM_CHANNELS
 // (cuda_rasterizer/config.h:15); 6 renders TWO targets that share geometry (GauSTAR's RGB + depth-as-colour
 // passes, refine.py:552 and :607) in one walk -- alpha, T, termination and n_contrib do not depend on colour,
 // so channels 0-2 / 3-5 are bit-identical to two separate 3-channel renders.
 #include "gsr_internal.h"
+#include <cstdlib>
+#include <mutex>
 
 namespace gsr {
+
+// Helper stream + fork/join events for the long-tile path, one set per device, created on first use and kept for the
+// life of the process (like the profiler's event pool, the only other state the library holds).  GSR_FWD_SIDE_STREAM=0
+// keeps everything on the caller's stream.
+static bool fwd_side_stream(hipStream_t* side, hipEvent_t* fork, hipEvent_t* join)
+{
+    struct Side { hipStream_t s = nullptr; hipEvent_t f = nullptr, j = nullptr; bool ok = false, tried = false; };
+    static Side sides[64];
+    static std::mutex mu;
+    static const bool enabled = !(getenv("GSR_FWD_SIDE_STREAM") && getenv("GSR_FWD_SIDE_STREAM")[0] == '0');
+    if (!enabled) return false;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    std::lock_guard<std::mutex> lk(mu);
+    Side& sd = sides[dev];
+    if (!sd.tried) {
+        sd.tried = true;
+        sd.ok = hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) == hipSuccess &&
+                hipEventCreateWithFlags(&sd.f, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&sd.j, hipEventDisableTiming) == hipSuccess;
+    }
+    if (!sd.ok) return false;
+    *side = sd.s; *fork = sd.f; *join = sd.j;
+    return true;
+}
 
 template <int C>
 struct __attribute__((aligned(16))) Slot {   // 48 B (C = 3) / 64 B (C = 6) per fetched instance
@@ -72,13 +113,145 @@ __device__ __forceinline__ Fetched<C> fetch_record(uint32_t gid, const float4* _
 
 constexpr int QCAP = 64 + 4;   // queue capacity per quadrant (+4: the 4-deep loop reads whole words)
 
+template <int C> struct PixState { float T; float Cc[C]; uint32_t last; bool done; };
+
+// One 64-entry batch for one wave (8x8 pixels, DPP row = 4x4 quadrant): park the fetched instances in LDS, build the
+// four quadrant queues, blend.  TERM = false drops the termination logic (segment pre-reduction).
+template <int C, bool TERM>
+__device__ __forceinline__ void walk_batch(Slot<C>* __restrict__ ent, uint8_t (*qi)[QCAP], const Fetched<C>& cur, uint32_t base,
+                                           unsigned long long alive, int lane, int row, int sx, int sy, float pxf, float pyf,
+                                           PixState<C>& ps)
+{
+    constexpr int CV = (C + 3) / 4;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t k = base + lane;
+    ent[lane].a = cur.a;
+    ent[lane].b = make_float4(cur.b.x, cur.b.y, __uint_as_float(k + 1), 0.f);
+#pragma unroll
+    for (int v = 0; v < CV; v++)
+        reinterpret_cast<float4*>(ent[lane].col)[v] =
+            make_float4(cur.col[4 * v], 4 * v + 1 < C ? cur.col[4 * v + 1] : 0.f, 4 * v + 2 < C ? cur.col[4 * v + 2] : 0.f,
+                        4 * v + 3 < C ? cur.col[4 * v + 3] : 0.f);
+    // exact reachability test against each quadrant that still has an unsaturated pixel
+    int cnt[4];
+#pragma unroll
+    for (int qd = 0; qd < 4; qd++) {
+        const float X0 = (float)(sx + (qd & 1) * 4) - cur.a.x, Y0 = (float)(sy + (qd >> 1) * 4) - cur.a.y;
+        const bool keep = ((alive >> (16 * qd)) & 0xffffull) != 0ull &&
+                          block_min_half_quad(cur.a.z, cur.a.w, cur.b.x, X0, X0 + 3.f, Y0, Y0 + 3.f) <= cur.b.z;
+        const unsigned long long m = __ballot(keep);
+        cnt[qd] = __popcll(m);
+        if (keep) qi[qd][__popcll(m & lt)] = (uint8_t)lane;
+        if (lane < 4) qi[qd][cnt[qd] + lane] = 64;   // pad to a multiple of 4 with the neutral instance
+    }
+    const int my_cnt = row == 0 ? cnt[0] : row == 1 ? cnt[1] : row == 2 ? cnt[2] : cnt[3];
+    const int max_cnt = max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3]));
+    __builtin_amdgcn_wave_barrier();
+    const uint8_t* myq = qi[row];
+    for (int j = 0; j < max_cnt; j += 4) {
+        // four queue positions at once; rows past their own queue end read the neutral instance
+        const uint32_t packed = j < my_cnt ? *reinterpret_cast<const uint32_t*>(myq + j) : 0x40404040u;
+        float4 A[4], B[4], K[4][CV];
+        float alpha[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int e = (packed >> (8 * u)) & 0xff;
+            A[u] = ent[e].a; B[u] = ent[e].b;
+#pragma unroll
+            for (int v = 0; v < CV; v++) K[u][v] = reinterpret_cast<const float4*>(ent[e].col)[v];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const float dx = A[u].x - pxf, dy = A[u].y - pyf;
+            const float power = pair_power(A[u].z, A[u].w, B[u].x, dx, dy);
+            alpha[u] = fminf(ALPHA_MAX, B[u].y * __expf(power));
+            ok[u] = power <= 0.0f && alpha[u] >= ALPHA_MIN;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const float test_T = ps.T * (1.0f - alpha[u]);
+            const bool live = ok[u] && !ps.done;
+            const bool stop = TERM && live && test_T < T_EPS;
+            const bool upd = live && !stop;
+            ps.done = ps.done || stop;
+            const float w = upd ? alpha[u] * ps.T : 0.0f;
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) {
+                const float4 kv = K[u][ch / 4];
+                ps.Cc[ch] += (ch % 4 == 0 ? kv.x : ch % 4 == 1 ? kv.y : ch % 4 == 2 ? kv.z : kv.w) * w;
+            }
+            ps.T = upd ? test_T : ps.T;
+            ps.last = upd ? __float_as_uint(B[u].z) : ps.last;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int C>
+__device__ __forceinline__ void init_neutral(Slot<C>* ent, int lane)
+{
+    if (lane == 0) {   // neutral instance: opacity 0 never passes the alpha test
+        ent[64].a = make_float4(0.f, 0.f, 0.f, 0.f);
+        ent[64].b = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ch = 0; ch < (C + 3) / 4 * 4; ch++) ent[64].col[ch] = 0.f;
+    }
+}
+
+static_assert(SEG == 64, "a pre-reduced segment is one 64-entry batch");
+
+// Segment pre-reduction for long tiles: unit = (tile, 64-entry segment), one wave per unit and 8x8 block.
+template <int C>
+__global__ void __launch_bounds__(64)
+blend_fwd_partial_kernel(int W, int H, int gx, uint32_t long_thr, const uint2* __restrict__ ranges,
+                         const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ unit_tile,
+                         const uint32_t* __restrict__ point_list, const float4* __restrict__ g0,
+                         const float4* __restrict__ g1, const float* __restrict__ feats, float4* __restrict__ part,
+                         uint32_t* __restrict__ part_last)
+{
+    constexpr int SV = snap_vecs(C);
+    __shared__ Slot<C> entries[64 + 1];
+    __shared__ __attribute__((aligned(4))) uint8_t qidx[4][QCAP];
+    // same XCD-aware placement as the backward: the four blocks of a unit on one XCD, runs of 8 units per XCD
+    const uint32_t n_units = gridDim.x >> 2;
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t grp = slot >> 2;
+    uint32_t unit = (grp >> 3) * 64u + xcd * 8u + (grp & 7u);
+    uint32_t wave = slot & 3u;
+    const uint32_t full = (n_units >> 6) << 6;
+    if (blockIdx.x >= full * 4u) { unit = blockIdx.x >> 2; wave = blockIdx.x & 3u; }
+    const int tile = (int)unit_tile[unit];
+    const uint2 rg = ranges[tile];
+    const uint32_t n = rg.y - rg.x;
+    if (n <= long_thr) return;
+    const int lane = threadIdx.x, row = lane >> 4;
+    const uint32_t unit0 = seg_off[tile];
+    const uint32_t base = (unit - unit0) * 64u;
+    const int tx = tile % gx, ty = tile / gx;
+    const int sx = tx * TILE + (int)(wave & 1) * SUB, sy = ty * TILE + (int)(wave >> 1) * SUB;
+    const int px = sx + (row & 1) * 4 + (lane & 3), py = sy + (row >> 1) * 4 + ((lane >> 2) & 3);
+    const int pix_in_tile = 16 * (py - ty * TILE) + (px - tx * TILE);
+    init_neutral<C>(entries, lane);
+    PixState<C> ps;
+    ps.T = 1.0f; ps.last = 0; ps.done = !(px < W && py < H);
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) ps.Cc[ch] = 0.f;
+    const Fetched<C> cur = fetch_record<C>(fetch_id(base + lane, n, point_list + rg.x), g0, g1, feats);
+    walk_batch<C, false>(entries, qidx, cur, base, ~0ull, lane, row, sx, sy, (float)px, (float)py, ps);
+    store_snapshot<C>(part + ((size_t)unit * 256 + pix_in_tile) * SV, ps.T, ps.Cc);
+    part_last[(size_t)unit * 256 + pix_in_tile] = ps.last;
+}
+
+// The common case keeps its blend loop inline (the shared walk_batch() costs it 16 VGPRs = one wave per SIMD).
 template <int C>
 __global__ void __launch_bounds__(256)
 blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ order,
                  const uint32_t* __restrict__ point_list, const float4* __restrict__ g0,
                  const float4* __restrict__ g1, const float* __restrict__ feats, const float* __restrict__ bg,
                  float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                 const uint32_t* __restrict__ seg_off, float4* __restrict__ snap, uint64_t* __restrict__ trace)
+                 const uint32_t* __restrict__ seg_off, float4* __restrict__ snap, uint32_t skip_above,
+                 uint64_t* __restrict__ trace)
 {
     const uint64_t t_start = trace ? wall_clock64() : 0;
     constexpr int SV = snap_vecs(C);
@@ -97,6 +270,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
 
     const uint2 rg = ranges[tile];
     const uint32_t n = rg.y - rg.x;
+    if (n > skip_above) return;   // long tile: blend_fwd_long_kernel renders it (concurrently, on the helper stream)
     const uint32_t unit0 = seg_off[tile];
     const uint32_t* list = point_list + rg.x;
     Slot<C>* ent = entries[wave];
@@ -209,16 +383,129 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     }
 }
 
-void launch_blend_fwd(int C, int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
-                      float* out_color, hipStream_t st)
+// Long tiles: steps through the pre-reduced segments (see the file header); one workgroup = one tile, like the main
+// kernel, launched over the front of `order` where the longest lists sit.
+template <int C>
+__global__ void __launch_bounds__(256)
+blend_fwd_long_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ order,
+                      const uint32_t* __restrict__ point_list, const float4* __restrict__ g0,
+                      const float4* __restrict__ g1, const float* __restrict__ feats, const float* __restrict__ bg,
+                      float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                      const uint32_t* __restrict__ seg_off, float4* __restrict__ snap, uint32_t long_thr,
+                      const float4* __restrict__ part, const uint32_t* __restrict__ part_last)
+{
+    constexpr int SV = snap_vecs(C);
+    __shared__ Slot<C> entries[4][64 + 1];
+    __shared__ __attribute__((aligned(4))) uint8_t qidx[4][4][QCAP];
+    const int tile = (int)order[blockIdx.x];
+    const uint2 rg = ranges[tile];
+    const uint32_t n = rg.y - rg.x;
+    if (n <= long_thr) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = lane >> 4;
+    const int tx = tile % gx, ty = tile / gx;
+    const int sx = tx * TILE + (wave & 1) * SUB, sy = ty * TILE + (wave >> 1) * SUB;
+    const int px = sx + (row & 1) * 4 + (lane & 3), py = sy + (row >> 1) * 4 + ((lane >> 2) & 3);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    const int pix_in_tile = 16 * (py - ty * TILE) + (px - tx * TILE);
+    const uint32_t unit0 = seg_off[tile];
+    const uint32_t* list = point_list + rg.x;
+    Slot<C>* ent = entries[wave];
+    uint8_t (*qi)[QCAP] = qidx[wave];
+    init_neutral<C>(ent, lane);
+    PixState<C> ps;
+    ps.T = 1.0f; ps.last = 0; ps.done = !inside;
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) ps.Cc[ch] = 0.f;
+
+    float Pn = 1.f, Cn[C];
+    uint32_t Ln = 0;
+    const size_t pbase = (size_t)unit0 * 256 + pix_in_tile;
+    load_snapshot<C>(part + pbase * SV, Pn, Cn);
+    Ln = part_last[pbase];
+    for (uint32_t base = 0; base < n; base += 64) {
+        const unsigned long long alive = __ballot(!ps.done);
+        if (alive == 0ull) break;
+        if (base != 0 && !ps.done)
+            store_snapshot<C>(snap + ((size_t)(unit0 + base / SEG) * 256 + pix_in_tile) * SV, ps.T, ps.Cc);
+        const float Ps = Pn;
+        float Cs[C];
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) Cs[ch] = Cn[ch];
+        const uint32_t Ls = Ln;
+        if (base + 64 < n) {   // next segment's record is requested before this one is consumed
+            const size_t pn = pbase + (size_t)(base / 64 + 1) * 256;
+            load_snapshot<C>(part + pn * SV, Pn, Cn);
+            Ln = part_last[pn];
+        }
+        const float Tn = ps.T * Ps;
+        if (__ballot(!ps.done && Tn < T_EPS) == 0ull) {   // nobody can terminate inside this segment
+            if (!ps.done) {
+#pragma unroll
+                for (int ch = 0; ch < C; ch++) ps.Cc[ch] += ps.T * Cs[ch];
+                ps.T = Tn;
+                ps.last = Ls ? Ls : ps.last;
+            }
+        } else {
+            const Fetched<C> cur = fetch_record<C>(fetch_id(base + lane, n, list), g0, g1, feats);
+            walk_batch<C, true>(ent, qi, cur, base, alive, lane, row, sx, sy, pxf, pyf, ps);
+        }
+    }
+    if (inside) {
+        const size_t pix = (size_t)W * py + px;
+        const size_t HW = (size_t)H * W;
+        final_T[pix] = ps.T;
+        n_contrib[pix] = ps.last;
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) out_color[ch * HW + pix] = ps.Cc[ch] + ps.T * bg[ch];
+        store_snapshot<C>(snap + ((size_t)unit0 * 256 + pix_in_tile) * SV, ps.T, ps.Cc);   // n > SEG always here
+    }
+}
+
+template <int C>
+static void launch_fwd_c(int W, int H, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im,
+                         BinState b, float* out_color, hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);
-    if (C == 6)
-        blend_fwd_kernel<6><<<t.T, 256, 0, st>>>(W, H, t.gx, im.ranges, im.order, b.point_list, g.g0, g.g1, feats, bg,
-                                                 out_color, im.final_T, im.n_contrib, im.seg_off, b.snap, g_trace);
-    else
-        blend_fwd_kernel<3><<<t.T, 256, 0, st>>>(W, H, t.gx, im.ranges, im.order, b.point_list, g.g0, g.g1, feats, bg,
-                                                 out_color, im.final_T, im.n_contrib, im.seg_off, b.snap, g_trace);
+    static const uint32_t long_thr = getenv("GSR_FWD_LONG") ? (uint32_t)atoi(getenv("GSR_FWD_LONG")) : 4096u;
+    const bool use_long = U > 0 && max_count > long_thr && long_thr >= (uint32_t)SEG;
+    hipStream_t side = st;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // the helper stream and its two events are shared by every host thread rendering on this device: the whole
+    // fork .. join enqueue sequence is atomic (a wait binds to the record that precedes it at enqueue time)
+    static std::mutex enqueue_mu;
+    std::unique_lock<std::mutex> lk(enqueue_mu, std::defer_lock);
+    if (use_long) lk.lock();
+    if (use_long && fwd_side_stream(&side, &ev_fork, &ev_join)) {
+        // fork: the long tiles are reduced and rendered on a helper stream while the main kernel renders the rest
+        (void)hipEventRecord(ev_fork, st);
+        (void)hipStreamWaitEvent(side, ev_fork, 0);
+    }
+    if (use_long) {
+        blend_fwd_partial_kernel<C><<<4 * U, 64, 0, side>>>(W, H, t.gx, long_thr, im.ranges, im.seg_off, b.unit_tile, b.point_list,
+                                                           g.g0, g.g1, feats, b.part, b.part_last);
+        // the long tiles are the front of `order` (length classes of 32, snake within bands of 256); the kernel checks
+        // each tile's length itself, so the launch only has to cover them: bands until the first all-short band would
+        // need a read-back, so cover every non-empty tile's band count conservatively with T (empty ones exit at once)
+        blend_fwd_long_kernel<C><<<t.T, 256, 0, side>>>(W, H, t.gx, im.ranges, im.order, b.point_list, g.g0, g.g1, feats, bg,
+                                                       out_color, im.final_T, im.n_contrib, im.seg_off, b.snap, long_thr, b.part,
+                                                       b.part_last);
+    }
+    blend_fwd_kernel<C><<<t.T, 256, 0, st>>>(W, H, t.gx, im.ranges, im.order, b.point_list, g.g0, g.g1, feats, bg, out_color,
+                                             im.final_T, im.n_contrib, im.seg_off, b.snap, use_long ? long_thr : 0xffffffffu,
+                                             g_trace);
+    if (use_long && side != st) {   // join
+        (void)hipEventRecord(ev_join, side);
+        (void)hipStreamWaitEvent(st, ev_join, 0);
+    }
+}
+
+void launch_blend_fwd(int C, int W, int H, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g,
+                      ImageState im, BinState b, float* out_color, hipStream_t st)
+{
+    if (C == 6) launch_fwd_c<6>(W, H, U, max_count, bg, feats, g, im, b, out_color, st);
+    else launch_fwd_c<3>(W, H, U, max_count, bg, feats, g, im, b, out_color, st);
 }
 
 }  // namespace gsr

@@ -106,6 +106,8 @@ struct BinState {            // per instance / per segment
     float4* snap;            // [U][256][snap_vecs(C)] per-pixel {T, C0, C1, ...} BEFORE the first instance of segment
                              // u (u not the first segment of its tile; that slot holds the FINAL {T, C...} when the
                              // tile has more than one segment); pixel index = 16*(y - tile_y0) + (x - tile_x0)
+    float4* part;            // [U][256][snap_vecs(C)] segment pre-reduction of long tiles: {prod(1 - alpha), sum c alpha T_local}
+    uint32_t* part_last;     // [U][256] last contributing list position (1-based) inside the segment, 0 = none
     size_t bytes;
 };
 inline BinState carve_bin(void* base, int R, int U, int C = 3)
@@ -115,6 +117,8 @@ inline BinState carve_bin(void* base, int R, int U, int C = 3)
     s.point_list = (uint32_t*)(b + o); o = align_up(o + 4 * (size_t)R);
     s.unit_tile = (uint32_t*)(b + o); o = align_up(o + 4 * (size_t)U);
     s.snap = (float4*)(b + o); o = align_up(o + sizeof(float4) * 256 * (size_t)snap_vecs(C) * (size_t)U);
+    s.part = (float4*)(b + o); o = align_up(o + sizeof(float4) * 256 * (size_t)snap_vecs(C) * (size_t)U);
+    s.part_last = (uint32_t*)(b + o); o = align_up(o + sizeof(uint32_t) * 256 * (size_t)U);
     s.bytes = o + 256;
     return s;
 }
@@ -166,7 +170,7 @@ void launch_preprocess(int P, int D, int M, const float* means3D, const float* s
 void launch_tile_scan(ImageState im, int T, hipStream_t st);
 void launch_scatter(int P, int W, int H, GeomState g, ImageState im, BinState b, hipStream_t st);
 void launch_tile_sort(int W, int H, uint32_t max_count, ImageState im, BinState b, hipStream_t st);
-void launch_blend_fwd(int C, int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
+void launch_blend_fwd(int C, int W, int H, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
                       float* out_color, hipStream_t st);
 void launch_blend_bwd(int C, int W, int H, int U, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
                       const float* dL_dpix, float* grad_acc, hipStream_t st);

@@ -352,3 +352,35 @@ def test_non_default_stream_and_degree_validation():
         GaussianRasterizer(mk(3))(**args)          # 9 coefficients cannot hold degree 3
     with pytest.raises(_lib.GsrError, match="sh degree"):
         GaussianRasterizer(mk(4))(**args)
+
+
+def test_long_tile_forward_path_in_a_subprocess():
+    """The segment pre-reduction path of the forward blend (gsr_blend_fwd.hip, tiles above GSR_FWD_LONG entries; default
+    4 096, read once per process) forced down to 128 entries so that ordinary scenes take it: images, internal state and
+    gradients must still match the oracle -- including tiles whose pixels terminate inside pre-reduced segments."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.getcwd(), "tests")); sys.path.insert(0, os.getcwd())
+import parity
+from gaustar_amd import scene
+for seed, opac in ((1, (0.6, 0.99)), (2, (0.02, 0.1))):
+    rng = np.random.default_rng(seed)
+    gs = scene.random_gaussians(6000, rng, scale_range=(0.03, 0.12), box=((-0.4, 0.4), (-0.3, 0.3), (-0.5, 0.5)))
+    gs.opacities[:] = rng.uniform(*opac, (gs.P, 1)).astype(np.float32)
+    cam = scene.look_at_camera((0.1, 0.0, -4.0), (0, 0, 0), 96, 80, fovx=0.5, znear=0.01)
+    kw = dict(means3D=gs.means3D, opacities=gs.opacities, view=cam.viewmatrix, proj=cam.projmatrix, campos=cam.campos, W=cam.W, H=cam.H,
+              tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=np.array([0.3, 0.1, 0.6], np.float32), shs=None, colors_precomp=gs.colors_precomp,
+              scales=gs.scales, rotations=gs.rotations, cov3D_precomp=None, sh_degree=0, scale_modifier=1.0)
+    dpix = rng.normal(size=(3, cam.H, cam.W)).astype(np.float32)
+    st, g = parity.run_oracle(kw, dpix)
+    assert (st["ranges"][:, 1] - st["ranges"][:, 0]).max() > 1000
+    hip = parity.run_hip(kw, dpix)
+    parity.compare_hip_to(hip, st["color"], st["radii"], g, what="long-tile path seed %d" % seed)
+print("LONG_PATH_OK")
+'''
+    env = dict(os.environ, GSR_FWD_LONG="128")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "LONG_PATH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
