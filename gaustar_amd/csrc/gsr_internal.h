@@ -381,8 +381,23 @@ __device__ __forceinline__ void sh_stage_load(float* __restrict__ lds, const flo
 {
     const int W3 = 3 * M, RS = sh_row_stride(M);
     const long long rows = (long long)P - (long long)g_base;
-    const int n_words = (int)(rows >= 64 ? 64 : (rows > 0 ? rows : 0)) * W3;
+    const int n_rows = (int)(rows >= 64 ? 64 : (rows > 0 ? rows : 0));
     const float* s = src + g_base * (size_t)W3;
+    if ((W3 & 3) == 0) {   // rows are whole float4s (M = 4, 16): 16-byte loads, a row never shares one with its neighbour
+        const int V = W3 >> 2, n_vec = n_rows * V;
+        const float4* s4 = reinterpret_cast<const float4*>(s);   // g_base is a multiple of 64: 16-byte aligned
+        int g = lane / V, k = lane - g * V;
+        const int dg = 64 / V, dk = 64 - dg * V;
+        for (int w = lane; w < n_vec; w += 64) {
+            const float4 v = s4[w];
+            float* d = lds + g * RS + 4 * k;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            g += dg; k += dk;
+            if (k >= V) { k -= V; g++; }
+        }
+        return;
+    }
+    const int n_words = n_rows * W3;
     int g = lane / W3, k = lane - g * W3;
     for (int w = lane; w < n_words; w += 64) {
         lds[g * RS + k] = s[w];
@@ -395,8 +410,22 @@ __device__ __forceinline__ void sh_stage_store(const float* __restrict__ lds, fl
 {
     const int W3 = 3 * M, RS = sh_row_stride(M);
     const long long rows = (long long)P - (long long)g_base;
-    const int n_words = (int)(rows >= 64 ? 64 : (rows > 0 ? rows : 0)) * W3;
+    const int n_rows = (int)(rows >= 64 ? 64 : (rows > 0 ? rows : 0));
     float* d = dst + g_base * (size_t)W3;
+    if ((W3 & 3) == 0) {
+        const int V = W3 >> 2, n_vec = n_rows * V;
+        float4* d4 = reinterpret_cast<float4*>(d);
+        int g = lane / V, k = lane - g * V;
+        const int dg = 64 / V, dk = 64 - dg * V;
+        for (int w = lane; w < n_vec; w += 64) {
+            const float* r = lds + g * RS + 4 * k;
+            d4[w] = make_float4(r[0], r[1], r[2], r[3]);
+            g += dg; k += dk;
+            if (k >= V) { k -= V; g++; }
+        }
+        return;
+    }
+    const int n_words = n_rows * W3;
     int g = lane / W3, k = lane - g * W3;
     for (int w = lane; w < n_words; w += 64) {
         d[w] = lds[g * RS + k];
