@@ -185,14 +185,14 @@ int gsr_forward_stage2_mt(int P, int R, int max_tile_instances, int num_segments
         GSR_CHECK_LAUNCH("scatter_kernel");
         {
             Scope sc(ST_TILE_SORT, st);
-            launch_tile_sort(W, H, (uint32_t)max_tile_instances, im, b, st);
+            launch_tile_sort(W, H, R, (uint32_t)max_tile_instances, im, b, st);
         }
         GSR_CHECK_LAUNCH("tile_sort_kernel");
     }
     const float* feats = colors_precomp ? colors_precomp : g.rgb;
     {
         Scope sc(ST_BLEND_FWD, st);
-        launch_blend_fwd(C, W, H, num_segments, (uint32_t)(max_tile_instances > 0 ? max_tile_instances : 0), background, feats, g, im, b,
+        launch_blend_fwd(C, W, H, R, num_segments, (uint32_t)(max_tile_instances > 0 ? max_tile_instances : 0), background, feats, g, im, b,
                          out_color, st);
     }
     GSR_CHECK_LAUNCH("blend_fwd_kernel");

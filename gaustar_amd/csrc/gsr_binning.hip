@@ -482,7 +482,7 @@ tile_sort_big_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
     else sort_tile_in_registers<16>(s, gk, out, n, 16384u);
 }
 
-void launch_tile_sort(int W, int H, uint32_t max_count, ImageState im, BinState b, hipStream_t st)
+void launch_tile_sort(int W, int H, int R, uint32_t max_count, ImageState im, BinState b, hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);
     // GSR_DEBUG_SORT_CAP=64 forces the global-memory fallback for every tile above 64 instances (tests).
@@ -505,7 +505,7 @@ void launch_tile_sort(int W, int H, uint32_t max_count, ImageState im, BinState 
         }
         const uint32_t cap = max_count > 16384u ? 16384u : max_count;
         uint32_t np2 = 4096; while (np2 < cap) np2 <<= 1;
-        tile_sort_big_kernel<<<t.T, 1024, (size_t)np2 * 8, st>>>(im.ranges, im.order, b.keys, b.point_list);
+        tile_sort_big_kernel<<<front_of_order(R, t.T), 1024, (size_t)np2 * 8, st>>>(im.ranges, im.order, b.keys, b.point_list);
     }
     if (max_count > 16384 || (lds_sort && max_count > 2048)) {
         static bool attr_set = false;

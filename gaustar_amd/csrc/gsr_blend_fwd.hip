@@ -464,7 +464,7 @@ blend_fwd_long_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, co
 }
 
 template <int C>
-static void launch_fwd_c(int W, int H, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im,
+static void launch_fwd_c(int W, int H, int R, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im,
                          BinState b, float* out_color, hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);
@@ -485,10 +485,8 @@ static void launch_fwd_c(int W, int H, int U, uint32_t max_count, const float* b
     if (use_long) {
         blend_fwd_partial_kernel<C><<<4 * U, 64, 0, side>>>(W, H, t.gx, long_thr, im.ranges, im.seg_off, b.unit_tile, b.point_list,
                                                            g.g0, g.g1, feats, b.part, b.part_last);
-        // the long tiles are the front of `order` (length classes of 32, snake within bands of 256); the kernel checks
-        // each tile's length itself, so the launch only has to cover them: bands until the first all-short band would
-        // need a read-back, so cover every non-empty tile's band count conservatively with T (empty ones exit at once)
-        blend_fwd_long_kernel<C><<<t.T, 256, 0, side>>>(W, H, t.gx, im.ranges, im.order, b.point_list, g.g0, g.g1, feats, bg,
+        // the long tiles sit at the front of `order` (front_of_order); the kernel checks each tile's length itself
+        blend_fwd_long_kernel<C><<<long_thr >= 2017u ? front_of_order(R, t.T) : t.T, 256, 0, side>>>(W, H, t.gx, im.ranges, im.order, b.point_list, g.g0, g.g1, feats, bg,
                                                        out_color, im.final_T, im.n_contrib, im.seg_off, b.snap, long_thr, b.part,
                                                        b.part_last);
     }
@@ -501,11 +499,11 @@ static void launch_fwd_c(int W, int H, int U, uint32_t max_count, const float* b
     }
 }
 
-void launch_blend_fwd(int C, int W, int H, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g,
+void launch_blend_fwd(int C, int W, int H, int R, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g,
                       ImageState im, BinState b, float* out_color, hipStream_t st)
 {
-    if (C == 6) launch_fwd_c<6>(W, H, U, max_count, bg, feats, g, im, b, out_color, st);
-    else launch_fwd_c<3>(W, H, U, max_count, bg, feats, g, im, b, out_color, st);
+    if (C == 6) launch_fwd_c<6>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, st);
+    else launch_fwd_c<3>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, st);
 }
 
 }  // namespace gsr

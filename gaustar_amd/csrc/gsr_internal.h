@@ -169,8 +169,16 @@ void launch_preprocess(int P, int D, int M, const float* means3D, const float* s
                        hipStream_t st);
 void launch_tile_scan(ImageState im, int T, hipStream_t st);
 void launch_scatter(int P, int W, int H, GeomState g, ImageState im, BinState b, hipStream_t st);
-void launch_tile_sort(int W, int H, uint32_t max_count, ImageState im, BinState b, hipStream_t st);
-void launch_blend_fwd(int C, int W, int H, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
+void launch_tile_sort(int W, int H, int R, uint32_t max_count, ImageState im, BinState b, hipStream_t st);
+// Launch positions [0, front_of_order(R, T)) of `order` hold every tile with 2 017 or more entries: they all fall into
+// length class 0, which sits at the front, there are at most R / 2017 of them, and the snake only permutes within
+// bands of 256.  Kernels that only concern such tiles are launched over this prefix instead of all T tiles.
+inline int front_of_order(int R, int T)
+{
+    const long long bound = ((long long)(R > 0 ? R : 0) / 2017 + 1 + 255) / 256 * 256;
+    return (int)(bound < (long long)T ? bound : (long long)T);
+}
+void launch_blend_fwd(int C, int W, int H, int R, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
                       float* out_color, hipStream_t st);
 void launch_blend_bwd(int C, int W, int H, int U, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
                       const float* dL_dpix, float* grad_acc, hipStream_t st);
