@@ -384,3 +384,13 @@ print("LONG_PATH_OK")
     env = dict(os.environ, GSR_FWD_LONG="128")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "LONG_PATH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_hostile_inputs_neither_hang_nor_fault():
+    """NaN / Inf / huge / degenerate parameters (tests/devtools/fuzz_inputs.py) must come back from forward + backward:
+    no hang, no device fault.  (Values are garbage in the reference too and are not compared.)"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "devtools", "fuzz_inputs.py")], cwd=ROOT,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "FUZZ_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
