@@ -19,9 +19,16 @@
 namespace gsr {
 
 constexpr int LR = 5;                 // window radius (window_size 11, loss_utils.py:36)
-constexpr int LT = 32;                // output tile edge
-constexpr int LI = LT + 2 * LR;       // input tile edge (42)
+#ifndef GSR_SSIM_TILE_H
+#define GSR_SSIM_TILE_H 16
+#endif
+constexpr int LT = 32;                // output tile width
+constexpr int LTY = GSR_SSIM_TILE_H;  // output tile height (16: 25 KB of LDS per workgroup -> 6 workgroups per CU)
+constexpr int LI = LT + 2 * LR;       // input tile width (42)
+constexpr int LIY = LTY + 2 * LR;     // input tile height
 constexpr int LP = LI + 1;            // padded LDS row of the input tile
+constexpr int RPT = LTY / 8;          // output rows per thread in the vertical pass (256 threads = 32 columns x 8 groups)
+static_assert(LTY % 8 == 0, "eight row groups");
 // gaussian(11, 1.5) exactly as loss_utils.py:23-25 builds it (float32 of exp(), divided by the float32 sum)
 __device__ constexpr float GW[11] = {0x1.0d956cp-10f, 0x1.f1fe02p-8f, 0x1.26eb18p-5f, 0x1.bff0fep-4f, 0x1.b43c3ep-3f,
                                      0x1.10656p-2f,   0x1.b43c3ep-3f, 0x1.bff0fep-4f, 0x1.26eb18p-5f, 0x1.f1fe02p-8f,
@@ -46,23 +53,38 @@ __device__ __forceinline__ float block_sum_256(float v, float* red)
 __global__ void __launch_bounds__(256)
 ssim_stats_kernel(int H, int W, View x, View y, float* __restrict__ D, float* __restrict__ partials)
 {
-    __shared__ float X[LI * LP], Y[LI * LP];
-    __shared__ float Hq[5][LI * LT];
+    __shared__ float X[LIY * LP], Y[LIY * LP];
+    __shared__ float Hq[5][LIY * LT];
     __shared__ float red[4];
     const int tid = threadIdx.x;
-    const int tx0 = blockIdx.x * LT, ty0 = blockIdx.y * LT, ch = blockIdx.z;
+    const int tx0 = blockIdx.x * LT, ty0 = blockIdx.y * LTY, ch = blockIdx.z;
     const float* xp = x.p + ch * x.sc;
     const float* yp = y.p + ch * y.sc;
-    for (int i = tid; i < LI * LI; i += 256) {
+    // all of a thread's tile loads are issued before the first one is consumed (a rolled loop paid one full memory
+    // latency per iteration: 5.8 of the workgroup's 9.6 us)
+    constexpr int NL = (LIY * LI + 255) / 256;
+    float xv[NL], yv[NL];
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        const int i = tid + k * 256;
         const int r = i / LI, c = i - r * LI;
         const int gy = ty0 + r - LR, gx = tx0 + c - LR;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        X[r * LP + c] = in ? xp[gy * x.sy + gx * x.sx] : 0.f;
-        Y[r * LP + c] = in ? yp[gy * y.sy + gx * y.sx] : 0.f;
+        const bool in = i < LIY * LI && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        xv[k] = in ? xp[gy * x.sy + gx * x.sx] : 0.f;
+        yv[k] = in ? yp[gy * y.sy + gx * y.sx] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        const int i = tid + k * 256;
+        if (i < LIY * LI) {
+            const int r = i / LI, c = i - r * LI;
+            X[r * LP + c] = xv[k];
+            Y[r * LP + c] = yv[k];
+        }
     }
     __syncthreads();
     // horizontal: 42 rows x 32 columns, five windowed quantities
-    for (int i = tid; i < LI * LT; i += 256) {
+    for (int i = tid; i < LIY * LT; i += 256) {
         const int r = i / LT, c = i - r * LT;
         float hx = 0.f, hy = 0.f, hxx = 0.f, hyy = 0.f, hxy = 0.f;
 #pragma unroll
@@ -74,15 +96,15 @@ ssim_stats_kernel(int H, int W, View x, View y, float* __restrict__ D, float* __
     }
     __syncthreads();
     // vertical: thread = (column c, group of 4 rows); 14 rows of each quantity slide through registers
-    const int c = tid & 31, r0 = (tid >> 5) * 4;
-    float out[5][4];
+    const int c = tid & 31, r0 = (tid >> 5) * RPT;
+    float out[5][RPT];
 #pragma unroll
     for (int q = 0; q < 5; q++) {
-        float col[14];
+        float col[RPT + 10];
 #pragma unroll
-        for (int k = 0; k < 14; k++) col[k] = Hq[q][(r0 + k) * LT + c];
+        for (int k = 0; k < RPT + 10; k++) col[k] = Hq[q][(r0 + k) * LT + c];
 #pragma unroll
-        for (int o = 0; o < 4; o++) {
+        for (int o = 0; o < RPT; o++) {
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < 11; k++) s += GW[k] * col[o + k];
@@ -92,7 +114,7 @@ ssim_stats_kernel(int H, int W, View x, View y, float* __restrict__ D, float* __
     float l1 = 0.f, ssum = 0.f;
     const size_t plane = (size_t)H * W;
 #pragma unroll
-    for (int o = 0; o < 4; o++) {
+    for (int o = 0; o < RPT; o++) {
         const int gy = ty0 + r0 + o, gx = tx0 + c;
         if (gy < H && gx < W) {
             const float mu1 = out[0][o], mu2 = out[1][o];
@@ -148,22 +170,34 @@ l1_ssim_finalize_kernel(int n_wg, const float* __restrict__ partials, double inv
 __global__ void __launch_bounds__(256)
 ssim_grad_kernel(int H, int W, View x, View y, const float* __restrict__ D, float ca, float cb, ViewW g)
 {
-    __shared__ float T[3][LI * LP];
-    __shared__ float Hq[3][LI * LT];
+    __shared__ float T[3][LIY * LP];
+    __shared__ float Hq[3][LIY * LT];
     const int tid = threadIdx.x;
-    const int tx0 = blockIdx.x * LT, ty0 = blockIdx.y * LT, ch = blockIdx.z;
+    const int tx0 = blockIdx.x * LT, ty0 = blockIdx.y * LTY, ch = blockIdx.z;
     const size_t plane = (size_t)H * W, vol = (size_t)gridDim.z * plane;
-    for (int i = tid; i < LI * LI; i += 256) {
+    constexpr int NL = (LIY * LI + 255) / 256;
+    float dv[NL][3];
+#pragma unroll
+    for (int k = 0; k < NL; k++) {   // every load in flight before the first LDS store (see ssim_stats_kernel)
+        const int i = tid + k * 256;
         const int r = i / LI, c = i - r * LI;
         const int gy = ty0 + r - LR, gx = tx0 + c - LR;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const bool in = i < LIY * LI && gy >= 0 && gy < H && gx >= 0 && gx < W;
         const size_t o_ = (size_t)ch * plane + (size_t)(in ? gy : 0) * W + (in ? gx : 0);
-        T[0][r * LP + c] = in ? D[o_] : 0.f;
-        T[1][r * LP + c] = in ? D[vol + o_] : 0.f;
-        T[2][r * LP + c] = in ? D[2 * vol + o_] : 0.f;
+        dv[k][0] = in ? D[o_] : 0.f;
+        dv[k][1] = in ? D[vol + o_] : 0.f;
+        dv[k][2] = in ? D[2 * vol + o_] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        const int i = tid + k * 256;
+        if (i < LIY * LI) {
+            const int r = i / LI, c = i - r * LI;
+            T[0][r * LP + c] = dv[k][0]; T[1][r * LP + c] = dv[k][1]; T[2][r * LP + c] = dv[k][2];
+        }
     }
     __syncthreads();
-    for (int i = tid; i < LI * LT; i += 256) {
+    for (int i = tid; i < LIY * LT; i += 256) {
         const int r = i / LT, c = i - r * LT;
         float h0 = 0.f, h1 = 0.f, h2 = 0.f;
 #pragma unroll
@@ -174,15 +208,15 @@ ssim_grad_kernel(int H, int W, View x, View y, const float* __restrict__ D, floa
         Hq[0][i] = h0; Hq[1][i] = h1; Hq[2][i] = h2;
     }
     __syncthreads();
-    const int c = tid & 31, r0 = (tid >> 5) * 4;
-    float out[3][4];
+    const int c = tid & 31, r0 = (tid >> 5) * RPT;
+    float out[3][RPT];
 #pragma unroll
     for (int q = 0; q < 3; q++) {
-        float col[14];
+        float col[RPT + 10];
 #pragma unroll
-        for (int k = 0; k < 14; k++) col[k] = Hq[q][(r0 + k) * LT + c];
+        for (int k = 0; k < RPT + 10; k++) col[k] = Hq[q][(r0 + k) * LT + c];
 #pragma unroll
-        for (int o = 0; o < 4; o++) {
+        for (int o = 0; o < RPT; o++) {
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < 11; k++) s += GW[k] * col[o + k];
@@ -190,7 +224,7 @@ ssim_grad_kernel(int H, int W, View x, View y, const float* __restrict__ D, floa
         }
     }
 #pragma unroll
-    for (int o = 0; o < 4; o++) {
+    for (int o = 0; o < RPT; o++) {
         const int gy = ty0 + r0 + o, gx = tx0 + c;
         if (gy < H && gx < W) {
             const float xv = x.p[ch * x.sc + gy * x.sy + gx * x.sx], yv = y.p[ch * y.sc + gy * y.sy + gx * y.sx];
@@ -205,7 +239,7 @@ ssim_grad_kernel(int H, int W, View x, View y, const float* __restrict__ D, floa
 size_t l1_ssim_workspace_bytes(int C, int H, int W)
 {
     const size_t n = (size_t)C * H * W;
-    const size_t n_wg = (size_t)C * ((H + LT - 1) / LT) * ((W + LT - 1) / LT);
+    const size_t n_wg = (size_t)C * ((H + LTY - 1) / LTY) * ((W + LT - 1) / LT);
     return align_up(3 * n * sizeof(float)) + align_up(2 * n_wg * sizeof(float)) + 256;
 }
 
@@ -215,7 +249,7 @@ void launch_l1_ssim(int C, int H, int W, const float* pred, const long long* ps,
     const size_t n = (size_t)C * H * W;
     float* D = static_cast<float*>(workspace);
     float* partials = reinterpret_cast<float*>(static_cast<char*>(workspace) + align_up(3 * n * sizeof(float)));
-    const dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT, C);
+    const dim3 grid((W + LT - 1) / LT, (H + LTY - 1) / LTY, C);
     const int n_wg = (int)(grid.x * grid.y * grid.z);
     const View x{pred, ps[0], ps[1], ps[2]}, y{gt, gs_[0], gs_[1], gs_[2]};
     ssim_stats_kernel<<<grid, 256, 0, st>>>(H, W, x, y, D, partials);
