@@ -1,0 +1,275 @@
+"""Host-side counterpart of the reference's render harness:
+`SuGaR.render_image_gaussian_rasterizer` and the properties it reads (gaustar_scene/sugar_model.py:1065-1311, :417-508,
+:442-450, :674-718), assembled from this package's fused ops.  The reference module itself cannot be imported here
+(open3d / pytorch3d), so this mirrors its interface -- same parameter names in the state dict, same argument names
+and return conventions of the render call -- for the mesh-bound ("binded_to_surface_mesh") case GauSTAR uses.
+
+    model = SurfaceGaussians.from_checkpoint(formats.load_sugar_checkpoint("2000.pt"), device)
+    image = model.render_image_gaussian_rasterizer(camera=cam, bg_color=[0, 1, 0], sh_deg=3)          # [H,W,3]
+    rgb, depth = model.render_rgb_depth(camera=cam, bg_color=[0, 1, 0], max_depth=10.0, sh_deg=3)     # one pass
+
+What differs from the reference, by design: per-camera matrices are built once and cached on the device (the reference
+redoes a numpy inverse and three uploads per call, :1129-1163); points / scaling / quaternions come from one fused kernel
+(and one backward) per parameter version instead of ~50 elementwise kernels per property access.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import producers, scene
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+BARY_COORDS = {  # sugar_model.py:186-226
+    1: [[1 / 3, 1 / 3, 1 / 3]],
+    3: [[1 / 2, 1 / 4, 1 / 4], [1 / 4, 1 / 2, 1 / 4], [1 / 4, 1 / 4, 1 / 2]],
+    4: [[1 / 3, 1 / 3, 1 / 3], [2 / 3, 1 / 6, 1 / 6], [1 / 6, 2 / 3, 1 / 6], [1 / 6, 1 / 6, 2 / 3]],
+    6: [[2 / 3, 1 / 6, 1 / 6], [1 / 6, 2 / 3, 1 / 6], [1 / 6, 1 / 6, 2 / 3], [1 / 6, 5 / 12, 5 / 12], [5 / 12, 1 / 6, 5 / 12],
+        [5 / 12, 5 / 12, 1 / 6]],
+}
+
+
+@dataclass
+class NerfCamera:
+    """One camera as CamerasWrapper holds it: `c2w` is the [3,4] (or [4,4]) NeRF 'transform_matrix' -- camera-to-world
+    with OpenGL/Blender axes (Y up, Z back) --, pinhole intrinsics in pixels."""
+    c2w: np.ndarray
+    fx: float
+    fy: float
+    width: int
+    height: int
+    znear: float = 1e-4
+    zfar: float = 100.0
+    principal_ndc: Sequence[float] = (0.0, 0.0)   # p3d K[0,0,2], K[0,1,2]; 0 when cx = W/2, cy = H/2 (cameras.py:276-277)
+    _cache: Dict = field(default_factory=dict, repr=False)
+
+    def rasterizer_camera(self) -> scene.Camera:
+        """sugar_model.py:1129-1163: flip to COLMAP axes, invert, R stored transposed, world_view = getWorld2View(R, T)^T,
+        proj = getProjectionMatrix(...)^T with the principal-point entries, full = world_view @ proj."""
+        c2w = np.eye(4)
+        c2w[:np.asarray(self.c2w).shape[0], :] = np.asarray(self.c2w, dtype=np.float64)
+        c2w[:3, 1:3] *= -1                                    # :1134
+        w2c = np.linalg.inv(c2w)                              # :1138
+        R, T = np.transpose(w2c[:3, :3]), w2c[:3, 3]          # :1139-1140
+        fovx, fovy = scene.focal2fov(self.fx, self.width), scene.focal2fov(self.fy, self.height)
+        view_t = scene.get_world2view(R, T).transpose()       # :1149-1150
+        proj_t = scene.get_projection_matrix(self.znear, self.zfar, fovx, fovy).transpose().copy()
+        proj_t[2, 0] = -float(self.principal_ndc[0])          # :1159-1160
+        proj_t[2, 1] = -float(self.principal_ndc[1])
+        full_t = (view_t @ proj_t).astype(np.float32)
+        campos = np.asarray(self.c2w, dtype=np.float64)[:3, 3]    # p3d get_camera_center() = camera position
+        return scene.Camera(W=int(self.width), H=int(self.height), tanfovx=math.tan(fovx * 0.5), tanfovy=math.tan(fovy * 0.5),
+                            viewmatrix=np.ascontiguousarray(view_t, dtype=np.float32), projmatrix=np.ascontiguousarray(full_t),
+                            campos=campos.astype(np.float32))
+
+    def on_device(self, device):
+        """(Camera, viewmatrix, full_proj, campos) with the three tensors resident on `device`, built once."""
+        key = str(device)
+        if key not in self._cache:
+            cam = self.rasterizer_camera()
+            t = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(device)
+            self._cache[key] = (cam, t(cam.viewmatrix), t(cam.projmatrix), t(cam.campos))
+        return self._cache[key]
+
+
+def nerf_camera_from_scene(cam: scene.Camera, znear: float = 1e-4, zfar: float = 100.0) -> NerfCamera:
+    """The NeRF-convention camera that produces `cam` (tests: scene.look_at_camera builds COLMAP-axes cameras)."""
+    w2c = np.asarray(cam.viewmatrix, dtype=np.float64).T
+    c2w = np.linalg.inv(w2c)
+    c2w[:3, 1:3] *= -1
+    fx = cam.W / (2.0 * cam.tanfovx)
+    fy = cam.H / (2.0 * cam.tanfovy)
+    return NerfCamera(c2w=c2w[:3, :], fx=fx, fy=fy, width=cam.W, height=cam.H, znear=znear, zfar=zfar)
+
+
+class SurfaceGaussians(nn.Module):
+    """Gaussians bound to a triangle mesh: SuGaR with binded_to_surface_mesh = True (sugar_model.py:160-403), parameters
+    under the reference's names so that a reference state dict loads with load_state_dict."""
+
+    def __init__(self, verts: torch.Tensor, faces: torch.Tensor, n_gaussians_per_surface_triangle: int = 6,
+                 sh_levels: int = 4, surface_mesh_thickness: float = 1e-6, min_gaussian_scale: Optional[float] = None,
+                 max_gaussian_scale: Optional[float] = None, loose_bind: bool = False):
+        super().__init__()
+        G = int(n_gaussians_per_surface_triangle)
+        if G not in BARY_COORDS:
+            raise ValueError("n_gaussians_per_surface_triangle must be 1, 3, 4 or 6")
+        F = int(faces.shape[0])
+        N = F * G
+        dev = verts.device
+        self.n_gaussians_per_surface_triangle = G
+        self.sh_levels = int(sh_levels)
+        self.min_gaussian_scale, self.max_gaussian_scale = min_gaussian_scale, max_gaussian_scale
+        self.return_one_densities = False
+        self._points = nn.Parameter(verts.detach().clone().float())
+        self.register_buffer("_surface_mesh_faces", faces.detach().clone().long())
+        self.register_buffer("surface_triangle_bary_coords", torch.tensor(BARY_COORDS[G], dtype=torch.float32, device=dev)[..., None])
+        self.register_buffer("surface_mesh_thickness", torch.tensor(float(surface_mesh_thickness), device=dev))
+        # initial in-plane scale: the inscribed-circle radius of the face (sugar_model.py:216, :357)
+        fv = self._points.detach()[self._surface_mesh_faces]
+        edge = torch.stack([(fv[:, 0] - fv[:, 1]).norm(dim=-1), (fv[:, 1] - fv[:, 2]).norm(dim=-1), (fv[:, 2] - fv[:, 0]).norm(dim=-1)], -1)
+        radius = {1: 1 / (2 * math.sqrt(3)), 3: 1 / (2 * (math.sqrt(3) + 1)), 4: 1 / (4 * math.sqrt(3)), 6: 1 / (4 + 2 * math.sqrt(3))}[G]
+        init = (edge.min(dim=-1).values * radius).clamp(min=1e-8).log()
+        self._scales = nn.Parameter(init[:, None, None].expand(F, G, 2).reshape(N, 2).contiguous())
+        self._quaternions = nn.Parameter(torch.tensor([1.0, 0.0], device=dev).repeat(N, 1))          # 2-D rotation, identity
+        self.all_densities = nn.Parameter(torch.full((N, 1), 2.2, device=dev))                      # sigmoid ~ 0.9
+        self._sh_coordinates_dc = nn.Parameter(torch.zeros(N, 1, 3, device=dev))
+        self._sh_coordinates_rest = nn.Parameter(torch.zeros(N, self.sh_levels ** 2 - 1, 3, device=dev))
+        self._loose_bind = bool(loose_bind)
+        if loose_bind:
+            self._delta_t = nn.Parameter(torch.zeros(N, 3, device=dev))
+            self._delta_r = nn.Parameter(torch.tensor([1.0, 0.0, 0.0, 0.0], device=dev).repeat(N, 1))
+        self._geom_cache = None
+
+    # -------------------------------------------------------------------------------- construction from a checkpoint
+    @classmethod
+    def from_checkpoint(cls, ckpt: Dict, device, **kw) -> "SurfaceGaussians":
+        """`ckpt` = formats.load_sugar_checkpoint(path)."""
+        N, F = ckpt["raw_scales"].shape[0], ckpt["faces"].shape[0]
+        m = cls(ckpt["verts"].to(device), ckpt["faces"].to(device), n_gaussians_per_surface_triangle=N // F,
+                sh_levels=int(round(math.sqrt(ckpt["sh"].shape[1]))), loose_bind=ckpt.get("delta_r") is not None,
+                surface_mesh_thickness=ckpt["thickness"] if ckpt.get("thickness") is not None else 1e-6, **kw)
+        with torch.no_grad():
+            m._scales.copy_(ckpt["raw_scales"]); m._quaternions.copy_(ckpt["raw_complex"])
+            m.all_densities.copy_(ckpt["densities"].view(-1, 1))
+            m._sh_coordinates_dc.copy_(ckpt["sh"][:, :1]); m._sh_coordinates_rest.copy_(ckpt["sh"][:, 1:])
+            if m._loose_bind:
+                m._delta_t.copy_(ckpt["delta_t"]); m._delta_r.copy_(ckpt["delta_r"])
+        return m
+
+    # -------------------------------------------------------------------------------- the reference's properties
+    @property
+    def device(self):
+        return self._points.device
+
+    @property
+    def n_points(self) -> int:
+        return int(self._scales.shape[0])
+
+    def _geometry(self):
+        """(points, scaling, quaternions) from one fused call, shared by the three properties while no parameter
+        changes (the reference recomputes each property from scratch on every access)."""
+        params = [self._points, self._scales, self._quaternions] + ([self._delta_t, self._delta_r] if self._loose_bind else [])
+        key = (tuple(p._version for p in params), torch.is_grad_enabled())
+        if self._geom_cache is None or self._geom_cache[0] != key:
+            out = producers.mesh_bound_gaussians(
+                self._points, self._surface_mesh_faces, self.surface_triangle_bary_coords[..., 0], self._scales,
+                self._quaternions, float(self.surface_mesh_thickness), self.min_gaussian_scale, self.max_gaussian_scale,
+                self._delta_t if self._loose_bind else None, self._delta_r if self._loose_bind else None)
+            self._geom_cache = (key, out)
+        return self._geom_cache[1]
+
+    @property
+    def points(self):                 # sugar_model.py:417-435
+        return self._geometry()[0]
+
+    @property
+    def scaling(self):                # :457-476
+        return self._geometry()[1]
+
+    @property
+    def quaternions(self):            # :478-508
+        return self._geometry()[2]
+
+    @property
+    def strengths(self):              # :442-447
+        if self.return_one_densities:
+            return torch.ones_like(self.all_densities.view(-1, 1))
+        return torch.sigmoid(self.all_densities.view(-1, 1))
+
+    @property
+    def sh_coordinates(self):         # :449-450
+        return torch.cat([self._sh_coordinates_dc, self._sh_coordinates_rest], dim=1)
+
+    def get_points_rgb(self, positions=None, camera_centers=None, directions=None, sh_levels=None, sh_coordinates=None):
+        """sugar_model.py:674-718 (one camera centre; the `directions` variant is not provided)."""
+        if directions is not None or camera_centers is None:
+            raise NotImplementedError("get_points_rgb: only the camera_centers form is provided")
+        positions = self.points if positions is None else positions
+        sh = self.sh_coordinates if sh_coordinates is None else sh_coordinates
+        levels = self.sh_levels if sh_levels is None else int(sh_levels)
+        return producers.points_rgb(positions, camera_centers, sh, levels)
+
+    # -------------------------------------------------------------------------------- rendering
+    def _settings(self, camera: NerfCamera, bg: torch.Tensor, sh_degree: int):
+        cam, view, proj, campos = camera.on_device(self.device)
+        return GaussianRasterizationSettings(image_height=cam.H, image_width=cam.W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg,
+                                             scale_modifier=1.0, viewmatrix=view, projmatrix=proj, sh_degree=int(sh_degree),
+                                             campos=campos, prefiltered=False, debug=False), view, campos
+
+    def _scales_for_render(self, use_solid_surface: bool, use_same_scale_in_all_directions: bool):
+        scales = self.scaling
+        if use_same_scale_in_all_directions:                                  # :1226-1228
+            scales = scales.mean(dim=-1, keepdim=True).expand(-1, 3)
+        if use_solid_surface:                                                 # :1230-1232
+            scales = scales.clone()
+            mean_scale = scales[..., 1:].mean()
+            scales[..., 1:] = torch.maximum(mean_scale, scales[..., 1:])
+        return scales
+
+    def render_image_gaussian_rasterizer(self, camera: NerfCamera, bg_color=None, sh_deg: Optional[int] = None,
+                                         sh_rotations=None, compute_color_in_rasterizer: bool = False,
+                                         compute_covariance_in_rasterizer: bool = True, return_2d_radii: bool = False,
+                                         quaternions=None, use_solid_surface: bool = False,
+                                         use_same_scale_in_all_directions: bool = False, return_opacities: bool = False,
+                                         return_colors: bool = False, positions=None, point_colors=None):
+        """sugar_model.py:1065-1311 with `camera` in place of (nerf_cameras, camera_indices).  Returns the image [H,W,3]
+        or, with return_2d_radii / return_opacities / return_colors, the reference's dict."""
+        if sh_rotations is not None or not compute_covariance_in_rasterizer:
+            raise NotImplementedError("sh_rotations / precomputed 3-D covariances are not part of this counterpart")
+        dev = self.device
+        bg = torch.zeros(3, device=dev) if bg_color is None else torch.as_tensor(bg_color, dtype=torch.float32, device=dev)
+        sh_deg = self.sh_levels - 1 if sh_deg is None else int(sh_deg)
+        settings, _view, campos = self._settings(camera, bg, sh_deg)
+        positions = self.points if positions is None else positions
+        shs = splat_colors = None
+        if point_colors is None:
+            if compute_color_in_rasterizer:
+                shs = self.sh_coordinates                                     # :1208
+            else:
+                splat_colors = self.get_points_rgb(positions=positions, camera_centers=campos, sh_levels=sh_deg + 1)
+        else:
+            splat_colors = point_colors                                       # :1211
+        splat_opacities = self.strengths.view(-1, 1)
+        quaternions = self.quaternions if quaternions is None else quaternions
+        scales = self._scales_for_render(use_solid_surface, use_same_scale_in_all_directions)
+        screenspace_points = torch.zeros(self.n_points, 3, dtype=positions.dtype, requires_grad=True, device=dev)
+        if return_2d_radii:
+            screenspace_points.retain_grad()
+        rendered_image, radii = GaussianRasterizer(settings)(means3D=positions, means2D=screenspace_points, shs=shs,
+                                                            colors_precomp=splat_colors, opacities=splat_opacities,
+                                                            scales=scales, rotations=quaternions, cov3D_precomp=None)
+        image = rendered_image.transpose(0, 1).transpose(1, 2)                # :1298
+        if not (return_2d_radii or return_opacities or return_colors):
+            return image
+        outputs = {"image": image, "radii": radii, "viewspace_points": screenspace_points}
+        if return_opacities:
+            outputs["opacities"] = splat_opacities
+        if return_colors:
+            outputs["colors"] = splat_colors
+        return outputs
+
+    def view_depth_colors(self, camera: NerfCamera, positions=None):
+        """refine.py:603-605: view-space z of every Gaussian, expanded to three channels."""
+        _cam, view, _proj, _campos = camera.on_device(self.device)
+        positions = self.points if positions is None else positions
+        return (positions @ view[:3, 2:3] + view[3, 2]).expand(-1, 3)
+
+    def render_rgb_depth(self, camera: NerfCamera, bg_color=None, max_depth: float = 10.0, sh_deg: Optional[int] = None):
+        """The two renders of a refinement iteration (refine.py:552 RGB, :607 depth-as-colour with bg = max_depth) as ONE
+        6-channel pass: -> (rgb [H,W,3], depth [H,W])."""
+        dev = self.device
+        bg_rgb = torch.zeros(3, device=dev) if bg_color is None else torch.as_tensor(bg_color, dtype=torch.float32, device=dev)
+        bg6 = torch.cat([bg_rgb, torch.full((3,), float(max_depth), device=dev)])
+        sh_deg = self.sh_levels - 1 if sh_deg is None else int(sh_deg)
+        settings, _view, campos = self._settings(camera, bg6, 0)
+        positions = self.points
+        colors6 = torch.cat([self.get_points_rgb(positions=positions, camera_centers=campos, sh_levels=sh_deg + 1),
+                             self.view_depth_colors(camera, positions)], dim=1)
+        img, _ = GaussianRasterizer(settings)(means3D=positions, means2D=torch.zeros_like(positions), opacities=self.strengths,
+                                              colors_precomp=colors6, scales=self.scaling, rotations=self.quaternions)
+        return img[:3].permute(1, 2, 0), img[3]

@@ -1,0 +1,108 @@
+"""GPU: the render-harness counterpart (gaustar_amd/harness.py) against the oracle pieces:
+camera matrices (sugar_model.py:1129-1163), properties via the producer oracle, image via the rasterizer oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(level=2, loose=False, seed=0):
+    from gaustar_amd import harness, scene
+    v, f = scene.icosphere(level, radius=0.9, center=(0.0, 1.2, 0.0))
+    g = torch.Generator().manual_seed(seed)
+    m = harness.SurfaceGaussians(torch.from_numpy(v).float().cuda(), torch.from_numpy(f).long().cuda(), sh_levels=4,
+                                 surface_mesh_thickness=3e-6, loose_bind=loose)
+    with torch.no_grad():
+        m._quaternions.copy_(torch.randn(m.n_points, 2, generator=g))
+        m._scales.add_(0.3 * torch.randn(m.n_points, 2, generator=g).cuda())
+        m._sh_coordinates_dc.copy_(torch.rand(m.n_points, 1, 3, generator=g) * 2 - 1)
+        m._sh_coordinates_rest.copy_(0.2 * (torch.rand(m.n_points, 15, 3, generator=g) - 0.5))
+        if loose:
+            m._delta_t.copy_(0.005 * torch.randn(m.n_points, 3, generator=g))
+            m._delta_r.copy_(torch.tensor([1.0, 0, 0, 0]) + 0.2 * torch.randn(m.n_points, 4, generator=g))
+    return m
+
+
+def test_camera_matrices_follow_the_nerf_to_colmap_recipe(hip_lib):
+    from gaustar_amd import harness, scene
+    ref = scene.look_at_camera((0.7, 1.9, 2.8), (0.0, 1.2, 0.0), 320, 200, focal_px=250.0)     # COLMAP-axes construction
+    cam = harness.nerf_camera_from_scene(ref).rasterizer_camera()
+    np.testing.assert_allclose(cam.viewmatrix, ref.viewmatrix, atol=2e-6)
+    np.testing.assert_allclose(cam.projmatrix, ref.projmatrix, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(cam.campos, ref.campos, atol=2e-6)
+    assert abs(cam.tanfovx - ref.tanfovx) < 1e-6 and abs(cam.tanfovy - ref.tanfovy) < 1e-6
+    off = harness.NerfCamera(c2w=harness.nerf_camera_from_scene(ref).c2w, fx=250.0, fy=250.0, width=320, height=200,
+                             principal_ndc=(0.05, -0.02)).rasterizer_camera()
+    # the principal point only enters rows 2 of the transposed projection (sugar_model.py:1159-1160)
+    d = off.projmatrix - ref.projmatrix
+    p = np.zeros((4, 4)); p[2, 0], p[2, 1] = -0.05, 0.02
+    np.testing.assert_allclose(d, (ref.viewmatrix.astype(np.float64) @ p).astype(np.float32), atol=1e-6)
+
+
+@pytest.mark.parametrize("loose,in_rasterizer", [(False, False), (True, True)])
+def test_render_matches_oracle_composition(loose, in_rasterizer, hip_lib):
+    from gaustar_amd import harness, scene
+    from oracle import producers_oracle as po
+    m = _model(2, loose)
+    ncam = harness.nerf_camera_from_scene(scene.look_at_camera((0.5, 1.6, 2.6), (0.0, 1.2, 0.0), 200, 160, focal_px=170.0))
+    bg = [0.0, 1.0, 0.0]
+    out = m.render_image_gaussian_rasterizer(camera=ncam, bg_color=bg, sh_deg=3, compute_color_in_rasterizer=in_rasterizer,
+                                             return_2d_radii=True, return_opacities=True, return_colors=not in_rasterizer)
+    img = out["image"]
+    assert tuple(img.shape) == (160, 200, 3) and out["radii"].shape[0] == m.n_points
+    loss = (img * torch.linspace(0.5, 1.5, 3, device=img.device)).sum()
+    loss.backward()
+    assert m._points.grad is not None and m._scales.grad is not None and m._quaternions.grad is not None
+    assert out["viewspace_points"].grad is not None and torch.isfinite(m._points.grad).all()
+
+    # the same composition from the oracles (CPU)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    pts, scl, quat = po.mesh_bound_gaussians(sd["_points"], sd["_surface_mesh_faces"], sd["surface_triangle_bary_coords"][..., 0],
+                                             sd["_scales"], sd["_quaternions"], float(sd["surface_mesh_thickness"]), None, None,
+                                             sd.get("_delta_t"), sd.get("_delta_r"))
+    cam = ncam.rasterizer_camera()
+    sh = torch.cat([sd["_sh_coordinates_dc"], sd["_sh_coordinates_rest"]], 1)
+    kw = dict(means3D=pts.numpy(), opacities=torch.sigmoid(sd["all_densities"]).numpy(), view=cam.viewmatrix, proj=cam.projmatrix,
+              campos=cam.campos, W=cam.W, H=cam.H, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=np.array(bg, np.float32),
+              scales=scl.numpy(), rotations=quat.numpy(), cov3D_precomp=None, scale_modifier=1.0)
+    if in_rasterizer:
+        kw.update(shs=sh.numpy(), colors_precomp=None, sh_degree=3)
+    else:
+        kw.update(shs=None, colors_precomp=po.points_rgb(pts, torch.from_numpy(cam.campos)[None], sh, 4).numpy(), sh_degree=0)
+    st, _ = parity.run_oracle(kw)
+    parity.check_image(img.detach().permute(2, 0, 1).cpu().numpy(), st["color"], "harness image vs oracle composition", tol=2e-4)
+
+
+def test_fused_rgb_depth_equals_the_two_reference_style_renders(hip_lib):
+    from gaustar_amd import harness, scene
+    m = _model(3, False, seed=3)
+    ncam = harness.nerf_camera_from_scene(scene.look_at_camera((-0.6, 1.0, 2.7), (0.0, 1.2, 0.0), 256, 192, focal_px=200.0))
+    with torch.no_grad():
+        rgb, depth = m.render_rgb_depth(camera=ncam, bg_color=[0.0, 1.0, 0.0], max_depth=10.0, sh_deg=3)
+        a = m.render_image_gaussian_rasterizer(camera=ncam, bg_color=[0.0, 1.0, 0.0], sh_deg=3)
+        b = m.render_image_gaussian_rasterizer(camera=ncam, bg_color=[10.0, 10.0, 10.0], sh_deg=0,
+                                               point_colors=m.view_depth_colors(ncam))[..., 0]     # refine.py:603-616
+    assert torch.equal(rgb, a) and torch.equal(depth, b)
+
+
+def test_checkpoint_round_trip_through_the_model(tmp_path, hip_lib):
+    from gaustar_amd import formats, harness
+    m = _model(1, True, seed=5)
+    sd = m.state_dict()
+    path = os.path.join(tmp_path, "7000.pt")
+    formats.save_sugar_checkpoint(path, sd["_points"], sd["_surface_mesh_faces"], sd["_scales"], sd["_quaternions"],
+                                  sd["all_densities"], torch.cat([sd["_sh_coordinates_dc"], sd["_sh_coordinates_rest"]], 1),
+                                  float(sd["surface_mesh_thickness"]), sd["_delta_t"], sd["_delta_r"])
+    m2 = harness.SurfaceGaussians.from_checkpoint(formats.load_sugar_checkpoint(path), "cuda")
+    for k, v in sd.items():
+        assert torch.equal(m2.state_dict()[k].cpu(), v.cpu()), k
+    assert torch.equal(m2.points, m.points) and torch.equal(m2.quaternions, m.quaternions)
+    # a reference-style state dict loads by name
+    m3 = harness.SurfaceGaussians(sd["_points"], sd["_surface_mesh_faces"], loose_bind=True, surface_mesh_thickness=1.0)
+    m3.load_state_dict(sd)
+    assert torch.equal(m3.scaling, m.scaling)
