@@ -35,7 +35,7 @@ tr = trace.cpu().numpy().astype(np.float64) / 100.0   # microseconds
 print("R", Rn, "max", maxc, "units", U)
 for name, arr in (("fwd", tr[:2 * T].reshape(T, 2)), ("bwd", tr[2 * T:].reshape(U, 2))):
     st, en = arr[:, 0], arr[:, 1]
-    ok = en > 0
+    ok = (en > 0) & (st > 0)   # a unit whose first block left early (nothing to replay) has no start stamp
     t0 = st[ok].min()
     st, en = st - t0, en - t0
     dur = en - st
