@@ -1,0 +1,50 @@
+"""Dev tool: N random small scenes (sizes, counts, opacity ranges, SH degree / precomputed colours / precomputed
+covariances, scale modifiers, channel counts) through the HIP path and the oracle, tolerances of tests/parity.py."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import parity
+from gaustar_amd import scene
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+fails = 0
+for case in range(N):
+    rng = np.random.default_rng(1000 + case)
+    W, H = int(rng.integers(1, 260)), int(rng.integers(1, 200))
+    P = int(rng.choice([1, 7, 100, 1500, 6000]))
+    deg = int(rng.integers(0, 4))
+    mode = rng.choice(["sh", "rgb", "rgb6"])
+    s_lo = float(rng.choice([0.005, 0.03, 0.2]))
+    gs = scene.random_gaussians(P, rng, sh_degree=deg, with_sh=(mode == "sh"), scale_range=(s_lo, s_lo * float(rng.choice([2, 10]))))
+    lo = float(rng.choice([0.003, 0.3, 0.9]))
+    gs.opacities[:] = rng.uniform(lo, min(1.0, lo * 3 + 0.01), (P, 1)).astype(np.float32)
+    cam = scene.look_at_camera((float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)), -float(rng.uniform(2.5, 5))), (0, 0, 0), W, H,
+                               fovx=float(rng.uniform(0.4, 1.2)), znear=0.01)
+    sm = float(rng.choice([1.0, 0.6, 1.7]))
+    kw = dict(means3D=gs.means3D, opacities=gs.opacities, view=cam.viewmatrix, proj=cam.projmatrix, campos=cam.campos, W=W, H=H,
+              tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=rng.uniform(0, 1, 3).astype(np.float32), shs=gs.shs if mode == "sh" else None,
+              colors_precomp=None if mode == "sh" else gs.colors_precomp, scales=gs.scales, rotations=gs.rotations, cov3D_precomp=None,
+              sh_degree=deg if mode == "sh" else 0, scale_modifier=sm)
+    dpix = rng.normal(size=(3, H, W)).astype(np.float32)
+    try:
+        st, g = parity.run_oracle(kw, dpix)
+        if mode == "rgb6":
+            extra = rng.uniform(0, 3, (P, 3)).astype(np.float32)
+            kw2 = dict(kw, colors_precomp=extra, bg=np.full(3, 7.0, np.float32))
+            d2 = rng.normal(size=(3, H, W)).astype(np.float32)
+            st2, g2 = parity.run_oracle(kw2, d2)
+            kw6 = dict(kw, colors_precomp=np.concatenate([gs.colors_precomp, extra], 1), bg=np.concatenate([kw["bg"], kw2["bg"]]))
+            hip = parity.run_hip(kw6, np.concatenate([dpix, d2]))
+            assert np.array_equal(hip["radii"], st["radii"])
+            parity.check_image(hip["color"][:3], st["color"]); parity.check_image(hip["color"][3:], st2["color"])
+            parity.check_grad(hip["dL_dcolors"][:, :3], g["dL_dcolors"]); parity.check_grad(hip["dL_dcolors"][:, 3:], g2["dL_dcolors"])
+            for k in ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dmeans2D"):
+                parity.check_grad(hip[k], np.asarray(g[k], np.float64).reshape(hip[k].shape) + np.asarray(g2[k], np.float64).reshape(hip[k].shape), k)
+        else:
+            hip = parity.run_hip(kw, dpix)
+            parity.compare_hip_to(hip, st["color"], st["radii"], g, what=f"case {case}")
+    except AssertionError as e:
+        fails += 1
+        print(f"case {case}: W={W} H={H} P={P} mode={mode} deg={deg} sm={sm}: FAIL {str(e)[:200]}")
+print(f"random parity sweep: {N - fails}/{N} passed")
