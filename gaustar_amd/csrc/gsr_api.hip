@@ -176,7 +176,13 @@ int gsr_forward_stage2_mt(int P, int R, int max_tile_instances, int num_segments
     hipStream_t st = (hipStream_t)stream;
     ImageState im = carve_image(image_buffer, W, H);
     GeomState g = carve_geom(geom_buffer, P > 0 ? P : 0);
-    BinState b = carve_bin(binning_buffer, R > 0 ? R : 0, num_segments > 0 ? num_segments : 0, C);
+    // num_segments < 0: forward-only render (same buffer size as for |num_segments|, snapshots not written);
+    // num_segments = 0 with R > 0: forward-only and no per-unit areas at all (long tiles are walked serially)
+    const bool forward_only = num_segments <= 0;
+    if (num_segments < 0) num_segments = -num_segments;
+    BinState b = carve_bin(binning_buffer, R > 0 ? R : 0, num_segments, C);
+    if (num_segments == 0) { b.unit_tile = nullptr; b.part = nullptr; b.part_last = nullptr; }
+    if (forward_only) b.snap = nullptr;
     if (R > 0) {
         {
             Scope sc(ST_SCATTER, st);
@@ -259,6 +265,8 @@ int gsr_backward_mt(int P, int D, int M, int R, int num_segments, int num_channe
     if (!cov3D_precomp && (!scales || !rotations || !dL_dscale || !dL_drot))
         return fail_msg("gsr_backward: scales/rotations and their gradients are required without cov3D_precomp");
     if (R > 0 && !binning_buffer) return fail_msg("gsr_backward: binning_buffer is null");
+    if (R > 0 && num_segments <= 0)
+        return fail_msg("gsr_backward: the forward ran in forward-only mode (num_segments = 0 at stage 2)");
     if (!channels_ok(num_channels)) return fail_msg("gsr_backward: num_channels must be 3 or 6");
     if (num_channels != 3 && !colors_precomp)
         return fail_msg("gsr_backward: multi-target renders need precomputed colours [P, num_channels]");

@@ -230,7 +230,7 @@ scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __
     const size_t Tp = shard_stride(T);
     // side job of the first T threads: expand the per-tile segment counts into the unit -> tile table
     // (it lives in the binning buffer, which did not exist yet when the scan kernel ran)
-    if (idx < T) {
+    if (unit_tile != nullptr && idx < T) {   // nullptr: forward-only render, no unit table
         const uint32_t u0 = seg_off[idx], u1 = seg_off[idx + 1];
         for (uint32_t u = u0; u < u1; u++) unit_tile[u] = (uint32_t)idx;
     }

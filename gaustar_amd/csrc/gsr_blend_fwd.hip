@@ -20,7 +20,8 @@
 //
 // n_contrib stores the 1-based list position of the last blended instance, as the reference does.
 // At every SEG-th list position the running (T, C) of the pixels still alive is snapshotted for the
-// segment-parallel backward pass (gsr_blend_bwd.hip).
+// segment-parallel backward pass (gsr_blend_bwd.hip) -- unless the caller announced a forward-only render
+// (num_segments = 0 at stage 2: no snapshot area, no stores).
 //
 // LONG TILES.  A tile's walk is serial per pixel, so the kernel's span used to be its longest tile (a 1 600-entry tile
 // takes 95 us while the whole image needs 68 us of machine time; close-up views with 10 000-entry tiles were entirely
@@ -298,7 +299,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         if (alive == 0ull) break;
         // segment boundary: snapshot the running state of every pixel still alive (the backward blend
         // starts its segments from these instead of replaying the whole list)
-        if (base != 0 && (base % SEG) == 0 && !done)
+        if (snap != nullptr && base != 0 && (base % SEG) == 0 && !done)
             store_snapshot<C>(snap + ((size_t)(unit0 + base / SEG) * 256 + pix_in_tile) * SV, T, Cc);
         const Fetched<C> cur = nxt;
         nxt = fetch_record<C>(gid_nxt, g0, g1, feats);      // records of batch +1 (ids arrived during the last batch)
@@ -375,7 +376,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         for (int ch = 0; ch < C; ch++) out_color[ch * HW + pix] = Cc[ch] + T * bg[ch];
         // a tile with more than one segment: the first unit's snapshot slot (never used as a boundary) keeps the
         // final (T, C), from which the backward derives "colour behind a boundary" = C_final - C_snap
-        if (n > (uint32_t)SEG) store_snapshot<C>(snap + ((size_t)unit0 * 256 + pix_in_tile) * SV, T, Cc);
+        if (snap != nullptr && n > (uint32_t)SEG) store_snapshot<C>(snap + ((size_t)unit0 * 256 + pix_in_tile) * SV, T, Cc);
     }
     if (trace && lane == 0) {   // last wave to finish wins the end stamp
         if (wave == 0) trace[2 * blockIdx.x] = t_start;
@@ -427,7 +428,7 @@ blend_fwd_long_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, co
     for (uint32_t base = 0; base < n; base += 64) {
         const unsigned long long alive = __ballot(!ps.done);
         if (alive == 0ull) break;
-        if (base != 0 && !ps.done)
+        if (snap != nullptr && base != 0 && !ps.done)
             store_snapshot<C>(snap + ((size_t)(unit0 + base / SEG) * 256 + pix_in_tile) * SV, ps.T, ps.Cc);
         const float Ps = Pn;
         float Cs[C];
@@ -459,7 +460,7 @@ blend_fwd_long_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, co
         n_contrib[pix] = ps.last;
 #pragma unroll
         for (int ch = 0; ch < C; ch++) out_color[ch * HW + pix] = ps.Cc[ch] + ps.T * bg[ch];
-        store_snapshot<C>(snap + ((size_t)unit0 * 256 + pix_in_tile) * SV, ps.T, ps.Cc);   // n > SEG always here
+        if (snap != nullptr) store_snapshot<C>(snap + ((size_t)unit0 * 256 + pix_in_tile) * SV, ps.T, ps.Cc);   // n > SEG always here
     }
 }
 
@@ -469,7 +470,7 @@ static void launch_fwd_c(int W, int H, int R, int U, uint32_t max_count, const f
 {
     const Tiles t = tiles_of(W, H);
     static const uint32_t long_thr = getenv("GSR_FWD_LONG") ? (uint32_t)atoi(getenv("GSR_FWD_LONG")) : 4096u;
-    const bool use_long = U > 0 && max_count > long_thr && long_thr >= (uint32_t)SEG;
+    const bool use_long = U > 0 && b.part != nullptr && max_count > long_thr && long_thr >= (uint32_t)SEG;
     hipStream_t side = st;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // the helper stream and its two events are shared by every host thread rendering on this device: the whole

@@ -94,7 +94,7 @@ def _require_gpu(t: torch.Tensor, what: str):
 # --------------------------------------------------------------------------------------------
 def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rotations, scale_modifier,
                                cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
-                               image_width, sh, degree, campos, prefiltered, debug):
+                               image_width, sh, degree, campos, prefiltered, debug, need_backward=True):
     """-> (num_rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer), like
     RasterizeGaussiansCUDA (DGR/rasterize_points.cu:35-115), plus two more elements: the longest
     per-tile instance list (informational) and the number of list segments (backward work units)."""
@@ -128,19 +128,21 @@ def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rot
             float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix),
             _ptr(campos), W, H, float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(radii), _ptr(geom),
             _ptr(img), ctypes.byref(R), ctypes.byref(maxc), ctypes.byref(nseg), st), "gsr_forward_stage1")
+        # forward-only renders hand stage 2 the NEGATED segment count: no per-segment snapshots are written (gsr.h)
+        nseg2 = nseg.value if need_backward else -nseg.value
         if C == 3:
             binning = torch.empty(lib.gsr_binning_bytes(R.value, nseg.value), **byte_opts)
             _lib.check(lib.gsr_forward_stage2(
-                P, R.value, maxc.value, nseg.value, W, H, _ptr(background), _ptr(colors), _ptr(geom), _ptr(binning),
+                P, R.value, maxc.value, nseg2, W, H, _ptr(background), _ptr(colors), _ptr(geom), _ptr(binning),
                 _ptr(img), _ptr(out_color), st), "gsr_forward_stage2")
         else:
             binning = torch.empty(lib.gsr_binning_bytes_mt(R.value, nseg.value, C), **byte_opts)
             _lib.check(lib.gsr_forward_stage2_mt(
-                P, R.value, maxc.value, nseg.value, C, W, H, _ptr(background), _ptr(colors), _ptr(geom), _ptr(binning),
+                P, R.value, maxc.value, nseg2, C, W, H, _ptr(background), _ptr(colors), _ptr(geom), _ptr(binning),
                 _ptr(img), _ptr(out_color), st), "gsr_forward_stage2_mt")
         if debug:
             torch.cuda.synchronize(dev)   # surface asynchronous faults here, like CHECK_CUDA(..., debug)
-    return R.value, out_color, radii, geom, binning, img, maxc.value, nseg.value
+    return R.value, out_color, radii, geom, binning, img, maxc.value, (nseg.value if need_backward else 0)
 
 
 def rasterize_gaussians_backward_native(background, means3D, radii, colors, scales, rotations, scale_modifier,
@@ -230,13 +232,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         if raster_settings.debug:
             cpu_args = cpu_deep_copy_tuple(args)   # copy them before they can be corrupted (ref :83-90)
             try:
-                out = rasterize_gaussians_native(*args)
+                out = rasterize_gaussians_native(*args, need_backward=any(ctx.needs_input_grad))
             except Exception as ex:
                 torch.save(cpu_args, "snapshot_fw.dump")
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                 raise ex
         else:
-            out = rasterize_gaussians_native(*args)
+            out = rasterize_gaussians_native(*args, need_backward=any(ctx.needs_input_grad))
         num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, _max_tile, num_segments = out
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered

@@ -73,7 +73,10 @@ int gsr_forward_stage1(int P, int D, int M, const float* means3D, const float* s
 /* Forward, second half: instance scatter into per-tile buckets, per-tile depth sort, alpha
  * blend.  Replaces rasterizer_impl.cu:283-335 (duplicateWithKeys, SortPairs,
  * identifyTileRanges, FORWARD::render = forward.cu:261-374).
- *   out_color [3,H,W] planar; binning scratch sized by gsr_binning_bytes(R, num_segments). */
+ *   out_color [3,H,W] planar; binning scratch sized by gsr_binning_bytes(R, num_segments).
+ *   FORWARD-ONLY renders (no gsr_backward will follow): pass -num_segments here (binning scratch still sized with
+ *   +num_segments): the per-segment snapshots the backward resumes from are not written.  num_segments = 0 also
+ *   renders forward-only, with a binning buffer sized by gsr_binning_bytes(R, 0). */
 int gsr_forward_stage2(int P, int R, int max_tile_instances, int num_segments, int W, int H, const float* background,
                        const float* colors_precomp, void* geom_buffer, void* binning_buffer, void* image_buffer,
                        float* out_color, gsr_stream_t stream);

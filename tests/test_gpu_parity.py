@@ -394,3 +394,35 @@ def test_hostile_inputs_neither_hang_nor_fault():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "devtools", "fuzz_inputs.py")], cwd=ROOT,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "FUZZ_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_forward_only_mode_skips_snapshots_but_not_pixels():
+    """Under torch.no_grad() (or when no input requires grad) stage 2 gets the negated segment count and writes no
+    per-segment snapshots; image and radii must be bit-identical to the differentiable call, and the C ABI refuses a
+    backward on such a forward."""
+    import ctypes
+    import torch
+    from gaustar_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib, scene
+    from gaustar_amd import rasterizer as R
+    rng = np.random.default_rng(12)
+    gs = scene.random_gaussians(5000, rng, scale_range=(0.03, 0.1), box=((-0.4, 0.4), (-0.3, 0.3), (-0.5, 0.5)))
+    gs.opacities[:] = rng.uniform(0.02, 0.2, (gs.P, 1)).astype(np.float32)      # lists span several segments
+    cam = scene.look_at_camera((0, 0, -4.0), (0, 0, 0), 128, 96, fovx=0.5, znear=0.01)
+    dev = torch.device("cuda:0")
+    t = lambda x, g=False: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev).requires_grad_(g)
+    s = GaussianRasterizationSettings(cam.H, cam.W, cam.tanfovx, cam.tanfovy, t(np.array([0.1, 0.2, 0.3])), 1.0, t(cam.viewmatrix),
+                                      t(cam.projmatrix), 0, t(cam.campos), False, False)
+    args = dict(means2D=torch.zeros(gs.P, 3, device=dev), colors_precomp=t(gs.colors_precomp), scales=t(gs.scales), rotations=t(gs.rotations))
+    img_g, rad_g = GaussianRasterizer(s)(means3D=t(gs.means3D, True), opacities=t(gs.opacities, True), **args)
+    with torch.no_grad():
+        img_n, rad_n = GaussianRasterizer(s)(means3D=t(gs.means3D), opacities=t(gs.opacities), **args)
+    assert torch.equal(img_g.detach(), img_n) and torch.equal(rad_g, rad_n)
+    e = torch.Tensor([])
+    out = R.rasterize_gaussians_native(s.bg, t(gs.means3D), t(gs.colors_precomp), t(gs.opacities), t(gs.scales), t(gs.rotations), 1.0, e,
+                                       s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, cam.H, cam.W, e, 0, s.campos, False, False,
+                                       need_backward=False)
+    assert out[0] > 0 and out[7] == 0 and torch.equal(out[1], img_n)
+    with pytest.raises(_lib.GsrError, match="forward-only"):
+        R.rasterize_gaussians_backward_native(s.bg, t(gs.means3D), out[2], t(gs.colors_precomp), t(gs.scales), t(gs.rotations), 1.0, e,
+                                              s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, torch.ones_like(img_n), e, 0, s.campos,
+                                              out[3], out[0], out[4], out[5], False, num_segments=0)
