@@ -441,16 +441,21 @@ blend_fwd_long_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, co
             Ln = part_last[pn];
         }
         const float Tn = ps.T * Ps;
-        if (__ballot(!ps.done && Tn < T_EPS) == 0ull) {   // nobody can terminate inside this segment
-            if (!ps.done) {
+        const bool term = !ps.done && Tn < T_EPS;          // this pixel can terminate inside the segment
+        const unsigned long long walkers = __ballot(term);
+        const bool was_done = ps.done;
+        if (!was_done && !term) {                           // everybody else takes the pre-reduced segment
 #pragma unroll
-                for (int ch = 0; ch < C; ch++) ps.Cc[ch] += ps.T * Cs[ch];
-                ps.T = Tn;
-                ps.last = Ls ? Ls : ps.last;
-            }
-        } else {
+            for (int ch = 0; ch < C; ch++) ps.Cc[ch] += ps.T * Cs[ch];
+            ps.T = Tn;
+            ps.last = Ls ? Ls : ps.last;
+        }
+        if (walkers != 0ull) {
+            // only the pixels that can terminate walk the batch: quadrants without one are culled away entirely
             const Fetched<C> cur = fetch_record<C>(fetch_id(base + lane, n, list), g0, g1, feats);
-            walk_batch<C, true>(ent, qi, cur, base, alive, lane, row, sx, sy, pxf, pyf, ps);
+            ps.done = !term;
+            walk_batch<C, true>(ent, qi, cur, base, walkers, lane, row, sx, sy, pxf, pyf, ps);
+            ps.done = term ? ps.done : was_done;
         }
     }
     if (inside) {
