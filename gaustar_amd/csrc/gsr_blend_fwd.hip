@@ -29,13 +29,13 @@
 // every 64-entry segment INDEPENDENTLY (one wave per segment and 8x8 block, like the backward's units) to the
 // per-pixel pair  P_s = prod (1 - alpha),  C_s = sum c alpha T_local  (T_local starts at 1) and the last contributing
 // position; the main kernel then steps through a long tile's segments in O(1) each:  C += T * C_s,  T *= P_s.
-// Termination stays exact: T can only fall below 1e-4 inside segment s if T * P_s < 1e-4, and then that one batch is
-// walked the ordinary way for the whole wave.  Pixels of the skipped segments see the same products in a different
+// Termination stays exact: T can only fall below 1e-4 inside segment s if T * P_s < 1e-4, and then the pixel walks that
+// one segment itself (see blend_fwd_long_kernel).  Pixels of the skipped segments see the same products in a different
 // association (T * (a * b) instead of (T * a) * b): ulp-level, far inside the 1e-4 parity bound.
-// Measured: the walk is needed in every segment in which ANY of a wave's 64 pixels terminates, and on an opaque surface
-// those are many -- with the threshold at 512..1 024 the path costs more than it saves on config C (0.166 vs 0.096 ms) and
-// B; it pays for close-up views with lists of thousands of entries (config D: 0.55 -> 0.40 ms), hence the default.  The
-// long tiles run on a helper stream, concurrently with the main kernel.
+// Measured (MI355X): config D (1 M Gaussians, lists up to 11 787 entries) forward 0.56 -> 0.32 ms with the default
+// threshold of 4 096.  Lower thresholds do not pay: config C's forward is throughput-bound, not bound by its longest tiles
+// (skipping every tile above 1 024 entries outright leaves the main kernel at 0.095 of 0.097 ms), so the pre-reduction is
+// pure extra work there (0.44 vs 0.39 ms per view at 1 024); at 2 048 config B's two 2 116-entry tiles cost more than they save.
 //
 // The kernel is a template over the number of colour channels C: 3 is the reference's NUM_CHANNELS
 // (cuda_rasterizer/config.h:15); 6 renders TWO targets that share geometry (GauSTAR's RGB + depth-as-colour
@@ -43,34 +43,8 @@
 // so channels 0-2 / 3-5 are bit-identical to two separate 3-channel renders.
 #include "gsr_internal.h"
 #include <cstdlib>
-#include <mutex>
 
 namespace gsr {
-
-// Helper stream + fork/join events for the long-tile path, one set per device, created on first use and kept for the
-// life of the process (like the profiler's event pool, the only other state the library holds).  GSR_FWD_SIDE_STREAM=0
-// keeps everything on the caller's stream.
-static bool fwd_side_stream(hipStream_t* side, hipEvent_t* fork, hipEvent_t* join)
-{
-    struct Side { hipStream_t s = nullptr; hipEvent_t f = nullptr, j = nullptr; bool ok = false, tried = false; };
-    static Side sides[64];
-    static std::mutex mu;
-    static const bool enabled = !(getenv("GSR_FWD_SIDE_STREAM") && getenv("GSR_FWD_SIDE_STREAM")[0] == '0');
-    if (!enabled) return false;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-    std::lock_guard<std::mutex> lk(mu);
-    Side& sd = sides[dev];
-    if (!sd.tried) {
-        sd.tried = true;
-        sd.ok = hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) == hipSuccess &&
-                hipEventCreateWithFlags(&sd.f, hipEventDisableTiming) == hipSuccess &&
-                hipEventCreateWithFlags(&sd.j, hipEventDisableTiming) == hipSuccess;
-    }
-    if (!sd.ok) return false;
-    *side = sd.s; *fork = sd.f; *join = sd.j;
-    return true;
-}
 
 template <int C>
 struct __attribute__((aligned(16))) Slot {   // 48 B (C = 3) / 64 B (C = 6) per fetched instance
@@ -271,7 +245,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
 
     const uint2 rg = ranges[tile];
     const uint32_t n = rg.y - rg.x;
-    if (n > skip_above) return;   // long tile: blend_fwd_long_kernel renders it (concurrently, on the helper stream)
+    if (n > skip_above) return;   // long tile: blend_fwd_long_kernel renders it
     const uint32_t unit0 = seg_off[tile];
     const uint32_t* list = point_list + rg.x;
     Slot<C>* ent = entries[wave];
@@ -386,6 +360,14 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
 
 // Long tiles: steps through the pre-reduced segments (see the file header); one workgroup = one tile, like the main
 // kernel, launched over the front of `order` where the longest lists sit.
+//
+// Termination.  A pixel can only fall below T = 1e-4 inside segment s if T * P_s < 1e-4.  Such a pixel is PARKED at the
+// start of s (its state frozen) while the others step on; when every pixel of the wave is done or parked, each parked
+// lane walks ITS OWN segment serially -- 64 entries, gathered per lane, the same per-pair arithmetic and order as
+// the batch walk (no culling is needed for correctness: a culled pair fails the alpha test anyway) -- all parked
+// lanes at once, each in a different segment.  A wave's 64 pixels terminate in up to 64 different segments; walking
+// a whole batch for the wave whenever one of them did made this path a loss on opaque surfaces.  In the rare case
+// that the exact walk does not terminate after all (T * P_s was within rounding of 1e-4), the lane steps on.
 template <int C>
 __global__ void __launch_bounds__(256)
 blend_fwd_long_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ order,
@@ -396,76 +378,118 @@ blend_fwd_long_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, co
                       const float4* __restrict__ part, const uint32_t* __restrict__ part_last)
 {
     constexpr int SV = snap_vecs(C);
-    __shared__ Slot<C> entries[4][64 + 1];
-    __shared__ __attribute__((aligned(4))) uint8_t qidx[4][4][QCAP];
     const int tile = (int)order[blockIdx.x];
     const uint2 rg = ranges[tile];
     const uint32_t n = rg.y - rg.x;
     if (n <= long_thr) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row = lane >> 4;
     const int tx = tile % gx, ty = tile / gx;
     const int sx = tx * TILE + (wave & 1) * SUB, sy = ty * TILE + (wave >> 1) * SUB;
-    const int px = sx + (row & 1) * 4 + (lane & 3), py = sy + (row >> 1) * 4 + ((lane >> 2) & 3);
+    const int px = sx + (lane & 7), py = sy + (lane >> 3);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
     const int pix_in_tile = 16 * (py - ty * TILE) + (px - tx * TILE);
     const uint32_t unit0 = seg_off[tile];
     const uint32_t* list = point_list + rg.x;
-    Slot<C>* ent = entries[wave];
-    uint8_t (*qi)[QCAP] = qidx[wave];
-    init_neutral<C>(ent, lane);
-    PixState<C> ps;
-    ps.T = 1.0f; ps.last = 0; ps.done = !inside;
-#pragma unroll
-    for (int ch = 0; ch < C; ch++) ps.Cc[ch] = 0.f;
-
-    float Pn = 1.f, Cn[C];
-    uint32_t Ln = 0;
+    const uint32_t n_seg = (n + 63u) / 64u;
     const size_t pbase = (size_t)unit0 * 256 + pix_in_tile;
-    load_snapshot<C>(part + pbase * SV, Pn, Cn);
-    Ln = part_last[pbase];
-    for (uint32_t base = 0; base < n; base += 64) {
-        const unsigned long long alive = __ballot(!ps.done);
-        if (alive == 0ull) break;
-        if (snap != nullptr && base != 0 && !ps.done)
-            store_snapshot<C>(snap + ((size_t)(unit0 + base / SEG) * 256 + pix_in_tile) * SV, ps.T, ps.Cc);
-        const float Ps = Pn;
-        float Cs[C];
+
+    float T = 1.0f, Cc[C];
 #pragma unroll
-        for (int ch = 0; ch < C; ch++) Cs[ch] = Cn[ch];
-        const uint32_t Ls = Ln;
-        if (base + 64 < n) {   // next segment's record is requested before this one is consumed
-            const size_t pn = pbase + (size_t)(base / 64 + 1) * 256;
-            load_snapshot<C>(part + pn * SV, Pn, Cn);
-            Ln = part_last[pn];
-        }
-        const float Tn = ps.T * Ps;
-        const bool term = !ps.done && Tn < T_EPS;          // this pixel can terminate inside the segment
-        const unsigned long long walkers = __ballot(term);
-        const bool was_done = ps.done;
-        if (!was_done && !term) {                           // everybody else takes the pre-reduced segment
+    for (int ch = 0; ch < C; ch++) Cc[ch] = 0.f;
+    uint32_t last = 0;
+    bool done = !inside;
+    uint32_t seg = 0;                 // next segment this pixel has to consume
+    while (true) {
+        // ---- step through pre-reduced segments until the pixel is done, parked or out of segments
+        bool parked = false;
+        {
+            float Pn = 1.f, Cn[C];
+            uint32_t Ln = 0;
 #pragma unroll
-            for (int ch = 0; ch < C; ch++) ps.Cc[ch] += ps.T * Cs[ch];
-            ps.T = Tn;
-            ps.last = Ls ? Ls : ps.last;
+            for (int ch = 0; ch < C; ch++) Cn[ch] = 0.f;
+            // the wave advances in lock step over segment indices; lanes join at their own `seg`
+            uint32_t s_lo = done ? n_seg : seg;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) s_lo = min(s_lo, (uint32_t)__shfl_xor((int)s_lo, d, 64));
+            if (s_lo < n_seg) {
+                load_snapshot<C>(part + (pbase + (size_t)s_lo * 256) * SV, Pn, Cn);
+                Ln = part_last[pbase + (size_t)s_lo * 256];
+            }
+            for (uint32_t s = s_lo; s < n_seg; s++) {
+                const bool active = !done && !parked && seg == s;
+                if (__ballot(!done && !parked) == 0ull) break;
+                if (snap != nullptr && s != 0 && active)
+                    store_snapshot<C>(snap + ((size_t)(unit0 + s) * 256 + pix_in_tile) * SV, T, Cc);
+                const float Ps = Pn;
+                float Cs[C];
+#pragma unroll
+                for (int ch = 0; ch < C; ch++) Cs[ch] = Cn[ch];
+                const uint32_t Ls = Ln;
+                if (s + 1 < n_seg) {   // next segment's record is requested before this one is consumed
+                    load_snapshot<C>(part + (pbase + (size_t)(s + 1) * 256) * SV, Pn, Cn);
+                    Ln = part_last[pbase + (size_t)(s + 1) * 256];
+                }
+                if (active) {
+                    const float Tn = T * Ps;
+                    if (Tn < T_EPS) {
+                        parked = true;                      // may terminate inside segment s: walk it exactly below
+                    } else {
+#pragma unroll
+                        for (int ch = 0; ch < C; ch++) Cc[ch] += T * Cs[ch];
+                        T = Tn;
+                        last = Ls ? Ls : last;
+                        seg = s + 1;
+                    }
+                }
+            }
+            if (!done && !parked && seg >= n_seg) done = true;   // consumed the whole list without terminating
         }
-        if (walkers != 0ull) {
-            // only the pixels that can terminate walk the batch: quadrants without one are culled away entirely
-            const Fetched<C> cur = fetch_record<C>(fetch_id(base + lane, n, list), g0, g1, feats);
-            ps.done = !term;
-            walk_batch<C, true>(ent, qi, cur, base, walkers, lane, row, sx, sy, pxf, pyf, ps);
-            ps.done = term ? ps.done : was_done;
+        if (__ballot(parked) == 0ull) break;
+        // ---- every parked lane walks its own segment [64 seg, 64 seg + 64) serially; two-stage gather prefetch
+        {
+            const uint32_t base = seg * 64u;
+            const uint32_t cnt = parked ? min(64u, n - base) : 0u;
+            uint32_t cmax = cnt;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, d, 64));
+            Fetched<C> nxt = fetch_record<C>(cnt > 0u ? list[base] : 0xffffffffu, g0, g1, feats);
+            uint32_t gid_nxt = cnt > 1u ? list[base + 1] : 0xffffffffu;
+            for (uint32_t k = 0; k < cmax; k++) {
+                const Fetched<C> cur = nxt;
+                nxt = fetch_record<C>(gid_nxt, g0, g1, feats);
+                gid_nxt = k + 2 < cnt ? list[base + k + 2] : 0xffffffffu;
+                if (k < cnt && !done) {
+                    const float dx = cur.a.x - pxf, dy = cur.a.y - pyf;
+                    const float power = pair_power(cur.a.z, cur.a.w, cur.b.x, dx, dy);
+                    const float alpha = fminf(ALPHA_MAX, cur.b.y * __expf(power));
+                    if (power <= 0.0f && alpha >= ALPHA_MIN) {
+                        const float test_T = T * (1.0f - alpha);
+                        if (test_T < T_EPS) {
+                            done = true;
+                        } else {
+                            const float w = alpha * T;
+#pragma unroll
+                            for (int ch = 0; ch < C; ch++) Cc[ch] += cur.col[ch] * w;
+                            T = test_T;
+                            last = base + k + 1u;
+                        }
+                    }
+                }
+            }
+            if (parked) seg = seg + 1;          // if it did not terminate after all, it continues with the next segment
+            if (parked && !done && seg >= n_seg) done = true;
         }
+        if (__ballot(!done) == 0ull) break;
     }
     if (inside) {
         const size_t pix = (size_t)W * py + px;
         const size_t HW = (size_t)H * W;
-        final_T[pix] = ps.T;
-        n_contrib[pix] = ps.last;
+        final_T[pix] = T;
+        n_contrib[pix] = last;
 #pragma unroll
-        for (int ch = 0; ch < C; ch++) out_color[ch * HW + pix] = ps.Cc[ch] + ps.T * bg[ch];
-        if (snap != nullptr) store_snapshot<C>(snap + ((size_t)unit0 * 256 + pix_in_tile) * SV, ps.T, ps.Cc);   // n > SEG always here
+        for (int ch = 0; ch < C; ch++) out_color[ch * HW + pix] = Cc[ch] + T * bg[ch];
+        if (snap != nullptr) store_snapshot<C>(snap + ((size_t)unit0 * 256 + pix_in_tile) * SV, T, Cc);   // n > SEG always here
     }
 }
 
@@ -476,33 +500,20 @@ static void launch_fwd_c(int W, int H, int R, int U, uint32_t max_count, const f
     const Tiles t = tiles_of(W, H);
     static const uint32_t long_thr = getenv("GSR_FWD_LONG") ? (uint32_t)atoi(getenv("GSR_FWD_LONG")) : 4096u;
     const bool use_long = U > 0 && b.part != nullptr && max_count > long_thr && long_thr >= (uint32_t)SEG;
-    hipStream_t side = st;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // the helper stream and its two events are shared by every host thread rendering on this device: the whole
-    // fork .. join enqueue sequence is atomic (a wait binds to the record that precedes it at enqueue time)
-    static std::mutex enqueue_mu;
-    std::unique_lock<std::mutex> lk(enqueue_mu, std::defer_lock);
-    if (use_long) lk.lock();
-    if (use_long && fwd_side_stream(&side, &ev_fork, &ev_join)) {
-        // fork: the long tiles are reduced and rendered on a helper stream while the main kernel renders the rest
-        (void)hipEventRecord(ev_fork, st);
-        (void)hipStreamWaitEvent(side, ev_fork, 0);
-    }
+    // Everything stays on the caller's stream.  Running the long tiles on a helper stream beside the main kernel was
+    // measured and rejected: once a second hardware queue is in use, EVERY later step of the process got ~0.16 ms slower
+    // on this stack (0.386 -> 0.55 ms per config-C view after a single use), far more than the overlap ever saved.
     if (use_long) {
-        blend_fwd_partial_kernel<C><<<4 * U, 64, 0, side>>>(W, H, t.gx, long_thr, im.ranges, im.seg_off, b.unit_tile, b.point_list,
+        blend_fwd_partial_kernel<C><<<4 * U, 64, 0, st>>>(W, H, t.gx, long_thr, im.ranges, im.seg_off, b.unit_tile, b.point_list,
                                                            g.g0, g.g1, feats, b.part, b.part_last);
         // the long tiles sit at the front of `order` (front_of_order); the kernel checks each tile's length itself
-        blend_fwd_long_kernel<C><<<long_thr >= 2017u ? front_of_order(R, t.T) : t.T, 256, 0, side>>>(W, H, t.gx, im.ranges, im.order, b.point_list, g.g0, g.g1, feats, bg,
-                                                       out_color, im.final_T, im.n_contrib, im.seg_off, b.snap, long_thr, b.part,
-                                                       b.part_last);
+        blend_fwd_long_kernel<C><<<long_thr >= 2017u ? front_of_order(R, t.T) : t.T, 256, 0, st>>>(
+            W, H, t.gx, im.ranges, im.order, b.point_list, g.g0, g.g1, feats, bg, out_color, im.final_T, im.n_contrib, im.seg_off,
+            b.snap, long_thr, b.part, b.part_last);
     }
     blend_fwd_kernel<C><<<t.T, 256, 0, st>>>(W, H, t.gx, im.ranges, im.order, b.point_list, g.g0, g.g1, feats, bg, out_color,
                                              im.final_T, im.n_contrib, im.seg_off, b.snap, use_long ? long_thr : 0xffffffffu,
                                              g_trace);
-    if (use_long && side != st) {   // join
-        (void)hipEventRecord(ev_join, side);
-        (void)hipStreamWaitEvent(st, ev_join, 0);
-    }
 }
 
 void launch_blend_fwd(int C, int W, int H, int R, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g,
