@@ -500,9 +500,9 @@ static void launch_fwd_c(int W, int H, int R, int U, uint32_t max_count, const f
     const Tiles t = tiles_of(W, H);
     static const uint32_t long_thr = getenv("GSR_FWD_LONG") ? (uint32_t)atoi(getenv("GSR_FWD_LONG")) : 4096u;
     const bool use_long = U > 0 && b.part != nullptr && max_count > long_thr && long_thr >= (uint32_t)SEG;
-    // Everything stays on the caller's stream.  Running the long tiles on a helper stream beside the main kernel was
-    // measured and rejected: once a second hardware queue is in use, EVERY later step of the process got ~0.16 ms slower
-    // on this stack (0.386 -> 0.55 ms per config-C view after a single use), far more than the overlap ever saved.
+    // Everything stays on the caller's stream.  Running the long tiles on a library-owned helper stream (fork / join
+    // events) beside the main kernel was measured and rejected: after a single use EVERY later step of the process was
+    // ~0.16 ms slower (0.386 -> 0.55 ms per config-C view), far more than the overlap ever saved.
     if (use_long) {
         blend_fwd_partial_kernel<C><<<4 * U, 64, 0, st>>>(W, H, t.gx, long_thr, im.ranges, im.seg_off, b.unit_tile, b.point_list,
                                                            g.g0, g.g1, feats, b.part, b.part_last);
