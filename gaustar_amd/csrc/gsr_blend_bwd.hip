@@ -163,6 +163,7 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
 
     // Per-pixel start state at the far end of the segment.
     float T = T_final;
+    const float tf_bg = T_final * bg_dot_dpixel;
     // acc = colour composited BEHIND the current list position as seen from it (the reference's accum_rec).  The
     // reference folds contributor i into accum_rec lazily, when it reaches contributor i-1 (last_alpha / last_color,
     // backward.cu:505-520); folding it right after use is the same arithmetic on the same operands one step earlier
@@ -299,19 +300,20 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                 if (__ballot(live) != 0ull) {
                     touched |= 1ull << j;
                     if (live) {
+                        // accum_rec' = alpha c + (1 - alpha) accum_rec written as accum_rec + alpha (c - accum_rec):
+                        // the difference is needed for dL_dalpha anyway (one fma per channel instead of mul + fma);
+                        // T_final * bg . dL_dpix is a per-pixel constant.  14 vector instructions per live pair.
                         const float rinv = __builtin_amdgcn_rcpf(1.f - alpha);
                         T = T * rinv;
                         w = alpha * T;
-                        const float one_minus = 1.f - alpha;
-                        float dL_dalpha = 0.f;
+                        float s = 0.f;
 #pragma unroll
                         for (int ch = 0; ch < C; ch++) {
-                            dL_dalpha += (cc[ch] - acc[ch]) * dp[ch];
-                            acc[ch] = alpha * cc[ch] + one_minus * acc[ch];
+                            const float d = cc[ch] - acc[ch];
+                            s = __builtin_fmaf(d, dp[ch], s);
+                            acc[ch] = __builtin_fmaf(alpha, d, acc[ch]);
                         }
-                        dL_dalpha *= T;
-                        dL_dalpha -= (T_final * rinv) * bg_dot_dpixel;
-                        r = G * dL_dalpha;
+                        r = G * __builtin_fmaf(s, T, -(rinv * tf_bg));
                     }
                 }
             }
