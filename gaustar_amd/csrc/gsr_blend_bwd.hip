@@ -44,7 +44,7 @@ namespace gsr {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // LDS queue slot of one fetched instance, as floats:
-//   [0] x  [1] y  [2] gaussian id (uint bits)  [3] conic_a  [4] conic_b  [5] conic_c  [6] opacity
+//   [0] x  [1] y  [2] gaussian id (uint bits)  [3..5] conic a, b, c in the exp2 domain (conic_to_exp2)  [6] opacity
 //   [7] list position (uint bits)  [8 ..] colour channels            -> 12 floats (C = 3), 16 floats (C = 6)
 // Once the instance's w and r are out only x, y and the id are still needed: the 6 + C moments overwrite
 // floats [3 .. 8 + C] (no separate moment table -> more resident waves).
@@ -259,8 +259,10 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     if (keep) {
         const int slot = __popcll(m & ((1ull << lane) - 1ull));
         float4* qs = reinterpret_cast<float4*>(&qf[slot * SF]);
-        qs[0] = make_float4(cur.a.x, cur.a.y, __uint_as_float(cur.gid), cur.a.z);
-        qs[1] = make_float4(cur.a.w, cur.b.x, cur.b.y, __uint_as_float((uint32_t)k));
+        float a2 = cur.a.z, b2 = cur.a.w, c2 = cur.b.x;
+        conic_to_exp2(a2, b2, c2);   // exp2-domain conic, the same roundings as the forward's slots
+        qs[0] = make_float4(cur.a.x, cur.a.y, __uint_as_float(cur.gid), a2);
+        qs[1] = make_float4(b2, c2, cur.b.y, __uint_as_float((uint32_t)k));
 #pragma unroll
         for (int v = 2; v < L::VECS; v++) {
             const int c0 = 4 * (v - 2);
@@ -293,8 +295,8 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                 }
                 const int pos = (int)__float_as_uint(B.w);
                 const float dx = A.x - pxf, dy = A.y - pyf;
-                const float power = pair_power(A.w, B.x, B.y, dx, dy);
-                const float G = __expf(power);
+                const float power = pair_exp2_arg(A.w, B.x, B.y, dx, dy);
+                const float G = __builtin_amdgcn_exp2f(power);
                 const float alpha = fminf(ALPHA_MAX, B.z * G);
                 const bool live = pos < my_lim && power <= 0.0f && alpha >= ALPHA_MIN;
                 if (__ballot(live) != 0ull) {

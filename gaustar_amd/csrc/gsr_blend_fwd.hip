@@ -48,8 +48,8 @@ namespace gsr {
 
 template <int C>
 struct __attribute__((aligned(16))) Slot {   // 48 B (C = 3) / 64 B (C = 6) per fetched instance
-    float4 a;                        // x, y, conic_a, conic_b
-    float4 b;                        // conic_c, opacity, list position + 1 (as uint bits), -
+    float4 a;                        // x, y, conic a, b (exp2 domain, see conic_to_exp2)
+    float4 b;                        // conic c (exp2 domain), opacity, list position + 1 (as uint bits), -
     float col[(C + 3) / 4 * 4];      // colour channels
 };
 
@@ -100,8 +100,12 @@ __device__ __forceinline__ void walk_batch(Slot<C>* __restrict__ ent, uint8_t (*
     constexpr int CV = (C + 3) / 4;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const uint32_t k = base + lane;
-    ent[lane].a = cur.a;
-    ent[lane].b = make_float4(cur.b.x, cur.b.y, __uint_as_float(k + 1), 0.f);
+    {
+        float a2 = cur.a.z, b2 = cur.a.w, c2 = cur.b.x;
+        conic_to_exp2(a2, b2, c2);
+        ent[lane].a = make_float4(cur.a.x, cur.a.y, a2, b2);
+        ent[lane].b = make_float4(c2, cur.b.y, __uint_as_float(k + 1), 0.f);
+    }
 #pragma unroll
     for (int v = 0; v < CV; v++)
         reinterpret_cast<float4*>(ent[lane].col)[v] =
@@ -139,8 +143,8 @@ __device__ __forceinline__ void walk_batch(Slot<C>* __restrict__ ent, uint8_t (*
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const float dx = A[u].x - pxf, dy = A[u].y - pyf;
-            const float power = pair_power(A[u].z, A[u].w, B[u].x, dx, dy);
-            alpha[u] = fminf(ALPHA_MAX, B[u].y * __expf(power));
+            const float power = pair_exp2_arg(A[u].z, A[u].w, B[u].x, dx, dy);   // exp2 domain, see conic_to_exp2
+            alpha[u] = fminf(ALPHA_MAX, B[u].y * __builtin_amdgcn_exp2f(power));
             ok[u] = power <= 0.0f && alpha[u] >= ALPHA_MIN;
         }
 #pragma unroll
@@ -279,8 +283,12 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         nxt = fetch_record<C>(gid_nxt, g0, g1, feats);      // records of batch +1 (ids arrived during the last batch)
         gid_nxt = fetch_id(base + 128 + lane, n, list);     // ids of batch +2
         const uint32_t k = base + lane;
-        ent[lane].a = cur.a;
-        ent[lane].b = make_float4(cur.b.x, cur.b.y, __uint_as_float(k + 1), 0.f);
+        {
+            float a2 = cur.a.z, b2 = cur.a.w, c2 = cur.b.x;
+            conic_to_exp2(a2, b2, c2);
+            ent[lane].a = make_float4(cur.a.x, cur.a.y, a2, b2);
+            ent[lane].b = make_float4(c2, cur.b.y, __uint_as_float(k + 1), 0.f);
+        }
 #pragma unroll
         for (int v = 0; v < CV; v++)
             reinterpret_cast<float4*>(ent[lane].col)[v] =
@@ -318,8 +326,8 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const float dx = A[u].x - pxf, dy = A[u].y - pyf;
-                const float power = pair_power(A[u].z, A[u].w, B[u].x, dx, dy);
-                alpha[u] = fminf(ALPHA_MAX, B[u].y * __expf(power));
+                const float power = pair_exp2_arg(A[u].z, A[u].w, B[u].x, dx, dy);   // exp2 domain, see conic_to_exp2
+                alpha[u] = fminf(ALPHA_MAX, B[u].y * __builtin_amdgcn_exp2f(power));
                 ok[u] = power <= 0.0f && alpha[u] >= ALPHA_MIN;
             }
 #pragma unroll
@@ -461,8 +469,10 @@ blend_fwd_long_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, co
                 gid_nxt = k + 2 < cnt ? list[base + k + 2] : 0xffffffffu;
                 if (k < cnt && !done) {
                     const float dx = cur.a.x - pxf, dy = cur.a.y - pyf;
-                    const float power = pair_power(cur.a.z, cur.a.w, cur.b.x, dx, dy);
-                    const float alpha = fminf(ALPHA_MAX, cur.b.y * __expf(power));
+                    float a2 = cur.a.z, b2 = cur.a.w, c2 = cur.b.x;
+                    conic_to_exp2(a2, b2, c2);   // the same roundings as the batch walk's queued slots
+                    const float power = pair_exp2_arg(a2, b2, c2, dx, dy);
+                    const float alpha = fminf(ALPHA_MAX, cur.b.y * __builtin_amdgcn_exp2f(power));
                     if (power <= 0.0f && alpha >= ALPHA_MIN) {
                         const float test_T = T * (1.0f - alpha);
                         if (test_T < T_EPS) {

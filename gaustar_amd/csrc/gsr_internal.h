@@ -442,14 +442,24 @@ __device__ __forceinline__ void sh_stage_store(const float* __restrict__ lds, fl
     }
 }
 
-// Gaussian exponent of one (pixel, splat) pair: -0.5*(a dx^2 + c dy^2) - b dx dy (forward.cu:334).
-// Written with explicit fused steps and contraction disabled so that the forward and the backward
-// blend kernels round identically (they must agree on every alpha >= 1/255 decision).
-__device__ __forceinline__ float pair_power(float ca, float cb, float cc, float dx, float dy)
+// Gaussian exponent of one (pixel, splat) pair: power = -0.5*(a dx^2 + c dy^2) - b dx dy (forward.cu:334), evaluated in
+// the exp2 domain: the kernels scale the conic ONCE per queued instance (conic_to_exp2) by -0.5*log2(e) / -log2(e), so a
+// pair costs two multiplies and two fused steps and its result feeds v_exp_f32 directly (exp(power) = exp2(power*log2 e);
+// the reference's __expf is that multiply followed by the same instruction).  sign(result) = sign(power), so the
+// reference's `power > 0` skip reads the same.  Explicit fused steps with contraction disabled: the forward and the
+// backward blend kernels must round identically (they have to agree on every alpha >= 1/255 decision).
+__device__ __forceinline__ void conic_to_exp2(float& ca, float& cb, float& cc)
 {
 #pragma clang fp contract(off)
-    const float q = __builtin_fmaf(cc * dy, dy, (ca * dx) * dx);
-    return __builtin_fmaf(-(cb * dx), dy, -0.5f * q);
+    ca *= -0.72134752044448170368f;   // -0.5 * log2(e)
+    cb *= -1.44269504088896340736f;   // -log2(e)
+    cc *= -0.72134752044448170368f;
+}
+__device__ __forceinline__ float pair_exp2_arg(float a2, float b2, float c2, float dx, float dy)
+{
+#pragma clang fp contract(off)
+    const float u = __builtin_fmaf(a2, dx, b2 * dy);
+    return __builtin_fmaf(c2 * dy, dy, u * dx);
 }
 
 // Exact culling primitive: min over the rectangle [X0,X1]x[Y0,Y1] (coordinates relative to the splat
