@@ -16,7 +16,7 @@ namespace gsr { uint64_t* g_trace = nullptr; }
 
 namespace {
 thread_local std::string g_err;
-thread_local uint32_t* g_pinned = nullptr;   // 16-byte pinned landing pad for the stage-1 read-back
+thread_local uint32_t* g_pinned = nullptr;   // pinned, device-mapped landing pad for the stage-1 totals (written by tile_scan)
 
 // ---- optional per-kernel timing (gsr_profile_*): HIP events on the launch stream around every stage.
 enum Stage { ST_PREPROCESS = 0, ST_TILE_SCAN, ST_SCATTER, ST_TILE_SORT, ST_BLEND_FWD, ST_ZERO_FILL, ST_BLEND_BWD,
@@ -139,13 +139,14 @@ int gsr_forward_stage1(int P, int D, int M, const float* means3D, const float* s
         }
         GSR_CHECK_LAUNCH("preprocess_kernel");
     }
+    // 16-byte pinned landing pad, mapped into the device's address space: tile_scan stores the totals into it directly
+    if (!g_pinned)
+        GSR_CHECK(hipHostMalloc((void**)&g_pinned, 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
     {
         Scope sc(ST_TILE_SCAN, st);
-        launch_tile_scan(im, t.T, st);
+        launch_tile_scan(im, t.T, g_pinned, st);
     }
     GSR_CHECK_LAUNCH("tile_scan_kernel");
-    if (!g_pinned) GSR_CHECK(hipHostMalloc((void**)&g_pinned, 64, hipHostMallocDefault));
-    GSR_CHECK(hipMemcpyAsync(g_pinned, im.totals, 16, hipMemcpyDeviceToHost, st));
     GSR_CHECK(hipStreamSynchronize(st));   // the forward's single host sync (cf. rasterizer_impl.cu:281)
     *num_rendered = (int)g_pinned[0];
     *max_tile_instances = (int)g_pinned[1];
