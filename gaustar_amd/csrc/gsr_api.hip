@@ -4,6 +4,7 @@
 #include "../../include/gsr.h"
 #include "gsr_internal.h"
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -16,6 +17,7 @@ namespace gsr { uint64_t* g_trace = nullptr; }
 
 namespace {
 thread_local std::string g_err;
+thread_local uint32_t g_pinned_seq = 0;
 thread_local uint32_t* g_pinned = nullptr;   // pinned, device-mapped landing pad for the stage-1 totals (written by tile_scan)
 
 // ---- optional per-kernel timing (gsr_profile_*): HIP events on the launch stream around every stage.
@@ -139,15 +141,35 @@ int gsr_forward_stage1(int P, int D, int M, const float* means3D, const float* s
         }
         GSR_CHECK_LAUNCH("preprocess_kernel");
     }
-    // 16-byte pinned landing pad, mapped into the device's address space: tile_scan stores the totals into it directly
-    if (!g_pinned)
+    // Pinned landing pad, mapped into the device's address space: tile_scan stores the four totals and then this call's
+    // sequence number into it.  The host polls the sequence word instead of blocking in hipStreamSynchronize (whose
+    // interrupt wake-up costs tens of microseconds of idle GPU per view); every few thousand polls it asks the stream
+    // whether it finished or faulted, so a failed kernel ends the wait with its error.  GSR_SYNC_SPIN=0 -> plain sync.
+    if (!g_pinned) {
         GSR_CHECK(hipHostMalloc((void**)&g_pinned, 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
+        memset(g_pinned, 0, 64);
+    }
+    static const bool spin = !(getenv("GSR_SYNC_SPIN") && atoi(getenv("GSR_SYNC_SPIN")) == 0);
+    const uint32_t seq = ++g_pinned_seq ? g_pinned_seq : ++g_pinned_seq;   // never 0 (the pad's initial value)
     {
         Scope sc(ST_TILE_SCAN, st);
-        launch_tile_scan(im, t.T, g_pinned, st);
+        launch_tile_scan(im, t.T, g_pinned, seq, st);
     }
     GSR_CHECK_LAUNCH("tile_scan_kernel");
-    GSR_CHECK(hipStreamSynchronize(st));   // the forward's single host sync (cf. rasterizer_impl.cu:281)
+    if (spin) {
+        const volatile uint32_t* flag = g_pinned + 4;
+        for (uint32_t polls = 1; *flag != seq; polls++) {
+            if ((polls & 4095u) == 0u) {
+                const hipError_t q = hipStreamQuery(st);
+                if (q == hipSuccess) break;              // kernel retired: its stores are visible
+                if (q != hipErrorNotReady) GSR_CHECK(q);   // a fault surfaces here
+            }
+            __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    } else {
+        GSR_CHECK(hipStreamSynchronize(st));   // the forward's single host sync (cf. rasterizer_impl.cu:281)
+    }
     *num_rendered = (int)g_pinned[0];
     *max_tile_instances = (int)g_pinned[1];
     *num_segments = (int)g_pinned[3];

@@ -43,8 +43,8 @@ static_assert(NHIST <= 2048 && NHIST % 2 == 0, "two histogram entries per thread
 template <int PER>
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges,
-                 uint32_t* __restrict__ totals, uint32_t* __restrict__ host_totals, uint32_t* __restrict__ order,
-                 uint32_t* __restrict__ seg_off)
+                 uint32_t* __restrict__ totals, uint32_t* __restrict__ host_totals, uint32_t host_seq,
+                 uint32_t* __restrict__ order, uint32_t* __restrict__ seg_off)
 {
     static_assert((NSHARD & (NSHARD - 1)) == 0, "shard = workgroup index & (NSHARD - 1)");
     __shared__ uint32_t wave_sum[16];
@@ -170,10 +170,14 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
         totals[1] = gmax;
         totals[2] = (uint32_t)T - empty;
         totals[3] = total_seg;
-        // the host's copy goes straight into its pinned, device-mapped landing pad (visible once the stream is
-        // synchronised): no separate device-to-host copy (a 5 us blit kernel plus its dispatch) in front of the sync
-        if (host_totals)
+        // The host's copy goes straight into its pinned, device-mapped landing pad -- no separate device-to-host copy
+        // (a 5 us blit kernel plus its dispatch) -- followed by the call's sequence number with system-scope release:
+        // the host polls that word (gsr_forward_stage1) and starts launching stage 2 while this kernel still builds
+        // `order`; stage 2 is stream-ordered behind this kernel either way.
+        if (host_totals) {
             *reinterpret_cast<uint4*>(host_totals) = make_uint4(total, gmax, (uint32_t)T - empty, total_seg);
+            __hip_atomic_store(&host_totals[4], host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         seg_off[T] = total_seg;
     }
     // exclusive prefix over the flattened [bucket][copy] histogram (in place): two entries per thread
@@ -210,12 +214,12 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
     }
 }
 
-void launch_tile_scan(ImageState im, int T, uint32_t* host_totals, hipStream_t st)
+void launch_tile_scan(ImageState im, int T, uint32_t* host_totals, uint32_t host_seq, hipStream_t st)
 {
     if (T <= 8 * 1024)          // up to 1920x1088: counts stay in registers
-        tile_scan_kernel<8><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.totals, host_totals, im.order, im.seg_off);
+        tile_scan_kernel<8><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.totals, host_totals, host_seq, im.order, im.seg_off);
     else                        // any larger grid (gsr_forward_stage1 caps T at 262 144 = 8k x 8k)
-        tile_scan_kernel<0><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.totals, host_totals, im.order, im.seg_off);
+        tile_scan_kernel<0><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.totals, host_totals, host_seq, im.order, im.seg_off);
 }
 
 // One thread per Gaussian: claim a slot in every reachable tile's bucket and store the sort key.  Walks exactly

@@ -167,7 +167,7 @@ void launch_preprocess(int P, int D, int M, const float* means3D, const float* s
                        const float* cov3D_precomp, const float* view, const float* proj, const float* campos, int W,
                        int H, float tan_fovx, float tan_fovy, int* radii, GeomState g, ImageState im,
                        hipStream_t st);
-void launch_tile_scan(ImageState im, int T, uint32_t* host_totals, hipStream_t st);
+void launch_tile_scan(ImageState im, int T, uint32_t* host_totals, uint32_t host_seq, hipStream_t st);
 void launch_scatter(int P, int W, int H, GeomState g, ImageState im, BinState b, hipStream_t st);
 void launch_tile_sort(int W, int H, int R, uint32_t max_count, ImageState im, BinState b, hipStream_t st);
 // Launch positions [0, front_of_order(R, T)) of `order` hold every tile with 2 017 or more entries: they all fall into
