@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 
 using namespace gsr;
@@ -157,12 +158,16 @@ int gsr_forward_stage1(int P, int D, int M, const float* means3D, const float* s
     }
     GSR_CHECK_LAUNCH("tile_scan_kernel");
     if (spin) {
+        // Normal waits are far below a millisecond and touch nothing but the pad.  The stream is only consulted (did it
+        // finish or fault?) once a wait has lasted 2 ms, then every 2 ms: hipStreamQuery takes runtime locks.
         const volatile uint32_t* flag = g_pinned + 4;
+        auto next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
         for (uint32_t polls = 1; *flag != seq; polls++) {
-            if ((polls & 4095u) == 0u) {
+            if ((polls & 1023u) == 0u && std::chrono::steady_clock::now() >= next_query) {
                 const hipError_t q = hipStreamQuery(st);
                 if (q == hipSuccess) break;              // kernel retired: its stores are visible
                 if (q != hipErrorNotReady) GSR_CHECK(q);   // a fault surfaces here
+                next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
             }
             __builtin_ia32_pause();
         }

@@ -56,6 +56,13 @@ struct __attribute__((aligned(16))) Slot {   // 48 B (C = 3) / 64 B (C = 6) per 
 template <int C>
 struct Fetched { float4 a, b; float col[C]; };
 
+// LDS byte address -> pointer into the LDS address space
+template <int C>
+__device__ __forceinline__ const Slot<C>* lds_slot(uint32_t addr)
+{
+    return (const Slot<C>*)(const __attribute__((address_space(3))) Slot<C>*)(uintptr_t)addr;
+}
+
 // Two-stage software pipeline over the dependent gather (list -> id -> records): ids are fetched two batches
 // ahead, records one batch ahead, so neither load latency sits on the per-batch critical path.
 __device__ __forceinline__ uint32_t fetch_id(uint32_t k, uint32_t n, const uint32_t* __restrict__ list)
@@ -236,7 +243,9 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     constexpr int SV = snap_vecs(C);
     constexpr int CV = (C + 3) / 4;                                   // float4s of colour per slot
     __shared__ Slot<C> entries[4][64 + 1];                            // [wave][batch lane]; slot 64 = neutral
-    __shared__ __attribute__((aligned(4))) uint8_t qidx[4][4][QCAP];  // [wave][quadrant][queue position]
+    // [wave][quadrant][queue position] -> LDS byte address of the queued slot (absolute, so a queue word feeds
+    // ds_read directly: one extract per entry instead of extract + multiply-add)
+    __shared__ __attribute__((aligned(8))) uint16_t qidx[4][4][QCAP];
     const int tile = (int)order[blockIdx.x];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = lane >> 4;                                        // DPP row = quadrant
@@ -253,7 +262,11 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     const uint32_t unit0 = seg_off[tile];
     const uint32_t* list = point_list + rg.x;
     Slot<C>* ent = entries[wave];
-    uint8_t (*qi)[QCAP] = qidx[wave];
+    uint16_t (*qi)[QCAP] = qidx[wave];
+    const uint32_t ent_lds = (uint32_t)(uintptr_t)ent;                       // LDS byte address of this wave's slots
+    const uint16_t my_slot = (uint16_t)(ent_lds + lane * (uint32_t)sizeof(Slot<C>));
+    const uint32_t neutral = ent_lds + 64u * (uint32_t)sizeof(Slot<C>);
+    const uint2 neutral4 = make_uint2(neutral * 0x10001u, neutral * 0x10001u);
 
     if (lane == 0) {   // neutral instance: opacity 0 never passes the alpha test
         ent[64].a = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -303,25 +316,26 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                               block_min_half_quad(cur.a.z, cur.a.w, cur.b.x, X0, X0 + 3.f, Y0, Y0 + 3.f) <= cur.b.z;
             const unsigned long long m = __ballot(keep);
             cnt[qd] = __popcll(m);
-            if (keep) qi[qd][__popcll(m & lt)] = (uint8_t)lane;
-            if (lane < 4) qi[qd][cnt[qd] + lane] = 64;   // pad to a multiple of 4 with the neutral instance
+            if (keep) qi[qd][__popcll(m & lt)] = my_slot;
+            if (lane < 4) qi[qd][cnt[qd] + lane] = (uint16_t)neutral;   // pad to a multiple of 4 with the neutral instance
         }
         const int my_cnt = row == 0 ? cnt[0] : row == 1 ? cnt[1] : row == 2 ? cnt[2] : cnt[3];
         const int max_cnt = max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3]));
         __builtin_amdgcn_wave_barrier();
-        const uint8_t* myq = qi[row];
+        const uint16_t* myq = qi[row];
         for (int j = 0; j < max_cnt; j += 4) {
             // four queue positions at once; rows past their own queue end read the neutral instance
-            const uint32_t packed = j < my_cnt ? *reinterpret_cast<const uint32_t*>(myq + j) : 0x40404040u;
+            const uint2 packed = j < my_cnt ? *reinterpret_cast<const uint2*>(myq + j) : neutral4;
             float4 A[4], B[4], K[4][CV];
             float alpha[4];
             bool ok[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const int e = (packed >> (8 * u)) & 0xff;
-                A[u] = ent[e].a; B[u] = ent[e].b;
+                const uint32_t word = u < 2 ? packed.x : packed.y;
+                const Slot<C>* sl = lds_slot<C>((u & 1) ? word >> 16 : word & 0xffffu);
+                A[u] = sl->a; B[u] = sl->b;
 #pragma unroll
-                for (int v = 0; v < CV; v++) K[u][v] = reinterpret_cast<const float4*>(ent[e].col)[v];
+                for (int v = 0; v < CV; v++) K[u][v] = reinterpret_cast<const float4*>(sl->col)[v];
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -335,7 +349,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                 const float test_T = T * (1.0f - alpha[u]);
                 const bool live = ok[u] && !done;
                 const bool stop = live && test_T < T_EPS;
-                const bool upd = live && !stop;
+                const bool upd = live != stop;   // stop implies live: one lane-mask xor instead of a second compare
                 done = done || stop;
                 const float w = upd ? alpha[u] * T : 0.0f;
 #pragma unroll
