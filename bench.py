@@ -163,6 +163,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     device = torch.device("cuda", (local % max(ndev, 1)) if world > 1 else 0)
     torch.cuda.set_device(device)
+    # one process per GPU, pinned to a few cores of the GPU's NUMA node (see gaustar_amd.dist.bind_to_local_cpus);
+    # ranks whose GPUs share a node take disjoint cores.  GSR_BENCH_NO_PIN=1 leaves placement to the OS.
+    cpus_before = os.sched_getaffinity(0)
+    pinned = []
+    if os.environ.get("GSR_BENCH_NO_PIN", "0") != "1":
+        node_of = [tuple(gdist._gpu_local_cpus(i)) for i in range(ndev)]
+        same = [i for i in range(ndev) if node_of[i] == node_of[device.index]] if world > 1 else [device.index]
+        pinned = gdist.bind_to_local_cpus(device.index, slot=same.index(device.index), slots=len(same))
     lib = _lib.load()
 
     gs, cams, bg, params, means2D, rasters, dpix = build_workload(device, rank)
@@ -236,7 +244,13 @@ def main():
                          "path_frac": round(path_gbs / HBM_PEAK_GBS / world, 5),
                          "instrumented_ms_per_step": round(dt_prof / args.steps * 1e3, 4), "kernels": kern},
         }
+        out["config"]["host_cpus_pinned"] = len(pinned)
         if world == 1 and not args.no_cpu_baseline:
+            try:   # the CPU baseline gets every core the process started with
+                for tid in os.listdir("/proc/self/task"):
+                    os.sched_setaffinity(int(tid), cpus_before)
+            except OSError:
+                pass
             out["cpu_baseline"] = cpu_baseline(gs, cams, bg)
         print(json.dumps(out), flush=True)
     if world > 1:

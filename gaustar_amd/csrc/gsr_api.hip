@@ -84,7 +84,7 @@ int fail_msg(const char* msg)
 
 extern "C" {
 
-int gsr_abi_version(void) { return 7; }
+int gsr_abi_version(void) { return 8; }
 
 const char* gsr_last_error(void) { return g_err.c_str(); }
 
@@ -179,6 +179,30 @@ int gsr_forward_stage1(int P, int D, int M, const float* means3D, const float* s
     *max_tile_instances = (int)g_pinned[1];
     *num_segments = (int)g_pinned[3];
     return 0;
+}
+
+int gsr_forward_fused(int P, int D, int M, int num_channels, int need_backward, const float* means3D, const float* shs,
+                      const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                      const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                      const float* projmatrix, const float* campos, int W, int H, float tan_fovx, float tan_fovy,
+                      int prefiltered, const float* background, int* radii, void* geom_buffer, void* image_buffer,
+                      void* binning_buffer, size_t binning_capacity, float* out_color, int* num_rendered,
+                      int* max_tile_instances, int* num_segments, int* blended, gsr_stream_t stream)
+{
+    if (!blended) { g_err.clear(); return fail_msg("gsr_forward_fused: null output pointer"); }
+    *blended = 0;
+    if (!channels_ok(num_channels)) { g_err.clear(); return fail_msg("gsr_forward_fused: num_channels must be 3 or 6"); }
+    const int rc = gsr_forward_stage1(P, D, M, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                                      cov3D_precomp, viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, prefiltered,
+                                      radii, geom_buffer, image_buffer, num_rendered, max_tile_instances, num_segments, stream);
+    if (rc != 0) return rc;
+    if (gsr_binning_bytes_mt(*num_rendered, *num_segments, num_channels) > binning_capacity || (*num_rendered > 0 && !binning_buffer))
+        return 0;   // the guess was too small: the caller allocates exactly and runs stage 2 itself
+    const int rc2 = gsr_forward_stage2_mt(P, *num_rendered, *max_tile_instances, need_backward ? *num_segments : -*num_segments,
+                                          num_channels, W, H, background, colors_precomp, geom_buffer, binning_buffer,
+                                          image_buffer, out_color, stream);
+    if (rc2 == 0) *blended = 1;
+    return rc2;
 }
 
 int gsr_forward_stage2(int P, int R, int max_tile_instances, int num_segments, int W, int H, const float* background,

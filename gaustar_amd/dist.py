@@ -40,6 +40,74 @@ def init_from_env(backend: str | None = None) -> tuple:
     return rank, world, local
 
 
+def _parse_cpulist(text: str) -> List[int]:
+    cpus: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def _gpu_local_cpus(device_index: int) -> List[int]:
+    """CPUs of the NUMA node the GPU hangs off (sysfs local_cpulist of its PCI function); [] if unknown."""
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/local_cpulist") as f:
+            return _parse_cpulist(f.read())
+    except Exception:
+        return []
+
+
+def _physical_cores(cpus: Sequence[int]) -> List[int]:
+    """One logical CPU per physical core (the lowest-numbered hardware thread), in ascending order."""
+    out, seen = [], set()
+    for c in sorted(cpus):
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as f:
+                first = min(_parse_cpulist(f.read()))
+        except Exception:
+            first = c
+        if first not in seen:
+            seen.add(first)
+            out.append(c)
+    return out
+
+
+def bind_to_local_cpus(device_index: int = 0, slot: int = 0, slots: int = 1, cores: int = 8) -> List[int]:
+    """Pin this process (every thread it has, and those it creates later) to `cores` physical cores of the NUMA node
+    its GPU is attached to.  One step of the rasterizer is a ping-pong between the Python thread, PyTorch's autograd
+    thread and the HIP runtime's threads, with the GPU waiting on the host once per view (the num_rendered
+    read-back): left to roam over 2 x 64 cores the scheduler now and then parks those threads sockets apart, and a
+    view costs 0.365 ms instead of 0.330 ms (MI355X, 2-socket EPYC 9575F; any compact set of >= 4 cores avoids it).
+    `slot`/`slots`: this process's position among the processes sharing the node (e.g. local rank among the 4 GPUs of
+    a socket), so that ranks take disjoint cores.  Returns the CPUs bound to ([] = nothing changed: no sysfs entry, or
+    the current affinity mask leaves no room).  The reference trainer is single-process and leaves placement to the OS."""
+    try:
+        allowed = set(os.sched_getaffinity(0))
+    except AttributeError:
+        return []
+    local = [c for c in _physical_cores(_gpu_local_cpus(device_index)) if c in allowed]
+    if not local:
+        local = _physical_cores(sorted(allowed))
+    per = max(1, min(cores, len(local) // max(slots, 1)))
+    mine = local[(slot % max(slots, 1)) * per:(slot % max(slots, 1)) * per + per]
+    if len(mine) < min(4, len(local)):
+        return []
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(tid), mine)
+            except OSError:
+                pass
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return []
+    return mine
+
+
 def world_size() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 

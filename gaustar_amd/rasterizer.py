@@ -15,6 +15,7 @@ memory.  No CPU fallback exists: tensors must be on a HIP device and the extensi
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import NamedTuple
 
 import torch
@@ -92,6 +93,11 @@ def _require_gpu(t: torch.Tensor, what: str):
 # Binding-level functions: same positional signatures as the reference's `_C` module
 # (DGR/rasterize_points.h:17-66), implemented over the C ABI.
 # --------------------------------------------------------------------------------------------
+# device index -> bytes of binning scratch to hand gsr_forward_fused up front (1.25x the largest need seen so far)
+_BINNING_HINT: dict = {}
+_FUSED = os.environ.get("GSR_FUSED_FORWARD", "1") != "0"   # 0: always stage 1, allocate exactly, stage 2
+
+
 def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rotations, scale_modifier,
                                cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
                                image_width, sh, degree, campos, prefiltered, debug, need_backward=True):
@@ -121,22 +127,27 @@ def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rot
         radii = torch.empty(P, dtype=torch.int32, device=dev)
         geom = torch.empty(lib.gsr_geom_bytes(P), **byte_opts)
         img = torch.empty(lib.gsr_image_bytes(W, H), **byte_opts)
-        R, maxc, nseg = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        R, maxc, nseg, blended = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         st = _stream()
-        _lib.check(lib.gsr_forward_stage1(
-            P, int(degree), M, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales),
-            float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix),
-            _ptr(campos), W, H, float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(radii), _ptr(geom),
-            _ptr(img), ctypes.byref(R), ctypes.byref(maxc), ctypes.byref(nseg), st), "gsr_forward_stage1")
-        # forward-only renders hand stage 2 the NEGATED segment count: no per-segment snapshots are written (gsr.h)
-        nseg2 = nseg.value if need_backward else -nseg.value
-        if C == 3:
-            binning = torch.empty(lib.gsr_binning_bytes(R.value, nseg.value), **byte_opts)
-            _lib.check(lib.gsr_forward_stage2(
-                P, R.value, maxc.value, nseg2, W, H, _ptr(background), _ptr(colors), _ptr(geom), _ptr(binning),
-                _ptr(img), _ptr(out_color), st), "gsr_forward_stage2")
-        else:
-            binning = torch.empty(lib.gsr_binning_bytes_mt(R.value, nseg.value, C), **byte_opts)
+        # The binning scratch is sized BEFORE num_rendered is known, from what earlier views on this device needed
+        # (x1.25): the library then goes from the stage-1 read-back straight into the stage-2 launches, and the GPU does
+        # not idle while Python allocates and re-enters.  First view, or a guess that turns out too small: blended = 0,
+        # and stage 2 runs below over an exactly sized buffer (the reference's order of events, rasterize_points.cu:82-112).
+        hint = _BINNING_HINT.get(dev.index, 0) if _FUSED else 0
+        binning = torch.empty(hint, **byte_opts)
+        _lib.check(lib.gsr_forward_fused(
+            P, int(degree), M, C, int(bool(need_backward)), _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity),
+            _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix),
+            _ptr(campos), W, H, float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(background), _ptr(radii),
+            _ptr(geom), _ptr(img), _ptr(binning), hint, _ptr(out_color), ctypes.byref(R), ctypes.byref(maxc),
+            ctypes.byref(nseg), ctypes.byref(blended), st), "gsr_forward_fused")
+        need = int(lib.gsr_binning_bytes_mt(R.value, nseg.value, C))
+        if need * 5 // 4 > hint:
+            _BINNING_HINT[dev.index] = (need * 5 // 4 + (1 << 20) - 1) >> 20 << 20
+        if not blended.value:
+            # forward-only renders hand stage 2 the NEGATED segment count: no per-segment snapshots are written (gsr.h)
+            nseg2 = nseg.value if need_backward else -nseg.value
+            binning = torch.empty(need, **byte_opts)
             _lib.check(lib.gsr_forward_stage2_mt(
                 P, R.value, maxc.value, nseg2, C, W, H, _ptr(background), _ptr(colors), _ptr(geom), _ptr(binning),
                 _ptr(img), _ptr(out_color), st), "gsr_forward_stage2_mt")

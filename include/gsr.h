@@ -91,6 +91,21 @@ int gsr_forward_stage2_mt(int P, int R, int max_tile_instances, int num_segments
                           const float* background, const float* colors_precomp, void* geom_buffer, void* binning_buffer,
                           void* image_buffer, float* out_color, gsr_stream_t stream);
 
+/* Both halves in one call over a binning buffer the caller sized IN ADVANCE from a guess (e.g. 1.25x what the last
+ * view needed): when gsr_binning_bytes_mt(R, num_segments, num_channels) <= binning_capacity the library goes straight
+ * from the stage-1 read-back into the stage-2 launches and sets *blended = 1 -- the GPU does not idle while the caller
+ * allocates and re-enters (10-15 us per view through a Python binding).  Otherwise *blended = 0, nothing of stage 2 has
+ * run, and the caller allocates exactly and calls gsr_forward_stage2[_mt] as usual.  need_backward = 0 renders
+ * forward-only (see gsr_forward_stage2).  Same replaced reference code as the two stages
+ * (DGR/cuda_rasterizer/rasterizer_impl.cu:198-335). */
+int gsr_forward_fused(int P, int D, int M, int num_channels, int need_backward, const float* means3D, const float* shs,
+                      const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                      const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                      const float* projmatrix, const float* campos, int W, int H, float tan_fovx, float tan_fovy,
+                      int prefiltered, const float* background, int* radii, void* geom_buffer, void* image_buffer,
+                      void* binning_buffer, size_t binning_capacity, float* out_color, int* num_rendered,
+                      int* max_tile_instances, int* num_segments, int* blended, gsr_stream_t stream);
+
 /* One-call forward with the reference's allocator-callback shape.  Replaces
  * CudaRasterizer::Rasterizer::forward (DGR/cuda_rasterizer/rasterizer.h:31-55).
  * Returns num_rendered through *num_rendered [host]. */

@@ -2,7 +2,10 @@
 import os
 import socket
 
+import pytest
 import torch
+
+from conftest import ROOT
 import torch.multiprocessing as mp
 
 
@@ -105,3 +108,29 @@ def test_sweep_sharding_and_gather_world_size_2():
     expect = [[float(i), float(i * i)] for i in range(n)]
     for rank, mine, full in res:
         assert mine == list(range(rank, n, 2)) and full == expect
+
+
+def test_bind_to_local_cpus_in_a_subprocess():
+    """Pins a child process (never the test runner) and checks the mask it ends up with: a compact subset of what it was
+    allowed before, disjoint between two slots."""
+    import subprocess, sys, json
+    code = r'''
+import json, os, sys
+sys.path.insert(0, %r)
+from gaustar_amd import dist
+assert dist._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+before = sorted(os.sched_getaffinity(0))
+a = dist.bind_to_local_cpus(0, slot=0, slots=2, cores=4)
+now = sorted(os.sched_getaffinity(0))
+for t in os.listdir("/proc/self/task"):
+    os.sched_setaffinity(int(t), before)
+b = dist.bind_to_local_cpus(0, slot=1, slots=2, cores=4)
+print(json.dumps(dict(before=before, a=a, now=now, b=b)))
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    if len(d["before"]) < 8:
+        pytest.skip("fewer than 8 CPUs allowed here")
+    assert d["a"] and d["now"] == sorted(d["a"]) and set(d["a"]) <= set(d["before"])
+    assert d["b"] and not (set(d["a"]) & set(d["b"]))

@@ -426,3 +426,36 @@ def test_forward_only_mode_skips_snapshots_but_not_pixels():
         R.rasterize_gaussians_backward_native(s.bg, t(gs.means3D), out[2], t(gs.colors_precomp), t(gs.scales), t(gs.rotations), 1.0, e,
                                               s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, torch.ones_like(img_n), e, 0, s.campos,
                                               out[3], out[0], out[4], out[5], False, num_segments=0)
+
+
+def test_fused_forward_equals_two_stage_forward():
+    """gsr_forward_fused (binning scratch sized in advance from earlier views) vs the reference's order of events
+    (stage 1, allocate exactly, stage 2): identical images, radii and gradients -- with no hint (two-stage), with a
+    sufficient hint (fused), and with a hint that turns out too small (fallback inside one call)."""
+    from gaustar_amd import rasterizer as R, scene
+    rng = np.random.default_rng(21)
+    gs = scene.random_gaussians(6000, rng, scale_range=(0.02, 0.1))
+    cam = scene.look_at_camera((0.2, 0.1, -4.0), (0, 0, 0), 320, 200, fovx=0.8, znear=0.01)
+    kw = dict(means3D=gs.means3D, opacities=gs.opacities, view=cam.viewmatrix, proj=cam.projmatrix, campos=cam.campos,
+              W=cam.W, H=cam.H, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=np.array([0.3, 0.1, 0.6], np.float32), shs=None,
+              colors_precomp=gs.colors_precomp, scales=gs.scales, rotations=gs.rotations, cov3D_precomp=None, sh_degree=0)
+    dpix = rng.normal(size=(3, cam.H, cam.W)).astype(np.float32)
+    saved = dict(R._BINNING_HINT)
+    try:
+        R._BINNING_HINT.clear()
+        two_stage = parity.run_hip(kw, dpix)                  # no hint yet: stage 2 runs as a separate call
+        hint = R._BINNING_HINT[0]
+        assert hint > 0
+        fused = parity.run_hip(kw, dpix)                      # hint covers the need: one call
+        R._BINNING_HINT[0] = 4096                             # far too small: falls back after stage 1
+        small = parity.run_hip(kw, dpix)
+        assert R._BINNING_HINT[0] == hint                     # and the hint recovers
+    finally:
+        R._BINNING_HINT.clear()
+        R._BINNING_HINT.update(saved)
+    for other, what in ((fused, "fused"), (small, "undersized hint")):
+        for k in ("color", "radii", "dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dscales", "dL_drotations"):
+            if k in ("color", "radii"):
+                assert np.array_equal(two_stage[k], other[k]), f"{what}: {k} differs from the two-stage forward"
+            else:   # gradients are sums of float atomics: order-dependent in the last bits
+                parity.check_grad(other[k], two_stage[k], f"{what} {k}")
