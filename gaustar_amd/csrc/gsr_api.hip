@@ -181,13 +181,19 @@ int gsr_forward_stage1(int P, int D, int M, const float* means3D, const float* s
     return 0;
 }
 
+namespace {
+int forward_stage2_impl(int P, int R, int max_tile_instances, int num_segments, int num_channels, int W, int H,
+                        const float* background, const float* colors_precomp, void* geom_buffer, void* binning_buffer,
+                        void* image_buffer, float* out_color, void* grad_scratch, gsr_stream_t stream);
+}
+
 int gsr_forward_fused(int P, int D, int M, int num_channels, int need_backward, const float* means3D, const float* shs,
                       const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
                       const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
                       const float* projmatrix, const float* campos, int W, int H, float tan_fovx, float tan_fovy,
                       int prefiltered, const float* background, int* radii, void* geom_buffer, void* image_buffer,
-                      void* binning_buffer, size_t binning_capacity, float* out_color, int* num_rendered,
-                      int* max_tile_instances, int* num_segments, int* blended, gsr_stream_t stream)
+                      void* binning_buffer, size_t binning_capacity, void* grad_scratch, float* out_color,
+                      int* num_rendered, int* max_tile_instances, int* num_segments, int* blended, gsr_stream_t stream)
 {
     if (!blended) { g_err.clear(); return fail_msg("gsr_forward_fused: null output pointer"); }
     *blended = 0;
@@ -198,9 +204,9 @@ int gsr_forward_fused(int P, int D, int M, int num_channels, int need_backward, 
     if (rc != 0) return rc;
     if (gsr_binning_bytes_mt(*num_rendered, *num_segments, num_channels) > binning_capacity || (*num_rendered > 0 && !binning_buffer))
         return 0;   // the guess was too small: the caller allocates exactly and runs stage 2 itself
-    const int rc2 = gsr_forward_stage2_mt(P, *num_rendered, *max_tile_instances, need_backward ? *num_segments : -*num_segments,
-                                          num_channels, W, H, background, colors_precomp, geom_buffer, binning_buffer,
-                                          image_buffer, out_color, stream);
+    const int rc2 = forward_stage2_impl(P, *num_rendered, *max_tile_instances, need_backward ? *num_segments : -*num_segments,
+                                        num_channels, W, H, background, colors_precomp, geom_buffer, binning_buffer,
+                                        image_buffer, out_color, need_backward ? grad_scratch : nullptr, stream);
     if (rc2 == 0) *blended = 1;
     return rc2;
 }
@@ -213,9 +219,11 @@ int gsr_forward_stage2(int P, int R, int max_tile_instances, int num_segments, i
                                  geom_buffer, binning_buffer, image_buffer, out_color, stream);
 }
 
-int gsr_forward_stage2_mt(int P, int R, int max_tile_instances, int num_segments, int num_channels, int W, int H,
-                          const float* background, const float* colors_precomp, void* geom_buffer, void* binning_buffer,
-                          void* image_buffer, float* out_color, gsr_stream_t stream)
+namespace {
+// grad_scratch != nullptr: the backward's accumulation table, cleared by the forward blend on the side (gsr_forward_fused)
+int forward_stage2_impl(int P, int R, int max_tile_instances, int num_segments, int num_channels, int W, int H,
+                        const float* background, const float* colors_precomp, void* geom_buffer, void* binning_buffer,
+                        void* image_buffer, float* out_color, void* grad_scratch, gsr_stream_t stream)
 {
     g_err.clear();
     if (W <= 0 || H <= 0) return fail_msg("gsr_forward_stage2: image size must be positive");
@@ -251,10 +259,19 @@ int gsr_forward_stage2_mt(int P, int R, int max_tile_instances, int num_segments
     {
         Scope sc(ST_BLEND_FWD, st);
         launch_blend_fwd(C, W, H, R, num_segments, (uint32_t)(max_tile_instances > 0 ? max_tile_instances : 0), background, feats, g, im, b,
-                         out_color, st);
+                         out_color, grad_scratch, grad_scratch ? gsr_grad_scratch_bytes(P > 0 ? P : 0) : 0, st);
     }
     GSR_CHECK_LAUNCH("blend_fwd_kernel");
     return 0;
+}
+}  // namespace
+
+int gsr_forward_stage2_mt(int P, int R, int max_tile_instances, int num_segments, int num_channels, int W, int H,
+                          const float* background, const float* colors_precomp, void* geom_buffer, void* binning_buffer,
+                          void* image_buffer, float* out_color, gsr_stream_t stream)
+{
+    return forward_stage2_impl(P, R, max_tile_instances, num_segments, num_channels, W, H, background, colors_precomp,
+                               geom_buffer, binning_buffer, image_buffer, out_color, nullptr, stream);
 }
 
 int gsr_forward(gsr_alloc_fn geometry_buffer, gsr_alloc_fn binning_buffer, gsr_alloc_fn image_buffer, void* alloc_ctx,
@@ -293,7 +310,7 @@ int gsr_backward(int P, int D, int M, int R, int num_segments, const float* back
     return gsr_backward_mt(P, D, M, R, num_segments, 3, background, W, H, means3D, shs, colors_precomp, scales,
                            scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy,
                            radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, grad_scratch, dL_dmean2D,
-                           dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, stream);
+                           dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, 0, stream);
 }
 
 int gsr_backward_mt(int P, int D, int M, int R, int num_segments, int num_channels, const float* background, int W,
@@ -303,7 +320,7 @@ int gsr_backward_mt(int P, int D, int M, int R, int num_segments, int num_channe
                  const float* campos, float tan_fovx, float tan_fovy, const int* radii, const void* geom_buffer,
                  const void* binning_buffer, const void* image_buffer, const float* dL_dpix, void* grad_scratch,
                  float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
-                 float* dL_dsh, float* dL_dscale, float* dL_drot, gsr_stream_t stream)
+                 float* dL_dsh, float* dL_dscale, float* dL_drot, int grad_scratch_zeroed, gsr_stream_t stream)
 {
     g_err.clear();
     if (P <= 0) return 0;
@@ -330,7 +347,7 @@ int gsr_backward_mt(int P, int D, int M, int R, int num_segments, int num_channe
     // Zero the packed moment records (the only atomic targets); every output tensor is written outright
     // by geom_bwd (cf. the nine zeroed tensors of rasterize_points.cu:151-159).
     float* grad_acc = static_cast<float*>(grad_scratch);
-    {
+    if (!grad_scratch_zeroed) {   // otherwise the forward blend cleared it on the side (gsr_forward_fused)
         Scope sc(ST_ZERO_FILL, st);
         GSR_CHECK(hipMemsetAsync(grad_acc, 0, gsr_grad_scratch_bytes(P), st));
     }

@@ -237,9 +237,17 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                  const float4* __restrict__ g1, const float* __restrict__ feats, const float* __restrict__ bg,
                  float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                  const uint32_t* __restrict__ seg_off, float4* __restrict__ snap, uint32_t skip_above,
-                 uint64_t* __restrict__ trace)
+                 float4* __restrict__ zero_ptr, uint32_t zero_n, uint64_t* __restrict__ trace)
 {
     const uint64_t t_start = trace ? wall_clock64() : 0;
+    // Side job: the backward's accumulation table (48 B per Gaussian) has to be zero before blend_bwd runs.  When the
+    // caller hands it over at forward time every workgroup clears its slice here -- the kernel is issue-bound and leaves
+    // HBM idle -- instead of a separate fill (a 5 us blit plus its dispatch) in front of the backward.
+    if (zero_ptr != nullptr) {
+        const uint32_t per = (zero_n + gridDim.x - 1u) / gridDim.x;
+        const uint32_t i0 = blockIdx.x * per, i1 = min(zero_n, i0 + per);
+        for (uint32_t i = i0 + threadIdx.x; i < i1; i += 256u) zero_ptr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     constexpr int SV = snap_vecs(C);
     constexpr int CV = (C + 3) / 4;                                   // float4s of colour per slot
     __shared__ Slot<C> entries[4][64 + 1];                            // [wave][batch lane]; slot 64 = neutral
@@ -519,7 +527,7 @@ blend_fwd_long_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, co
 
 template <int C>
 static void launch_fwd_c(int W, int H, int R, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im,
-                         BinState b, float* out_color, hipStream_t st)
+                         BinState b, float* out_color, void* zero_ptr, size_t zero_bytes, hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);
     static const uint32_t long_thr = getenv("GSR_FWD_LONG") ? (uint32_t)atoi(getenv("GSR_FWD_LONG")) : 4096u;
@@ -537,14 +545,14 @@ static void launch_fwd_c(int W, int H, int R, int U, uint32_t max_count, const f
     }
     blend_fwd_kernel<C><<<t.T, 256, 0, st>>>(W, H, t.gx, im.ranges, im.order, b.point_list, g.g0, g.g1, feats, bg, out_color,
                                              im.final_T, im.n_contrib, im.seg_off, b.snap, use_long ? long_thr : 0xffffffffu,
-                                             g_trace);
+                                             static_cast<float4*>(zero_ptr), (uint32_t)(zero_bytes / 16), g_trace);
 }
 
 void launch_blend_fwd(int C, int W, int H, int R, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g,
-                      ImageState im, BinState b, float* out_color, hipStream_t st)
+                      ImageState im, BinState b, float* out_color, void* zero_ptr, size_t zero_bytes, hipStream_t st)
 {
-    if (C == 6) launch_fwd_c<6>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, st);
-    else launch_fwd_c<3>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, st);
+    if (C == 6) launch_fwd_c<6>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, zero_ptr, zero_bytes, st);
+    else launch_fwd_c<3>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, zero_ptr, zero_bytes, st);
 }
 
 }  // namespace gsr

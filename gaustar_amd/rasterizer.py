@@ -100,7 +100,8 @@ _FUSED = os.environ.get("GSR_FUSED_FORWARD", "1") != "0"   # 0: always stage 1, 
 
 def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rotations, scale_modifier,
                                cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
-                               image_width, sh, degree, campos, prefiltered, debug, need_backward=True):
+                               image_width, sh, degree, campos, prefiltered, debug, need_backward=True,
+                               scratch_box=None):
     """-> (num_rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer), like
     RasterizeGaussiansCUDA (DGR/rasterize_points.cu:35-115), plus two more elements: the longest
     per-tile instance list (informational) and the number of list segments (backward work units)."""
@@ -135,12 +136,19 @@ def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rot
         # and stage 2 runs below over an exactly sized buffer (the reference's order of events, rasterize_points.cu:82-112).
         hint = _BINNING_HINT.get(dev.index, 0) if _FUSED else 0
         binning = torch.empty(hint, **byte_opts)
+        # The backward's accumulation table rides along (callers that will run a backward pass a list as scratch_box):
+        # the forward blend clears it on the side, and the backward skips its own fill.
+        scratch = None
+        if need_backward and scratch_box is not None and hint > 0:
+            scratch = torch.empty(lib.gsr_grad_scratch_bytes(P), **byte_opts)
         _lib.check(lib.gsr_forward_fused(
             P, int(degree), M, C, int(bool(need_backward)), _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity),
             _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix),
             _ptr(campos), W, H, float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(background), _ptr(radii),
-            _ptr(geom), _ptr(img), _ptr(binning), hint, _ptr(out_color), ctypes.byref(R), ctypes.byref(maxc),
-            ctypes.byref(nseg), ctypes.byref(blended), st), "gsr_forward_fused")
+            _ptr(geom), _ptr(img), _ptr(binning), hint, _ptr(scratch), _ptr(out_color), ctypes.byref(R),
+            ctypes.byref(maxc), ctypes.byref(nseg), ctypes.byref(blended), st), "gsr_forward_fused")
+        if scratch is not None and blended.value:
+            scratch_box.append(scratch)   # cleared by the forward blend: good for exactly one backward
         need = int(lib.gsr_binning_bytes_mt(R.value, nseg.value, C))
         if need * 5 // 4 > hint:
             _BINNING_HINT[dev.index] = (need * 5 // 4 + (1 << 20) - 1) >> 20 << 20
@@ -159,7 +167,7 @@ def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rot
 def rasterize_gaussians_backward_native(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                         cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                         sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug,
-                                        num_segments=0):
+                                        num_segments=0, zeroed_scratch=None):
     """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
     dL_drotations), like RasterizeGaussiansBackwardCUDA (DGR/rasterize_points.cu:117-196)."""
     lib = _lib.load()
@@ -184,7 +192,9 @@ def rasterize_gaussians_backward_native(background, means3D, radii, colors, scal
         dL_dmeans3D = torch.empty(P, 3, **f32)
         dL_dmeans2D = torch.empty(P, 3, **f32)
         dL_dcolors = torch.empty(P, C, **f32)
-        grad_scratch = torch.empty(lib.gsr_grad_scratch_bytes(P), dtype=torch.uint8, device=dev)
+        # zeroed_scratch: the table the forward blend cleared on the side (gsr_forward_fused); otherwise the call fills it
+        prezeroed = zeroed_scratch is not None and zeroed_scratch.numel() == lib.gsr_grad_scratch_bytes(P)
+        grad_scratch = zeroed_scratch if prezeroed else torch.empty(lib.gsr_grad_scratch_bytes(P), dtype=torch.uint8, device=dev)
         dL_dopacity = torch.empty(P, 1, **f32)
         dL_dcov3D = torch.empty(P, 6, **f32)
         dL_dsh = torch.empty(P, M, 3, **f32)
@@ -196,11 +206,8 @@ def rasterize_gaussians_backward_native(background, means3D, radii, colors, scal
                 _ptr(campos), float(tan_fovx), float(tan_fovy), _ptr(radii), _ptr(geomBuffer), _ptr(binningBuffer),
                 _ptr(imageBuffer), _ptr(dL_dout_color), _ptr(grad_scratch), _ptr(dL_dmeans2D), _ptr(dL_dopacity),
                 _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales),
-                _ptr(dL_drotations), _stream())
-        if C == 3:
-            _lib.check(lib.gsr_backward(*head, *tail), "gsr_backward")
-        else:
-            _lib.check(lib.gsr_backward_mt(*head, C, *tail), "gsr_backward_mt")
+                _ptr(dL_drotations))
+        _lib.check(lib.gsr_backward_mt(*head, C, *tail, int(prezeroed), _stream()), "gsr_backward_mt")
         if debug:
             torch.cuda.synchronize(dev)
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
@@ -240,21 +247,23 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raster_settings.projmatrix, raster_settings.tanfovx, raster_settings.tanfovy,
                 raster_settings.image_height, raster_settings.image_width, sh, raster_settings.sh_degree,
                 raster_settings.campos, raster_settings.prefiltered, raster_settings.debug)
+        box = []   # receives the backward's accumulation table when the forward cleared it on the side
         if raster_settings.debug:
             cpu_args = cpu_deep_copy_tuple(args)   # copy them before they can be corrupted (ref :83-90)
             try:
-                out = rasterize_gaussians_native(*args, need_backward=any(ctx.needs_input_grad))
+                out = rasterize_gaussians_native(*args, need_backward=any(ctx.needs_input_grad), scratch_box=box)
             except Exception as ex:
                 torch.save(cpu_args, "snapshot_fw.dump")
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                 raise ex
         else:
-            out = rasterize_gaussians_native(*args, need_backward=any(ctx.needs_input_grad))
+            out = rasterize_gaussians_native(*args, need_backward=any(ctx.needs_input_grad), scratch_box=box)
         num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, _max_tile, num_segments = out
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
         ctx.num_segments = num_segments
         ctx.opacity_shape = opacities.shape
+        ctx.zeroed_scratch = box[0] if box else None
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                               binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii)
@@ -269,6 +278,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             return (None,) * 9
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
          imgBuffer) = ctx.saved_tensors
+        zeroed, ctx.zeroed_scratch = ctx.zeroed_scratch, None   # one use: a second backward (retain_graph) fills its own
         args = (raster_settings.bg, means3D, radii, colors_precomp, scales, rotations,
                 raster_settings.scale_modifier, cov3Ds_precomp, raster_settings.viewmatrix,
                 raster_settings.projmatrix, raster_settings.tanfovx, raster_settings.tanfovy, grad_out_color, sh,
@@ -277,13 +287,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         if raster_settings.debug:
             cpu_args = cpu_deep_copy_tuple(args)
             try:
-                grads_native = rasterize_gaussians_backward_native(*args, num_segments=ctx.num_segments)
+                grads_native = rasterize_gaussians_backward_native(*args, num_segments=ctx.num_segments, zeroed_scratch=zeroed)
             except Exception as ex:
                 torch.save(cpu_args, "snapshot_bw.dump")
                 print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise ex
         else:
-            grads_native = rasterize_gaussians_backward_native(*args, num_segments=ctx.num_segments)
+            grads_native = rasterize_gaussians_backward_native(*args, num_segments=ctx.num_segments, zeroed_scratch=zeroed)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = grads_native
 

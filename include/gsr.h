@@ -96,15 +96,18 @@ int gsr_forward_stage2_mt(int P, int R, int max_tile_instances, int num_segments
  * from the stage-1 read-back into the stage-2 launches and sets *blended = 1 -- the GPU does not idle while the caller
  * allocates and re-enters (10-15 us per view through a Python binding).  Otherwise *blended = 0, nothing of stage 2 has
  * run, and the caller allocates exactly and calls gsr_forward_stage2[_mt] as usual.  need_backward = 0 renders
- * forward-only (see gsr_forward_stage2).  Same replaced reference code as the two stages
+ * forward-only (see gsr_forward_stage2).  grad_scratch (may be NULL): gsr_grad_scratch_bytes(P) bytes that the
+ * following gsr_backward_mt will use as its grad_scratch; when *blended = 1 (and need_backward) the forward blend has
+ * cleared them on the side, and that backward may be called with grad_scratch_zeroed = 1 (once: the backward leaves
+ * the contents undefined).  Same replaced reference code as the two stages
  * (DGR/cuda_rasterizer/rasterizer_impl.cu:198-335). */
 int gsr_forward_fused(int P, int D, int M, int num_channels, int need_backward, const float* means3D, const float* shs,
                       const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
                       const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
                       const float* projmatrix, const float* campos, int W, int H, float tan_fovx, float tan_fovy,
                       int prefiltered, const float* background, int* radii, void* geom_buffer, void* image_buffer,
-                      void* binning_buffer, size_t binning_capacity, float* out_color, int* num_rendered,
-                      int* max_tile_instances, int* num_segments, int* blended, gsr_stream_t stream);
+                      void* binning_buffer, size_t binning_capacity, void* grad_scratch, float* out_color,
+                      int* num_rendered, int* max_tile_instances, int* num_segments, int* blended, gsr_stream_t stream);
 
 /* One-call forward with the reference's allocator-callback shape.  Replaces
  * CudaRasterizer::Rasterizer::forward (DGR/cuda_rasterizer/rasterizer.h:31-55).
@@ -134,7 +137,9 @@ int gsr_backward(int P, int D, int M, int R, int num_segments, const float* back
 
 /* Backward of a num_channels render (see gsr_forward_stage2_mt): dL_dpix [num_channels,H,W], dL_dcolor
  * [P,num_channels]; every other gradient is the sum over the targets, i.e. what autograd would accumulate from
- * the separate backward passes of the reference.  num_channels = 3 is gsr_backward. */
+ * the separate backward passes of the reference.  num_channels = 3 is gsr_backward.
+ * grad_scratch_zeroed = 1: the caller guarantees grad_scratch is all zero (gsr_forward_fused cleared it) and the
+ * library skips its own fill; 0: the fill is part of the call, as in gsr_backward. */
 int gsr_backward_mt(int P, int D, int M, int R, int num_segments, int num_channels, const float* background, int W,
                     int H, const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
                     float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
@@ -142,7 +147,7 @@ int gsr_backward_mt(int P, int D, int M, int R, int num_segments, int num_channe
                     const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
                     const float* dL_dpix, void* grad_scratch, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
                     float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                    gsr_stream_t stream);
+                    int grad_scratch_zeroed, gsr_stream_t stream);
 
 /* Near-plane visibility test.  Replaces CudaRasterizer::Rasterizer::markVisible
  * (DGR/cuda_rasterizer/rasterizer.h:24-29; rasterizer_impl.cu:54-66, :141-153).

@@ -459,3 +459,31 @@ def test_fused_forward_equals_two_stage_forward():
                 assert np.array_equal(two_stage[k], other[k]), f"{what}: {k} differs from the two-stage forward"
             else:   # gradients are sums of float atomics: order-dependent in the last bits
                 parity.check_grad(other[k], two_stage[k], f"{what} {k}")
+
+
+def test_two_backward_passes_over_one_forward_agree():
+    """The fused forward hands the backward an accumulation table it cleared on the side; that is good for ONE backward.
+    A second one over the same graph (retain_graph=True) must fill its own and give the same gradients."""
+    import torch
+    from gaustar_amd import GaussianRasterizationSettings, GaussianRasterizer, scene
+    rng = np.random.default_rng(33)
+    gs = scene.random_gaussians(3000, rng, scale_range=(0.02, 0.1))
+    cam = scene.look_at_camera((0.1, 0.0, -4.0), (0, 0, 0), 160, 120, fovx=0.8, znear=0.01)
+    dev = torch.device("cuda:0")
+    t = lambda x, g=False: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev).requires_grad_(g)
+    s = GaussianRasterizationSettings(cam.H, cam.W, cam.tanfovx, cam.tanfovy, t(np.array([0.1, 0.2, 0.3])), 1.0, t(cam.viewmatrix),
+                                      t(cam.projmatrix), 0, t(cam.campos), False, False)
+    m3, op, sc, ro, co = t(gs.means3D, True), t(gs.opacities, True), t(gs.scales, True), t(gs.rotations, True), t(gs.colors_precomp, True)
+    d = torch.randn(3, cam.H, cam.W, device=dev)
+    grads = []
+    for _ in range(2):   # the first render has no size hint (two-stage); the second takes the fused path
+        img, _r = GaussianRasterizer(s)(means3D=m3, means2D=torch.zeros(gs.P, 3, device=dev), opacities=op, colors_precomp=co,
+                                        scales=sc, rotations=ro)
+        for rep in range(2):
+            for p in (m3, op, sc, ro, co):
+                p.grad = None
+            img.backward(d, retain_graph=(rep == 0))
+            grads.append([p.grad.clone().cpu().numpy() for p in (m3, op, sc, ro, co)])
+    for other in grads[1:]:
+        for a, b, name in zip(grads[0], other, ("means3D", "opacity", "scales", "rotations", "colors")):
+            parity.check_grad(b, a, f"repeated backward: dL_d{name}")
