@@ -10,7 +10,9 @@
 #include <vector>
 #include <atomic>
 #include <chrono>
+#include <map>
 #include <mutex>
+#include <utility>
 
 using namespace gsr;
 
@@ -98,12 +100,46 @@ size_t gsr_binning_bytes_mt(int R, int num_segments, int num_channels)
 size_t gsr_binning_bytes(int R, int num_segments) { return gsr_binning_bytes_mt(R, num_segments, 3); }
 size_t gsr_grad_scratch_bytes(int P) { return (size_t)48 * (size_t)(P > 0 ? P : 0) + 256; }
 
-int gsr_forward_stage1(int P, int D, int M, const float* means3D, const float* shs, const float* colors_precomp,
-                       const float* opacities, const float* scales, float scale_modifier, const float* rotations,
-                       const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
-                       const float* campos, int W, int H, float tan_fovx, float tan_fovy, int prefiltered, int* radii,
-                       void* geom_buffer, void* image_buffer, int* num_rendered, int* max_tile_instances,
-                       int* num_segments, gsr_stream_t stream)
+namespace {
+// ---- self-cleaning tile counters (gsr_forward_fused only).  The per-(shard, tile) counters and scatter cursors must be
+// zero when preprocess starts; carved from the caller's (fresh) image buffer that costs a fill per view -- a 5 us blit
+// plus its dispatch in front of a 23 us kernel.  The fused forward instead keeps them in a library-owned block per
+// (device, stream) that the forward blend -- the last kernel of the forward, one workgroup per tile -- hands back zeroed.
+// `clean` is host-side bookkeeping of that invariant: it is dropped while a call is in flight and only restored once the
+// cleaning kernel has been launched (or the block has been re-filled), so any failure in between costs one fill later.
+struct Counters { uint32_t* base = nullptr; size_t words = 0; bool clean = false; };
+std::mutex g_cnt_mu;
+std::map<std::pair<int, hipStream_t>, Counters> g_cnt;
+
+// -> a zeroed block of at least `words` uint32 for (current device, st), marked in flight; nullptr: use the image buffer
+Counters* acquire_counters(hipStream_t st, size_t words)
+{
+    const char* e_own = getenv("GSR_OWN_COUNTERS");   // read per call: tools/ab_env.py flips it inside one process
+    const bool off = e_own && e_own[0] == '0';
+    int dev = 0;
+    if (off || hipGetDevice(&dev) != hipSuccess) return nullptr;
+    Counters* c;
+    {
+        std::lock_guard<std::mutex> lk(g_cnt_mu);
+        c = &g_cnt[std::make_pair(dev, st)];   // std::map: the address stays valid
+    }
+    if (c->words < words) {
+        if (c->base) { (void)hipStreamSynchronize(st); (void)hipFree(c->base); }
+        c->base = nullptr; c->words = 0; c->clean = false;
+        if (hipMalloc((void**)&c->base, 4 * words) != hipSuccess) { (void)hipGetLastError(); c->base = nullptr; return nullptr; }
+        c->words = words;
+    }
+    if (!c->clean && hipMemsetAsync(c->base, 0, 4 * c->words, st) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    c->clean = false;   // in flight
+    return c;
+}
+
+int forward_stage1_impl(int P, int D, int M, const float* means3D, const float* shs, const float* colors_precomp,
+                        const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                        const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                        const float* campos, int W, int H, float tan_fovx, float tan_fovy, int prefiltered, int* radii,
+                        void* geom_buffer, void* image_buffer, int* num_rendered, int* max_tile_instances,
+                        int* num_segments, uint32_t* counters, gsr_stream_t stream)
 {
     (void)prefiltered;   // the reference only uses it to trap on a culled point (auxiliary.h:156-160)
     g_err.clear();
@@ -130,9 +166,14 @@ int gsr_forward_stage1(int P, int D, int M, const float* means3D, const float* s
     hipStream_t st = (hipStream_t)stream;
     const Tiles t = tiles_of(W, H);
     ImageState im = carve_image(image_buffer, W, H);
-    // counters and cursors are adjacent in the image buffer: one fill covers both
-    GSR_CHECK(hipMemsetAsync(im.tile_count, 0,
-                             (size_t)((char*)(im.tile_cursor + shard_stride(t.T) * NSHARD) - (char*)im.tile_count), st));
+    if (counters) {   // library-owned, already zero (acquire_counters)
+        im.tile_count = counters;
+        im.tile_cursor = counters + (size_t)shard_stride(t.T) * NSHARD;
+    } else {
+        // counters and cursors are adjacent in the image buffer: one fill covers both
+        GSR_CHECK(hipMemsetAsync(im.tile_count, 0,
+                                 (size_t)((char*)(im.tile_cursor + shard_stride(t.T) * NSHARD) - (char*)im.tile_count), st));
+    }
     if (P > 0) {
         GeomState g = carve_geom(geom_buffer, P);
         {
@@ -180,11 +221,24 @@ int gsr_forward_stage1(int P, int D, int M, const float* means3D, const float* s
     *num_segments = (int)g_pinned[3];
     return 0;
 }
+}  // namespace
+
+int gsr_forward_stage1(int P, int D, int M, const float* means3D, const float* shs, const float* colors_precomp,
+                       const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                       const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                       const float* campos, int W, int H, float tan_fovx, float tan_fovy, int prefiltered, int* radii,
+                       void* geom_buffer, void* image_buffer, int* num_rendered, int* max_tile_instances,
+                       int* num_segments, gsr_stream_t stream)
+{
+    return forward_stage1_impl(P, D, M, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                               cov3D_precomp, viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, prefiltered, radii,
+                               geom_buffer, image_buffer, num_rendered, max_tile_instances, num_segments, nullptr, stream);
+}
 
 namespace {
 int forward_stage2_impl(int P, int R, int max_tile_instances, int num_segments, int num_channels, int W, int H,
                         const float* background, const float* colors_precomp, void* geom_buffer, void* binning_buffer,
-                        void* image_buffer, float* out_color, void* grad_scratch, gsr_stream_t stream);
+                        void* image_buffer, float* out_color, void* grad_scratch, uint32_t* counters, gsr_stream_t stream);
 }
 
 int gsr_forward_fused(int P, int D, int M, int num_channels, int need_backward, const float* means3D, const float* shs,
@@ -198,16 +252,35 @@ int gsr_forward_fused(int P, int D, int M, int num_channels, int need_backward, 
     if (!blended) { g_err.clear(); return fail_msg("gsr_forward_fused: null output pointer"); }
     *blended = 0;
     if (!channels_ok(num_channels)) { g_err.clear(); return fail_msg("gsr_forward_fused: num_channels must be 3 or 6"); }
-    const int rc = gsr_forward_stage1(P, D, M, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
-                                      cov3D_precomp, viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, prefiltered,
-                                      radii, geom_buffer, image_buffer, num_rendered, max_tile_instances, num_segments, stream);
-    if (rc != 0) return rc;
-    if (gsr_binning_bytes_mt(*num_rendered, *num_segments, num_channels) > binning_capacity || (*num_rendered > 0 && !binning_buffer))
-        return 0;   // the guess was too small: the caller allocates exactly and runs stage 2 itself
+    hipStream_t st = (hipStream_t)stream;
+    const bool sane = W > 0 && H > 0 && (long long)tiles_of(W > 0 ? W : 1, H > 0 ? H : 1).T <= 256ll * 1024 && image_buffer && P > 0;
+    const size_t cnt_words = sane ? 2 * (size_t)shard_stride(tiles_of(W, H).T) * NSHARD : 0;
+    Counters* own = sane ? acquire_counters(st, cnt_words) : nullptr;
+    const int rc = forward_stage1_impl(P, D, M, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                                       cov3D_precomp, viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, prefiltered,
+                                       radii, geom_buffer, image_buffer, num_rendered, max_tile_instances, num_segments,
+                                       own ? own->base : nullptr, stream);
+    if (rc != 0) return rc;   // (own stays marked dirty: re-filled on its next use)
+    if (gsr_binning_bytes_mt(*num_rendered, *num_segments, num_channels) > binning_capacity || (*num_rendered > 0 && !binning_buffer)) {
+        // the guess was too small: the caller allocates exactly and runs stage 2 itself -- over the image buffer's own
+        // counters, so they get this call's counts (cursors are still zero) and the library's block is filled again
+        if (own) {
+            ImageState im = carve_image(image_buffer, W, H);
+            GSR_CHECK(hipMemcpyAsync(im.tile_count, own->base, 4 * cnt_words / 2, hipMemcpyDeviceToDevice, st));
+            GSR_CHECK(hipMemsetAsync(im.tile_cursor, 0, 4 * cnt_words / 2, st));
+            GSR_CHECK(hipMemsetAsync(own->base, 0, 4 * cnt_words / 2, st));
+            own->clean = true;
+        }
+        return 0;
+    }
     const int rc2 = forward_stage2_impl(P, *num_rendered, *max_tile_instances, need_backward ? *num_segments : -*num_segments,
                                         num_channels, W, H, background, colors_precomp, geom_buffer, binning_buffer,
-                                        image_buffer, out_color, need_backward ? grad_scratch : nullptr, stream);
-    if (rc2 == 0) *blended = 1;
+                                        image_buffer, out_color, need_backward ? grad_scratch : nullptr,
+                                        own ? own->base : nullptr, stream);
+    if (rc2 == 0) {
+        *blended = 1;
+        if (own) own->clean = true;   // the forward blend zeroes every tile's counters and cursors
+    }
     return rc2;
 }
 
@@ -223,7 +296,7 @@ namespace {
 // grad_scratch != nullptr: the backward's accumulation table, cleared by the forward blend on the side (gsr_forward_fused)
 int forward_stage2_impl(int P, int R, int max_tile_instances, int num_segments, int num_channels, int W, int H,
                         const float* background, const float* colors_precomp, void* geom_buffer, void* binning_buffer,
-                        void* image_buffer, float* out_color, void* grad_scratch, gsr_stream_t stream)
+                        void* image_buffer, float* out_color, void* grad_scratch, uint32_t* counters, gsr_stream_t stream)
 {
     g_err.clear();
     if (W <= 0 || H <= 0) return fail_msg("gsr_forward_stage2: image size must be positive");
@@ -235,6 +308,10 @@ int forward_stage2_impl(int P, int R, int max_tile_instances, int num_segments, 
     const int C = num_channels;
     hipStream_t st = (hipStream_t)stream;
     ImageState im = carve_image(image_buffer, W, H);
+    if (counters) {   // library-owned counters of the fused forward; the blend hands them back zeroed
+        im.tile_count = counters;
+        im.tile_cursor = counters + (size_t)shard_stride(tiles_of(W, H).T) * NSHARD;
+    }
     GeomState g = carve_geom(geom_buffer, P > 0 ? P : 0);
     // num_segments < 0: forward-only render (same buffer size as for |num_segments|, snapshots not written);
     // num_segments = 0 with R > 0: forward-only and no per-unit areas at all (long tiles are walked serially)
@@ -259,7 +336,7 @@ int forward_stage2_impl(int P, int R, int max_tile_instances, int num_segments, 
     {
         Scope sc(ST_BLEND_FWD, st);
         launch_blend_fwd(C, W, H, R, num_segments, (uint32_t)(max_tile_instances > 0 ? max_tile_instances : 0), background, feats, g, im, b,
-                         out_color, grad_scratch, grad_scratch ? gsr_grad_scratch_bytes(P > 0 ? P : 0) : 0, st);
+                         out_color, grad_scratch, grad_scratch ? gsr_grad_scratch_bytes(P > 0 ? P : 0) : 0, counters, st);
     }
     GSR_CHECK_LAUNCH("blend_fwd_kernel");
     return 0;
@@ -271,7 +348,7 @@ int gsr_forward_stage2_mt(int P, int R, int max_tile_instances, int num_segments
                           void* image_buffer, float* out_color, gsr_stream_t stream)
 {
     return forward_stage2_impl(P, R, max_tile_instances, num_segments, num_channels, W, H, background, colors_precomp,
-                               geom_buffer, binning_buffer, image_buffer, out_color, nullptr, stream);
+                               geom_buffer, binning_buffer, image_buffer, out_color, nullptr, nullptr, stream);
 }
 
 int gsr_forward(gsr_alloc_fn geometry_buffer, gsr_alloc_fn binning_buffer, gsr_alloc_fn image_buffer, void* alloc_ctx,

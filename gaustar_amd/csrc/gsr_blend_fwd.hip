@@ -237,7 +237,8 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                  const float4* __restrict__ g1, const float* __restrict__ feats, const float* __restrict__ bg,
                  float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                  const uint32_t* __restrict__ seg_off, float4* __restrict__ snap, uint32_t skip_above,
-                 float4* __restrict__ zero_ptr, uint32_t zero_n, uint64_t* __restrict__ trace)
+                 float4* __restrict__ zero_ptr, uint32_t zero_n, uint32_t* __restrict__ counters, uint32_t counters_tp,
+                 uint64_t* __restrict__ trace)
 {
     const uint64_t t_start = trace ? wall_clock64() : 0;
     // Side job: the backward's accumulation table (48 B per Gaussian) has to be zero before blend_bwd runs.  When the
@@ -255,6 +256,10 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     // ds_read directly: one extract per entry instead of extract + multiply-add)
     __shared__ __attribute__((aligned(8))) uint16_t qidx[4][4][QCAP];
     const int tile = (int)order[blockIdx.x];
+    // Second side job (fused forward): this tile's eight shard counters and eight scatter cursors live in a library-owned
+    // block that has to be all zero again for the next view's preprocess; scatter, their last reader, is done.
+    if (counters != nullptr && threadIdx.x < 2 * NSHARD)
+        counters[(size_t)threadIdx.x * counters_tp + tile] = 0u;      // rows 0-7: counts, rows 8-15: cursors ([16][Tp])
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = lane >> 4;                                        // DPP row = quadrant
     const int tx = tile % gx, ty = tile / gx;
@@ -527,7 +532,7 @@ blend_fwd_long_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, co
 
 template <int C>
 static void launch_fwd_c(int W, int H, int R, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im,
-                         BinState b, float* out_color, void* zero_ptr, size_t zero_bytes, hipStream_t st)
+                         BinState b, float* out_color, void* zero_ptr, size_t zero_bytes, uint32_t* counters, hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);
     static const uint32_t long_thr = getenv("GSR_FWD_LONG") ? (uint32_t)atoi(getenv("GSR_FWD_LONG")) : 4096u;
@@ -545,14 +550,16 @@ static void launch_fwd_c(int W, int H, int R, int U, uint32_t max_count, const f
     }
     blend_fwd_kernel<C><<<t.T, 256, 0, st>>>(W, H, t.gx, im.ranges, im.order, b.point_list, g.g0, g.g1, feats, bg, out_color,
                                              im.final_T, im.n_contrib, im.seg_off, b.snap, use_long ? long_thr : 0xffffffffu,
-                                             static_cast<float4*>(zero_ptr), (uint32_t)(zero_bytes / 16), g_trace);
+                                             static_cast<float4*>(zero_ptr), (uint32_t)(zero_bytes / 16), counters,
+                                             (uint32_t)shard_stride(t.T), g_trace);
 }
 
 void launch_blend_fwd(int C, int W, int H, int R, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g,
-                      ImageState im, BinState b, float* out_color, void* zero_ptr, size_t zero_bytes, hipStream_t st)
+                      ImageState im, BinState b, float* out_color, void* zero_ptr, size_t zero_bytes, uint32_t* counters,
+                      hipStream_t st)
 {
-    if (C == 6) launch_fwd_c<6>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, zero_ptr, zero_bytes, st);
-    else launch_fwd_c<3>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, zero_ptr, zero_bytes, st);
+    if (C == 6) launch_fwd_c<6>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, zero_ptr, zero_bytes, counters, st);
+    else launch_fwd_c<3>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, zero_ptr, zero_bytes, counters, st);
 }
 
 }  // namespace gsr

@@ -179,7 +179,7 @@ inline int front_of_order(int R, int T)
     return (int)(bound < (long long)T ? bound : (long long)T);
 }
 void launch_blend_fwd(int C, int W, int H, int R, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
-                      float* out_color, void* zero_ptr, size_t zero_bytes, hipStream_t st);
+                      float* out_color, void* zero_ptr, size_t zero_bytes, uint32_t* counters, hipStream_t st);
 void launch_blend_bwd(int C, int W, int H, int U, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
                       const float* dL_dpix, float* grad_acc, hipStream_t st);
 void launch_geom_bwd(int P, int D, int M, const float* means3D, const float* shs, const float* scales,

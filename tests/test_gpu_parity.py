@@ -487,3 +487,36 @@ def test_two_backward_passes_over_one_forward_agree():
     for other in grads[1:]:
         for a, b, name in zip(grads[0], other, ("means3D", "opacity", "scales", "rotations", "colors")):
             parity.check_grad(b, a, f"repeated backward: dL_d{name}")
+
+
+def test_library_owned_counters_survive_size_changes_and_fallbacks():
+    """The fused forward keeps the tile counters in a library-owned, self-cleaning block.  Alternate image sizes (other
+    tile counts, other row strides in the same block), force the undersized-hint fallback in between (counts copied back
+    to the image buffer, block re-filled) and compare every render with GSR-independent ground truth: the same view
+    rendered through the plain two-stage entry points."""
+    import torch
+    from gaustar_amd import rasterizer as R, scene
+    rng = np.random.default_rng(55)
+    gs = scene.random_gaussians(5000, rng, scale_range=(0.02, 0.12))
+    sizes = [(320, 200), (97, 61), (640, 360), (97, 61), (320, 200), (33, 17), (640, 360)]
+    saved = dict(R._BINNING_HINT)
+    try:
+        for i, (W, H) in enumerate(sizes):
+            cam = scene.look_at_camera((0.2, 0.1, -4.0), (0, 0, 0), W, H, fovx=0.8, znear=0.01)
+            kw = dict(means3D=gs.means3D, opacities=gs.opacities, view=cam.viewmatrix, proj=cam.projmatrix, campos=cam.campos,
+                      W=W, H=H, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=np.array([0.3, 0.1, 0.6], np.float32), shs=None,
+                      colors_precomp=gs.colors_precomp, scales=gs.scales, rotations=gs.rotations, cov3D_precomp=None, sh_degree=0)
+            R._BINNING_HINT.clear()
+            truth = parity.run_hip(kw)                      # no hint: stage 1 over the library's block, copy-back, stage 2
+            R._BINNING_HINT[0] = 1 << 28
+            fused = parity.run_hip(kw)                      # fused, self-cleaning
+            if i % 2:
+                R._BINNING_HINT[0] = 4096
+                assert np.array_equal(parity.run_hip(kw)["color"], truth["color"])   # undersized hint
+                R._BINNING_HINT[0] = 1 << 28
+            again = parity.run_hip(kw)                      # the block must have come back clean
+            for other in (fused, again):
+                assert np.array_equal(other["color"], truth["color"]) and np.array_equal(other["radii"], truth["radii"]), (W, H)
+    finally:
+        R._BINNING_HINT.clear()
+        R._BINNING_HINT.update(saved)
