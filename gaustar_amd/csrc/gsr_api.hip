@@ -320,6 +320,7 @@ int forward_stage2_impl(int P, int R, int max_tile_instances, int num_segments, 
     BinState b = carve_bin(binning_buffer, R > 0 ? R : 0, num_segments, C);
     if (num_segments == 0) { b.unit_tile = nullptr; b.part = nullptr; b.part_last = nullptr; }
     if (forward_only) b.snap = nullptr;
+    bool sort_in_blend = false;
     if (R > 0) {
         {
             Scope sc(ST_SCATTER, st);
@@ -328,7 +329,9 @@ int forward_stage2_impl(int P, int R, int max_tile_instances, int num_segments, 
         GSR_CHECK_LAUNCH("scatter_kernel");
         {
             Scope sc(ST_TILE_SORT, st);
-            launch_tile_sort(W, H, R, (uint32_t)max_tile_instances, im, b, st);
+            const char* e_fuse = getenv("GSR_SORT_IN_BLEND");   // read per call (tools/ab_env.py); "0": separate sort kernel
+            const bool fuse = !(e_fuse && e_fuse[0] == '0');
+            sort_in_blend = launch_tile_sort(W, H, R, (uint32_t)max_tile_instances, im, b, fuse, st);
         }
         GSR_CHECK_LAUNCH("tile_sort_kernel");
     }
@@ -336,7 +339,7 @@ int forward_stage2_impl(int P, int R, int max_tile_instances, int num_segments, 
     {
         Scope sc(ST_BLEND_FWD, st);
         launch_blend_fwd(C, W, H, R, num_segments, (uint32_t)(max_tile_instances > 0 ? max_tile_instances : 0), background, feats, g, im, b,
-                         out_color, grad_scratch, grad_scratch ? gsr_grad_scratch_bytes(P > 0 ? P : 0) : 0, counters, st);
+                         out_color, grad_scratch, grad_scratch ? gsr_grad_scratch_bytes(P > 0 ? P : 0) : 0, counters, sort_in_blend, st);
     }
     GSR_CHECK_LAUNCH("blend_fwd_kernel");
     return 0;

@@ -8,6 +8,7 @@
 // raw float bits, all positive), ties by ascending Gaussian id -- which is what the reference's
 // STABLE radix sort yields because duplicateWithKeys emits instances in id order.
 #include "gsr_internal.h"
+#include "gsr_sort.h"
 #include <cstdlib>
 
 namespace gsr {
@@ -353,104 +354,7 @@ tile_sort_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
     }
 }
 
-// ---- register-resident bitonic sort for buckets of up to 2 048 keys (every tile of a typical view).
-// The LDS network above moves 32 bytes through LDS per compare-exchange; with eight workgroups per CU that
-// traffic, not the comparisons, bounded the kernel.  Here every thread keeps E consecutive keys in registers
-// (blocked layout, 256 threads, E = 2 / 4 / 8 for 512 / 1 024 / 2 048 padded keys):
-//   stride <  E        compare-exchange between two registers of the thread;
-//   stride <  64 E     partner key comes from lane ^ (stride / E): DPP quad permutes (1, 2), ds_swizzle (4, 8, 16),
-//                      ds_bpermute (32) -- crossbar only, no LDS storage, no barrier;
-//   stride >= 64 E     the only stages that cross waves: one round trip through LDS (at most 3 of the 66 stages).
-template <int D>
-__device__ __forceinline__ uint32_t lane_xor_u32(uint32_t v)
-{
-    if constexpr (D == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);         // quad_perm [1,0,3,2]
-    else if constexpr (D == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
-    else if constexpr (D == 4) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);               // xor 4 (bit-mask mode)
-    else if constexpr (D == 8) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x201F);
-    else if constexpr (D == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);
-    else return (uint32_t)__shfl_xor((int)v, 32, 64);
-}
-// one cross-lane stage: every key meets the key of lane ^ D held in the same register slot
-template <int E, int D>
-__device__ __forceinline__ void cross_lane_stage(uint64_t (&v)[E], uint32_t e0, uint32_t k, int lane)
-{
-    const bool lower = (lane & D) == 0;
-#pragma unroll
-    for (int r = 0; r < E; r++) {
-        const uint64_t pv = ((uint64_t)lane_xor_u32<D>((uint32_t)(v[r] >> 32)) << 32) | lane_xor_u32<D>((uint32_t)v[r]);
-        const bool asc = ((e0 + r) & k) == 0;
-        const bool take_min = lower == asc;
-        const bool gt = v[r] > pv;
-        v[r] = (gt == take_min) ? pv : v[r];
-    }
-}
-
-template <int E>
-__device__ __forceinline__ void sort_tile_in_registers(uint64_t* __restrict__ s, const uint64_t* __restrict__ gk,
-                                                       uint32_t* __restrict__ out, uint32_t n, uint32_t np2)
-{
-    const int tid = threadIdx.x, lane = tid & 63;
-    const uint32_t e0 = (uint32_t)tid * E;
-    // waves that own no key leave; cross-wave stages (and their barriers) exist only if np2 > 64 E, in which case
-    // every wave below np2 / (64 E) stays -- and np2 = 256 E means all four
-    if (e0 >= np2) {
-        if (np2 > 64u * E) {   // keep the barrier count of the active waves (uniform per wave)
-            for (uint32_t k = 128u * E; k <= np2; k <<= 1)
-                for (uint32_t j = k >> 1; j >= 64u * E; j >>= 1) { __syncthreads(); __syncthreads(); }
-        }
-        return;
-    }
-    uint64_t v[E];
-#pragma unroll
-    for (int r = 0; r < E; r++) v[r] = e0 + r < n ? gk[e0 + r] : ~0ull;
-    for (uint32_t k = 2; k <= np2; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            if (j < (uint32_t)E) {
-#pragma unroll
-                for (int jj = 1; jj < E; jj <<= 1) {
-                    if ((uint32_t)jj != j) continue;
-#pragma unroll
-                    for (int r = 0; r < E; r++) {
-                        if (r & jj) continue;
-                        const bool asc = ((e0 + r) & k) == 0;
-                        const uint64_t a = v[r], b = v[r | jj];
-                        const bool gt = a > b;
-                        const uint64_t mn = gt ? b : a, mx = gt ? a : b;
-                        v[r] = asc ? mn : mx;
-                        v[r | jj] = asc ? mx : mn;
-                    }
-                }
-            } else if (j < 64u * E) {
-                switch (j / E) {   // one uniform branch per stage; the exchange pattern is an immediate
-                    case 1: cross_lane_stage<E, 1>(v, e0, k, lane); break;
-                    case 2: cross_lane_stage<E, 2>(v, e0, k, lane); break;
-                    case 4: cross_lane_stage<E, 4>(v, e0, k, lane); break;
-                    case 8: cross_lane_stage<E, 8>(v, e0, k, lane); break;
-                    case 16: cross_lane_stage<E, 16>(v, e0, k, lane); break;
-                    default: cross_lane_stage<E, 32>(v, e0, k, lane); break;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < E; r++) s[e0 + r] = v[r];
-                __syncthreads();
-                const bool lower = (e0 & j) == 0;
-#pragma unroll
-                for (int r = 0; r < E; r++) {
-                    const uint64_t pv = s[(e0 + r) ^ j];
-                    const bool asc = ((e0 + r) & k) == 0;
-                    const bool take_min = lower == asc;
-                    const bool gt = v[r] > pv;
-                    v[r] = (gt == take_min) ? pv : v[r];
-                }
-                __syncthreads();
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < E; r++)
-        if (e0 + r < n) out[e0 + r] = (uint32_t)v[r];
-}
+// (the register-resident bitonic sort lives in gsr_sort.h: blend_fwd can run it in front of its blend)
 
 __global__ void __launch_bounds__(256)
 tile_sort_reg_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ order, const uint64_t* __restrict__ keys,
@@ -462,15 +366,7 @@ tile_sort_reg_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
     if (n == 0 || n > 2048u) return;     // longer lists: tile_sort_kernel<16384, 2048, true>
     const uint64_t* gk = keys + rg.x;
     uint32_t* out = point_list + rg.x;
-    if (n == 1) {
-        if (threadIdx.x == 0) out[0] = (uint32_t)gk[0];
-        return;
-    }
-    uint32_t np2 = 2;
-    while (np2 < n) np2 <<= 1;
-    if (np2 <= 512u) sort_tile_in_registers<2>(s, gk, out, n, np2);
-    else if (np2 == 1024u) sort_tile_in_registers<4>(s, gk, out, n, np2);
-    else sort_tile_in_registers<8>(s, gk, out, n, np2);
+    sort_small_tile(s, gk, out, n);
 }
 
 // Lists of 2 049 .. 16 384 entries (close-up views: a few dozen tiles of a 1 M-Gaussian model): the same register network
@@ -491,17 +387,21 @@ tile_sort_big_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
     else sort_tile_in_registers<16>(s, gk, out, n, 16384u);
 }
 
-void launch_tile_sort(int W, int H, int R, uint32_t max_count, ImageState im, BinState b, hipStream_t st)
+bool launch_tile_sort(int W, int H, int R, uint32_t max_count, ImageState im, BinState b, bool blend_sorts_small, hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);
+    bool left_small = false;
     // GSR_DEBUG_SORT_CAP=64 forces the global-memory fallback for every tile above 64 instances (tests).
     static const char* dbg = getenv("GSR_DEBUG_SORT_CAP");
     if (dbg && dbg[0] == '6') {
         tile_sort_kernel<64, 0, true><<<t.T, 256, 64 * 8, st>>>(im.ranges, im.order, b.keys, b.point_list);
-        return;
+        return false;
     }
     static const bool lds_sort = getenv("GSR_SORT_LDS") != nullptr;   // A/B switch: the LDS network for every tile
     if (lds_sort) tile_sort_kernel<2048, 0, false><<<t.T, 256, 2048 * 8, st>>>(im.ranges, im.order, b.keys, b.point_list);
+    // the forward blend sorts each of these lists right before walking it -- unless its long-tile path (which needs sorted
+    // lists before the main kernel runs) reaches below 2 048 entries (GSR_FWD_LONG set low, tests)
+    else if (blend_sorts_small && !(max_count > fwd_long_threshold() && fwd_long_threshold() < 2048u)) left_small = true;
     else tile_sort_reg_kernel<<<t.T, 256, 0, st>>>(im.ranges, im.order, b.keys, b.point_list);
     if (max_count > 2048 && !lds_sort) {
         // the longest lists sit at the front of `order` (32-entry length classes, snake within bands of 256): every tile
@@ -528,6 +428,7 @@ void launch_tile_sort(int W, int H, int R, uint32_t max_count, ImageState im, Bi
         else   // only the lists the register kernels do not take: the global-memory network
             tile_sort_kernel<16384, 16384, true><<<t.T, 256, 16384 * 8, st>>>(im.ranges, im.order, b.keys, b.point_list);
     }
+    return left_small;
 }
 
 }  // namespace gsr

@@ -42,6 +42,7 @@
 // passes, refine.py:552 and :607) in one walk -- alpha, T, termination and n_contrib do not depend on colour,
 // so channels 0-2 / 3-5 are bit-identical to two separate 3-channel renders.
 #include "gsr_internal.h"
+#include "gsr_sort.h"
 #include <cstdlib>
 
 namespace gsr {
@@ -233,7 +234,7 @@ blend_fwd_partial_kernel(int W, int H, int gx, uint32_t long_thr, const uint2* _
 template <int C>
 __global__ void __launch_bounds__(256)
 blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ order,
-                 const uint32_t* __restrict__ point_list, const float4* __restrict__ g0,
+                 uint32_t* point_list, const uint64_t* __restrict__ sort_keys, const float4* __restrict__ g0,
                  const float4* __restrict__ g1, const float* __restrict__ feats, const float* __restrict__ bg,
                  float* __restrict__ out_color, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                  const uint32_t* __restrict__ seg_off, float4* __restrict__ snap, uint32_t skip_above,
@@ -251,10 +252,15 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     }
     constexpr int SV = snap_vecs(C);
     constexpr int CV = (C + 3) / 4;                                   // float4s of colour per slot
-    __shared__ Slot<C> entries[4][64 + 1];                            // [wave][batch lane]; slot 64 = neutral
-    // [wave][quadrant][queue position] -> LDS byte address of the queued slot (absolute, so a queue word feeds
-    // ds_read directly: one extract per entry instead of extract + multiply-add)
-    __shared__ __attribute__((aligned(8))) uint16_t qidx[4][4][QCAP];
+    // LDS: entries[wave][batch lane] (slot 64 = neutral) | qidx[wave][quadrant][queue position] = LDS byte address of the
+    // queued slot (absolute, so a queue word feeds ds_read directly: one extract per entry instead of extract +
+    // multiply-add).  The sort in front of the blend (below) uses the same bytes for its cross-wave stages.
+    constexpr size_t ENT_BYTES = sizeof(Slot<C>) * 4 * (64 + 1), Q_BYTES = sizeof(uint16_t) * 4 * 4 * QCAP;
+    constexpr size_t LDS_BYTES = ENT_BYTES + Q_BYTES > 2048 * 8 ? ENT_BYTES + Q_BYTES : 2048 * 8;
+    static_assert(ENT_BYTES % 8 == 0, "queue words are read as 8-byte pairs");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    Slot<C> (*entries)[64 + 1] = reinterpret_cast<Slot<C>(*)[64 + 1]>(smem);
+    uint16_t (*qidx)[4][QCAP] = reinterpret_cast<uint16_t(*)[4][QCAP]>(smem + ENT_BYTES);
     const int tile = (int)order[blockIdx.x];
     // Second side job (fused forward): this tile's eight shard counters and eight scatter cursors live in a library-owned
     // block that has to be all zero again for the next view's preprocess; scatter, their last reader, is done.
@@ -272,6 +278,14 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     const uint2 rg = ranges[tile];
     const uint32_t n = rg.y - rg.x;
     if (n > skip_above) return;   // long tile: blend_fwd_long_kernel renders it
+    // Depth sort of this tile's list, right here (lists up to 2 048 entries; longer ones were sorted by tile_sort_big_kernel
+    // before this launch).  As a kernel of its own the sort is latency-bound (key loads, cross-lane exchanges, barriers:
+    // 25 us at a fraction of the vector ALU) and the blend then starts from a cold chip; inside the blend kernel one
+    // tile's sort overlaps the other resident tiles' blending, and the sorted ids are read back while still in L2.
+    if (sort_keys != nullptr) {
+        if (n >= 1u && n <= 2048u) sort_small_tile(reinterpret_cast<uint64_t*>(smem), sort_keys + rg.x, point_list + rg.x, n);
+        __syncthreads();   // ids visible to the four waves; the sort's LDS is free for the queues
+    }
     const uint32_t unit0 = seg_off[tile];
     const uint32_t* list = point_list + rg.x;
     Slot<C>* ent = entries[wave];
@@ -532,10 +546,11 @@ blend_fwd_long_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, co
 
 template <int C>
 static void launch_fwd_c(int W, int H, int R, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im,
-                         BinState b, float* out_color, void* zero_ptr, size_t zero_bytes, uint32_t* counters, hipStream_t st)
+                         BinState b, float* out_color, void* zero_ptr, size_t zero_bytes, uint32_t* counters, bool sort_small,
+                         hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);
-    static const uint32_t long_thr = getenv("GSR_FWD_LONG") ? (uint32_t)atoi(getenv("GSR_FWD_LONG")) : 4096u;
+    const uint32_t long_thr = fwd_long_threshold();
     const bool use_long = U > 0 && b.part != nullptr && max_count > long_thr && long_thr >= (uint32_t)SEG;
     // Everything stays on the caller's stream.  Running the long tiles on a library-owned helper stream (fork / join
     // events) beside the main kernel was measured and rejected: after a single use EVERY later step of the process was
@@ -548,7 +563,8 @@ static void launch_fwd_c(int W, int H, int R, int U, uint32_t max_count, const f
             W, H, t.gx, im.ranges, im.order, b.point_list, g.g0, g.g1, feats, bg, out_color, im.final_T, im.n_contrib, im.seg_off,
             b.snap, long_thr, b.part, b.part_last);
     }
-    blend_fwd_kernel<C><<<t.T, 256, 0, st>>>(W, H, t.gx, im.ranges, im.order, b.point_list, g.g0, g.g1, feats, bg, out_color,
+    blend_fwd_kernel<C><<<t.T, 256, 0, st>>>(W, H, t.gx, im.ranges, im.order, b.point_list, sort_small ? b.keys : nullptr,
+                                             g.g0, g.g1, feats, bg, out_color,
                                              im.final_T, im.n_contrib, im.seg_off, b.snap, use_long ? long_thr : 0xffffffffu,
                                              static_cast<float4*>(zero_ptr), (uint32_t)(zero_bytes / 16), counters,
                                              (uint32_t)shard_stride(t.T), g_trace);
@@ -556,10 +572,10 @@ static void launch_fwd_c(int W, int H, int R, int U, uint32_t max_count, const f
 
 void launch_blend_fwd(int C, int W, int H, int R, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g,
                       ImageState im, BinState b, float* out_color, void* zero_ptr, size_t zero_bytes, uint32_t* counters,
-                      hipStream_t st)
+                      bool sort_small, hipStream_t st)
 {
-    if (C == 6) launch_fwd_c<6>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, zero_ptr, zero_bytes, counters, st);
-    else launch_fwd_c<3>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, zero_ptr, zero_bytes, counters, st);
+    if (C == 6) launch_fwd_c<6>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, zero_ptr, zero_bytes, counters, sort_small, st);
+    else launch_fwd_c<3>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, zero_ptr, zero_bytes, counters, sort_small, st);
 }
 
 }  // namespace gsr

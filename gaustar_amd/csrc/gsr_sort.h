@@ -1,0 +1,125 @@
+// gsr_sort.h -- register-resident bitonic sort of one tile's 64-bit keys (depth bits << 32 | Gaussian id), shared by
+// tile_sort_reg_kernel / tile_sort_big_kernel (gsr_binning.hip) and the forward blend, which can sort a tile's list
+// itself right before walking it (gsr_blend_fwd.hip).  Replaces the per-tile share of the reference's device-wide
+// cub::DeviceRadixSort::SortPairs (DGR/cuda_rasterizer/rasterizer_impl.cu:301-307).
+#pragma once
+#include "gsr_internal.h"
+
+namespace gsr {
+
+// ---- register-resident bitonic sort for buckets of up to 2 048 keys (every tile of a typical view).
+// The LDS network above moves 32 bytes through LDS per compare-exchange; with eight workgroups per CU that
+// traffic, not the comparisons, bounded the kernel.  Here every thread keeps E consecutive keys in registers
+// (blocked layout, 256 threads, E = 2 / 4 / 8 for 512 / 1 024 / 2 048 padded keys):
+//   stride <  E        compare-exchange between two registers of the thread;
+//   stride <  64 E     partner key comes from lane ^ (stride / E): DPP quad permutes (1, 2), ds_swizzle (4, 8, 16),
+//                      ds_bpermute (32) -- crossbar only, no LDS storage, no barrier;
+//   stride >= 64 E     the only stages that cross waves: one round trip through LDS (at most 3 of the 66 stages).
+template <int D>
+__device__ __forceinline__ uint32_t lane_xor_u32(uint32_t v)
+{
+    if constexpr (D == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);         // quad_perm [1,0,3,2]
+    else if constexpr (D == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
+    else if constexpr (D == 4) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);               // xor 4 (bit-mask mode)
+    else if constexpr (D == 8) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x201F);
+    else if constexpr (D == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);
+    else return (uint32_t)__shfl_xor((int)v, 32, 64);
+}
+// one cross-lane stage: every key meets the key of lane ^ D held in the same register slot
+template <int E, int D>
+__device__ __forceinline__ void cross_lane_stage(uint64_t (&v)[E], uint32_t e0, uint32_t k, int lane)
+{
+    const bool lower = (lane & D) == 0;
+#pragma unroll
+    for (int r = 0; r < E; r++) {
+        const uint64_t pv = ((uint64_t)lane_xor_u32<D>((uint32_t)(v[r] >> 32)) << 32) | lane_xor_u32<D>((uint32_t)v[r]);
+        const bool asc = ((e0 + r) & k) == 0;
+        const bool take_min = lower == asc;
+        const bool gt = v[r] > pv;
+        v[r] = (gt == take_min) ? pv : v[r];
+    }
+}
+
+template <int E>
+__device__ __forceinline__ void sort_tile_in_registers(uint64_t* __restrict__ s, const uint64_t* __restrict__ gk,
+                                                       uint32_t* __restrict__ out, uint32_t n, uint32_t np2)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t e0 = (uint32_t)tid * E;
+    // waves that own no key leave; cross-wave stages (and their barriers) exist only if np2 > 64 E, in which case
+    // every wave below np2 / (64 E) stays -- and np2 = 256 E means all four
+    if (e0 >= np2) {
+        if (np2 > 64u * E) {   // keep the barrier count of the active waves (uniform per wave)
+            for (uint32_t k = 128u * E; k <= np2; k <<= 1)
+                for (uint32_t j = k >> 1; j >= 64u * E; j >>= 1) { __syncthreads(); __syncthreads(); }
+        }
+        return;
+    }
+    uint64_t v[E];
+#pragma unroll
+    for (int r = 0; r < E; r++) v[r] = e0 + r < n ? gk[e0 + r] : ~0ull;
+    for (uint32_t k = 2; k <= np2; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            if (j < (uint32_t)E) {
+#pragma unroll
+                for (int jj = 1; jj < E; jj <<= 1) {
+                    if ((uint32_t)jj != j) continue;
+#pragma unroll
+                    for (int r = 0; r < E; r++) {
+                        if (r & jj) continue;
+                        const bool asc = ((e0 + r) & k) == 0;
+                        const uint64_t a = v[r], b = v[r | jj];
+                        const bool gt = a > b;
+                        const uint64_t mn = gt ? b : a, mx = gt ? a : b;
+                        v[r] = asc ? mn : mx;
+                        v[r | jj] = asc ? mx : mn;
+                    }
+                }
+            } else if (j < 64u * E) {
+                switch (j / E) {   // one uniform branch per stage; the exchange pattern is an immediate
+                    case 1: cross_lane_stage<E, 1>(v, e0, k, lane); break;
+                    case 2: cross_lane_stage<E, 2>(v, e0, k, lane); break;
+                    case 4: cross_lane_stage<E, 4>(v, e0, k, lane); break;
+                    case 8: cross_lane_stage<E, 8>(v, e0, k, lane); break;
+                    case 16: cross_lane_stage<E, 16>(v, e0, k, lane); break;
+                    default: cross_lane_stage<E, 32>(v, e0, k, lane); break;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < E; r++) s[e0 + r] = v[r];
+                __syncthreads();
+                const bool lower = (e0 & j) == 0;
+#pragma unroll
+                for (int r = 0; r < E; r++) {
+                    const uint64_t pv = s[(e0 + r) ^ j];
+                    const bool asc = ((e0 + r) & k) == 0;
+                    const bool take_min = lower == asc;
+                    const bool gt = v[r] > pv;
+                    v[r] = (gt == take_min) ? pv : v[r];
+                }
+                __syncthreads();
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < E; r++)
+        if (e0 + r < n) out[e0 + r] = (uint32_t)v[r];
+}
+
+// One tile of 1 .. 2 048 keys, 256 threads, s = 2 048 x 8 bytes of LDS (used by the cross-wave stages only).
+// Must be called by all 256 threads of the workgroup (it contains workgroup barriers).
+__device__ __forceinline__ void sort_small_tile(uint64_t* __restrict__ s, const uint64_t* __restrict__ gk,
+                                                uint32_t* __restrict__ out, uint32_t n)
+{
+    if (n == 1) {
+        if (threadIdx.x == 0) out[0] = (uint32_t)gk[0];
+        return;
+    }
+    uint32_t np2 = 2;
+    while (np2 < n) np2 <<= 1;
+    if (np2 <= 512u) sort_tile_in_registers<2>(s, gk, out, n, np2);
+    else if (np2 == 1024u) sort_tile_in_registers<4>(s, gk, out, n, np2);
+    else sort_tile_in_registers<8>(s, gk, out, n, np2);
+}
+
+}  // namespace gsr
