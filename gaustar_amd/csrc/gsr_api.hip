@@ -461,7 +461,7 @@ int gsr_sh_to_rgb(int P, int D, int M, const float* positions, const float* camp
     hipStream_t st = (hipStream_t)stream;
     {
         Scope sc(ST_PRODUCERS, st);
-        launch_sh_to_rgb(P, D, M, positions, campos, shs, rgb, st);
+        launch_sh_to_rgb(P, D, M, positions, campos, shs, nullptr, rgb, st);
     }
     GSR_CHECK_LAUNCH("sh_to_rgb_kernel");
     return 0;
@@ -479,7 +479,42 @@ int gsr_sh_to_rgb_backward(int P, int D, int M, const float* positions, const fl
     hipStream_t st = (hipStream_t)stream;
     {
         Scope sc(ST_PRODUCERS, st);
-        launch_sh_to_rgb_bwd(P, D, M, positions, campos, shs, dL_drgb, dL_dsh, dL_dpos, st);
+        launch_sh_to_rgb_bwd(P, D, M, positions, campos, shs, nullptr, dL_drgb, dL_dsh, dL_dpos, st);
+    }
+    GSR_CHECK_LAUNCH("sh_to_rgb_bwd_kernel");
+    return 0;
+}
+
+int gsr_sh_to_rgbd(int P, int D, int M, const float* positions, const float* campos, const float* shs,
+                   const float* viewmatrix, float* colors6, gsr_stream_t stream)
+{
+    g_err.clear();
+    if (P <= 0) return 0;
+    if (!positions || !campos || !shs || !viewmatrix || !colors6) return fail_msg("gsr_sh_to_rgbd: required pointer is null");
+    if (D < 0 || D > 3 || (D + 1) * (D + 1) > M) return fail_msg("gsr_sh_to_rgbd: sh degree must be 0..3 and fit in M coefficients");
+    hipStream_t st = (hipStream_t)stream;
+    {
+        Scope sc(ST_PRODUCERS, st);
+        launch_sh_to_rgb(P, D, M, positions, campos, shs, viewmatrix, colors6, st);
+    }
+    GSR_CHECK_LAUNCH("sh_to_rgb_kernel");
+    return 0;
+}
+
+int gsr_sh_to_rgbd_backward(int P, int D, int M, const float* positions, const float* campos, const float* shs,
+                            const float* viewmatrix, const float* dL_dcolors6, float* dL_dsh, float* dL_dpos,
+                            gsr_stream_t stream)
+{
+    g_err.clear();
+    if (P <= 0) return 0;
+    if (!positions || !campos || !shs || !viewmatrix || !dL_dcolors6 || !dL_dsh || !dL_dpos)
+        return fail_msg("gsr_sh_to_rgbd_backward: required pointer is null");
+    if (D < 0 || D > 3 || (D + 1) * (D + 1) > M)
+        return fail_msg("gsr_sh_to_rgbd_backward: sh degree must be 0..3 and fit in M coefficients");
+    hipStream_t st = (hipStream_t)stream;
+    {
+        Scope sc(ST_PRODUCERS, st);
+        launch_sh_to_rgb_bwd(P, D, M, positions, campos, shs, viewmatrix, dL_dcolors6, dL_dsh, dL_dpos, st);
     }
     GSR_CHECK_LAUNCH("sh_to_rgb_bwd_kernel");
     return 0;

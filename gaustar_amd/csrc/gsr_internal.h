@@ -125,10 +125,10 @@ inline BinState carve_bin(void* base, int R, int U, int C = 3)
 }
 
 // producers of rasterizer inputs (gsr_producers.hip)
-void launch_sh_to_rgb(int P, int D, int M, const float* positions, const float* campos, const float* shs, float* rgb,
-                      hipStream_t st);
-void launch_sh_to_rgb_bwd(int P, int D, int M, const float* positions, const float* campos, const float* shs,
-                          const float* dL_drgb, float* dL_dsh, float* dL_dpos, hipStream_t st);
+void launch_sh_to_rgb(int P, int D, int M, const float* positions, const float* campos, const float* shs, const float* view,
+                      float* out, hipStream_t st);
+void launch_sh_to_rgb_bwd(int P, int D, int M, const float* positions, const float* campos, const float* shs, const float* view,
+                          const float* dL_dout, float* dL_dsh, float* dL_dpos, hipStream_t st);
 
 void launch_mesh_gaussians(int F, int G, const float* verts, const long long* faces, const float* bary,
                            const float* raw_scales, const float* raw_complex, float thickness, float min_scale,

@@ -14,7 +14,7 @@ namespace gsr {
 
 __global__ void __launch_bounds__(256)
 sh_to_rgb_kernel(int P, int D, int M, const float* __restrict__ positions, const float* __restrict__ campos,
-                 const float* __restrict__ shs, float* __restrict__ rgb)
+                 const float* __restrict__ shs, const float* __restrict__ view, float* __restrict__ rgb, int stride)
 {
     extern __shared__ float sh_lds[];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -33,15 +33,20 @@ sh_to_rgb_kernel(int P, int D, int M, const float* __restrict__ positions, const
     const float* sh = wave_rows + lane * sh_row_stride(M);
     float cr = 0.f, cg = 0.f, cb = 0.f;
     for (int k = 0; k < nb; k++) { cr += basis[k] * sh[3 * k]; cg += basis[k] * sh[3 * k + 1]; cb += basis[k] * sh[3 * k + 2]; }
-    rgb[3 * i] = fmaxf(cr + 0.5f, 0.0f);
-    rgb[3 * i + 1] = fmaxf(cg + 0.5f, 0.0f);
-    rgb[3 * i + 2] = fmaxf(cb + 0.5f, 0.0f);
+    float* o = rgb + (size_t)stride * i;
+    o[0] = fmaxf(cr + 0.5f, 0.0f);
+    o[1] = fmaxf(cg + 0.5f, 0.0f);
+    o[2] = fmaxf(cb + 0.5f, 0.0f);
+    if (view != nullptr) {   // second target of a two-target render: view-space depth as a colour (refine.py:603-605)
+        const float z = p.x * view[2] + p.y * view[6] + p.z * view[10] + view[14];   // (p, 1) . column 2 of the view matrix
+        o[3] = z; o[4] = z; o[5] = z;
+    }
 }
 
 __global__ void __launch_bounds__(256)
 sh_to_rgb_bwd_kernel(int P, int D, int M, const float* __restrict__ positions, const float* __restrict__ campos,
-                     const float* __restrict__ shs, const float* __restrict__ dL_drgb, float* __restrict__ dL_dsh,
-                     float* __restrict__ dL_dpos)
+                     const float* __restrict__ shs, const float* __restrict__ view, const float* __restrict__ dL_drgb,
+                     int stride, float* __restrict__ dL_dsh, float* __restrict__ dL_dpos)
 {
     extern __shared__ float sh_lds[];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -52,10 +57,15 @@ sh_to_rgb_bwd_kernel(int P, int D, int M, const float* __restrict__ positions, c
     if (idx < P) {
         const size_t i = (size_t)idx;
         const Vec3 p = load3(positions, i);
-        const float dcol[3] = {dL_drgb[3 * i], dL_drgb[3 * i + 1], dL_drgb[3 * i + 2]};
+        const float* gi = dL_drgb + (size_t)stride * i;
+        const float dcol[3] = {gi[0], gi[1], gi[2]};
         float gx = 0.f, gy = 0.f, gz = 0.f;
         float* row = wave_rows + lane * sh_row_stride(M);
         sh_colour_backward(D, M, p, campos, row, dcol, row, gx, gy, gz);   // gradient row replaces the coefficient row
+        if (view != nullptr) {   // the three depth channels all carry d z / d p = column 2 of the view matrix
+            const float gzv = gi[3] + gi[4] + gi[5];
+            gx += gzv * view[2]; gy += gzv * view[6]; gz += gzv * view[10];
+        }
         dL_dpos[3 * i] = gx; dL_dpos[3 * i + 1] = gy; dL_dpos[3 * i + 2] = gz;
     }
     __builtin_amdgcn_wave_barrier();
@@ -301,16 +311,18 @@ void launch_mesh_gaussians_bwd(int F, int G, const float* verts, const long long
                                                               dL_draw_scales, dL_draw_complex, dL_ddelta_t, dL_ddelta_r);
 }
 
-void launch_sh_to_rgb(int P, int D, int M, const float* positions, const float* campos, const float* shs, float* rgb,
-                      hipStream_t st)
+// view == nullptr: rgb [P,3]; otherwise rgb + depth-as-colour [P,6] (gsr_sh_to_rgbd)
+void launch_sh_to_rgb(int P, int D, int M, const float* positions, const float* campos, const float* shs, const float* view,
+                      float* out, hipStream_t st)
 {
-    sh_to_rgb_kernel<<<(P + 255) / 256, 256, sh_stage_bytes(M, 4), st>>>(P, D, M, positions, campos, shs, rgb);
+    sh_to_rgb_kernel<<<(P + 255) / 256, 256, sh_stage_bytes(M, 4), st>>>(P, D, M, positions, campos, shs, view, out, view ? 6 : 3);
 }
 
-void launch_sh_to_rgb_bwd(int P, int D, int M, const float* positions, const float* campos, const float* shs,
-                          const float* dL_drgb, float* dL_dsh, float* dL_dpos, hipStream_t st)
+void launch_sh_to_rgb_bwd(int P, int D, int M, const float* positions, const float* campos, const float* shs, const float* view,
+                          const float* dL_dout, float* dL_dsh, float* dL_dpos, hipStream_t st)
 {
-    sh_to_rgb_bwd_kernel<<<(P + 255) / 256, 256, sh_stage_bytes(M, 4), st>>>(P, D, M, positions, campos, shs, dL_drgb, dL_dsh, dL_dpos);
+    sh_to_rgb_bwd_kernel<<<(P + 255) / 256, 256, sh_stage_bytes(M, 4), st>>>(P, D, M, positions, campos, shs, view, dL_dout,
+                                                                              view ? 6 : 3, dL_dsh, dL_dpos);
 }
 
 }  // namespace gsr

@@ -266,10 +266,10 @@ class SurfaceGaussians(nn.Module):
         bg_rgb = torch.zeros(3, device=dev) if bg_color is None else torch.as_tensor(bg_color, dtype=torch.float32, device=dev)
         bg6 = torch.cat([bg_rgb, torch.full((3,), float(max_depth), device=dev)])
         sh_deg = self.sh_levels - 1 if sh_deg is None else int(sh_deg)
-        settings, _view, campos = self._settings(camera, bg6, 0)
+        settings, view, campos = self._settings(camera, bg6, 0)
         positions = self.points
-        colors6 = torch.cat([self.get_points_rgb(positions=positions, camera_centers=campos, sh_levels=sh_deg + 1),
-                             self.view_depth_colors(camera, positions)], dim=1)
+        # SH colours and view-space depth of every Gaussian from one fused producer (no cat, no skinny matmul)
+        colors6 = producers.points_rgb_depth(positions, campos, self.sh_coordinates, sh_deg + 1, view)
         img, _ = GaussianRasterizer(settings)(means3D=positions, means2D=torch.zeros_like(positions), opacities=self.strengths,
                                               colors_precomp=colors6, scales=self.scaling, rotations=self.quaternions)
         return img[:3].permute(1, 2, 0), img[3]

@@ -22,8 +22,10 @@ def _p(t):
 
 
 class _PointsRGB(torch.autograd.Function):
+    """view is None: rgb [P,3]; otherwise rgb + view-space depth as a second colour target [P,6] (points_rgb_depth)."""
+
     @staticmethod
-    def forward(ctx, positions, camera_center, sh_coordinates, sh_levels):
+    def forward(ctx, positions, camera_center, sh_coordinates, sh_levels, view=None):
         lib = _lib.load()
         if not positions.is_cuda:
             raise RuntimeError("gaustar_amd.producers: positions must live on a HIP (cuda) device -- there is no CPU path")
@@ -42,25 +44,36 @@ class _PointsRGB(torch.autograd.Function):
             raise RuntimeError("camera_center must hold one 3-vector (shape (3,) or (1, 3))")
         sh = sh_coordinates.detach().to(torch.float32).contiguous()
         P = int(pos.size(0))
-        rgb = torch.empty(P, 3, dtype=torch.float32, device=dev)
+        if view is not None:
+            if tuple(view.shape) != (4, 4):
+                raise RuntimeError("viewmatrix must be (4, 4), as handed to the rasterizer")
+            view = view.detach().to(dev, torch.float32).contiguous()
+        rgb = torch.empty(P, 3 if view is None else 6, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(lib.gsr_sh_to_rgb(P, D, M, _p(pos), _p(cam), _p(sh), _p(rgb), _stream()), "gsr_sh_to_rgb")
-        ctx.save_for_backward(pos, cam, sh)
+            if view is None:
+                _lib.check(lib.gsr_sh_to_rgb(P, D, M, _p(pos), _p(cam), _p(sh), _p(rgb), _stream()), "gsr_sh_to_rgb")
+            else:
+                _lib.check(lib.gsr_sh_to_rgbd(P, D, M, _p(pos), _p(cam), _p(sh), _p(view), _p(rgb), _stream()), "gsr_sh_to_rgbd")
+        ctx.save_for_backward(pos, cam, sh, view)
         ctx.D = D
         return rgb
 
     @staticmethod
     def backward(ctx, dL_drgb):
         lib = _lib.load()
-        pos, cam, sh = ctx.saved_tensors
+        pos, cam, sh, view = ctx.saved_tensors
         P, M = int(pos.size(0)), int(sh.size(1))
         g = dL_drgb.to(torch.float32).contiguous()
         dsh = torch.empty_like(sh)
         dpos = torch.empty_like(pos)
         with torch.cuda.device(pos.device):
-            _lib.check(lib.gsr_sh_to_rgb_backward(P, ctx.D, M, _p(pos), _p(cam), _p(sh), _p(g), _p(dsh), _p(dpos),
-                                                  _stream()), "gsr_sh_to_rgb_backward")
-        return dpos, None, dsh, None
+            if view is None:
+                _lib.check(lib.gsr_sh_to_rgb_backward(P, ctx.D, M, _p(pos), _p(cam), _p(sh), _p(g), _p(dsh), _p(dpos),
+                                                      _stream()), "gsr_sh_to_rgb_backward")
+            else:
+                _lib.check(lib.gsr_sh_to_rgbd_backward(P, ctx.D, M, _p(pos), _p(cam), _p(sh), _p(view), _p(g), _p(dsh),
+                                                       _p(dpos), _stream()), "gsr_sh_to_rgbd_backward")
+        return dpos, None, dsh, None, None
 
 
 def points_rgb(positions: torch.Tensor, camera_centers: torch.Tensor, sh_coordinates: torch.Tensor,
@@ -69,6 +82,16 @@ def points_rgb(positions: torch.Tensor, camera_centers: torch.Tensor, sh_coordin
     camera_centers)) + 0.5, 0), sugar_model.py:698-716 with one camera centre ((3,) or (1,3)), sh_coordinates
     [P, n_coeffs, 3] as SuGaR stores them (sugar_model.py:449-450)."""
     return _PointsRGB.apply(positions, camera_centers, sh_coordinates, int(sh_levels))
+
+
+def points_rgb_depth(positions: torch.Tensor, camera_centers: torch.Tensor, sh_coordinates: torch.Tensor, sh_levels: int,
+                     viewmatrix: torch.Tensor) -> torch.Tensor:
+    """colors[P,6] for the one-pass RGB + depth render: columns 0-2 = points_rgb(...), columns 3-5 = the view-space
+    depth of every position, three times -- the `point_depth.expand(-1, 3)` GauSTAR renders as colours
+    (gaustar_trainers/refine.py:603-605).  viewmatrix: the (4, 4) world-to-view matrix handed to the rasterizer
+    (row-vector convention, sugar_model.py:1149).  One kernel each way instead of eval_sh + a skinny matmul + cat and
+    their autograd mirror; the gradient w.r.t. viewmatrix is not provided (cameras are fixed in the trainer)."""
+    return _PointsRGB.apply(positions, camera_centers, sh_coordinates, int(sh_levels), viewmatrix)
 
 
 class _MeshGaussians(torch.autograd.Function):

@@ -176,6 +176,17 @@ int gsr_sh_to_rgb(int P, int D, int M, const float* positions, const float* camp
 int gsr_sh_to_rgb_backward(int P, int D, int M, const float* positions, const float* campos, const float* shs,
                            const float* dL_drgb, float* dL_dsh, float* dL_dpos, gsr_stream_t stream);
 
+/* Two-target variant for the one-pass RGB + depth render (gsr_forward_stage2_mt with 6 channels): colors6 [P,6] =
+ * {rgb as gsr_sh_to_rgb, z, z, z} with z = the view-space depth of the position, i.e. the `point_depth.expand(-1, 3)`
+ * GauSTAR renders as colours (gaustar_trainers/refine.py:603-605: world-to-view transform of sugar.points, component 2).
+ * viewmatrix [4,4] as handed to the rasterizer (row-vector convention: z = (p, 1) . column 2).  The backward adds the
+ * depth channels' gradient to dL_dpos.  Replaces torch.cat + two skinny GEMMs + their autograd mirror per iteration. */
+int gsr_sh_to_rgbd(int P, int D, int M, const float* positions, const float* campos, const float* shs,
+                   const float* viewmatrix, float* colors6, gsr_stream_t stream);
+int gsr_sh_to_rgbd_backward(int P, int D, int M, const float* positions, const float* campos, const float* shs,
+                            const float* viewmatrix, const float* dL_dcolors6, float* dL_dsh, float* dL_dpos,
+                            gsr_stream_t stream);
+
 /* gsr_mesh_gaussians replaces the properties SuGaR.points / .scaling / .quaternions for Gaussians bound to a
  * triangle mesh (gaustar_scene/sugar_model.py:417-435, :457-476, :478-508; pytorch3d 0.7.4 face normals,
  * quaternion_to_matrix, matrix_to_quaternion): Gaussian n = f*G + g of face f gets

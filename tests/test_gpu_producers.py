@@ -167,3 +167,35 @@ def test_mesh_bound_closed_form_properties(hip_lib):
     assert (R.transpose(1, 2) @ R - torch.eye(3)).abs().max() < 1e-5 and (torch.det(R) - 1).abs().max() < 1e-5
     assert (((p.cpu() - fv[:, 0].repeat_interleave(6, 0)) * n).sum(-1)).abs().max() < 1e-6
     assert (s[:, 0].cpu() == torch.tensor(3e-6)).all() and (s[:, 1:].cpu() > 0).all()
+
+
+@pytest.mark.parametrize("lv", [1, 4])
+def test_points_rgb_depth_equals_rgb_plus_view_depth(lv, hip_lib):
+    """points_rgb_depth [P,6] = {points_rgb (pinned above by the reference's eval_sh), z_view x 3} with
+    z_view = the reference's `transform_points(points)[..., 2:]` (refine.py:603), stated here in float64 from the same
+    view matrix the rasterizer gets; gradients: dL_dsh from the rgb half, dL_dpos = rgb part + (g3 + g4 + g5) * column 2."""
+    from gaustar_amd import producers, scene
+    z = np.load(KAT)
+    k = f"l{lv}"
+    cam = scene.look_at_camera((0.3, -0.2, -4.0), (0.1, 0.0, 0.0), 64, 48, fovx=0.7, znear=0.01)
+    view = torch.from_numpy(np.ascontiguousarray(cam.viewmatrix, dtype=np.float32)).cuda()
+    campos = torch.from_numpy(z[f"{k}_cam"]).cuda()
+    rng = np.random.default_rng(lv)
+    P = z[f"{k}_pos"].shape[0]
+    g6 = torch.from_numpy(np.concatenate([z[f"{k}_dL"], rng.normal(size=(P, 3)).astype(np.float32)], 1)).cuda()
+    pos = torch.from_numpy(z[f"{k}_pos"]).cuda().requires_grad_(True)
+    sh = torch.from_numpy(z[f"{k}_sh"]).cuda().requires_grad_(True)
+    out = producers.points_rgb_depth(pos, campos, sh, lv, view)
+    assert tuple(out.shape) == (P, 6)
+    out.backward(g6)
+    o = out.detach().cpu().numpy()
+    np.testing.assert_allclose(o[:, :3], z[f"{k}_colors"], rtol=1e-5, atol=2e-6)
+    V = cam.viewmatrix.astype(np.float64)
+    zv = z[f"{k}_pos"].astype(np.float64) @ V[:3, 2] + V[3, 2]
+    for c in (3, 4, 5):
+        np.testing.assert_allclose(o[:, c], zv, rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(sh.grad.cpu().numpy(), z[f"{k}_dsh"], rtol=1e-5, atol=2e-6)
+    dpos = z[f"{k}_dpos"].astype(np.float64) + g6[:, 3:].sum(1, keepdim=True).cpu().numpy().astype(np.float64) * V[:3, 2][None]
+    np.testing.assert_allclose(pos.grad.cpu().numpy(), dpos, rtol=1e-4, atol=3e-5)
+    with pytest.raises(RuntimeError, match=r"\(4, 4\)"):
+        producers.points_rgb_depth(pos, campos, sh, lv, view[:3])

@@ -32,11 +32,10 @@ def build(level, dev, seed=0):
 def render(p, faces, bary, cam_t, dev):
     view, proj, campos, bg6, H, W, tx, ty = cam_t
     pts, scl, quat = producers.mesh_bound_gaussians(p["verts"], faces, bary, p["raw_scales"], p["raw_complex"], 3e-6)
-    rgb = producers.points_rgb(pts, campos, p["sh"], 4)
-    depth = (pts @ view[:3, 2:3] + view[3, 2]).expand(-1, 3)          # refine.py:603-605
+    colors6 = producers.points_rgb_depth(pts, campos, p["sh"], 4, view)   # rgb + depth-as-colour (refine.py:603-605)
     s = GaussianRasterizationSettings(H, W, tx, ty, bg6, 1.0, view, proj, 0, campos, False, False)
     img, _ = GaussianRasterizer(s)(means3D=pts, means2D=torch.zeros_like(pts), opacities=torch.sigmoid(p["densities"]),
-                                   colors_precomp=torch.cat([rgb, depth], 1), scales=scl, rotations=quat)
+                                   colors_precomp=colors6, scales=scl, rotations=quat)
     return img
 
 
