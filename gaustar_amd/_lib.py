@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSR_LIB_PATH", os.path.join(_HERE, "libgsr_hip.so"))   # override: experiment variants
@@ -69,6 +69,8 @@ SIGNATURES = {
     "gsr_depth_l1_workspace_bytes": (c_size_t, []),
     "gsr_depth_l1": (c_int, [c_int, c_int, c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_longlong, c_float,
                              c_float, c_float, c_void_p, c_void_p, c_void_p, c_longlong, c_longlong, c_void_p]),
+    "gsr_adam_step": (c_int, [c_longlong, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_double, c_int,
+                              c_void_p]),
     "gsr_debug_set_trace": (c_int, [c_void_p]),
     "gsr_num_stages": (c_int, []),
     "gsr_stage_name": (c_char_p, [c_int]),

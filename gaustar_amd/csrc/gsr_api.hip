@@ -3,6 +3,7 @@
 // (DGR/cuda_rasterizer/rasterizer_impl.cu:141-153, :198-336, :340-434).
 #include "../../include/gsr.h"
 #include "gsr_internal.h"
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -25,10 +26,10 @@ thread_local uint32_t* g_pinned = nullptr;   // pinned, device-mapped landing pa
 
 // ---- optional per-kernel timing (gsr_profile_*): HIP events on the launch stream around every stage.
 enum Stage { ST_PREPROCESS = 0, ST_TILE_SCAN, ST_SCATTER, ST_TILE_SORT, ST_BLEND_FWD, ST_ZERO_FILL, ST_BLEND_BWD,
-             ST_GEOM_BWD, ST_LOSS, ST_PRODUCERS, ST_COUNT };
+             ST_GEOM_BWD, ST_LOSS, ST_PRODUCERS, ST_OPTIM, ST_COUNT };
 const char* const kStageNames[ST_COUNT] = {"preprocess_kernel", "tile_scan_kernel", "scatter_kernel",
                                            "tile_sort_kernel", "blend_fwd_kernel", "zero_fill", "blend_bwd_kernel",
-                                           "geom_bwd_kernel", "loss_kernels", "producer_kernels"};
+                                           "geom_bwd_kernel", "loss_kernels", "producer_kernels", "optimizer_kernels"};
 struct Rec { int stage; hipEvent_t a, b; };
 // Process-wide (PyTorch runs backward on its own autograd thread), guarded by a mutex.
 struct Profiler {
@@ -517,6 +518,27 @@ int gsr_sh_to_rgbd_backward(int P, int D, int M, const float* positions, const f
         launch_sh_to_rgb_bwd(P, D, M, positions, campos, shs, viewmatrix, dL_dcolors6, dL_dsh, dL_dpos, st);
     }
     GSR_CHECK_LAUNCH("sh_to_rgb_bwd_kernel");
+    return 0;
+}
+
+int gsr_adam_step(long long n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, double lr, double beta1,
+                  double beta2, double eps, int step, gsr_stream_t stream)
+{
+    g_err.clear();
+    if (n <= 0) return 0;
+    if (!param || !grad || !exp_avg || !exp_avg_sq) return fail_msg("gsr_adam_step: required pointer is null");
+    if (step < 1) return fail_msg("gsr_adam_step: step counts from 1");
+    if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15u)
+        return fail_msg("gsr_adam_step: arrays must be 16-byte aligned");
+    // bias corrections in double, as torch/optim/adam.py computes them in Python floats
+    const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
+    hipStream_t st = (hipStream_t)stream;
+    {
+        Scope sc(ST_OPTIM, st);
+        launch_adam(n, param, grad, exp_avg, exp_avg_sq, (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2,
+                    (float)(1.0 - beta2), (float)eps, (float)std::sqrt(bc2), st);
+    }
+    GSR_CHECK_LAUNCH("adam_kernel");
     return 0;
 }
 

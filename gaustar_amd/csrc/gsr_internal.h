@@ -125,6 +125,8 @@ inline BinState carve_bin(void* base, int R, int U, int C = 3)
 }
 
 // producers of rasterizer inputs (gsr_producers.hip)
+void launch_adam(long long n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float step_size,
+                 float one_minus_b1, float b2, float one_minus_b2, float eps, float bc2s, hipStream_t st);
 void launch_sh_to_rgb(int P, int D, int M, const float* positions, const float* campos, const float* shs, const float* view,
                       float* out, hipStream_t st);
 void launch_sh_to_rgb_bwd(int P, int D, int M, const float* positions, const float* campos, const float* shs, const float* view,

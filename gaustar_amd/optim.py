@@ -1,0 +1,58 @@
+"""Adam as GauSTAR configures it, one fused HIP kernel per parameter tensor.
+
+Host-side mirror of the optimiser in gaustar_scene/sugar_optimizer.py:87 -- `torch.optim.Adam(groups, lr=0.0, eps=1e-15)`
+with per-group learning rates that the trainer rewrites every iteration (:104-118) -- and of the update rule in
+torch/optim/adam.py::_single_tensor_adam (no weight decay, no amsgrad, not maximising).  `Adam` below is a
+`torch.optim.Optimizer`: same constructor arguments, same `param_groups`, same state keys (`step`, `exp_avg`,
+`exp_avg_sq`), so SuGaROptimizer-style wrappers and `state_dict()` round trips with torch.optim.Adam work unchanged;
+only `step()` differs: 28 bytes per parameter through one kernel (`gsr_adam_step`) instead of PyTorch's multi-tensor
+kernels.  There is no CPU path: parameters must be float32 HIP tensors."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 amsgrad: bool = False):
+        if weight_decay != 0.0 or amsgrad:
+            raise NotImplementedError("gaustar_amd.optim.Adam: weight_decay and amsgrad are not provided (GauSTAR uses neither)")
+        if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0):
+            raise ValueError("invalid Adam hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0.0, amsgrad=False))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        for group in self.param_groups:
+            lr, (b1, b2), eps = float(group["lr"]), group["betas"], float(group["eps"])
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("gaustar_amd.optim.Adam: parameters must be contiguous float32 tensors on a HIP (cuda) "
+                                       "device -- there is no CPU path")
+                if p.grad.is_sparse:
+                    raise RuntimeError("gaustar_amd.optim.Adam does not support sparse gradients")
+                st = self.state[p]
+                if len(st) == 0:   # same lazy state as torch.optim.Adam (step as a CPU scalar tensor)
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                g = p.grad if (p.grad.dtype == torch.float32 and p.grad.is_contiguous()) else p.grad.float().contiguous()
+                with torch.cuda.device(p.device):
+                    _lib.check(lib.gsr_adam_step(
+                        p.numel(), ctypes.c_void_p(p.data_ptr()), ctypes.c_void_p(g.data_ptr()),
+                        ctypes.c_void_p(st["exp_avg"].data_ptr()), ctypes.c_void_p(st["exp_avg_sq"].data_ptr()), lr, float(b1),
+                        float(b2), eps, int(st["step"].item()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                        "gsr_adam_step")
+        return loss

@@ -248,6 +248,14 @@ const char* gsr_stage_name(int stage);
 int gsr_profile_enable(int on);
 int gsr_profile_read(float* ms, int* counts, int reset);
 
+/* ---- Optimiser step.  gsr_adam_step replaces one parameter tensor's share of torch.optim.Adam.step() as GauSTAR
+ * configures it (gaustar_scene/sugar_optimizer.py:87, :99-101; torch/optim/adam.py::_single_tensor_adam without weight
+ * decay / amsgrad / maximize): in place on param, exp_avg, exp_avg_sq [n] f32 (16-byte aligned), grad [n] read only;
+ * step = the 1-based count of this update (bias corrections 1 - beta^step).  Hyper-parameters are doubles, as the
+ * reference holds them in Python floats: 1 - beta2 formed from a float32 beta2 would already be off by 1e-5. */
+int gsr_adam_step(long long n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, double lr, double beta1,
+                  double beta2, double eps, int step, gsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

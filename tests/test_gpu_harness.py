@@ -87,7 +87,10 @@ def test_fused_rgb_depth_equals_the_two_reference_style_renders(hip_lib):
         a = m.render_image_gaussian_rasterizer(camera=ncam, bg_color=[0.0, 1.0, 0.0], sh_deg=3)
         b = m.render_image_gaussian_rasterizer(camera=ncam, bg_color=[10.0, 10.0, 10.0], sh_deg=0,
                                                point_colors=m.view_depth_colors(ncam))[..., 0]     # refine.py:603-616
-    assert torch.equal(rgb, a) and torch.equal(depth, b)
+    # RGB: same colours into the same walk -> bit-identical.  Depth: the fused producer forms z = (p, 1) . column 2 of the
+    # view matrix in one kernel, view_depth_colors with a torch matmul: the inputs of the blend differ in the last bit
+    assert torch.equal(rgb, a)
+    assert torch.allclose(depth, b, rtol=2e-6, atol=2e-6)
 
 
 def test_checkpoint_round_trip_through_the_model(tmp_path, hip_lib):

@@ -10,7 +10,7 @@ import argparse, json, os, sys, time
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from gaustar_amd import GaussianRasterizationSettings, GaussianRasterizer, losses, producers, scene
+from gaustar_amd import GaussianRasterizationSettings, GaussianRasterizer, losses, optim, producers, scene
 
 BARY6 = [[2/3, 1/6, 1/6], [1/6, 2/3, 1/6], [1/6, 1/6, 2/3], [1/6, 5/12, 5/12], [5/12, 1/6, 5/12], [5/12, 5/12, 1/6]]
 MAX_DEPTH = 10.0
@@ -62,9 +62,9 @@ def run(a):
                         gt_depth))
     for v in params.values():
         v.requires_grad_(True)
-    opt = torch.optim.Adam([{"params": [params["verts"]], "lr": 2e-4}, {"params": [params["sh"]], "lr": 5e-3},
-                            {"params": [params["raw_scales"], params["raw_complex"], params["densities"]], "lr": 5e-3}],
-                           fused=True)
+    groups = [{"params": [params["verts"]], "lr": 2e-4}, {"params": [params["sh"]], "lr": 5e-3},
+              {"params": [params["raw_scales"], params["raw_complex"], params["densities"]], "lr": 5e-3}]
+    opt = torch.optim.Adam(groups, fused=True) if getattr(a, "torch_adam", False) else optim.Adam(groups)
     hist = []
 
     def step(i):
@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--steps", type=int, default=40); ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--level", type=int, default=6); ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of gaustar_amd.optim.Adam")
     print(json.dumps(run(ap.parse_args())))
 
 
