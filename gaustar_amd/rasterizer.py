@@ -152,6 +152,8 @@ def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rot
         need = int(lib.gsr_binning_bytes_mt(R.value, nseg.value, C))
         if need * 5 // 4 > hint:
             _BINNING_HINT[dev.index] = (need * 5 // 4 + (1 << 20) - 1) >> 20 << 20
+        elif need * 2 < hint:   # far too generous (one close-up view long ago): come down 10 % per call
+            _BINNING_HINT[dev.index] = max(need * 5 // 4, hint * 9 // 10 + (1 << 20) - 1) >> 20 << 20
         if not blended.value:
             # forward-only renders hand stage 2 the NEGATED segment count: no per-segment snapshots are written (gsr.h)
             nseg2 = nseg.value if need_backward else -nseg.value

@@ -88,3 +88,31 @@ def test_validation_errors_without_gpu(hip_lib):
     assert rc != 0 and hip_lib.gsr_last_error()
     # P == 0 backward is a no-op success (rasterize_points.cu:161)
     assert hip_lib.gsr_backward(0, 0, 0, 0, 0, null, 8, 8, *([null] * 4), 1.0, *([null] * 5), 0.5, 0.5, *([null] * 15)) == 0
+
+
+def test_fused_forward_and_new_entry_points_validate_without_gpu(hip_lib):
+    """gsr_forward_fused / gsr_backward_mt / gsr_sh_to_rgbd / gsr_adam_step: argument checks come before any device work."""
+    null = None
+    R, mx, ns, bl = ctypes.c_int(7), ctypes.c_int(7), ctypes.c_int(7), ctypes.c_int(7)
+    outs = (ctypes.byref(R), ctypes.byref(mx), ctypes.byref(ns))
+    # P > 0 with null arrays: stage 1's own validation fires, nothing was blended
+    rc = hip_lib.gsr_forward_fused(10, 0, 0, 3, 1, *([null] * 5), 1.0, *([null] * 5), 64, 64, 0.5, 0.5, 0, *([null] * 5), 0, null,
+                                   null, *outs, ctypes.byref(bl), null)
+    assert rc != 0 and b"null" in hip_lib.gsr_last_error() and bl.value == 0 and R.value == 0
+    rc = hip_lib.gsr_forward_fused(10, 0, 0, 4, 1, *([null] * 5), 1.0, *([null] * 5), 64, 64, 0.5, 0.5, 0, *([null] * 5), 0, null,
+                                   null, *outs, ctypes.byref(bl), null)
+    assert rc != 0 and b"num_channels" in hip_lib.gsr_last_error()
+    rc = hip_lib.gsr_forward_fused(10, 0, 0, 3, 1, *([null] * 5), 1.0, *([null] * 5), 64, 64, 0.5, 0.5, 0, *([null] * 5), 0, null,
+                                   null, *outs, null, null)
+    assert rc != 0 and b"null output" in hip_lib.gsr_last_error()
+    # backward_mt: the extra flag does not relax the pointer checks; P == 0 stays a no-op success
+    rc = hip_lib.gsr_backward_mt(5, 0, 0, 0, 0, 3, null, 8, 8, *([null] * 4), 1.0, *([null] * 5), 0.5, 0.5, *([null] * 14), 1, null)
+    assert rc != 0 and hip_lib.gsr_last_error()
+    assert hip_lib.gsr_backward_mt(0, 0, 0, 0, 0, 3, null, 8, 8, *([null] * 4), 1.0, *([null] * 5), 0.5, 0.5, *([null] * 14), 1, null) == 0
+    assert hip_lib.gsr_sh_to_rgbd(4, 0, 1, *([null] * 5), null) != 0 and b"null" in hip_lib.gsr_last_error()
+    assert hip_lib.gsr_sh_to_rgbd(0, 0, 1, *([null] * 5), null) == 0
+    assert hip_lib.gsr_adam_step(8, *([null] * 4), 1e-3, 0.9, 0.999, 1e-8, 1, null) != 0 and b"null" in hip_lib.gsr_last_error()
+    assert hip_lib.gsr_adam_step(0, *([null] * 4), 1e-3, 0.9, 0.999, 1e-8, 1, null) == 0
+    buf = (ctypes.c_float * 16)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert hip_lib.gsr_adam_step(8, p, p, p, p, 1e-3, 0.9, 0.999, 1e-8, 0, null) != 0 and b"step" in hip_lib.gsr_last_error()
