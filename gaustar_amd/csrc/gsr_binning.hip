@@ -259,12 +259,17 @@ scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __
                                  uint32_t base = 0;
                                  if (is_leader) {
                                      // slot = tile start + counts of the lower shards + position inside this shard
-                                     // (shard cursors start at zero; the scan kernel does not expand them)
-                                     uint32_t below = ranges[tile].x;
+                                     // (shard cursors start at zero; the scan kernel does not expand them).  All seven
+                                     // counts are loaded unconditionally so that they are in flight TOGETHER with the
+                                     // atomic; `if (s < shard) below += count[s]` compiles to seven dependent round trips.
+                                     uint32_t cnt[NSHARD - 1];
+                                     const uint32_t start = ranges[tile].x;
 #pragma unroll
-                                     for (int s_ = 0; s_ < NSHARD - 1; s_++)
-                                         if (s_ < shard) below += tile_count[s_ * Tp + tile];
-                                     base = below + atomicAdd(&tile_cursor[shard * Tp + tile], (uint32_t)group);
+                                     for (int s_ = 0; s_ < NSHARD - 1; s_++) cnt[s_] = tile_count[s_ * Tp + tile];
+                                     const uint32_t old = atomicAdd(&tile_cursor[shard * Tp + tile], (uint32_t)group);
+                                     base = start + old;
+#pragma unroll
+                                     for (int s_ = 0; s_ < NSHARD - 1; s_++) base += s_ < shard ? cnt[s_] : 0u;
                                  }
                                  base = __shfl(base, leader_lane, 64);
                                  if (tile >= 0) keys[base + (uint32_t)rank] = key;
