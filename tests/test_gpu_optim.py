@@ -23,6 +23,7 @@ def test_matches_torch_adam_over_many_steps(hip_lib):
     a = optim.Adam(ga, lr=0.0, eps=1e-15)
     b = torch.optim.Adam(gb, lr=0.0, eps=1e-15, foreach=False, fused=False)
     gen = torch.Generator(device=dev).manual_seed(11)
+    cpu_gen = torch.Generator().manual_seed(12)
     for it in range(60):
         for grp_a, grp_b in zip(a.param_groups, b.param_groups):       # the trainer rewrites learning rates every iteration
             grp_a["lr"] = grp_b["lr"] = grp_b["lr"] * 0.99
@@ -30,11 +31,14 @@ def test_matches_torch_adam_over_many_steps(hip_lib):
             if it % 7 == 3 and x.dim() == 1:
                 x.grad = y.grad = None                                  # a parameter without gradient is skipped, state untouched
                 continue
-            g = torch.randn(x.shape, device=dev, generator=gen) * (10.0 ** float(torch.randint(-6, 2, (1,)).item()))
+            g = torch.randn(x.shape, device=dev, generator=gen) * (10.0 ** float(torch.randint(-6, 2, (1,), generator=cpu_gen).item()))
             x.grad, y.grad = g.clone(), g.clone()
         a.step(); b.step()
-    for x, y in zip(pa, pb):
-        np.testing.assert_allclose(x.detach().cpu().numpy(), y.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)
+    for (x, y), grp in zip(zip(pa, pb), b.param_groups):
+        # each step moves a parameter by at most ~lr; the two implementations round that move differently by a few ulp
+        # (PyTorch's kernels are built with FMA contraction, adam_kernel without): 60 steps x lr x 2^-23 x a few
+        np.testing.assert_allclose(x.detach().cpu().numpy(), y.detach().cpu().numpy(), rtol=2e-6,
+                                   atol=max(1e-7, 60 * 1.0e-6 * (grp["lr"] / 0.99 ** 60)))
         sa, sb = a.state[x], b.state[y]
         assert float(sa["step"]) == float(sb["step"])
         # moments: gradients of very different magnitude were averaged in, so an element's rounding error scales with the
