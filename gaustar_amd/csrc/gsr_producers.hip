@@ -9,6 +9,7 @@
 // sh_colour_backward() with gsr_preprocess.hip / gsr_geom_bwd.hip.  One thread per point; sh is [P, M, 3]
 // (the reference's sh_coordinates layout), only the first (D+1)^2 coefficients are used.
 #include "gsr_internal.h"
+#include "gsr_sort.h"   // lane_xor_u32: DPP / ds_swizzle lane exchanges
 
 namespace gsr {
 
@@ -291,11 +292,139 @@ mesh_gaussians_bwd_kernel(int F, int G, const float* __restrict__ verts, const l
     atomicAdd(dL_dverts + 3 * i2, gv2.x); atomicAdd(dL_dverts + 3 * i2 + 1, gv2.y); atomicAdd(dL_dverts + 3 * i2 + 2, gv2.z);
 }
 
+// ---- G <= 8 (GauSTAR binds 1, 3, 4 or 6 Gaussians to a triangle): one LANE per Gaussian, eight lanes per face.
+// The per-face kernels above keep a single thread busy with a face's G Gaussians one after the other: 81 920 faces are
+// 1 280 waves, barely one per SIMD, and the chain of matrix / quaternion arithmetic runs at the latency of a lone wave
+// (24 us forward, 57 us backward for 491 520 Gaussians, against 36 MB of traffic).  Here every lane rebuilds the face frame
+// (its loads are the same addresses across the face's lanes) and does ONE Gaussian; the backward sums the 18 frame / vertex
+// gradient components over the face's eight lanes with three DPP exchanges each and lane 0 carries them to the vertices.
+constexpr int LPF = 8;   // lanes per face
+
+__device__ __forceinline__ float face_sum(float v)
+{
+    v += __uint_as_float(lane_xor_u32<1>(__float_as_uint(v)));
+    v += __uint_as_float(lane_xor_u32<2>(__float_as_uint(v)));
+    v += __uint_as_float(lane_xor_u32<4>(__float_as_uint(v)));
+    return v;
+}
+__device__ __forceinline__ V3 face_sum(V3 v) { return v3(face_sum(v.x), face_sum(v.y), face_sum(v.z)); }
+
+__global__ void __launch_bounds__(256)
+mesh_gaussians_fwd8_kernel(int F, int G, const float* __restrict__ verts, const long long* __restrict__ faces,
+                           const float* __restrict__ bary, const float* __restrict__ raw_scales,
+                           const float* __restrict__ raw_complex, float thickness, float min_scale, float max_scale,
+                           const float* __restrict__ delta_t, const float* __restrict__ delta_r,
+                           float* __restrict__ points, float* __restrict__ scaling, float* __restrict__ quats)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = t / LPF, g = t - f * LPF;
+    if (f >= F || g >= G) return;
+    const FaceFrame Ff = face_frame(verts, faces, (size_t)f);
+    const size_t n = (size_t)f * G + g;
+    V3 p = (bary[3 * g] * Ff.v0 + bary[3 * g + 1] * Ff.v1) + bary[3 * g + 2] * Ff.v2;   // :428-429
+    if (delta_t) p = p + ld3(delta_t, n);                                                 // :432
+    st3(points, n, p);
+    const float s0 = fmaxf(fminf(__expf(raw_scales[2 * n]), max_scale), min_scale);       // :461-465
+    const float s1 = fmaxf(fminf(__expf(raw_scales[2 * n + 1]), max_scale), min_scale);
+    st3(scaling, n, v3(thickness, s0, s1));                                               // :472-475
+    const GaussFrame Gf = gauss_frame(Ff, raw_complex, delta_r, n);
+    float q[4];
+    matrix_to_unit_quaternion(Gf.R, q);
+    reinterpret_cast<float4*>(quats)[n] = make_float4(q[0], q[1], q[2], q[3]);
+}
+
+__global__ void __launch_bounds__(256)
+mesh_gaussians_bwd8_kernel(int F, int G, const float* __restrict__ verts, const long long* __restrict__ faces,
+                           const float* __restrict__ bary, const float* __restrict__ raw_scales,
+                           const float* __restrict__ raw_complex, float min_scale, float max_scale,
+                           const float* __restrict__ delta_r, const float* __restrict__ dL_dpoints,
+                           const float* __restrict__ dL_dscaling, const float* __restrict__ dL_dquats,
+                           float* __restrict__ dL_dverts, float* __restrict__ dL_draw_scales,
+                           float* __restrict__ dL_draw_complex, float* __restrict__ dL_ddelta_t,
+                           float* __restrict__ dL_ddelta_r)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f_raw = t / LPF, g = t - f_raw * LPF;
+    const bool face_ok = f_raw < F;                 // whole groups of eight lanes share a face: the exchanges below stay in it
+    const int f = face_ok ? f_raw : F - 1;
+    const bool active = face_ok && g < G;
+    const FaceFrame Ff = face_frame(verts, faces, (size_t)f);
+    V3 gv0 = v3(0, 0, 0), gv1 = gv0, gv2 = gv0, gR0 = gv0, gbR1 = gv0, gbR2 = gv0;
+    if (active) {
+        const size_t n = (size_t)f * G + g;
+        const V3 gm = dL_dpoints ? ld3(dL_dpoints, n) : v3(0, 0, 0);
+        gv0 = bary[3 * g] * gm; gv1 = bary[3 * g + 1] * gm; gv2 = bary[3 * g + 2] * gm;
+        if (dL_ddelta_t) st3(dL_ddelta_t, n, gm);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {   // scales: exp, then clamp_max, clamp_min masks (x <= max, y >= min)
+            const float e = __expf(raw_scales[2 * n + j]);
+            const bool pass = e <= max_scale && fminf(e, max_scale) >= min_scale;
+            dL_draw_scales[2 * n + j] = (dL_dscaling && pass) ? dL_dscaling[3 * n + 1 + j] * e : 0.f;
+        }
+        const GaussFrame Gf = gauss_frame(Ff, raw_complex, delta_r, n);
+        float q[4];
+        matrix_to_unit_quaternion(Gf.R, q);
+        const float4 gq = dL_dquats ? reinterpret_cast<const float4*>(dL_dquats)[n] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const V3 qv = v3(q[1], q[2], q[3]), gqv = v3(gq.y, gq.z, gq.w);
+        const V3 Gw = 0.5f * (((-gq.x) * qv + q[0] * gqv) + cross(qv, gqv));           // dL/d(rotation vector)
+        V3 A[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) A[c] = 0.5f * cross(Gw, v3(Gf.R[0][c], Gf.R[1][c], Gf.R[2][c]));   // dL/dR = 1/2 [G]x R
+        V3 gB[3];
+        if (Gf.loose) {
+            const float hw = -2.0f * dot(Gw, Gf.dv);
+            const V3 hv = 2.0f * (Gf.dw * Gw - cross(Gf.dv, Gw));
+            const float il = 1.0f / Gf.ld;
+            if (dL_ddelta_r) reinterpret_cast<float4*>(dL_ddelta_r)[n] = make_float4(hw * il, hv.x * il, hv.y * il, hv.z * il);
+#pragma unroll
+            for (int c = 0; c < 3; c++)   // dL/dB = D^T dL/dR
+                gB[c] = v3(Gf.D[0][0] * A[c].x + Gf.D[1][0] * A[c].y + Gf.D[2][0] * A[c].z,
+                           Gf.D[0][1] * A[c].x + Gf.D[1][1] * A[c].y + Gf.D[2][1] * A[c].z,
+                           Gf.D[0][2] * A[c].x + Gf.D[1][2] * A[c].y + Gf.D[2][2] * A[c].z);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; c++) gB[c] = A[c];
+        }
+        gR0 = gB[0];
+        const float g_qc = dot(gB[1], Ff.bR1) + dot(gB[2], Ff.bR2), g_qs = dot(gB[1], Ff.bR2) - dot(gB[2], Ff.bR1);
+        gbR1 = Gf.qc * gB[1] - Gf.qs * gB[2];
+        gbR2 = Gf.qs * gB[1] + Gf.qc * gB[2];
+        const float inv = 1.0f / fmaxf(Gf.lq, 1e-12f);   // through the normalisation of the raw complex number (:493)
+        const float d = g_qc * Gf.qc + g_qs * Gf.qs;
+        const bool reg = Gf.lq > 1e-12f;
+        dL_draw_complex[2 * n] = reg ? inv * (g_qc - d * Gf.qc) : inv * g_qc;
+        dL_draw_complex[2 * n + 1] = reg ? inv * (g_qs - d * Gf.qs) : inv * g_qs;
+    }
+    // sum over the face's lanes (all 64 lanes take part in the exchanges), then face frame -> vertices on lane 0
+    gv0 = face_sum(gv0); gv1 = face_sum(gv1); gv2 = face_sum(gv2);
+    gR0 = face_sum(gR0); gbR1 = face_sum(gbR1); gbR2 = face_sum(gbR2);
+    if (!face_ok || g != 0) return;
+    const V3 gcr = normalize_bwd(Ff.bR2, Ff.lc, 1e-12f, gbR2);       // bR2 = normalize(R0 x bR1)
+    gR0 = gR0 + cross(Ff.bR1, gcr);
+    gbR1 = gbR1 + cross(gcr, Ff.R0);
+    const V3 ga = normalize_bwd(Ff.bR1, Ff.la, 1e-12f, gbR1);        // bR1 = normalize(v0 - v1)
+    gv0 = gv0 + ga; gv1 = gv1 - ga;
+    const V3 gn = normalize_bwd(Ff.R0, Ff.len, 1e-6f, gR0);          // R0 = normalize((e1 x e2) / max(|.|, 1e-6))
+    const V3 ge1 = cross(Ff.e2, gn), ge2 = cross(gn, Ff.e1);
+    gv1 = gv1 + ge1; gv2 = gv2 + ge2; gv0 = gv0 - (ge1 + ge2);
+    const size_t i0 = (size_t)faces[3 * (size_t)f], i1 = (size_t)faces[3 * (size_t)f + 1], i2 = (size_t)faces[3 * (size_t)f + 2];
+    atomicAdd(dL_dverts + 3 * i0, gv0.x); atomicAdd(dL_dverts + 3 * i0 + 1, gv0.y); atomicAdd(dL_dverts + 3 * i0 + 2, gv0.z);
+    atomicAdd(dL_dverts + 3 * i1, gv1.x); atomicAdd(dL_dverts + 3 * i1 + 1, gv1.y); atomicAdd(dL_dverts + 3 * i1 + 2, gv1.z);
+    atomicAdd(dL_dverts + 3 * i2, gv2.x); atomicAdd(dL_dverts + 3 * i2 + 1, gv2.y); atomicAdd(dL_dverts + 3 * i2 + 2, gv2.z);
+}
+
 void launch_mesh_gaussians(int F, int G, const float* verts, const long long* faces, const float* bary,
                            const float* raw_scales, const float* raw_complex, float thickness, float min_scale,
                            float max_scale, const float* delta_t, const float* delta_r, float* points, float* scaling,
                            float* quats, hipStream_t st)
 {
+    if (G <= LPF) {
+        const long long lanes = (long long)F * LPF;
+        mesh_gaussians_fwd8_kernel<<<(unsigned)((lanes + 255) / 256), 256, 0, st>>>(F, G, verts, faces, bary, raw_scales, raw_complex,
+                                                                                    thickness, min_scale, max_scale, delta_t, delta_r,
+                                                                                    points, scaling, quats);
+        return;
+    }
     mesh_gaussians_fwd_kernel<<<(F + 127) / 128, 128, 0, st>>>(F, G, verts, faces, bary, raw_scales, raw_complex, thickness,
                                                               min_scale, max_scale, delta_t, delta_r, points, scaling, quats);
 }
@@ -306,6 +435,14 @@ void launch_mesh_gaussians_bwd(int F, int G, const float* verts, const long long
                                const float* dL_dquats, float* dL_dverts, float* dL_draw_scales, float* dL_draw_complex,
                                float* dL_ddelta_t, float* dL_ddelta_r, hipStream_t st)
 {
+    if (G <= LPF) {
+        const long long lanes = (long long)F * LPF;
+        mesh_gaussians_bwd8_kernel<<<(unsigned)((lanes + 255) / 256), 256, 0, st>>>(F, G, verts, faces, bary, raw_scales, raw_complex,
+                                                                                    min_scale, max_scale, delta_r, dL_dpoints, dL_dscaling,
+                                                                                    dL_dquats, dL_dverts, dL_draw_scales, dL_draw_complex,
+                                                                                    dL_ddelta_t, dL_ddelta_r);
+        return;
+    }
     mesh_gaussians_bwd_kernel<<<(F + 127) / 128, 128, 0, st>>>(F, G, verts, faces, bary, raw_scales, raw_complex, min_scale,
                                                               max_scale, delta_r, dL_dpoints, dL_dscaling, dL_dquats, dL_dverts,
                                                               dL_draw_scales, dL_draw_complex, dL_ddelta_t, dL_ddelta_r);
