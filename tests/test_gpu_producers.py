@@ -199,3 +199,40 @@ def test_points_rgb_depth_equals_rgb_plus_view_depth(lv, hip_lib):
     np.testing.assert_allclose(pos.grad.cpu().numpy(), dpos, rtol=1e-4, atol=3e-5)
     with pytest.raises(RuntimeError, match=r"\(4, 4\)"):
         producers.points_rgb_depth(pos, campos, sh, lv, view[:3])
+
+
+@pytest.mark.parametrize("G", [1, 3, 8, 10])
+def test_mesh_bound_gaussians_other_counts_per_face(G, hip_lib):
+    """GauSTAR binds 1, 3, 4 or 6 Gaussians to a triangle (sugar_model.py:217-226); up to 8 take the lane-per-Gaussian
+    kernels, more than 8 the per-face loop.  Forward and vertex / parameter gradients against the torch restatement."""
+    from gaustar_amd import producers, scene
+    from oracle import producers_oracle
+    g = torch.Generator().manual_seed(40 + G)
+    v, f = scene.icosphere(2, radius=0.9, center=(0.0, 1.2, 0.0))
+    v = torch.from_numpy(v).float() + 0.01 * torch.randn(v.shape, generator=g)
+    f = torch.from_numpy(f).long()
+    N = f.shape[0] * G
+    bary = torch.rand(G, 3, generator=g) + 0.1
+    bary = bary / bary.sum(-1, keepdim=True)
+    rs, rc = torch.randn(N, 2, generator=g) * 0.4 - 4.0, torch.randn(N, 2, generator=g)
+    dt, dr = 0.01 * torch.randn(N, 3, generator=g), torch.randn(N, 4, generator=g) * 0.3 + torch.tensor([1.0, 0, 0, 0])
+    wp, wq = torch.randn(N, 3, generator=g), torch.randn(N, 3, generator=g)
+    W3 = torch.randn(3, 3, generator=g)
+
+    def run(fn, dev):
+        a = [t.clone().to(dev).requires_grad_(True) for t in (v, rs, rc, dt, dr)]
+        p, s, q = fn(a[0], f.to(dev), bary.to(dev), a[1], a[2], 3e-6, None, None, a[3], a[4])
+        r, i, j, k = q.unbind(-1)
+        R = torch.stack((1 - 2 * (j * j + k * k), 2 * (i * j - k * r), 2 * (i * k + j * r), 2 * (i * j + k * r),
+                         1 - 2 * (i * i + k * k), 2 * (j * k - i * r), 2 * (i * k - j * r), 2 * (j * k + i * r),
+                         1 - 2 * (i * i + j * j)), -1).reshape(-1, 3, 3)
+        ((p * wp.to(dev)).sum() + (s ** 2).sum() + ((R @ W3.to(dev)) * wq.to(dev)[:, :, None]).sum()).backward()
+        return p.detach().cpu(), s.detach().cpu(), [t.grad.cpu() for t in a]
+
+    p0, s0, g0 = run(producers_oracle.mesh_bound_gaussians, "cpu")
+    p1, s1, g1 = run(producers.mesh_bound_gaussians, "cuda")
+    np.testing.assert_allclose(p1.numpy(), p0.numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(s1.numpy(), s0.numpy(), rtol=2e-6, atol=0)
+    for name, a, b in zip(("verts", "raw_scales", "raw_complex", "delta_t", "delta_r"), g1, g0):
+        err = np.abs(a.numpy().astype(np.float64) - b.numpy()).max() / max(np.abs(b.numpy()).max(), 1e-30)
+        assert err < 2e-4, f"G={G} {name}: normalised max error {err:.3e}"
