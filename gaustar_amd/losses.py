@@ -147,3 +147,80 @@ def depth_mask_l1_loss(pred_depth: torch.Tensor, gt_depth: torch.Tensor, max_dep
     {gt > max_depth} (refine.py:634-660, depth_alpha = False).  parts = {depth term, mask term, #fg, #bg}."""
     loss, parts = _DepthL1.apply(pred_depth, gt_depth, float(max_depth), float(depth_factor), float(mask_factor))
     return (loss, parts) if return_parts else loss
+
+
+class _RGBDepthLoss(torch.autograd.Function):
+    """l1 + dssim on channels 0-2 and masked depth L1 on channel 3 of ONE [6,H,W] render; the gradient comes back as ONE
+    [6,H,W] tensor that both loss kernels wrote into (channels 4-5 zero)."""
+
+    @staticmethod
+    def forward(ctx, img6, gt_rgb, gt_depth, dssim_factor, margin, max_depth, depth_factor, mask_factor):
+        lib = _lib.load()
+        if not img6.is_cuda:
+            raise RuntimeError("gaustar_amd.losses: the render must live on a HIP (cuda) device -- there is no CPU path")
+        if img6.dim() != 3 or img6.size(0) != 6:
+            raise RuntimeError(f"the two-target render must have dimensions (6, H, W), got {tuple(img6.shape)}")
+        x = img6 if img6.dtype == torch.float32 else img6.float()
+        g_full = _chw_view(gt_rgb, "gt_rgb")
+        if tuple(g_full.shape) != (3,) + tuple(x.shape[1:]):
+            raise RuntimeError(f"gt_rgb {tuple(g_full.shape)} does not match the render {tuple(x.shape)}")
+        if gt_depth.dim() != 2 or tuple(gt_depth.shape) != tuple(x.shape[1:]):
+            raise RuntimeError(f"gt_depth must be (H, W) = {tuple(x.shape[1:])}, got {tuple(gt_depth.shape)}")
+        gd = gt_depth if gt_depth.dtype == torch.float32 else gt_depth.float()
+        p, g = _crop(x[:3], margin), _crop(g_full, margin)
+        C, H, W = (int(v) for v in p.shape)
+        if H <= 0 or W <= 0:
+            raise RuntimeError("the margin leaves an empty image")
+        d = x[3]
+        Hd, Wd = (int(v) for v in d.shape)
+        dev = x.device
+        need_grad = ctx.needs_input_grad[0]
+        with torch.cuda.device(dev):
+            ws = torch.empty(lib.gsr_l1_ssim_workspace_bytes(C, H, W), dtype=torch.uint8, device=dev)
+            wd = torch.empty(lib.gsr_depth_l1_workspace_bytes(), dtype=torch.uint8, device=dev)
+            out = torch.empty(7, dtype=torch.float32, device=dev)      # {loss, l1, ssim | depth term, mask term, #fg, #bg}
+            grad6 = gv = gdv = None
+            if need_grad:
+                grad6 = torch.empty_like(x, memory_format=torch.contiguous_format)
+                grad6[4:].zero_()
+                if margin is not None:
+                    grad6[:3].zero_()
+                gv, gdv = _crop(grad6[:3], margin), grad6[3]
+            vp = lambda t: ctypes.c_void_p(t.data_ptr())
+            _lib.check(lib.gsr_l1_ssim(
+                C, H, W, vp(p), p.stride(0), p.stride(1), p.stride(2), vp(g), g.stride(0), g.stride(1), g.stride(2),
+                float(dssim_factor), vp(ws), vp(out), vp(gv) if need_grad else None,
+                gv.stride(0) if need_grad else 0, gv.stride(1) if need_grad else 0, gv.stride(2) if need_grad else 0,
+                _stream()), "gsr_l1_ssim")
+            _lib.check(lib.gsr_depth_l1(
+                Hd, Wd, vp(d), d.stride(0), d.stride(1), vp(gd), gd.stride(0), gd.stride(1), float(max_depth),
+                float(depth_factor), float(mask_factor), vp(wd), ctypes.c_void_p(out.data_ptr() + 12),
+                vp(gdv) if need_grad else None, gdv.stride(0) if need_grad else 0, gdv.stride(1) if need_grad else 0,
+                _stream()), "gsr_depth_l1")
+        ctx.grad6 = grad6
+        ctx.in_dtype = img6.dtype
+        ctx.mark_non_differentiable(out)
+        return out[0] + out[3] + out[4], out
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_parts):
+        if ctx.grad6 is None or g_loss is None:
+            return (None,) * 8
+        return (ctx.grad6 * g_loss).to(ctx.in_dtype), None, None, None, None, None, None, None
+
+
+def rgb_depth_loss(render6: torch.Tensor, gt_rgb: torch.Tensor, gt_depth: torch.Tensor, max_depth: float,
+                   dssim_factor: float = 0.2, depth_factor: float = 1.0, mask_factor: float = 1.0,
+                   margin: Optional[Sequence[int]] = None, return_parts: bool = False):
+    """The image losses of one refinement iteration on the ONE-pass render (channels 0-2 RGB, channel 3 depth-as-colour):
+    l1_dssim_loss(render6[:3], gt_rgb, dssim_factor, margin) + depth_mask_l1_loss(render6[3], gt_depth, max_depth,
+    depth_factor, mask_factor) (refine.py:451-453, :584-594, :634-660).  Same two kernels as the separate functions; what
+    it saves is autograd's handling of the two slices (two zero-filled [6,H,W] tensors, two slice copies and their sum):
+    both kernels write into one gradient tensor.  parts = {l1+dssim loss, l1 mean, ssim mean, depth term, mask term,
+    #fg, #bg}."""
+    if gt_rgb.requires_grad or gt_depth.requires_grad:
+        raise NotImplementedError("gaustar_amd.losses: no gradient w.r.t. the ground truth")
+    loss, parts = _RGBDepthLoss.apply(render6, gt_rgb, gt_depth, float(dssim_factor),
+                                      None if margin is None else tuple(margin), float(max_depth), float(depth_factor),
+                                      float(mask_factor))
+    return (loss, parts) if return_parts else loss

@@ -107,3 +107,25 @@ def test_full_size_trainer_layouts_against_oracle(hip_lib):
     assert abs(dl.item() - (a + b).item()) <= 1e-5
     np.testing.assert_allclose(depth_img.grad.cpu().numpy()[0], p2.grad.numpy(), rtol=1e-5, atol=0)
     assert (depth_img.grad.cpu().numpy()[1:] == 0).all()
+
+
+@pytest.mark.parametrize("margin", [None, (3, 5, 2, 4)])
+def test_rgb_depth_loss_equals_the_two_separate_losses(margin, hip_lib):
+    """rgb_depth_loss on the [6,H,W] render = l1_dssim_loss on channels 0-2 + depth_mask_l1_loss on channel 3 (both pinned
+    above), value and gradient; channels 4-5 receive zero gradient."""
+    from gaustar_amd import losses
+    g = torch.Generator(device="cuda").manual_seed(8)
+    H, W = 70, 101
+    img = torch.rand(6, H, W, device="cuda", generator=g)
+    img[3:] = img[3:] * 12.0
+    gt_rgb = torch.rand(1, 3, H, W, device="cuda", generator=g)
+    gt_d = torch.rand(H, W, device="cuda", generator=g) * 14.0
+    a = img.clone().requires_grad_(True)
+    b = img.clone().requires_grad_(True)
+    la, parts = losses.rgb_depth_loss(a, gt_rgb, gt_d, 10.0, 0.2, 0.7, 0.3, margin=margin, return_parts=True)
+    lb = losses.l1_dssim_loss(b[:3], gt_rgb, 0.2, margin=margin) + losses.depth_mask_l1_loss(b[3], gt_d, 10.0, 0.7, 0.3)
+    (2.0 * la).backward()
+    (2.0 * lb).backward()
+    assert abs(float(la) - float(lb)) < 1e-6 and parts.numel() == 7
+    assert torch.equal(a.grad[4:], torch.zeros_like(a.grad[4:]))
+    assert torch.allclose(a.grad, b.grad, rtol=0, atol=1e-9) and float(a.grad[:4].abs().max()) > 0

@@ -14,6 +14,7 @@ from gaustar_amd import GaussianRasterizationSettings, GaussianRasterizer, losse
 
 BARY6 = [[2/3, 1/6, 1/6], [1/6, 2/3, 1/6], [1/6, 1/6, 2/3], [1/6, 5/12, 5/12], [5/12, 1/6, 5/12], [5/12, 5/12, 1/6]]
 MAX_DEPTH = 10.0
+_MEANS2D = None
 
 
 def build(level, dev, seed=0):
@@ -34,7 +35,10 @@ def render(p, faces, bary, cam_t, dev):
     pts, scl, quat = producers.mesh_bound_gaussians(p["verts"], faces, bary, p["raw_scales"], p["raw_complex"], 3e-6)
     colors6 = producers.points_rgb_depth(pts, campos, p["sh"], 4, view)   # rgb + depth-as-colour (refine.py:603-605)
     s = GaussianRasterizationSettings(H, W, tx, ty, bg6, 1.0, view, proj, 0, campos, False, False)
-    img, _ = GaussianRasterizer(s)(means3D=pts, means2D=torch.zeros_like(pts), opacities=torch.sigmoid(p["densities"]),
+    global _MEANS2D
+    if _MEANS2D is None or _MEANS2D.shape != pts.shape:   # never read by the rasterizer (it only carries a gradient in the
+        _MEANS2D = torch.zeros_like(pts)                   # reference's densifier): one tensor for the whole run
+    img, _ = GaussianRasterizer(s)(means3D=pts, means2D=_MEANS2D, opacities=torch.sigmoid(p["densities"]),
                                    colors_precomp=colors6, scales=scl, rotations=quat)
     return img
 
@@ -71,7 +75,7 @@ def run(a):
         ct, (gt_rgb, gt_depth) = cam_ts[i], gts[i]
         opt.zero_grad(set_to_none=True)
         img = render(params, faces, bary, ct, dev)
-        loss = losses.l1_dssim_loss(img[:3], gt_rgb, 0.2) + losses.depth_mask_l1_loss(img[3], gt_depth, MAX_DEPTH, 1.0, 0.5)
+        loss = losses.rgb_depth_loss(img, gt_rgb, gt_depth, MAX_DEPTH, 0.2, 1.0, 0.5)   # both image losses, one gradient tensor
         loss.backward()
         opt.step()
         hist.append(loss.detach())
