@@ -252,7 +252,7 @@ int gsr_forward_fused(int P, int D, int M, int num_channels, int need_backward, 
 {
     if (!blended) { g_err.clear(); return fail_msg("gsr_forward_fused: null output pointer"); }
     *blended = 0;
-    if (!channels_ok(num_channels)) { g_err.clear(); return fail_msg("gsr_forward_fused: num_channels must be 3 or 6"); }
+    if (!channels_ok(num_channels)) { g_err.clear(); return fail_msg("gsr_forward_fused: num_channels must be 3, 4 or 6"); }
     hipStream_t st = (hipStream_t)stream;
     const bool sane = W > 0 && H > 0 && (long long)tiles_of(W > 0 ? W : 1, H > 0 ? H : 1).T <= 256ll * 1024 && image_buffer && P > 0;
     const size_t cnt_words = sane ? 2 * (size_t)shard_stride(tiles_of(W, H).T) * NSHARD : 0;
@@ -303,7 +303,7 @@ int forward_stage2_impl(int P, int R, int max_tile_instances, int num_segments, 
     if (W <= 0 || H <= 0) return fail_msg("gsr_forward_stage2: image size must be positive");
     if (!background || !out_color || !image_buffer) return fail_msg("gsr_forward_stage2: required pointer is null");
     if (R > 0 && (!binning_buffer || !geom_buffer)) return fail_msg("gsr_forward_stage2: scratch buffer is null");
-    if (!channels_ok(num_channels)) return fail_msg("gsr_forward_stage2: num_channels must be 3 or 6");
+    if (!channels_ok(num_channels)) return fail_msg("gsr_forward_stage2: num_channels must be 3, 4 or 6");
     if (num_channels != 3 && !colors_precomp)
         return fail_msg("gsr_forward_stage2: multi-target renders need precomputed colours [P, num_channels]");
     const int C = num_channels;
@@ -417,7 +417,7 @@ int gsr_backward_mt(int P, int D, int M, int R, int num_segments, int num_channe
     if (R > 0 && !binning_buffer) return fail_msg("gsr_backward: binning_buffer is null");
     if (R > 0 && num_segments <= 0)
         return fail_msg("gsr_backward: the forward ran in forward-only mode (num_segments = 0 at stage 2)");
-    if (!channels_ok(num_channels)) return fail_msg("gsr_backward: num_channels must be 3 or 6");
+    if (!channels_ok(num_channels)) return fail_msg("gsr_backward: num_channels must be 3, 4 or 6");
     if (num_channels != 3 && !colors_precomp)
         return fail_msg("gsr_backward: multi-target renders need precomputed colours [P, num_channels]");
     const int C = num_channels;
@@ -462,7 +462,7 @@ int gsr_sh_to_rgb(int P, int D, int M, const float* positions, const float* camp
     hipStream_t st = (hipStream_t)stream;
     {
         Scope sc(ST_PRODUCERS, st);
-        launch_sh_to_rgb(P, D, M, positions, campos, shs, nullptr, rgb, st);
+        launch_sh_to_rgb(P, D, M, positions, campos, shs, nullptr, 0, rgb, st);
     }
     GSR_CHECK_LAUNCH("sh_to_rgb_kernel");
     return 0;
@@ -480,33 +480,35 @@ int gsr_sh_to_rgb_backward(int P, int D, int M, const float* positions, const fl
     hipStream_t st = (hipStream_t)stream;
     {
         Scope sc(ST_PRODUCERS, st);
-        launch_sh_to_rgb_bwd(P, D, M, positions, campos, shs, nullptr, dL_drgb, dL_dsh, dL_dpos, st);
+        launch_sh_to_rgb_bwd(P, D, M, positions, campos, shs, nullptr, 0, dL_drgb, dL_dsh, dL_dpos, st);
     }
     GSR_CHECK_LAUNCH("sh_to_rgb_bwd_kernel");
     return 0;
 }
 
 int gsr_sh_to_rgbd(int P, int D, int M, const float* positions, const float* campos, const float* shs,
-                   const float* viewmatrix, float* colors6, gsr_stream_t stream)
+                   const float* viewmatrix, int depth_channels, float* colors6, gsr_stream_t stream)
 {
     g_err.clear();
+    if (depth_channels != 1 && depth_channels != 3) return fail_msg("gsr_sh_to_rgbd: depth_channels must be 1 or 3");
     if (P <= 0) return 0;
     if (!positions || !campos || !shs || !viewmatrix || !colors6) return fail_msg("gsr_sh_to_rgbd: required pointer is null");
     if (D < 0 || D > 3 || (D + 1) * (D + 1) > M) return fail_msg("gsr_sh_to_rgbd: sh degree must be 0..3 and fit in M coefficients");
     hipStream_t st = (hipStream_t)stream;
     {
         Scope sc(ST_PRODUCERS, st);
-        launch_sh_to_rgb(P, D, M, positions, campos, shs, viewmatrix, colors6, st);
+        launch_sh_to_rgb(P, D, M, positions, campos, shs, viewmatrix, depth_channels, colors6, st);
     }
     GSR_CHECK_LAUNCH("sh_to_rgb_kernel");
     return 0;
 }
 
 int gsr_sh_to_rgbd_backward(int P, int D, int M, const float* positions, const float* campos, const float* shs,
-                            const float* viewmatrix, const float* dL_dcolors6, float* dL_dsh, float* dL_dpos,
-                            gsr_stream_t stream)
+                            const float* viewmatrix, int depth_channels, const float* dL_dcolors6, float* dL_dsh,
+                            float* dL_dpos, gsr_stream_t stream)
 {
     g_err.clear();
+    if (depth_channels != 1 && depth_channels != 3) return fail_msg("gsr_sh_to_rgbd_backward: depth_channels must be 1 or 3");
     if (P <= 0) return 0;
     if (!positions || !campos || !shs || !viewmatrix || !dL_dcolors6 || !dL_dsh || !dL_dpos)
         return fail_msg("gsr_sh_to_rgbd_backward: required pointer is null");
@@ -515,7 +517,7 @@ int gsr_sh_to_rgbd_backward(int P, int D, int M, const float* positions, const f
     hipStream_t st = (hipStream_t)stream;
     {
         Scope sc(ST_PRODUCERS, st);
-        launch_sh_to_rgb_bwd(P, D, M, positions, campos, shs, viewmatrix, dL_dcolors6, dL_dsh, dL_dpos, st);
+        launch_sh_to_rgb_bwd(P, D, M, positions, campos, shs, viewmatrix, depth_channels, dL_dcolors6, dL_dsh, dL_dpos, st);
     }
     GSR_CHECK_LAUNCH("sh_to_rgb_bwd_kernel");
     return 0;

@@ -38,6 +38,7 @@
 // grad_acc[gaussian][GRAD_RS] = {sum r, sum r dx, sum r dy, sum r dx^2, sum r dx dy, sum r dy^2, c_0 .. c_{C-1}}.
 #include "gsr_internal.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace gsr {
 
@@ -49,10 +50,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Once the instance's w and r are out only x, y and the id are still needed: the 6 + C moments overwrite
 // floats [3 .. 8 + C] (no separate moment table -> more resident waves).
 template <int C> struct SlotLayout {
-    static constexpr int FLOATS = (8 + C + 3) / 4 * 4;
-    static constexpr int VECS = FLOATS / 4;
     static constexpr int NM = 6 + C;        // moments per instance
     static constexpr int MOM0 = 3;          // first overwritten float
+    static constexpr int IN_FLOATS = (8 + C + 3) / 4 * 4, OUT_FLOATS = (MOM0 + NM + 3) / 4 * 4;
+    static constexpr int FLOATS = IN_FLOATS > OUT_FLOATS ? IN_FLOATS : OUT_FLOATS;   // C = 4: 12 in, 13 out -> 16
+    static constexpr int VECS = FLOATS / 4;
     static_assert(MOM0 + NM <= FLOATS, "moments must fit the slot");
 };
 
@@ -393,12 +395,14 @@ void launch_blend_bwd(int C, int W, int H, int U, const float* bg, const float* 
     // Residency knob: extra dynamic LDS lowers the number of co-resident units per CU (tuning only).
     static const int pad = getenv("GSR_BWD_LDS_PAD") ? atoi(getenv("GSR_BWD_LDS_PAD")) : 0;
     uint64_t* tr = g_trace ? g_trace + 2 * (size_t)t.T : nullptr;
-    if (C == 6)
-        blend_bwd_kernel<6><<<4 * U, 64, pad, st>>>(W, H, t.gx, im.ranges, im.seg_off, b.unit_tile, b.snap, b.point_list,
-                                                    g.g0, g.g1, feats, bg, im.final_T, im.n_contrib, dL_dpix, grad_acc, tr);
-    else
-        blend_bwd_kernel<3><<<4 * U, 64, pad, st>>>(W, H, t.gx, im.ranges, im.seg_off, b.unit_tile, b.snap, b.point_list,
-                                                    g.g0, g.g1, feats, bg, im.final_T, im.n_contrib, dL_dpix, grad_acc, tr);
+    const auto go = [&](auto tag) {
+        constexpr int CC = decltype(tag)::value;
+        blend_bwd_kernel<CC><<<4 * U, 64, pad, st>>>(W, H, t.gx, im.ranges, im.seg_off, b.unit_tile, b.snap, b.point_list,
+                                                     g.g0, g.g1, feats, bg, im.final_T, im.n_contrib, dL_dpix, grad_acc, tr);
+    };
+    if (C == 6) go(std::integral_constant<int, 6>{});
+    else if (C == 4) go(std::integral_constant<int, 4>{});
+    else go(std::integral_constant<int, 3>{});
 }
 
 }  // namespace gsr

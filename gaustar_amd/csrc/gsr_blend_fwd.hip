@@ -575,6 +575,7 @@ void launch_blend_fwd(int C, int W, int H, int R, int U, uint32_t max_count, con
                       bool sort_small, hipStream_t st)
 {
     if (C == 6) launch_fwd_c<6>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, zero_ptr, zero_bytes, counters, sort_small, st);
+    else if (C == 4) launch_fwd_c<4>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, zero_ptr, zero_bytes, counters, sort_small, st);
     else launch_fwd_c<3>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, zero_ptr, zero_bytes, counters, sort_small, st);
 }
 

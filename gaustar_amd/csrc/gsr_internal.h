@@ -97,7 +97,7 @@ constexpr int SEG = 64;
 // Channel count of a render: 3 = the reference's NUM_CHANNELS (cuda_rasterizer/config.h:15); 6 = two targets
 // sharing geometry, blended in one walk.  A snapshot is (T, C[0..C-1]) padded to whole float4s.
 __host__ __device__ constexpr int snap_vecs(int C) { return (C + 4) / 4; }
-__host__ __device__ constexpr bool channels_ok(int C) { return C == 3 || C == 6; }
+__host__ __device__ constexpr bool channels_ok(int C) { return C == 3 || C == 4 || C == 6; }
 constexpr int GRAD_RS = 12;  // floats per record of the backward accumulation table: 6 geometric moments + C <= 6 colours
 
 struct BinState {            // per instance / per segment
@@ -128,9 +128,9 @@ inline BinState carve_bin(void* base, int R, int U, int C = 3)
 void launch_adam(long long n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float step_size,
                  float one_minus_b1, float b2, float one_minus_b2, float eps, float bc2s, hipStream_t st);
 void launch_sh_to_rgb(int P, int D, int M, const float* positions, const float* campos, const float* shs, const float* view,
-                      float* out, hipStream_t st);
+                      int depth_channels, float* out, hipStream_t st);
 void launch_sh_to_rgb_bwd(int P, int D, int M, const float* positions, const float* campos, const float* shs, const float* view,
-                          const float* dL_dout, float* dL_dsh, float* dL_dpos, hipStream_t st);
+                          int depth_channels, const float* dL_dout, float* dL_dsh, float* dL_dpos, hipStream_t st);
 
 void launch_mesh_gaussians(int F, int G, const float* verts, const long long* faces, const float* bary,
                            const float* raw_scales, const float* raw_complex, float thickness, float min_scale,

@@ -40,7 +40,7 @@ sh_to_rgb_kernel(int P, int D, int M, const float* __restrict__ positions, const
     o[2] = fmaxf(cb + 0.5f, 0.0f);
     if (view != nullptr) {   // second target of a two-target render: view-space depth as a colour (refine.py:603-605)
         const float z = p.x * view[2] + p.y * view[6] + p.z * view[10] + view[14];   // (p, 1) . column 2 of the view matrix
-        o[3] = z; o[4] = z; o[5] = z;
+        for (int c = 3; c < stride; c++) o[c] = z;                                    // stride 6: z x 3, stride 4: z once
     }
 }
 
@@ -64,7 +64,8 @@ sh_to_rgb_bwd_kernel(int P, int D, int M, const float* __restrict__ positions, c
         float* row = wave_rows + lane * sh_row_stride(M);
         sh_colour_backward(D, M, p, campos, row, dcol, row, gx, gy, gz);   // gradient row replaces the coefficient row
         if (view != nullptr) {   // the three depth channels all carry d z / d p = column 2 of the view matrix
-            const float gzv = gi[3] + gi[4] + gi[5];
+            float gzv = gi[3];
+            for (int c = 4; c < stride; c++) gzv += gi[c];
             gx += gzv * view[2]; gy += gzv * view[6]; gz += gzv * view[10];
         }
         dL_dpos[3 * i] = gx; dL_dpos[3 * i + 1] = gy; dL_dpos[3 * i + 2] = gz;
@@ -448,18 +449,19 @@ void launch_mesh_gaussians_bwd(int F, int G, const float* verts, const long long
                                                               dL_draw_scales, dL_draw_complex, dL_ddelta_t, dL_ddelta_r);
 }
 
-// view == nullptr: rgb [P,3]; otherwise rgb + depth-as-colour [P,6] (gsr_sh_to_rgbd)
+// view == nullptr: rgb [P,3]; otherwise rgb + depth-as-colour [P, 3 + depth_channels] (gsr_sh_to_rgbd)
 void launch_sh_to_rgb(int P, int D, int M, const float* positions, const float* campos, const float* shs, const float* view,
-                      float* out, hipStream_t st)
+                      int depth_channels, float* out, hipStream_t st)
 {
-    sh_to_rgb_kernel<<<(P + 255) / 256, 256, sh_stage_bytes(M, 4), st>>>(P, D, M, positions, campos, shs, view, out, view ? 6 : 3);
+    sh_to_rgb_kernel<<<(P + 255) / 256, 256, sh_stage_bytes(M, 4), st>>>(P, D, M, positions, campos, shs, view, out,
+                                                                          view ? 3 + depth_channels : 3);
 }
 
 void launch_sh_to_rgb_bwd(int P, int D, int M, const float* positions, const float* campos, const float* shs, const float* view,
-                          const float* dL_dout, float* dL_dsh, float* dL_dpos, hipStream_t st)
+                          int depth_channels, const float* dL_dout, float* dL_dsh, float* dL_dpos, hipStream_t st)
 {
     sh_to_rgb_bwd_kernel<<<(P + 255) / 256, 256, sh_stage_bytes(M, 4), st>>>(P, D, M, positions, campos, shs, view, dL_dout,
-                                                                              view ? 6 : 3, dL_dsh, dL_dpos);
+                                                                              view ? 3 + depth_channels : 3, dL_dsh, dL_dpos);
 }
 
 }  // namespace gsr

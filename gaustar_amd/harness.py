@@ -261,15 +261,15 @@ class SurfaceGaussians(nn.Module):
 
     def render_rgb_depth(self, camera: NerfCamera, bg_color=None, max_depth: float = 10.0, sh_deg: Optional[int] = None):
         """The two renders of a refinement iteration (refine.py:552 RGB, :607 depth-as-colour with bg = max_depth) as ONE
-        6-channel pass: -> (rgb [H,W,3], depth [H,W])."""
+        4-channel pass (RGB + one depth channel): -> (rgb [H,W,3], depth [H,W])."""
         dev = self.device
         bg_rgb = torch.zeros(3, device=dev) if bg_color is None else torch.as_tensor(bg_color, dtype=torch.float32, device=dev)
-        bg6 = torch.cat([bg_rgb, torch.full((3,), float(max_depth), device=dev)])
+        bg6 = torch.cat([bg_rgb, torch.full((1,), float(max_depth), device=dev)])   # RGB + one depth channel
         sh_deg = self.sh_levels - 1 if sh_deg is None else int(sh_deg)
         settings, view, campos = self._settings(camera, bg6, 0)
         positions = self.points
         # SH colours and view-space depth of every Gaussian from one fused producer (no cat, no skinny matmul)
-        colors6 = producers.points_rgb_depth(positions, campos, self.sh_coordinates, sh_deg + 1, view)
+        colors6 = producers.points_rgb_depth(positions, campos, self.sh_coordinates, sh_deg + 1, view, depth_channels=1)
         img, _ = GaussianRasterizer(settings)(means3D=positions, means2D=torch.zeros_like(positions), opacities=self.strengths,
                                               colors_precomp=colors6, scales=self.scaling, rotations=self.quaternions)
         return img[:3].permute(1, 2, 0), img[3]

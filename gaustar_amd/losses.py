@@ -158,8 +158,8 @@ class _RGBDepthLoss(torch.autograd.Function):
         lib = _lib.load()
         if not img6.is_cuda:
             raise RuntimeError("gaustar_amd.losses: the render must live on a HIP (cuda) device -- there is no CPU path")
-        if img6.dim() != 3 or img6.size(0) != 6:
-            raise RuntimeError(f"the two-target render must have dimensions (6, H, W), got {tuple(img6.shape)}")
+        if img6.dim() != 3 or img6.size(0) not in (4, 6):
+            raise RuntimeError(f"the two-target render must have dimensions (6, H, W) or (4, H, W), got {tuple(img6.shape)}")
         x = img6 if img6.dtype == torch.float32 else img6.float()
         g_full = _chw_view(gt_rgb, "gt_rgb")
         if tuple(g_full.shape) != (3,) + tuple(x.shape[1:]):
@@ -182,7 +182,8 @@ class _RGBDepthLoss(torch.autograd.Function):
             grad6 = gv = gdv = None
             if need_grad:
                 grad6 = torch.empty_like(x, memory_format=torch.contiguous_format)
-                grad6[4:].zero_()
+                if x.size(0) > 4:
+                    grad6[4:].zero_()
                 if margin is not None:
                     grad6[:3].zero_()
                 gv, gdv = _crop(grad6[:3], margin), grad6[3]
@@ -212,7 +213,8 @@ class _RGBDepthLoss(torch.autograd.Function):
 def rgb_depth_loss(render6: torch.Tensor, gt_rgb: torch.Tensor, gt_depth: torch.Tensor, max_depth: float,
                    dssim_factor: float = 0.2, depth_factor: float = 1.0, mask_factor: float = 1.0,
                    margin: Optional[Sequence[int]] = None, return_parts: bool = False):
-    """The image losses of one refinement iteration on the ONE-pass render (channels 0-2 RGB, channel 3 depth-as-colour):
+    """The image losses of one refinement iteration on the ONE-pass render ([6,H,W] or [4,H,W]: channels 0-2 RGB, channel 3
+    depth-as-colour):
     l1_dssim_loss(render6[:3], gt_rgb, dssim_factor, margin) + depth_mask_l1_loss(render6[3], gt_depth, max_depth,
     depth_factor, mask_factor) (refine.py:451-453, :584-594, :634-660).  Same two kernels as the separate functions; what
     it saves is autograd's handling of the two slices (two zero-filled [6,H,W] tensors, two slice copies and their sum):

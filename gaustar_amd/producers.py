@@ -25,7 +25,7 @@ class _PointsRGB(torch.autograd.Function):
     """view is None: rgb [P,3]; otherwise rgb + view-space depth as a second colour target [P,6] (points_rgb_depth)."""
 
     @staticmethod
-    def forward(ctx, positions, camera_center, sh_coordinates, sh_levels, view=None):
+    def forward(ctx, positions, camera_center, sh_coordinates, sh_levels, view=None, depth_channels=3):
         lib = _lib.load()
         if not positions.is_cuda:
             raise RuntimeError("gaustar_amd.producers: positions must live on a HIP (cuda) device -- there is no CPU path")
@@ -48,14 +48,18 @@ class _PointsRGB(torch.autograd.Function):
             if tuple(view.shape) != (4, 4):
                 raise RuntimeError("viewmatrix must be (4, 4), as handed to the rasterizer")
             view = view.detach().to(dev, torch.float32).contiguous()
-        rgb = torch.empty(P, 3 if view is None else 6, dtype=torch.float32, device=dev)
+        if view is not None and depth_channels not in (1, 3):
+            raise RuntimeError("depth_channels must be 1 (colours [P,4]) or 3 (colours [P,6])")
+        rgb = torch.empty(P, 3 if view is None else 3 + int(depth_channels), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             if view is None:
                 _lib.check(lib.gsr_sh_to_rgb(P, D, M, _p(pos), _p(cam), _p(sh), _p(rgb), _stream()), "gsr_sh_to_rgb")
             else:
-                _lib.check(lib.gsr_sh_to_rgbd(P, D, M, _p(pos), _p(cam), _p(sh), _p(view), _p(rgb), _stream()), "gsr_sh_to_rgbd")
+                _lib.check(lib.gsr_sh_to_rgbd(P, D, M, _p(pos), _p(cam), _p(sh), _p(view), int(depth_channels), _p(rgb), _stream()),
+                           "gsr_sh_to_rgbd")
         ctx.save_for_backward(pos, cam, sh, view)
         ctx.D = D
+        ctx.depth_channels = int(depth_channels)
         return rgb
 
     @staticmethod
@@ -71,9 +75,9 @@ class _PointsRGB(torch.autograd.Function):
                 _lib.check(lib.gsr_sh_to_rgb_backward(P, ctx.D, M, _p(pos), _p(cam), _p(sh), _p(g), _p(dsh), _p(dpos),
                                                       _stream()), "gsr_sh_to_rgb_backward")
             else:
-                _lib.check(lib.gsr_sh_to_rgbd_backward(P, ctx.D, M, _p(pos), _p(cam), _p(sh), _p(view), _p(g), _p(dsh),
-                                                       _p(dpos), _stream()), "gsr_sh_to_rgbd_backward")
-        return dpos, None, dsh, None, None
+                _lib.check(lib.gsr_sh_to_rgbd_backward(P, ctx.D, M, _p(pos), _p(cam), _p(sh), _p(view), ctx.depth_channels, _p(g),
+                                                       _p(dsh), _p(dpos), _stream()), "gsr_sh_to_rgbd_backward")
+        return dpos, None, dsh, None, None, None
 
 
 def points_rgb(positions: torch.Tensor, camera_centers: torch.Tensor, sh_coordinates: torch.Tensor,
@@ -85,13 +89,14 @@ def points_rgb(positions: torch.Tensor, camera_centers: torch.Tensor, sh_coordin
 
 
 def points_rgb_depth(positions: torch.Tensor, camera_centers: torch.Tensor, sh_coordinates: torch.Tensor, sh_levels: int,
-                     viewmatrix: torch.Tensor) -> torch.Tensor:
+                     viewmatrix: torch.Tensor, depth_channels: int = 3) -> torch.Tensor:
     """colors[P,6] for the one-pass RGB + depth render: columns 0-2 = points_rgb(...), columns 3-5 = the view-space
     depth of every position, three times -- the `point_depth.expand(-1, 3)` GauSTAR renders as colours
     (gaustar_trainers/refine.py:603-605).  viewmatrix: the (4, 4) world-to-view matrix handed to the rasterizer
     (row-vector convention, sugar_model.py:1149).  One kernel each way instead of eval_sh + a skinny matmul + cat and
-    their autograd mirror; the gradient w.r.t. viewmatrix is not provided (cameras are fixed in the trainer)."""
-    return _PointsRGB.apply(positions, camera_centers, sh_coordinates, int(sh_levels), viewmatrix)
+    their autograd mirror; the gradient w.r.t. viewmatrix is not provided (cameras are fixed in the trainer).
+    depth_channels = 1 gives colors[P,4] = {rgb, z} for the 4-channel render (RGB + one scalar target)."""
+    return _PointsRGB.apply(positions, camera_centers, sh_coordinates, int(sh_levels), viewmatrix, int(depth_channels))
 
 
 class _MeshGaussians(torch.autograd.Function):

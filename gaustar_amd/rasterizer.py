@@ -71,13 +71,14 @@ def _stream():
 
 
 def _num_channels(colors, background) -> int:
-    """3 (the reference's NUM_CHANNELS) unless precomputed colours carry 6 columns: two targets that share
-    geometry (GauSTAR's RGB + depth-as-colour renders, refine.py:552 / :607) blended in one pass -- an extension,
-    see include/gsr.h::gsr_forward_stage2_mt."""
+    """3 (the reference's NUM_CHANNELS) unless precomputed colours carry 6 or 4 columns: two targets that share
+    geometry (GauSTAR's RGB + depth-as-colour renders, refine.py:552 / :607) blended in one pass -- 6 = two 3-channel
+    targets, 4 = RGB + one scalar target (the trainer only reads channel 0 of its depth render, refine.py:616) -- an
+    extension, see include/gsr.h::gsr_forward_stage2_mt."""
     C = 3
     if colors is not None and colors.numel() != 0:
-        if colors.ndimension() != 2 or int(colors.size(1)) not in (3, 6):
-            raise RuntimeError("colors_precomp must have dimensions (num_points, 3) or (num_points, 6)")
+        if colors.ndimension() != 2 or int(colors.size(1)) not in (3, 4, 6):
+            raise RuntimeError("colors_precomp must have dimensions (num_points, 3) or (num_points, 6) [or (num_points, 4)]")
         C = int(colors.size(1))
     if background.numel() != C:
         raise RuntimeError(f"bg must have {C} elements (one per colour channel), got {background.numel()}")

@@ -2,7 +2,7 @@
 gaustar_trainers/refined_mesh.py:729-775 (`detect_topo_err`) and :1083-1134 (final renders) -- every camera renders
 RGB and depth-as-colour of the same Gaussians, results are reduced to small per-view rows.
 
-Here each camera is ONE 6-channel forward (RGB + depth share preprocess / binning / sort / blend),
+Here each camera is ONE 4-channel forward (RGB + depth share preprocess / binning / sort / blend),
 under `torch.no_grad()`, and the cameras are sharded over the ranks of a `torch.distributed` job (one process per
 GPU; `nccl` = RCCL on ROCm, `gloo` for the CPU tests): rank r renders cameras r, r + world, r + 2 world, ...; the
 per-view rows are brought together with one all_gather.  There is no other communication."""
@@ -61,8 +61,8 @@ class ForwardSweep:
         self.rgb, self.sh, self.sh_levels = rgb, sh, int(sh_levels)
         self.max_depth = float(max_depth)
         dev = means3D.device
-        self.bg6 = torch.tensor(list(bg_rgb) + [self.max_depth] * 3, dtype=torch.float32, device=dev)
-        self.bg3 = self.bg6[3:].clone()
+        self.bg4 = torch.tensor(list(bg_rgb) + [self.max_depth], dtype=torch.float32, device=dev)   # RGB + one depth channel
+        self.bg3 = torch.full((3,), self.max_depth, dtype=torch.float32, device=dev)
         self._cam_cache = {}
 
     def _cam(self, cam):
@@ -78,11 +78,13 @@ class ForwardSweep:
         """-> (rgb [H,W,3], depth [H,W]): refined_mesh.py:733-760 in one pass."""
         from . import GaussianRasterizationSettings, GaussianRasterizer, producers
         view, proj, campos = self._cam(cam)
-        rgb = self.rgb if self.rgb is not None else producers.points_rgb(self.means3D, campos, self.sh, self.sh_levels)
-        depth = (self.means3D @ view[:3, 2:3] + view[3, 2]).expand(-1, 3)
-        s = GaussianRasterizationSettings(cam.H, cam.W, cam.tanfovx, cam.tanfovy, self.bg6, 1.0, view, proj, 0, campos, False, False)
-        img, _ = GaussianRasterizer(s)(means3D=self.means3D, means2D=torch.zeros_like(self.means3D), opacities=self.opacities,
-                                       colors_precomp=torch.cat([rgb, depth], 1), scales=self.scales, rotations=self.rotations)
+        if self.rgb is None:   # SH colours and view-space depth from one fused producer
+            colors4 = producers.points_rgb_depth(self.means3D, campos, self.sh, self.sh_levels, view, depth_channels=1)
+        else:
+            colors4 = torch.cat([self.rgb, self.means3D @ view[:3, 2:3] + view[3, 2]], 1)
+        s = GaussianRasterizationSettings(cam.H, cam.W, cam.tanfovx, cam.tanfovy, self.bg4, 1.0, view, proj, 0, campos, False, False)
+        img, _ = GaussianRasterizer(s)(means3D=self.means3D, means2D=self.means3D, opacities=self.opacities,   # means2D is never read
+                                       colors_precomp=colors4, scales=self.scales, rotations=self.rotations)
         return img[:3].permute(1, 2, 0), img[3]
 
     @torch.no_grad()

@@ -47,7 +47,7 @@ const char* gsr_last_error(void);
 size_t gsr_geom_bytes(int P);
 size_t gsr_image_bytes(int W, int H);
 size_t gsr_binning_bytes(int R, int num_segments);
-/* Same for a render with num_channels colour channels (3 or 6, see gsr_forward_stage2_mt). */
+/* Same for a render with num_channels colour channels (3, 4 or 6, see gsr_forward_stage2_mt). */
 size_t gsr_binning_bytes_mt(int R, int num_segments, int num_channels);
 /* Backward-only scratch: one packed 48-byte accumulation record per Gaussian.  Takes the place of the
  * dL_dconic [P,2,2] work tensor the reference binding allocates (DGR/rasterize_points.cu:154). */
@@ -86,7 +86,10 @@ int gsr_forward_stage2(int P, int R, int max_tile_instances, int num_segments, i
  * depth-as-colour in two full passes over identical geometry, gaustar_trainers/refine.py:552 and :607).
  * num_channels = 6 blends two 3-channel targets in ONE walk after ONE stage 1: colors_precomp is [P,6]
  * (required: no in-kernel SH for the extra channels), background [6], out_color [6,H,W] planar.  Channels 0-2
- * and 3-5 equal two separate 3-channel renders bit for bit.  num_channels = 3 is gsr_forward_stage2. */
+ * and 3-5 equal two separate 3-channel renders bit for bit.  num_channels = 4 is RGB + ONE scalar target (colors_precomp
+ * [P,4], background [4], out_color [4,H,W]): GauSTAR's depth render carries the same value in its three channels and the
+ * trainer reads only the first (refine.py:616), so channel 3 of a 4-channel render is that image at about the cost of a
+ * 3-channel render.  num_channels = 3 is gsr_forward_stage2. */
 int gsr_forward_stage2_mt(int P, int R, int max_tile_instances, int num_segments, int num_channels, int W, int H,
                           const float* background, const float* colors_precomp, void* geom_buffer, void* binning_buffer,
                           void* image_buffer, float* out_color, gsr_stream_t stream);
@@ -180,12 +183,14 @@ int gsr_sh_to_rgb_backward(int P, int D, int M, const float* positions, const fl
  * {rgb as gsr_sh_to_rgb, z, z, z} with z = the view-space depth of the position, i.e. the `point_depth.expand(-1, 3)`
  * GauSTAR renders as colours (gaustar_trainers/refine.py:603-605: world-to-view transform of sugar.points, component 2).
  * viewmatrix [4,4] as handed to the rasterizer (row-vector convention: z = (p, 1) . column 2).  The backward adds the
- * depth channels' gradient to dL_dpos.  Replaces torch.cat + two skinny GEMMs + their autograd mirror per iteration. */
+ * depth channels' gradient to dL_dpos.  depth_channels = 3: [P,6] as above; 1: [P,4] = {rgb, z}, for the 4-channel render
+ * (the trainer only reads channel 0 of its depth render, refine.py:616).  Replaces torch.cat + two skinny GEMMs + their
+ * autograd mirror per iteration. */
 int gsr_sh_to_rgbd(int P, int D, int M, const float* positions, const float* campos, const float* shs,
-                   const float* viewmatrix, float* colors6, gsr_stream_t stream);
+                   const float* viewmatrix, int depth_channels, float* colors6, gsr_stream_t stream);
 int gsr_sh_to_rgbd_backward(int P, int D, int M, const float* positions, const float* campos, const float* shs,
-                            const float* viewmatrix, const float* dL_dcolors6, float* dL_dsh, float* dL_dpos,
-                            gsr_stream_t stream);
+                            const float* viewmatrix, int depth_channels, const float* dL_dcolors6, float* dL_dsh,
+                            float* dL_dpos, gsr_stream_t stream);
 
 /* gsr_mesh_gaussians replaces the properties SuGaR.points / .scaling / .quaternions for Gaussians bound to a
  * triangle mesh (gaustar_scene/sugar_model.py:417-435, :457-476, :478-508; pytorch3d 0.7.4 face normals,

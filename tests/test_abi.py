@@ -99,7 +99,7 @@ def test_fused_forward_and_new_entry_points_validate_without_gpu(hip_lib):
     rc = hip_lib.gsr_forward_fused(10, 0, 0, 3, 1, *([null] * 5), 1.0, *([null] * 5), 64, 64, 0.5, 0.5, 0, *([null] * 5), 0, null,
                                    null, *outs, ctypes.byref(bl), null)
     assert rc != 0 and b"null" in hip_lib.gsr_last_error() and bl.value == 0 and R.value == 0
-    rc = hip_lib.gsr_forward_fused(10, 0, 0, 4, 1, *([null] * 5), 1.0, *([null] * 5), 64, 64, 0.5, 0.5, 0, *([null] * 5), 0, null,
+    rc = hip_lib.gsr_forward_fused(10, 0, 0, 5, 1, *([null] * 5), 1.0, *([null] * 5), 64, 64, 0.5, 0.5, 0, *([null] * 5), 0, null,
                                    null, *outs, ctypes.byref(bl), null)
     assert rc != 0 and b"num_channels" in hip_lib.gsr_last_error()
     rc = hip_lib.gsr_forward_fused(10, 0, 0, 3, 1, *([null] * 5), 1.0, *([null] * 5), 64, 64, 0.5, 0.5, 0, *([null] * 5), 0, null,
@@ -109,8 +109,9 @@ def test_fused_forward_and_new_entry_points_validate_without_gpu(hip_lib):
     rc = hip_lib.gsr_backward_mt(5, 0, 0, 0, 0, 3, null, 8, 8, *([null] * 4), 1.0, *([null] * 5), 0.5, 0.5, *([null] * 14), 1, null)
     assert rc != 0 and hip_lib.gsr_last_error()
     assert hip_lib.gsr_backward_mt(0, 0, 0, 0, 0, 3, null, 8, 8, *([null] * 4), 1.0, *([null] * 5), 0.5, 0.5, *([null] * 14), 1, null) == 0
-    assert hip_lib.gsr_sh_to_rgbd(4, 0, 1, *([null] * 5), null) != 0 and b"null" in hip_lib.gsr_last_error()
-    assert hip_lib.gsr_sh_to_rgbd(0, 0, 1, *([null] * 5), null) == 0
+    assert hip_lib.gsr_sh_to_rgbd(4, 0, 1, *([null] * 4), 3, null, null) != 0 and b"null" in hip_lib.gsr_last_error()
+    assert hip_lib.gsr_sh_to_rgbd(4, 0, 1, *([null] * 4), 2, null, null) != 0 and b"depth_channels" in hip_lib.gsr_last_error()
+    assert hip_lib.gsr_sh_to_rgbd(0, 0, 1, *([null] * 4), 1, null, null) == 0
     assert hip_lib.gsr_adam_step(8, *([null] * 4), 1e-3, 0.9, 0.999, 1e-8, 1, null) != 0 and b"null" in hip_lib.gsr_last_error()
     assert hip_lib.gsr_adam_step(0, *([null] * 4), 1e-3, 0.9, 0.999, 1e-8, 1, null) == 0
     buf = (ctypes.c_float * 16)()

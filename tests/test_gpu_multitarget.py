@@ -140,4 +140,30 @@ def test_argument_validation():
     with pytest.raises(RuntimeError, match="bg must have 3"):
         render(rng.uniform(0, 1, (50, 3)), np.zeros(6))
     with pytest.raises(RuntimeError, match=r"\(num_points, 3\) or \(num_points, 6\)"):
-        render(rng.uniform(0, 1, (50, 4)), np.zeros(4))
+        render(rng.uniform(0, 1, (50, 5)), np.zeros(5))
+    img4, _ = render(rng.uniform(0, 1, (50, 4)), np.zeros(4))
+    assert tuple(img4.shape) == (4, 32, 32)
+
+
+def test_four_channels_equal_the_first_four_of_six():
+    """4 channels = RGB + ONE scalar target: image channels 0-3 bit-identical to the 6-channel render whose channels 3-5
+    carry the same scalar; dL_dcolors[:, 3] = the sum of the 6-channel render's three depth columns when only channel 3
+    carries gradient (what the trainer does, refine.py:616), every other gradient identical up to atomics order."""
+    from gaustar_amd import scene
+    rng = np.random.default_rng(123)
+    gs = scene.random_gaussians(3000, rng, scale_range=(0.02, 0.1), box=((-0.3, 0.3), (-0.3, 0.3), (-0.5, 0.5)))
+    gs.opacities[:] = rng.uniform(0.02, 0.5, (gs.P, 1)).astype(np.float32)     # lists cross segment boundaries
+    cam = scene.look_at_camera((0.2, 0.1, -4.0), (0, 0, 0), 150, 90, fovx=0.6, znear=0.01)
+    rgb = rng.uniform(0, 1, (gs.P, 3)).astype(np.float32)
+    dep = scene.view_depth_colors(gs, cam)
+    bg_rgb = np.array([0.2, 0.7, 0.1], np.float32)
+    d4 = rng.normal(size=(4, cam.H, cam.W)).astype(np.float32)
+    d6 = np.concatenate([d4, np.zeros((2, cam.H, cam.W), np.float32)])
+    four = parity.run_hip(_kw(gs, cam, np.concatenate([bg_rgb, [10.0]]).astype(np.float32), np.concatenate([rgb, dep[:, :1]], 1)), d4)
+    six = parity.run_hip(_kw(gs, cam, np.concatenate([bg_rgb, np.full(3, 10.0, np.float32)]), np.concatenate([rgb, dep], 1)), d6)
+    assert four["color"].shape == (4, cam.H, cam.W) and four["dL_dcolors"].shape == (gs.P, 4)
+    assert np.array_equal(four["color"], six["color"][:4]) and np.array_equal(four["radii"], six["radii"])
+    parity.check_grad(four["dL_dcolors"][:, :3], six["dL_dcolors"][:, :3], "4ch dL_dcolors[rgb]")
+    parity.check_grad(four["dL_dcolors"][:, 3], six["dL_dcolors"][:, 3], "4ch dL_dcolors[depth]")
+    for k in SUMMED:
+        parity.check_grad(four[k], six[k], f"4ch {k}")

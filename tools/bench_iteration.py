@@ -14,6 +14,7 @@ from gaustar_amd import GaussianRasterizationSettings, GaussianRasterizer, losse
 
 BARY6 = [[2/3, 1/6, 1/6], [1/6, 2/3, 1/6], [1/6, 1/6, 2/3], [1/6, 5/12, 5/12], [5/12, 1/6, 5/12], [5/12, 5/12, 1/6]]
 MAX_DEPTH = 10.0
+CH = 4 if "--six" not in sys.argv else 6   # RGB + one depth channel (default) or + three identical ones
 _MEANS2D = None
 
 
@@ -33,7 +34,7 @@ def build(level, dev, seed=0):
 def render(p, faces, bary, cam_t, dev):
     view, proj, campos, bg6, H, W, tx, ty = cam_t
     pts, scl, quat = producers.mesh_bound_gaussians(p["verts"], faces, bary, p["raw_scales"], p["raw_complex"], 3e-6)
-    colors6 = producers.points_rgb_depth(pts, campos, p["sh"], 4, view)   # rgb + depth-as-colour (refine.py:603-605)
+    colors6 = producers.points_rgb_depth(pts, campos, p["sh"], 4, view, depth_channels=CH - 3)   # rgb + depth-as-colour (refine.py:603-605)
     s = GaussianRasterizationSettings(H, W, tx, ty, bg6, 1.0, view, proj, 0, campos, False, False)
     global _MEANS2D
     if _MEANS2D is None or _MEANS2D.shape != pts.shape:   # never read by the rasterizer (it only carries a gradient in the
@@ -49,7 +50,7 @@ def run(a):
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
     cams = scene.ring_cameras(5, 32, a.width, a.height, focal_px=1200.0 * a.width / 1920.0)
     cams = [cams[i % len(cams)] for i in range(a.steps + a.warmup)]
-    bg6 = torch.tensor([0.0, 1.0, 0.0, MAX_DEPTH, MAX_DEPTH, MAX_DEPTH], device=dev)
+    bg6 = torch.tensor([0.0, 1.0, 0.0] + [MAX_DEPTH] * (CH - 3), device=dev)
     cam_ts = [(t(c.viewmatrix), t(c.projmatrix), t(c.campos), bg6, c.H, c.W, c.tanfovx, c.tanfovy) for c in cams]
     # ground truth: the same surface, slightly deformed and recoloured
     with torch.no_grad():
@@ -97,6 +98,7 @@ def main():
     ap.add_argument("--steps", type=int, default=40); ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--level", type=int, default=6); ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--six", action="store_true", help="6-channel render (depth in three identical channels) instead of 4")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of gaustar_amd.optim.Adam")
     print(json.dumps(run(ap.parse_args())))
 
