@@ -12,8 +12,10 @@
 //  * Each wave walks the tile's depth-sorted list 64 instances at a time: lane i fetches instance i
 //    (coalesced id load two batches ahead, two 16-byte record gathers + colour one batch ahead), parks
 //    it in LDS, and tests it exactly (block_min_half_quad) against each of the four quadrants that still
-//    has an unsaturated pixel; a ballot + prefix-popcount per quadrant appends the lane's index to that
-//    quadrant's byte queue -- depth order is preserved per quadrant, which is all a pixel needs.
+//    has an unsaturated pixel; a ballot + prefix-popcount per quadrant appends the lane's slot (its LDS byte address,
+//    16 bits) to that quadrant's queue -- depth order is preserved per quadrant, which is all a pixel needs.
+//  * The tile's list is depth-sorted by the same workgroup right before the walk (lists of up to 2 048 entries, gsr_sort.h);
+//    two side jobs of the fused forward ride along (the backward's accumulation table and the tile's counters are cleared).
 //  * The blend loop is four queue slots deep and branch-free: the four exponents/alphas are independent
 //    and evaluated together, only the short T-update chain is serial.  Position, conic, opacity AND
 //    colour come from LDS (the reference gathers colour from global memory per pixel, forward.cu:355).
