@@ -406,10 +406,29 @@ __device__ __forceinline__ void sh_stage_load(float* __restrict__ lds, const flo
         const float4* s4 = reinterpret_cast<const float4*>(s);   // g_base is a multiple of 64: 16-byte aligned
         int g = lane / V, k = lane - g * V;
         const int dg = 64 / V, dk = 64 - dg * V;
-        for (int w = lane; w < n_vec; w += 64) {
-            const float4 v = s4[w];
+        // every 16-byte load of the wave's 64 rows is issued before the first one is parked in LDS (V <= 12 per lane for
+        // M <= 16): as a load -> wait -> ds_write loop this was up to twelve dependent trips to memory per wave
+        constexpr int MAXV = 12;
+        float4 v[MAXV];
+#pragma unroll
+        for (int i = 0; i < MAXV; i++) {
+            const int w = lane + 64 * i;
+            if (i < V && w < n_vec) v[i] = s4[w];
+        }
+#pragma unroll
+        for (int i = 0; i < MAXV; i++) {
+            const int w = lane + 64 * i;
+            if (i < V && w < n_vec) {
+                float* d = lds + g * RS + 4 * k;
+                d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+            }
+            g += dg; k += dk;
+            if (k >= V) { k -= V; g++; }
+        }
+        for (int w = lane + 64 * MAXV; w < n_vec; w += 64) {   // M > 16 (not used by the rasterizer): plain loop
+            const float4 vv = s4[w];
             float* d = lds + g * RS + 4 * k;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            d[0] = vv.x; d[1] = vv.y; d[2] = vv.z; d[3] = vv.w;
             g += dg; k += dk;
             if (k >= V) { k -= V; g++; }
         }
@@ -417,7 +436,20 @@ __device__ __forceinline__ void sh_stage_load(float* __restrict__ lds, const flo
     }
     const int n_words = n_rows * W3;
     int g = lane / W3, k = lane - g * W3;
-    for (int w = lane; w < n_words; w += 64) {
+    int w = lane;
+    // same idea for rows that are not whole float4s (M = 1, 9, ...): eight scalar loads in flight per trip
+    for (; w + 7 * 64 < n_words; w += 8 * 64) {
+        float t[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) t[i] = s[w + 64 * i];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            lds[g * RS + k] = t[i];
+            k += 64;
+            while (k >= W3) { k -= W3; g++; }
+        }
+    }
+    for (; w < n_words; w += 64) {
         lds[g * RS + k] = s[w];
         k += 64;
         while (k >= W3) { k -= W3; g++; }
