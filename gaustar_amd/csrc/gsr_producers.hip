@@ -320,21 +320,29 @@ mesh_gaussians_fwd8_kernel(int F, int G, const float* __restrict__ verts, const 
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int f = t / LPF, g = t - f * LPF;
     if (f >= F || g >= G) return;
-    const FaceFrame Ff = face_frame(verts, faces, (size_t)f);
     const size_t n = (size_t)f * G + g;
-    V3 p = (bary[3 * g] * Ff.v0 + bary[3 * g + 1] * Ff.v1) + bary[3 * g + 2] * Ff.v2;   // :428-429
-    if (delta_t) p = p + ld3(delta_t, n);                                                 // :432
-    st3(points, n, p);
-    const float s0 = fmaxf(fminf(__expf(raw_scales[2 * n]), max_scale), min_scale);       // :461-465
-    const float s1 = fmaxf(fminf(__expf(raw_scales[2 * n + 1]), max_scale), min_scale);
-    st3(scaling, n, v3(thickness, s0, s1));                                               // :472-475
+    // every input of the lane is requested before anything is stored or computed (loads behind stores or behind values
+    // derived from earlier loads each cost a full trip to memory)
+    const float b0 = bary[3 * g], b1 = bary[3 * g + 1], b2 = bary[3 * g + 2];
+    const float2 rs = reinterpret_cast<const float2*>(raw_scales)[n];
+    const V3 dt = delta_t ? ld3(delta_t, n) : v3(0.f, 0.f, 0.f);
+    const FaceFrame Ff = face_frame(verts, faces, (size_t)f);
     const GaussFrame Gf = gauss_frame(Ff, raw_complex, delta_r, n);
+    const V3 p = ((b0 * Ff.v0 + b1 * Ff.v1) + b2 * Ff.v2) + dt;                            // :428-432
+    const float s0 = fmaxf(fminf(__expf(rs.x), max_scale), min_scale);                    // :461-465
+    const float s1 = fmaxf(fminf(__expf(rs.y), max_scale), min_scale);
     float q[4];
     matrix_to_unit_quaternion(Gf.R, q);
+    st3(points, n, p);
+    st3(scaling, n, v3(thickness, s0, s1));                                               // :472-475
     reinterpret_cast<float4*>(quats)[n] = make_float4(q[0], q[1], q[2], q[3]);
 }
 
-__global__ void __launch_bounds__(256)
+#ifndef GSR_MESH_BWD_BLOCK
+#define GSR_MESH_BWD_BLOCK 256
+#endif
+constexpr int MBB = GSR_MESH_BWD_BLOCK;   // threads per workgroup of the backward: MBB / 8 faces share one LDS vertex table
+__global__ void __launch_bounds__(MBB)
 mesh_gaussians_bwd8_kernel(int F, int G, const float* __restrict__ verts, const long long* __restrict__ faces,
                            const float* __restrict__ bary, const float* __restrict__ raw_scales,
                            const float* __restrict__ raw_complex, float min_scale, float max_scale,
@@ -344,28 +352,42 @@ mesh_gaussians_bwd8_kernel(int F, int G, const float* __restrict__ verts, const 
                            float* __restrict__ dL_draw_complex, float* __restrict__ dL_ddelta_t,
                            float* __restrict__ dL_ddelta_r)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    // Vertex gradients of the workgroup's 32 faces meet in a small LDS table (open addressing on the vertex index)
+    // before they reach memory: neighbouring faces share vertices, and the 737 k scattered float atomics were 26 of this
+    // kernel's 47 us.  (Keeping each XCD on a contiguous eighth of the faces instead changed nothing.)
+    constexpr int VSLOTS = MBB / 2;   // 3 vertex references per face, 8 lanes per face: load factor <= 0.75
+    __shared__ uint32_t v_key[VSLOTS];
+    __shared__ float v_acc[VSLOTS][3];
+    for (int i = threadIdx.x; i < VSLOTS; i += blockDim.x) { v_key[i] = 0xffffffffu; v_acc[i][0] = 0.f; v_acc[i][1] = 0.f; v_acc[i][2] = 0.f; }
+    __syncthreads();
+    const int vb = (int)blockIdx.x;
+    const int t = vb * blockDim.x + threadIdx.x;
     const int f_raw = t / LPF, g = t - f_raw * LPF;
     const bool face_ok = f_raw < F;                 // whole groups of eight lanes share a face: the exchanges below stay in it
     const int f = face_ok ? f_raw : F - 1;
     const bool active = face_ok && g < G;
+    // all of the lane's own inputs are requested first -- they do not depend on the face -- then the face frame (indices ->
+    // vertices: two dependent trips that now overlap them); stores last
+    const size_t n = active ? (size_t)f * G + g : 0;
+    const V3 gm = dL_dpoints ? ld3(dL_dpoints, n) : v3(0, 0, 0);
+    const int gb = active ? g : 0;
+    const float b0 = bary[3 * gb], b1 = bary[3 * gb + 1], b2 = bary[3 * gb + 2];
+    const float2 rs = reinterpret_cast<const float2*>(raw_scales)[n];
+    const float gs[2] = {dL_dscaling ? dL_dscaling[3 * n + 1] : 0.f, dL_dscaling ? dL_dscaling[3 * n + 2] : 0.f};
+    const float4 gq = dL_dquats ? reinterpret_cast<const float4*>(dL_dquats)[n] : make_float4(0.f, 0.f, 0.f, 0.f);
     const FaceFrame Ff = face_frame(verts, faces, (size_t)f);
     V3 gv0 = v3(0, 0, 0), gv1 = gv0, gv2 = gv0, gR0 = gv0, gbR1 = gv0, gbR2 = gv0;
     if (active) {
-        const size_t n = (size_t)f * G + g;
-        const V3 gm = dL_dpoints ? ld3(dL_dpoints, n) : v3(0, 0, 0);
-        gv0 = bary[3 * g] * gm; gv1 = bary[3 * g + 1] * gm; gv2 = bary[3 * g + 2] * gm;
-        if (dL_ddelta_t) st3(dL_ddelta_t, n, gm);
-#pragma unroll
-        for (int j = 0; j < 2; j++) {   // scales: exp, then clamp_max, clamp_min masks (x <= max, y >= min)
-            const float e = __expf(raw_scales[2 * n + j]);
-            const bool pass = e <= max_scale && fminf(e, max_scale) >= min_scale;
-            dL_draw_scales[2 * n + j] = (dL_dscaling && pass) ? dL_dscaling[3 * n + 1 + j] * e : 0.f;
-        }
         const GaussFrame Gf = gauss_frame(Ff, raw_complex, delta_r, n);
+        gv0 = b0 * gm; gv1 = b1 * gm; gv2 = b2 * gm;
+        if (dL_ddelta_t) st3(dL_ddelta_t, n, gm);
+        {   // scales: exp, then clamp_max, clamp_min masks (x <= max, y >= min)
+            const float e0 = __expf(rs.x), e1 = __expf(rs.y);
+            const bool p0 = e0 <= max_scale && fminf(e0, max_scale) >= min_scale, p1 = e1 <= max_scale && fminf(e1, max_scale) >= min_scale;
+            reinterpret_cast<float2*>(dL_draw_scales)[n] = make_float2(p0 ? gs[0] * e0 : 0.f, p1 ? gs[1] * e1 : 0.f);
+        }
         float q[4];
         matrix_to_unit_quaternion(Gf.R, q);
-        const float4 gq = dL_dquats ? reinterpret_cast<const float4*>(dL_dquats)[n] : make_float4(0.f, 0.f, 0.f, 0.f);
         const V3 qv = v3(q[1], q[2], q[3]), gqv = v3(gq.y, gq.z, gq.w);
         const V3 Gw = 0.5f * (((-gq.x) * qv + q[0] * gqv) + cross(qv, gqv));           // dL/d(rotation vector)
         V3 A[3];
@@ -399,19 +421,41 @@ mesh_gaussians_bwd8_kernel(int F, int G, const float* __restrict__ verts, const 
     // sum over the face's lanes (all 64 lanes take part in the exchanges), then face frame -> vertices on lane 0
     gv0 = face_sum(gv0); gv1 = face_sum(gv1); gv2 = face_sum(gv2);
     gR0 = face_sum(gR0); gbR1 = face_sum(gbR1); gbR2 = face_sum(gbR2);
-    if (!face_ok || g != 0) return;
-    const V3 gcr = normalize_bwd(Ff.bR2, Ff.lc, 1e-12f, gbR2);       // bR2 = normalize(R0 x bR1)
-    gR0 = gR0 + cross(Ff.bR1, gcr);
-    gbR1 = gbR1 + cross(gcr, Ff.R0);
-    const V3 ga = normalize_bwd(Ff.bR1, Ff.la, 1e-12f, gbR1);        // bR1 = normalize(v0 - v1)
-    gv0 = gv0 + ga; gv1 = gv1 - ga;
-    const V3 gn = normalize_bwd(Ff.R0, Ff.len, 1e-6f, gR0);          // R0 = normalize((e1 x e2) / max(|.|, 1e-6))
-    const V3 ge1 = cross(Ff.e2, gn), ge2 = cross(gn, Ff.e1);
-    gv1 = gv1 + ge1; gv2 = gv2 + ge2; gv0 = gv0 - (ge1 + ge2);
-    const size_t i0 = (size_t)faces[3 * (size_t)f], i1 = (size_t)faces[3 * (size_t)f + 1], i2 = (size_t)faces[3 * (size_t)f + 2];
-    atomicAdd(dL_dverts + 3 * i0, gv0.x); atomicAdd(dL_dverts + 3 * i0 + 1, gv0.y); atomicAdd(dL_dverts + 3 * i0 + 2, gv0.z);
-    atomicAdd(dL_dverts + 3 * i1, gv1.x); atomicAdd(dL_dverts + 3 * i1 + 1, gv1.y); atomicAdd(dL_dverts + 3 * i1 + 2, gv1.z);
-    atomicAdd(dL_dverts + 3 * i2, gv2.x); atomicAdd(dL_dverts + 3 * i2 + 1, gv2.y); atomicAdd(dL_dverts + 3 * i2 + 2, gv2.z);
+    if (face_ok && g == 0) {
+        const V3 gcr = normalize_bwd(Ff.bR2, Ff.lc, 1e-12f, gbR2);       // bR2 = normalize(R0 x bR1)
+        gR0 = gR0 + cross(Ff.bR1, gcr);
+        gbR1 = gbR1 + cross(gcr, Ff.R0);
+        const V3 ga = normalize_bwd(Ff.bR1, Ff.la, 1e-12f, gbR1);        // bR1 = normalize(v0 - v1)
+        gv0 = gv0 + ga; gv1 = gv1 - ga;
+        const V3 gn = normalize_bwd(Ff.R0, Ff.len, 1e-6f, gR0);          // R0 = normalize((e1 x e2) / max(|.|, 1e-6))
+        const V3 ge1 = cross(Ff.e2, gn), ge2 = cross(gn, Ff.e1);
+        gv1 = gv1 + ge1; gv2 = gv2 + ge2; gv0 = gv0 - (ge1 + ge2);
+        const uint32_t vi[3] = {(uint32_t)faces[3 * (size_t)f], (uint32_t)faces[3 * (size_t)f + 1], (uint32_t)faces[3 * (size_t)f + 2]};
+        const V3 gv[3] = {gv0, gv1, gv2};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            uint32_t h = ((vi[c] * 2654435761u) >> 16) & (VSLOTS - 1);
+            bool placed = false;
+            for (int probe = 0; probe < 8 && !placed; probe++) {
+                const uint32_t prev = atomicCAS(&v_key[h], 0xffffffffu, vi[c]);
+                if (prev == 0xffffffffu || prev == vi[c]) {
+                    atomicAdd(&v_acc[h][0], gv[c].x); atomicAdd(&v_acc[h][1], gv[c].y); atomicAdd(&v_acc[h][2], gv[c].z);
+                    placed = true;
+                } else {
+                    h = (h + 1) & (VSLOTS - 1);
+                }
+            }
+            if (!placed) {
+                atomicAdd(dL_dverts + 3 * (size_t)vi[c], gv[c].x); atomicAdd(dL_dverts + 3 * (size_t)vi[c] + 1, gv[c].y);
+                atomicAdd(dL_dverts + 3 * (size_t)vi[c] + 2, gv[c].z);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < VSLOTS * 3; i += blockDim.x) {
+        const int sl = i / 3, c = i - sl * 3;
+        if (v_key[sl] != 0xffffffffu) atomicAdd(dL_dverts + 3 * (size_t)v_key[sl] + c, v_acc[sl][c]);
+    }
 }
 
 void launch_mesh_gaussians(int F, int G, const float* verts, const long long* faces, const float* bary,
@@ -438,7 +482,7 @@ void launch_mesh_gaussians_bwd(int F, int G, const float* verts, const long long
 {
     if (G <= LPF) {
         const long long lanes = (long long)F * LPF;
-        mesh_gaussians_bwd8_kernel<<<(unsigned)((lanes + 255) / 256), 256, 0, st>>>(F, G, verts, faces, bary, raw_scales, raw_complex,
+        mesh_gaussians_bwd8_kernel<<<(unsigned)((lanes + MBB - 1) / MBB), MBB, 0, st>>>(F, G, verts, faces, bary, raw_scales, raw_complex,
                                                                                     min_scale, max_scale, delta_r, dL_dpoints, dL_dscaling,
                                                                                     dL_dquats, dL_dverts, dL_draw_scales, dL_draw_complex,
                                                                                     dL_ddelta_t, dL_ddelta_r);
