@@ -301,13 +301,26 @@ depth_stats_kernel(int H, int W, const float* __restrict__ pred, long long psy, 
                    float* __restrict__ partials)
 {
     __shared__ float red[4];
-    const size_t n = (size_t)H * W;
     float sf = 0.f, nf = 0.f, sb = 0.f, nb = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const int yy = (int)(i / W), xx = (int)(i - (size_t)yy * W);
-        const float p = pred[yy * psy + xx * psx], g = gt[yy * gsy + xx * gsx];
-        if (g < max_depth) { sf += fabsf(p - g); nf += 1.f; }
-        else if (g > max_depth) { sb += fabsf(p - max_depth); nb += 1.f; }
+    // a workgroup walks whole rows (no 64-bit division per element), four elements of a thread in flight at a time
+    for (int yy = (int)blockIdx.x; yy < H; yy += (int)gridDim.x) {
+        const float* pr = pred + yy * psy;
+        const float* gr = gt + yy * gsy;
+        for (int x0 = (int)threadIdx.x; x0 < W; x0 += 4 * 256) {
+            float p[4], g[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int xx = x0 + 256 * u;
+                const bool in = xx < W;
+                p[u] = in ? pr[xx * psx] : 0.f;
+                g[u] = in ? gr[xx * gsx] : max_depth;   // == max_depth: neither foreground nor background
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (g[u] < max_depth) { sf += fabsf(p[u] - g[u]); nf += 1.f; }
+                else if (g[u] > max_depth) { sb += fabsf(p[u] - max_depth); nb += 1.f; }
+            }
+        }
     }
     const float a = block_sum_256(sf, red), b = block_sum_256(nf, red), c = block_sum_256(sb, red),
                 d = block_sum_256(nb, red);
@@ -351,12 +364,10 @@ depth_grad_kernel(int H, int W, const float* __restrict__ pred, long long psy, l
                   float mask_factor, const float* __restrict__ stats, float* __restrict__ grad, long long qsy,
                   long long qsx)
 {
-    const size_t n = (size_t)H * W;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float cf = depth_factor / stats[2], cb = mask_factor / stats[3];
-    const int yy = (int)(i / W), xx = (int)(i - (size_t)yy * W);
+    const int yy = (int)blockIdx.y, xx = (int)(blockIdx.x * 256 + threadIdx.x);   // grid = (ceil(W / 256), H): no division
+    if (xx >= W) return;
     const float p = pred[yy * psy + xx * psx], g = gt[yy * gsy + xx * gsx];
+    const float cf = depth_factor / stats[2], cb = mask_factor / stats[3];
     float v = 0.f;
     if (g < max_depth) { const float d = p - g; v = cf * (d > 0.f ? 1.f : d < 0.f ? -1.f : 0.f); }
     else if (g > max_depth) { const float d = p - max_depth; v = cb * (d > 0.f ? 1.f : d < 0.f ? -1.f : 0.f); }
@@ -370,13 +381,12 @@ void launch_depth_l1(int H, int W, const float* pred, const long long* ps, const
                      float max_depth, float depth_factor, float mask_factor, void* workspace, float* loss_out,
                      float* grad, const long long* gstr, hipStream_t st)
 {
-    const size_t n = (size_t)H * W;
-    const int n_wg = (int)((n + 255) / 256 < (size_t)DEPTH_WGS ? (n + 255) / 256 : (size_t)DEPTH_WGS);
+    const int n_wg = H < DEPTH_WGS ? H : DEPTH_WGS;   // workgroups walk whole rows
     float* partials = static_cast<float*>(workspace);
     depth_stats_kernel<<<n_wg, 256, 0, st>>>(H, W, pred, ps[0], ps[1], gt, gs_[0], gs_[1], max_depth, partials);
     depth_finalize_kernel<<<1, 256, 0, st>>>(n_wg, partials, depth_factor, mask_factor, loss_out);
     if (grad)
-        depth_grad_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(H, W, pred, ps[0], ps[1], gt, gs_[0], gs_[1],
+        depth_grad_kernel<<<dim3((unsigned)((W + 255) / 256), (unsigned)H), 256, 0, st>>>(H, W, pred, ps[0], ps[1], gt, gs_[0], gs_[1],
                                                                       max_depth, depth_factor, mask_factor, loss_out,
                                                                       grad, gstr[0], gstr[1]);
 }
