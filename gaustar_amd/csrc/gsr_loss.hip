@@ -69,20 +69,28 @@ ssim_stats_kernel(int H, int W, View x, View y, float* __restrict__ D, float* __
     // latency per iteration: 5.8 of the workgroup's 9.6 us)
     constexpr int NL = (LIY * LI + 255) / 256;
     float xv[NL], yv[NL];
+    // element i = tid + 256 k of the LIY x LI input tile: (row, column) advance by (256 / LI, 256 % LI) per k with at most
+    // one carry -- one division per thread instead of one per element, and one 64-bit address per thread plus deltas
+    constexpr int DR = 256 / LI, DC = 256 % LI;
+    static_assert((NL - 1) * DC + LI - 1 < 2 * LI, "at most one column carry");
+    const int lr0 = tid / LI, lc0 = tid - lr0 * LI;
+    const long long xb = (long long)(ty0 + lr0 - LR) * x.sy + (long long)(tx0 + lc0 - LR) * x.sx;
+    const long long yb = (long long)(ty0 + lr0 - LR) * y.sy + (long long)(tx0 + lc0 - LR) * y.sx;
 #pragma unroll
     for (int k = 0; k < NL; k++) {
-        const int i = tid + k * 256;
-        const int r = i / LI, c = i - r * LI;
+        const int wrap = lc0 + k * DC >= LI ? 1 : 0;
+        const int r = lr0 + k * DR + wrap, c = lc0 + k * DC - wrap * LI;
         const int gy = ty0 + r - LR, gx = tx0 + c - LR;
-        const bool in = i < LIY * LI && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        xv[k] = in ? xp[gy * x.sy + gx * x.sx] : 0.f;
-        yv[k] = in ? yp[gy * y.sy + gx * y.sx] : 0.f;
+        const bool in = tid + k * 256 < LIY * LI && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const int dr = k * DR + wrap, dc = k * DC - wrap * LI;
+        xv[k] = in ? xp[xb + dr * x.sy + dc * x.sx] : 0.f;
+        yv[k] = in ? yp[yb + dr * y.sy + dc * y.sx] : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < NL; k++) {
-        const int i = tid + k * 256;
-        if (i < LIY * LI) {
-            const int r = i / LI, c = i - r * LI;
+        if (tid + k * 256 < LIY * LI) {
+            const int wrap = lc0 + k * DC >= LI ? 1 : 0;
+            const int r = lr0 + k * DR + wrap, c = lc0 + k * DC - wrap * LI;
             X[r * LP + c] = xv[k];
             Y[r * LP + c] = yv[k];
         }
@@ -203,22 +211,25 @@ ssim_grad_kernel(int H, int W, View x, View y, const float* __restrict__ D, floa
     const size_t plane = (size_t)H * W, vol = (size_t)gridDim.z * plane;
     constexpr int NL = (LIY * LI + 255) / 256;
     float dv[NL][3];
+    constexpr int DR = 256 / LI, DC = 256 % LI;   // (row, column) step per 256 elements, see ssim_stats_kernel
+    const int lr0 = tid / LI, lc0 = tid - lr0 * LI;
+    const float* Db = D + (size_t)ch * plane;
 #pragma unroll
     for (int k = 0; k < NL; k++) {   // every load in flight before the first LDS store (see ssim_stats_kernel)
-        const int i = tid + k * 256;
-        const int r = i / LI, c = i - r * LI;
+        const int wrap = lc0 + k * DC >= LI ? 1 : 0;
+        const int r = lr0 + k * DR + wrap, c = lc0 + k * DC - wrap * LI;
         const int gy = ty0 + r - LR, gx = tx0 + c - LR;
-        const bool in = i < LIY * LI && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const size_t o_ = (size_t)ch * plane + (size_t)(in ? gy : 0) * W + (in ? gx : 0);
-        dv[k][0] = in ? D[o_] : 0.f;
-        dv[k][1] = in ? D[vol + o_] : 0.f;
-        dv[k][2] = in ? D[2 * vol + o_] : 0.f;
+        const bool in = tid + k * 256 < LIY * LI && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const size_t o_ = (size_t)((in ? gy : 0) * W + (in ? gx : 0));   // H * W < 2^31 for any image this kernel sees
+        dv[k][0] = in ? Db[o_] : 0.f;
+        dv[k][1] = in ? Db[vol + o_] : 0.f;
+        dv[k][2] = in ? Db[2 * vol + o_] : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < NL; k++) {
-        const int i = tid + k * 256;
-        if (i < LIY * LI) {
-            const int r = i / LI, c = i - r * LI;
+        if (tid + k * 256 < LIY * LI) {
+            const int wrap = lc0 + k * DC >= LI ? 1 : 0;
+            const int r = lr0 + k * DR + wrap, c = lc0 + k * DC - wrap * LI;
             T[0][r * LP + c] = dv[k][0]; T[1][r * LP + c] = dv[k][1]; T[2][r * LP + c] = dv[k][2];
         }
     }
