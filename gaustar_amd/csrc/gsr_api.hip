@@ -214,6 +214,13 @@ int forward_stage1_impl(int P, int D, int M, const float* means3D, const float* 
             __builtin_ia32_pause();
         }
         std::atomic_thread_fence(std::memory_order_acquire);
+        if (*flag != seq) {
+            // The stream reports the kernel retired but its store into the pad has not shown up: never observed, but a
+            // platform where device stores to mapped host memory are not coherent must not yield stale totals -- fetch
+            // them with an ordinary copy.
+            GSR_CHECK(hipMemcpyAsync(g_pinned, im.totals, 16, hipMemcpyDeviceToHost, st));
+            GSR_CHECK(hipStreamSynchronize(st));
+        }
     } else {
         GSR_CHECK(hipStreamSynchronize(st));   // the forward's single host sync (cf. rasterizer_impl.cu:281)
     }
