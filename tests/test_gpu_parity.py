@@ -129,16 +129,17 @@ def _ref_or_skip():
     return ref
 
 
-@pytest.mark.parametrize("cfg", ["B", "C", "D", "D_depth"])
+@pytest.mark.parametrize("cfg", ["B", "C", "C:3", "C:90", "C:141", "D", "D_depth"])
 def test_full_size_configs_against_reference_build(cfg):
-    """BASELINE.json configs[1..3] at full size: 200k / 491k / 1M mesh-bound Gaussians @1080p."""
+    """BASELINE.json configs[1..3] at full size: 200k / 491k / 1M mesh-bound Gaussians @1080p (config C: views from four
+    of the rig's five rings)."""
     ref = _ref_or_skip()
     from gaustar_amd import scene
     if cfg == "B":
         gs, cam, bg = scene.config_B()
-    elif cfg == "C":
+    elif cfg.startswith("C"):
         gs, cams, bg = scene.config_C()
-        cam = cams[37]
+        cam = cams[int(cfg.split(":")[1]) if ":" in cfg else 37]
     else:
         gs, cam, bg = scene.config_D()
         if cfg == "D_depth":          # refine.py:603-607 second pass: depth as colour, bg = 10
