@@ -175,8 +175,8 @@ void launch_scatter(int P, int W, int H, GeomState g, ImageState im, BinState b,
 // Lists longer than this are pre-reduced per segment before the forward blend steps through them (gsr_blend_fwd.hip).
 inline uint32_t fwd_long_threshold()
 {
-    static const uint32_t thr = getenv("GSR_FWD_LONG") ? (uint32_t)atoi(getenv("GSR_FWD_LONG")) : 4096u;
-    return thr;
+    const char* e = getenv("GSR_FWD_LONG");   // read per call: tools/ab_env.py flips it inside one process
+    return e ? (uint32_t)atoi(e) : 4096u;
 }
 // -> true if lists of up to 2 048 entries were left for the forward blend to sort (gsr_sort.h)
 bool launch_tile_sort(int W, int H, int R, uint32_t max_count, ImageState im, BinState b, bool blend_sorts_small, hipStream_t st);
