@@ -114,7 +114,12 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     static_assert(NM <= 16 && NM <= GRAD_RS, "moment columns must fit one MFMA tile and one record");
     static_assert((C + 1) * 64 <= 2 * GRP * RSTRIDE, "dL_dpix staging must fit the r|w table");
     const uint64_t t_start = trace ? wall_clock64() : 0;
-    __shared__ __attribute__((aligned(16))) float qf[64 * SF];             // queue slots (see SlotLayout)
+#ifndef GSR_BWD_QCAP
+#define GSR_BWD_QCAP 32
+#endif
+    constexpr int QCAP = GSR_BWD_QCAP;
+    static_assert(QCAP >= GRP && QCAP <= 64 && QCAP % GRP == 0, "queue capacity: whole MFMA groups, at most one batch");
+    __shared__ __attribute__((aligned(16))) float qf[QCAP * SF];   // queue slots (see SlotLayout)
     __shared__ __attribute__((aligned(16))) float Rm[2 * GRP * RSTRIDE];   // rows 0..7: r, rows 8..15: w, [row][pixel lane]
     float* const Wm = Rm + GRP * RSTRIDE;
     // one wave64 per workgroup: unit = (tile, segment), wave = 8x8 block of the tile.
@@ -257,9 +262,13 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     const bool keep = block_min_half_quad(cur.a.z, cur.a.w, cur.b.x, bx0 - cur.a.x, bx1 - cur.a.x, by0 - cur.a.y,
                                           by1 - cur.a.y) <= cur.b.z;
     const unsigned long long m = __ballot(keep);
-    const int cnt = __popcll(m);
-    if (keep) {
-        const int slot = __popcll(m & ((1ull << lane) - 1ull));
+    const int cnt_all = __popcll(m);
+    // The queue holds QCAP of the batch's up to 64 kept instances at a time (LDS per workgroup decides how many units are
+    // resident, and a typical batch keeps ~22): a batch that keeps more is worked off in chunks, back-to-front order intact.
+    for (int q0 = 0; q0 < cnt_all; q0 += QCAP) {
+    const int cnt = min(cnt_all - q0, QCAP);
+    const int slot = __popcll(m & ((1ull << lane) - 1ull)) - q0;
+    if (keep && slot >= 0 && slot < QCAP) {
         float4* qs = reinterpret_cast<float4*>(&qf[slot * SF]);
         float a2 = cur.a.z, b2 = cur.a.w, c2 = cur.b.x;
         conic_to_exp2(a2, b2, c2);   // exp2-domain conic, the same roundings as the forward's slots
@@ -379,7 +388,8 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             atomic_add_f32(grad_acc + g * GRAD_RS + v, qf[e * SF + MOM0 + v]);
         }
     }
-    __builtin_amdgcn_wave_barrier();   // the queue is rewritten by the next batch
+    __builtin_amdgcn_wave_barrier();   // the queue is rewritten by the next chunk / batch
+    }   // chunks of the batch
     }   // batches of the unit
     if (trace && lane == 0) {   // last wave to finish wins the end stamp (monotone clock, max via atomic)
         if (wave == 0) trace[2 * unit] = t_start;
