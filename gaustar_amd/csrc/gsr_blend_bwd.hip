@@ -126,7 +126,6 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     // XCD-aware placement: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the
     // naive map (unit = id / 4) would put the four blocks of a unit -- which gather the SAME instance records -- on
     // four different L2s.  Instead the four blocks of a unit take four consecutive slots of ONE XCD.
-#ifndef GSR_BWD_NAIVE_MAP
     // Units of one tile are consecutive and also share their pixels' dL_dpix / T / n_contrib and the tile's final
     // snapshot, so an XCD takes RUNS of 8 consecutive units: of every 64 units, XCD x owns [8x, 8x + 8).
     const uint32_t n_units = gridDim.x >> 2;
@@ -136,10 +135,6 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     uint32_t wave_sel = slot & 3u;
     const uint32_t full = (n_units >> 6) << 6;            // units covered by complete groups of 64
     if (blockIdx.x >= full * 4u) { unit = blockIdx.x >> 2; wave_sel = blockIdx.x & 3u; }   // ragged tail: plain map
-#else
-    const uint32_t unit = blockIdx.x >> 2;
-    const uint32_t wave_sel = blockIdx.x & 3u;
-#endif
     const int tile = (int)unit_tile[unit];
     const uint32_t unit0 = seg_off[tile];
     const int s0 = (int)(unit - unit0) * SEG;          // this unit covers list positions [s0, s1)
@@ -195,11 +190,9 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     // Nothing behind the deepest position any pixel of this wave replays can matter.  In every segment but a
     // pixel's last one that is simply the segment end (one ballot); only otherwise reduce.
     int wave_hi;
-#ifndef GSR_NO_HI_SHORTCUT
     if (__ballot(my_last >= s1) != 0ull) {
         wave_hi = s1;
     } else
-#endif
     {
         wave_hi = my_lim;
 #pragma unroll
@@ -210,9 +203,6 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
 
     // The unit is walked back to front in batches of 64 list positions; lane l of a batch takes position hi-1-l
     // (queue order == back-to-front order).
-#ifdef GSR_BWD_PREFETCH
-    FetchedB<C> nxt = fetch_instance_b<C>(wave_hi - 1 - lane, s0, list, g0, g1, feats);
-#endif
 
     // B operand of the contraction, constant over the unit.  MFMA step t (0..15) consumes the four pixels
     // p = 16*kap + t, kap = 0..3; in the B operand lane l carries row kap = l >> 4, column col = l & 15.
@@ -253,12 +243,7 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
 
     for (int hi = wave_hi; hi > s0; hi -= 64) {
     const int k = hi - 1 - lane;
-#ifdef GSR_BWD_PREFETCH
-    const FetchedB<C> cur = nxt;
-    if (hi - 64 > s0) nxt = fetch_instance_b<C>(hi - 65 - lane, s0, list, g0, g1, feats);
-#else
     const FetchedB<C> cur = fetch_instance_b<C>(k, s0, list, g0, g1, feats);
-#endif
     const bool keep = block_min_half_quad(cur.a.z, cur.a.w, cur.b.x, bx0 - cur.a.x, bx1 - cur.a.x, by0 - cur.a.y,
                                           by1 - cur.a.y) <= cur.b.z;
     const unsigned long long m = __ballot(keep);
