@@ -28,7 +28,7 @@ thread_local uint32_t* g_pinned = nullptr;   // pinned, device-mapped landing pa
 enum Stage { ST_PREPROCESS = 0, ST_TILE_SCAN, ST_SCATTER, ST_TILE_SORT, ST_BLEND_FWD, ST_ZERO_FILL, ST_BLEND_BWD,
              ST_GEOM_BWD, ST_LOSS, ST_PRODUCERS, ST_OPTIM, ST_COUNT };
 const char* const kStageNames[ST_COUNT] = {"preprocess_kernel", "tile_scan_kernel", "scatter_kernel",
-                                           "tile_sort_kernel", "blend_fwd_kernel", "zero_fill", "blend_bwd_kernel",
+                                           "tile_sort_mask_kernel", "blend_fwd_kernel", "zero_fill", "blend_bwd_kernel",
                                            "geom_bwd_kernel", "loss_kernels", "producer_kernels", "optimizer_kernels"};
 struct Rec { int stage; hipEvent_t a, b; };
 // Process-wide (PyTorch runs backward on its own autograd thread), guarded by a mutex.
@@ -87,7 +87,7 @@ int fail_msg(const char* msg)
 
 extern "C" {
 
-int gsr_abi_version(void) { return 8; }
+int gsr_abi_version(void) { return 9; }
 
 const char* gsr_last_error(void) { return g_err.c_str(); }
 
@@ -321,14 +321,12 @@ int forward_stage2_impl(int P, int R, int max_tile_instances, int num_segments, 
         im.tile_cursor = counters + (size_t)shard_stride(tiles_of(W, H).T) * NSHARD;
     }
     GeomState g = carve_geom(geom_buffer, P > 0 ? P : 0);
-    // num_segments < 0: forward-only render (same buffer size as for |num_segments|, snapshots not written);
-    // num_segments = 0 with R > 0: forward-only and no per-unit areas at all (long tiles are walked serially)
-    const bool forward_only = num_segments <= 0;
+    // num_segments < 0: forward-only render (same buffer size as for |num_segments|; the blended-instance words the
+    // backward would replay are not written back)
+    const bool forward_only = num_segments < 0;
     if (num_segments < 0) num_segments = -num_segments;
+    if (R > 0 && num_segments == 0) return fail_msg("gsr_forward_stage2: num_segments of stage 1 is required (it sizes the binning buffer)");
     BinState b = carve_bin(binning_buffer, R > 0 ? R : 0, num_segments, C);
-    if (num_segments == 0) { b.unit_tile = nullptr; b.part = nullptr; b.part_last = nullptr; }
-    if (forward_only) b.snap = nullptr;
-    bool sort_in_blend = false;
     if (R > 0) {
         {
             Scope sc(ST_SCATTER, st);
@@ -337,17 +335,19 @@ int forward_stage2_impl(int P, int R, int max_tile_instances, int num_segments, 
         GSR_CHECK_LAUNCH("scatter_kernel");
         {
             Scope sc(ST_TILE_SORT, st);
-            const char* e_fuse = getenv("GSR_SORT_IN_BLEND");   // read per call (tools/ab_env.py); "0": separate sort kernel
+            const char* e_fuse = getenv("GSR_SORT_WITH_MASKS");   // read per call (tools/ab_env.py); "0": separate sort kernel
             const bool fuse = !(e_fuse && e_fuse[0] == '0');
-            sort_in_blend = launch_tile_sort(W, H, R, (uint32_t)max_tile_instances, im, b, fuse, st);
+            const uint32_t maxc = (uint32_t)(max_tile_instances > 0 ? max_tile_instances : 0);
+            const bool sort_with_masks = launch_tile_sort(W, H, R, maxc, im, b, fuse, st);
+            launch_tile_masks(W, H, num_segments, maxc, sort_with_masks, g, im, b, st);
         }
-        GSR_CHECK_LAUNCH("tile_sort_kernel");
+        GSR_CHECK_LAUNCH("tile_sort_mask_kernel");
     }
     const float* feats = colors_precomp ? colors_precomp : g.rgb;
     {
         Scope sc(ST_BLEND_FWD, st);
-        launch_blend_fwd(C, W, H, R, num_segments, (uint32_t)(max_tile_instances > 0 ? max_tile_instances : 0), background, feats, g, im, b,
-                         out_color, grad_scratch, grad_scratch ? gsr_grad_scratch_bytes(P > 0 ? P : 0) : 0, counters, sort_in_blend, st);
+        launch_blend_fwd(C, W, H, background, feats, g, im, b, out_color, !forward_only, grad_scratch,
+                         grad_scratch ? gsr_grad_scratch_bytes(P > 0 ? P : 0) : 0, counters, st);
     }
     GSR_CHECK_LAUNCH("blend_fwd_kernel");
     return 0;
@@ -423,7 +423,7 @@ int gsr_backward_mt(int P, int D, int M, int R, int num_segments, int num_channe
         return fail_msg("gsr_backward: scales/rotations and their gradients are required without cov3D_precomp");
     if (R > 0 && !binning_buffer) return fail_msg("gsr_backward: binning_buffer is null");
     if (R > 0 && num_segments <= 0)
-        return fail_msg("gsr_backward: the forward ran in forward-only mode (num_segments = 0 at stage 2)");
+        return fail_msg("gsr_backward: num_segments of the forward is required (a forward-only render cannot be differentiated)");
     if (!channels_ok(num_channels)) return fail_msg("gsr_backward: num_channels must be 3, 4 or 6");
     if (num_channels != 3 && !colors_precomp)
         return fail_msg("gsr_backward: multi-target renders need precomputed colours [P, num_channels]");
@@ -732,6 +732,16 @@ int gsr_debug_export(int P, int R, int num_segments, int W, int H, const void* g
         BinState b = carve_bin(const_cast<void*>(binning_buffer), R, num_segments > 0 ? num_segments : 0);
         GSR_CHECK(hipMemcpyAsync(point_list, b.point_list, 4 * (size_t)R, hipMemcpyDeviceToDevice, st));
     }
+    return 0;
+}
+
+int gsr_debug_export_masks(int R, int num_segments, const void* binning_buffer, uint64_t* masks, gsr_stream_t stream)
+{
+    g_err.clear();
+    if (R <= 0 || num_segments <= 0) return 0;
+    if (!binning_buffer || !masks) return fail_msg("gsr_debug_export_masks: required pointer is null");
+    BinState b = carve_bin(const_cast<void*>(binning_buffer), R, num_segments);
+    GSR_CHECK(hipMemcpyAsync(masks, b.masks, 8 * 256 * (size_t)num_segments, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return 0;
 }
 

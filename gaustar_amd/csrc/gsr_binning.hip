@@ -239,8 +239,8 @@ scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __
     const int shard = (int)(blockIdx.x & (NSHARD - 1));
     const size_t Tp = shard_stride(T);
     // side job of the first T threads: expand the per-tile segment counts into the unit -> tile table
-    // (it lives in the binning buffer, which did not exist yet when the scan kernel ran)
-    if (unit_tile != nullptr && idx < T) {   // nullptr: forward-only render, no unit table
+    // (it lives in the binning buffer, which did not exist yet when the scan kernel ran; read by tile_mask_kernel)
+    if (idx < T) {
         const uint32_t u0 = seg_off[idx], u1 = seg_off[idx + 1];
         for (uint32_t u = u0; u < u1; u++) unit_tile[u] = (uint32_t)idx;
     }
@@ -359,7 +359,7 @@ tile_sort_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
     }
 }
 
-// (the register-resident bitonic sort lives in gsr_sort.h: blend_fwd can run it in front of its blend)
+// (the register-resident bitonic sort lives in gsr_sort.h: tile_sort_mask_kernel runs it in front of its masks)
 
 __global__ void __launch_bounds__(256)
 tile_sort_reg_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ order, const uint64_t* __restrict__ keys,
@@ -392,7 +392,7 @@ tile_sort_big_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
     else sort_tile_in_registers<16>(s, gk, out, n, 16384u);
 }
 
-bool launch_tile_sort(int W, int H, int R, uint32_t max_count, ImageState im, BinState b, bool blend_sorts_small, hipStream_t st)
+bool launch_tile_sort(int W, int H, int R, uint32_t max_count, ImageState im, BinState b, bool mask_sorts_small, hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);
     bool left_small = false;
@@ -404,9 +404,8 @@ bool launch_tile_sort(int W, int H, int R, uint32_t max_count, ImageState im, Bi
     }
     static const bool lds_sort = getenv("GSR_SORT_LDS") != nullptr;   // A/B switch: the LDS network for every tile
     if (lds_sort) tile_sort_kernel<2048, 0, false><<<t.T, 256, 2048 * 8, st>>>(im.ranges, im.order, b.keys, b.point_list);
-    // the forward blend sorts each of these lists right before walking it -- unless its long-tile path (which needs sorted
-    // lists before the main kernel runs) reaches below 2 048 entries (GSR_FWD_LONG set low, tests)
-    else if (blend_sorts_small && !(max_count > fwd_long_threshold() && fwd_long_threshold() < 2048u)) left_small = true;
+    // tile_sort_mask_kernel sorts each of these lists right before it builds the tile's masks (gsr_mask.hip)
+    else if (mask_sorts_small) left_small = true;
     else tile_sort_reg_kernel<<<t.T, 256, 0, st>>>(im.ranges, im.order, b.keys, b.point_list);
     if (max_count > 2048 && !lds_sort) {
         // the longest lists sit at the front of `order` (32-entry length classes, snake within bands of 256): every tile

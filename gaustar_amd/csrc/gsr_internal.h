@@ -87,15 +87,24 @@ inline ImageState carve_image(void* base, int W, int H)
     return s;
 }
 
-// A tile's depth-sorted list is cut into SEGMENTS of SEG instances.  The forward blend snapshots every
-// pixel's running (T, C) at the segment boundaries it crosses; the backward blend then treats each
-// (tile, segment) as an independent workgroup-sized unit.  Per-tile work ranges over three orders of
-// magnitude for a surface seen in perspective; segments bound the unit size, which is what lets the
-// hardware dispatcher balance the backward pass and cuts its serial chain.
+// A tile's depth-sorted list is cut into SEGMENTS of SEG = 64 instances (UNITS when counted over all tiles, U of them);
+// a unit carries one 64-bit mask word per pixel of its tile (gsr_mask.hip): candidates before the forward blend, the
+// instances actually blended after it.
 constexpr int SEG = 64;
 
+// List positions staged in LDS at a time by the blend kernels (gsr_blend_fwd.hip / gsr_blend_bwd.hip).  A wave's trip
+// count per chunk is the largest per-pixel count within the chunk, so longer chunks mean fewer trips (config C: 45 trips
+// per 8x8 block at 256, 36 at 512) at the price of LDS = resident workgroups.
+#ifndef GSR_FWD_CHUNK
+#define GSR_FWD_CHUNK 256
+#endif
+#ifndef GSR_BWD_CHUNK
+#define GSR_BWD_CHUNK 256
+#endif
+constexpr int FWD_CHUNK = GSR_FWD_CHUNK, BWD_CHUNK = GSR_BWD_CHUNK;
+
 // Channel count of a render: 3 = the reference's NUM_CHANNELS (cuda_rasterizer/config.h:15); 6 = two targets
-// sharing geometry, blended in one walk.  A snapshot is (T, C[0..C-1]) padded to whole float4s.
+// sharing geometry, blended in one walk; 4 = RGB + one scalar target.  A snapshot is (T, C[0..C-1]) padded to whole float4s.
 __host__ __device__ constexpr int snap_vecs(int C) { return (C + 4) / 4; }
 __host__ __device__ constexpr bool channels_ok(int C) { return C == 3 || C == 4 || C == 6; }
 constexpr int GRAD_RS = 12;  // floats per record of the backward accumulation table: 6 geometric moments + C <= 6 colours
@@ -104,11 +113,11 @@ struct BinState {            // per instance / per segment
     uint64_t* keys;          // [R] (depth_bits << 32) | gaussian, bucketed by tile, unsorted within the bucket
     uint32_t* point_list;    // [R] gaussian ids, tile-major, depth-ascending, ties by ascending id
     uint32_t* unit_tile;     // [U] tile of segment (unit) u; its segment index is u - seg_off[tile]
+    uint2* masks;            // [U][4 blocks][64 lanes] per-pixel 64-bit words over the unit's 64 list positions
+                             // {positions 0-31, positions 32-63}; block = 2*by + bx, lane = 8*(y % 8) + (x % 8)
     float4* snap;            // [U][256][snap_vecs(C)] per-pixel {T, C0, C1, ...} BEFORE the first instance of segment
                              // u (u not the first segment of its tile; that slot holds the FINAL {T, C...} when the
                              // tile has more than one segment); pixel index = 16*(y - tile_y0) + (x - tile_x0)
-    float4* part;            // [U][256][snap_vecs(C)] segment pre-reduction of long tiles: {prod(1 - alpha), sum c alpha T_local}
-    uint32_t* part_last;     // [U][256] last contributing list position (1-based) inside the segment, 0 = none
     size_t bytes;
 };
 inline BinState carve_bin(void* base, int R, int U, int C = 3)
@@ -117,9 +126,8 @@ inline BinState carve_bin(void* base, int R, int U, int C = 3)
     s.keys = (uint64_t*)(b + o); o = align_up(o + 8 * (size_t)R);
     s.point_list = (uint32_t*)(b + o); o = align_up(o + 4 * (size_t)R);
     s.unit_tile = (uint32_t*)(b + o); o = align_up(o + 4 * (size_t)U);
+    s.masks = (uint2*)(b + o); o = align_up(o + sizeof(uint2) * 256 * (size_t)U);
     s.snap = (float4*)(b + o); o = align_up(o + sizeof(float4) * 256 * (size_t)snap_vecs(C) * (size_t)U);
-    s.part = (float4*)(b + o); o = align_up(o + sizeof(float4) * 256 * (size_t)snap_vecs(C) * (size_t)U);
-    s.part_last = (uint32_t*)(b + o); o = align_up(o + sizeof(uint32_t) * 256 * (size_t)U);
     s.bytes = o + 256;
     return s;
 }
@@ -172,14 +180,10 @@ void launch_preprocess(int P, int D, int M, const float* means3D, const float* s
                        hipStream_t st);
 void launch_tile_scan(ImageState im, int T, uint32_t* host_totals, uint32_t host_seq, hipStream_t st);
 void launch_scatter(int P, int W, int H, GeomState g, ImageState im, BinState b, hipStream_t st);
-// Lists longer than this are pre-reduced per segment before the forward blend steps through them (gsr_blend_fwd.hip).
-inline uint32_t fwd_long_threshold()
-{
-    const char* e = getenv("GSR_FWD_LONG");   // read per call: tools/ab_env.py flips it inside one process
-    return e ? (uint32_t)atoi(e) : 4096u;
-}
-// -> true if lists of up to 2 048 entries were left for the forward blend to sort (gsr_sort.h)
-bool launch_tile_sort(int W, int H, int R, uint32_t max_count, ImageState im, BinState b, bool blend_sorts_small, hipStream_t st);
+// -> true if lists of up to 2 048 entries were left for tile_sort_mask_kernel to sort (gsr_mask.hip, gsr_sort.h)
+bool launch_tile_sort(int W, int H, int R, uint32_t max_count, ImageState im, BinState b, bool mask_sorts_small, hipStream_t st);
+// per-tile depth sort (lists up to 2 048 entries, if sort_here) + per-pixel candidate masks of every unit (gsr_mask.hip)
+void launch_tile_masks(int W, int H, int U, uint32_t max_count, bool sort_here, GeomState g, ImageState im, BinState b, hipStream_t st);
 // Launch positions [0, front_of_order(R, T)) of `order` hold every tile with 2 017 or more entries: they all fall into
 // length class 0, which sits at the front, there are at most R / 2017 of them, and the snake only permutes within
 // bands of 256.  Kernels that only concern such tiles are launched over this prefix instead of all T tiles.
@@ -188,8 +192,8 @@ inline int front_of_order(int R, int T)
     const long long bound = ((long long)(R > 0 ? R : 0) / 2017 + 1 + 255) / 256 * 256;
     return (int)(bound < (long long)T ? bound : (long long)T);
 }
-void launch_blend_fwd(int C, int W, int H, int R, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
-                      float* out_color, void* zero_ptr, size_t zero_bytes, uint32_t* counters, bool sort_small, hipStream_t st);
+void launch_blend_fwd(int C, int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
+                      float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, uint32_t* counters, hipStream_t st);
 void launch_blend_bwd(int C, int W, int H, int U, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
                       const float* dL_dpix, float* grad_acc, hipStream_t st);
 void launch_geom_bwd(int P, int D, int M, const float* means3D, const float* shs, const float* scales,
@@ -574,6 +578,45 @@ __device__ __forceinline__ void for_each_tile_aggregated(ushort4 rect, float px,
     TileWalker w(rect, px, py, ca, cb, cc, tau, gx, lane);
     TileVisit v;
     while (w.next_round(v)) f(v.tile, v.is_leader, v.group, v.rank, v.leader_lane);
+}
+
+// LDS record of one staged list instance, shared by the blend kernels: a = {x, y, conic a, conic b} and
+// b = {conic c, opacity, Gaussian id (uint bits), -} with the conic in the exp2 domain (conic_to_exp2: the forward and the
+// backward must round identically), then the colour channels padded to whole float4s.  48 B (C = 3, 4) / 64 B (C = 6).
+template <int C> struct __attribute__((aligned(16))) BlendRec { float4 a, b; float col[(C + 3) / 4 * 4]; };
+template <int C>
+__device__ __forceinline__ void store_rec(BlendRec<C>& r, float4 a, float4 b, uint32_t gid, const float* __restrict__ feats)
+{
+    float col[(C + 3) / 4 * 4];
+#pragma unroll
+    for (int ch = C; ch < (C + 3) / 4 * 4; ch++) col[ch] = 0.f;
+    if constexpr (C % 2 == 0) {   // rows of an even channel count are 8-byte aligned
+        const float2* pf = reinterpret_cast<const float2*>(feats + (size_t)C * gid);
+#pragma unroll
+        for (int ch = 0; ch < C; ch += 2) { const float2 v = pf[ch / 2]; col[ch] = v.x; col[ch + 1] = v.y; }
+    } else {
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) col[ch] = feats[(size_t)C * gid + ch];
+    }
+    float a2 = a.z, b2 = a.w, c2 = b.x;
+    conic_to_exp2(a2, b2, c2);
+    r.a = make_float4(a.x, a.y, a2, b2);
+    r.b = make_float4(c2, b.y, __uint_as_float(gid), 0.f);
+#pragma unroll
+    for (int v = 0; v < (C + 3) / 4; v++)
+        reinterpret_cast<float4*>(r.col)[v] = make_float4(col[4 * v], col[4 * v + 1], col[4 * v + 2], col[4 * v + 3]);
+}
+template <int C>
+__device__ __forceinline__ void load_cols(const BlendRec<C>& r, float (&c)[C])
+{
+#pragma unroll
+    for (int v = 0; v < (C + 3) / 4; v++) {
+        const float4 q = reinterpret_cast<const float4*>(r.col)[v];
+        if (4 * v < C) c[4 * v < C ? 4 * v : 0] = q.x;
+        if (4 * v + 1 < C) c[4 * v + 1 < C ? 4 * v + 1 : 0] = q.y;
+        if (4 * v + 2 < C) c[4 * v + 2 < C ? 4 * v + 2 : 0] = q.z;
+        if (4 * v + 3 < C) c[4 * v + 3 < C ? 4 * v + 3 : 0] = q.w;
+    }
 }
 
 // Snapshot record of one pixel: float4s {T, C0, C1, C2}, {C3, C4, C5, 0}, ...

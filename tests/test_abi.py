@@ -54,7 +54,7 @@ def test_ctypes_table_matches_header():
 def test_library_loads_and_exports_every_symbol(hip_lib):
     for name in _declared():
         assert hasattr(hip_lib, name), name
-    assert hip_lib.gsr_abi_version() == 8
+    assert hip_lib.gsr_abi_version() == 9
 
 
 def test_scratch_sizes(hip_lib):
@@ -66,12 +66,12 @@ def test_scratch_sizes(hip_lib):
     assert hip_lib.gsr_grad_scratch_bytes(500_000) == 48 * 500_000 + 256
     b = hip_lib.gsr_binning_bytes(1_000_000, 0)
     assert 12_000_000 <= b <= 12_000_000 + 2048
-    # per unit: unit table entry + snapshots + segment pre-reductions (same record) + their last-contributor positions
-    assert hip_lib.gsr_binning_bytes(1_000_000, 1000) - b == 1000 * (4 + 256 * 16 * 2 + 256 * 4) + 96
+    # per unit: unit table entry + one 64-bit mask word and one snapshot per pixel of the tile
+    assert hip_lib.gsr_binning_bytes(1_000_000, 1000) - b == 1000 * (4 + 256 * 8 + 256 * 16) + 96
     assert hip_lib.gsr_geom_bytes(0) > 0 and hip_lib.gsr_binning_bytes(0, 0) > 0
     # multi-target: 3 channels = the plain size; 6 channels double the per-pixel snapshot (two float4 instead of one)
     assert hip_lib.gsr_binning_bytes_mt(1_000_000, 1000, 3) == hip_lib.gsr_binning_bytes(1_000_000, 1000)
-    assert hip_lib.gsr_binning_bytes_mt(1_000_000, 1000, 6) - hip_lib.gsr_binning_bytes(1_000_000, 1000) == 2 * 1000 * 256 * 16
+    assert hip_lib.gsr_binning_bytes_mt(1_000_000, 1000, 6) - hip_lib.gsr_binning_bytes(1_000_000, 1000) == 1000 * 256 * 16
 
 
 def test_validation_errors_without_gpu(hip_lib):

@@ -355,10 +355,10 @@ def test_non_default_stream_and_degree_validation():
         GaussianRasterizer(mk(4))(**args)
 
 
-def test_long_tile_forward_path_in_a_subprocess():
-    """The segment pre-reduction path of the forward blend (gsr_blend_fwd.hip, tiles above GSR_FWD_LONG entries; default
-    4 096, read once per process) forced down to 128 entries so that ordinary scenes take it: images, internal state and
-    gradients must still match the oracle -- including tiles whose pixels terminate inside pre-reduced segments."""
+def test_lists_spanning_many_chunks():
+    """Tile lists of more than 1 000 entries: the blend kernels stage them in LDS several chunks at a time
+    (gsr_blend_fwd.hip), pixels terminate inside different chunks (opaque case) or never (translucent case); images,
+    internal state and gradients must still match the oracle."""
     import subprocess
     import sys
     code = r'''
@@ -379,11 +379,10 @@ for seed, opac in ((1, (0.6, 0.99)), (2, (0.02, 0.1))):
     st, g = parity.run_oracle(kw, dpix)
     assert (st["ranges"][:, 1] - st["ranges"][:, 0]).max() > 1000
     hip = parity.run_hip(kw, dpix)
-    parity.compare_hip_to(hip, st["color"], st["radii"], g, what="long-tile path seed %d" % seed)
+    parity.compare_hip_to(hip, st["color"], st["radii"], g, what="long lists seed %d" % seed)
 print("LONG_PATH_OK")
 '''
-    env = dict(os.environ, GSR_FWD_LONG="128")
-    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "LONG_PATH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
