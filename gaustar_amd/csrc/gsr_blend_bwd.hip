@@ -98,12 +98,14 @@ __device__ __forceinline__ void atomic_add_f32(float* p, float v)
 constexpr int GRP = GSR_BWD_GRP;   // instances per MFMA group: A-operand rows 0..GRP-1 carry their r, the next GRP rows their w
 constexpr int RSTRIDE = 68;     // floats per row of the r|w table: 64 pixels + 4 (16-byte aligned, spreads banks)
 
-static_assert(SEG % 64 == 0, "a unit is a whole number of 64-instance fetch batches");
+constexpr int BSEG = SNAP_SEG;
+static_assert(BSEG % 64 == 0, "a unit is a whole number of 64-instance fetch batches");
+constexpr int UPS = BSEG / 64;   // 64-entry mask units per backward unit
 
 template <int C>
 __global__ void __launch_bounds__(64)
 blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ seg_off,
-                 const uint32_t* __restrict__ unit_tile, const float4* __restrict__ snap,
+                 const uint32_t* __restrict__ unit_tile, const float4* __restrict__ snap, const uint2* __restrict__ masks,
                  const uint32_t* __restrict__ point_list, const float4* __restrict__ g0,
                  const float4* __restrict__ g1, const float* __restrict__ feats, const float* __restrict__ bg,
                  const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
@@ -137,7 +139,10 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     if (blockIdx.x >= full * 4u) { unit = blockIdx.x >> 2; wave_sel = blockIdx.x & 3u; }   // ragged tail: plain map
     const int tile = (int)unit_tile[unit];
     const uint32_t unit0 = seg_off[tile];
-    const int s0 = (int)(unit - unit0) * SEG;          // this unit covers list positions [s0, s1)
+    // unit ids count 64-entry segments (the granularity of the mask words); a backward unit spans UPS of them and is
+    // worked by the first one's workgroups
+    if ((unit - unit0) % UPS != 0u) return;
+    const int s0 = (int)(unit - unit0) * 64;           // this unit covers list positions [s0, s1)
     const int wave = (int)wave_sel, lane = threadIdx.x;
     const int tx = tile % gx, ty = tile / gx;
     const int sx = tx * TILE + (wave & 1) * SUB, sy = ty * TILE + (wave >> 1) * SUB;
@@ -148,7 +153,7 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
 
     const uint2 rg = ranges[tile];
     const int n = (int)(rg.y - rg.x);
-    const int s1 = min(s0 + SEG, n);
+    const int s1 = min(s0 + BSEG, n);
     const uint32_t* list = point_list + rg.x;
 
     const size_t pix = (size_t)W * py + px;
@@ -179,7 +184,21 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         // list position s1.  accum_rec at that point = colour composited behind s1, seen from s1.
         const int pidx = 16 * (py - ty * TILE) + (px - tx * TILE);
         float Ts, Tf, cs[C], cf[C];
-        load_snapshot<C>(snap + ((size_t)(unit + 1) * 256 + pidx) * SV, Ts, cs);
+        // The forward stored a snapshot whenever the pixel moved on to a word of a new segment (gsr_blend_fwd.hip); the
+        // first segment behind this unit in which the pixel blended anything has one, and nothing was blended between
+        // this unit's far end and that segment, so it is the state at list position s1.  (Words up to the one holding
+        // the pixel's last contributor are defined.)
+        uint32_t useg = unit + UPS;
+        const uint32_t u_end = unit0 + (uint32_t)(n + 63) / 64u;
+        while (true) {
+            uint32_t any = 0;
+#pragma unroll
+            for (int w = 0; w < UPS; w++)
+                if (useg + w < u_end) { const uint2 m = masks[((size_t)(useg + w) * 4 + wave) * 64 + lane]; any |= m.x | m.y; }
+            if (any != 0u || useg + UPS >= u_end) break;
+            useg += UPS;
+        }
+        load_snapshot<C>(snap + ((size_t)useg * 256 + pidx) * SV, Ts, cs);
         load_snapshot<C>(snap + ((size_t)unit0 * 256 + pidx) * SV, Tf, cf);   // final (T, C) kept in the tile's first slot
         const float inv = __builtin_amdgcn_rcpf(Ts);
         T = Ts;
@@ -392,7 +411,7 @@ void launch_blend_bwd(int C, int W, int H, int U, const float* bg, const float* 
     uint64_t* tr = g_trace ? g_trace + 2 * (size_t)t.T : nullptr;
     const auto go = [&](auto tag) {
         constexpr int CC = decltype(tag)::value;
-        blend_bwd_kernel<CC><<<4 * U, 64, pad, st>>>(W, H, t.gx, im.ranges, im.seg_off, b.unit_tile, b.snap, b.point_list,
+        blend_bwd_kernel<CC><<<4 * U, 64, pad, st>>>(W, H, t.gx, im.ranges, im.seg_off, b.unit_tile, b.snap, b.masks, b.point_list,
                                                      g.g0, g.g1, feats, bg, im.final_T, im.n_contrib, dL_dpix, grad_acc, tr);
     };
     if (C == 6) go(std::integral_constant<int, 6>{});

@@ -55,8 +55,9 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     }
     using R = BlendRec<C>;
     constexpr int NH = CH / 32;                                       // 32-bit mask words per lane and chunk
+    constexpr int PT = CH / 256;                                      // list positions per thread and chunk
     static_assert(CH % 256 == 0 && NH <= 32, "a chunk is a whole number of 256-thread fetch rounds; nz is one dword");
-    __shared__ R rec[CH];
+    __shared__ R rec[CH + 1];                                         // slot CH: the neutral instance
     __shared__ uint32_t mk[4][NH][64];                                // [wave][word][lane]
     const int tile = (int)order[blockIdx.x];
     // Second side job (fused forward): this tile's eight shard counters and eight scatter cursors live in a library-owned
@@ -70,7 +71,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     const float pxf = (float)px, pyf = (float)py;
     constexpr int SV = snap_vecs(C);
     const int pix_in_tile = 16 * (py - ty * TILE) + (px - tx * TILE);
-    const bool keep_masks = snap != nullptr;   // a backward pass may follow
+    const bool keep = snap != nullptr;   // a backward pass may follow
 
     const uint2 rg = ranges[tile];
     const uint32_t n = rg.y - rg.x;
@@ -78,92 +79,145 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     const uint32_t* list = point_list + rg.x;
     uint2* const my_masks = masks + ((size_t)unit0 * 4 + wave) * 64 + lane;   // + 256 per unit
 
+    // The kernel's span is its longest tile (a pixel's walk is serial), and co-resident waves share a SIMD's issue slots:
+    // long lists get issue priority so that they do not also run at 1/7 speed (0.088 -> 0.084 ms on config C).
+    if (n > 1024u) __builtin_amdgcn_s_setprio(3);
+    else if (n > 704u) __builtin_amdgcn_s_setprio(2);
+    else if (n > 448u) __builtin_amdgcn_s_setprio(1);
+    if (threadIdx.x == 0) {   // neutral instance: opacity 0 never passes the alpha test; lanes without a candidate read it
+        rec[CH].a = make_float4(0.f, 0.f, 0.f, 0.f);
+        rec[CH].b = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ch = 0; ch < (C + 3) / 4 * 4; ch++) rec[CH].col[ch] = 0.f;
+    }
+
     float T = 1.0f;
     float Cc[C];
 #pragma unroll
     for (int ch = 0; ch < C; ch++) Cc[ch] = 0.f;
     uint32_t last = 0;
     bool done = !inside;
-    uint32_t snap_next = 1;   // next segment boundary (tile-local unit index) this pixel has not snapshotted yet
+    uint32_t seg_cur = 0;   // segment (SNAP_SEG list positions) of the word this pixel consumed last
+
+    // Two-stage software pipeline over the dependent gather (list -> id -> records): ids are fetched two chunks ahead,
+    // records and mask words one chunk ahead, so no global-memory latency sits between a chunk's barrier and its walk.
+    uint32_t gid_nxt[PT];
+    float4 a_nxt[PT], b_nxt[PT];
+    float col_nxt[PT][C];
+    uint2 m_nxt[NH / 2];
+    const auto fetch_ids = [&](uint32_t c0) {
+#pragma unroll
+        for (int q = 0; q < PT; q++) {
+            const uint32_t k = c0 + q * 256 + threadIdx.x;
+            gid_nxt[q] = k < n ? list[k] : 0xffffffffu;
+        }
+    };
+    const auto fetch_records = [&]() {
+#pragma unroll
+        for (int q = 0; q < PT; q++) {
+            const uint32_t gid = gid_nxt[q];
+            if (gid != 0xffffffffu) {
+                a_nxt[q] = g0[gid];
+                b_nxt[q] = g1[gid];
+                if constexpr (C % 2 == 0) {   // rows of an even channel count are 8-byte aligned
+                    const float2* pf = reinterpret_cast<const float2*>(feats + (size_t)C * gid);
+#pragma unroll
+                    for (int ch = 0; ch < C; ch += 2) { const float2 v = pf[ch / 2]; col_nxt[q][ch] = v.x; col_nxt[q][ch + 1] = v.y; }
+                } else {
+#pragma unroll
+                    for (int ch = 0; ch < C; ch++) col_nxt[q][ch] = feats[(size_t)C * gid + ch];
+                }
+            }
+        }
+    };
+    const auto fetch_masks = [&](uint32_t c0) {
+#pragma unroll
+        for (int w = 0; w < NH / 2; w++) {
+            m_nxt[w] = make_uint2(0u, 0u);
+            if ((c0 >> 6) + w < n_units) m_nxt[w] = my_masks[(size_t)((c0 >> 6) + w) * 256];
+        }
+    };
+    fetch_ids(0);
+    fetch_masks(0);
+    fetch_records();
+    uint32_t gid_cur[PT];
+#pragma unroll
+    for (int q = 0; q < PT; q++) gid_cur[q] = gid_nxt[q];
+    fetch_ids(CH);
 
     for (uint32_t c0 = 0; c0 < n; c0 += CH) {
         // every pixel of the tile saturated: stop (also the barrier that frees the LDS of the previous chunk)
         if (__syncthreads_or(!done) == 0) break;
-        // ---- park the chunk's records
+        // ---- park the chunk's records; request the next chunk's
 #pragma unroll
-        for (int q = 0; q < CH / 256; q++) {
-            const uint32_t k = c0 + q * 256 + threadIdx.x;
-            if (k < n) {
-                const uint32_t gid = list[k];
-                const float4 a = g0[gid], b = g1[gid];
-                store_rec<C>(rec[q * 256 + threadIdx.x], a, b, gid, feats);
-            }
-        }
-        // ---- this wave's candidate words of the chunk -> LDS; nz = which of them are non-empty
+        for (int q = 0; q < PT; q++)
+            if (gid_cur[q] != 0xffffffffu) store_rec<C>(rec[q * 256 + threadIdx.x], a_nxt[q], b_nxt[q], gid_cur[q], col_nxt[q]);
         const uint32_t u_lo = c0 >> 6;
         uint32_t nz = 0;
 #pragma unroll
         for (int w = 0; w < NH / 2; w++) {
-            uint2 m = make_uint2(0u, 0u);
-            if (u_lo + w < n_units && !done) m = my_masks[(size_t)(u_lo + w) * 256];
+            const uint2 m = done ? make_uint2(0u, 0u) : m_nxt[w];
             mk[wave][2 * w][lane] = m.x;
             mk[wave][2 * w + 1][lane] = m.y;
             nz |= (m.x != 0u ? 1u : 0u) << (2 * w) | (m.y != 0u ? 1u : 0u) << (2 * w + 1);
         }
+#pragma unroll
+        for (int q = 0; q < PT; q++) gid_cur[q] = gid_nxt[q];
+        fetch_records();
+        fetch_masks(c0 + CH);
+        fetch_ids(c0 + 2 * CH);
         __syncthreads();
-        // ---- the walk: every lane through its own candidates
-        uint32_t cur = 0, bl = 0;
-        int h = -1;
-        bool active = nz != 0u;   // (done lanes loaded empty words)
+        // ---- the walk: every lane through its own candidates.  (h, cur) = the word being consumed and its remaining
+        // bits, bl = the bits of it that were blended, (nh, nw) = the next non-empty word, already read.
+        uint32_t cur = 0, bl = 0, nw = 0, nz_zero = 0;
+        int h = 0, nh = 0;
+        bool started = false;
+        if (nz != 0u) { nh = __builtin_ctz(nz); nz &= nz - 1u; nw = mk[wave][nh][lane]; }
         while (true) {
-            if (active && cur == 0u) {
-                if (h >= 0) mk[wave][h][lane] = __builtin_bitreverse32(bl);   // the word just finished: what was blended
-                if (nz == 0u) {
-                    active = false; h = -1;
-                } else {
-                    h = __builtin_ctz(nz);
-                    nz &= nz - 1u;
-                    cur = mk[wave][h][lane];
-                    bl = 0u;
-                    // the pixel is about to consume instances of segment u_new: its running (T, C) is the state at every
-                    // segment boundary it has crossed since its last word -- what the segment-parallel backward resumes from
-                    if (keep_masks) {
-                        const uint32_t u_new = u_lo + ((uint32_t)h >> 1);
-                        for (; snap_next <= u_new; snap_next++)
-                            store_snapshot<C>(snap + ((size_t)(unit0 + snap_next) * 256 + pix_in_tile) * SV, T, Cc);
-                    }
+            if (cur == 0u && (nw != 0u || started)) {
+                if (started) mk[wave][h][lane] = __builtin_bitreverse32(bl);   // the word just finished: what was blended
+                started = nw != 0u;
+                h = nh; cur = nw; bl = 0u; nw = 0u;
+                if (nz != 0u) { nh = __builtin_ctz(nz); nz &= nz - 1u; nw = mk[wave][nh][lane]; }
+                // first word of a new segment: the running (T, C) is the pixel's state at the segment's boundary (and at
+                // every boundary it skipped) -- what the backward blend's units resume from (gsr_blend_bwd.hip)
+                const uint32_t seg_new = (c0 + (uint32_t)h * 32u) / (uint32_t)SNAP_SEG;
+                if (keep && started && seg_new != seg_cur) {
+                    seg_cur = seg_new;
+                    store_snapshot<C>(snap + ((size_t)(unit0 + seg_new * (SNAP_SEG / 64)) * 256 + pix_in_tile) * SV, T, Cc);
                 }
             }
-            if (__ballot(active) == 0ull) break;
-            if (active) {
-                const int j = __builtin_ctz(cur);
-                cur &= cur - 1u;
-                const int slot = h * 32 + j;
-                const float4 A = rec[slot].a, B = rec[slot].b;
-                const float dx = A.x - pxf, dy = A.y - pyf;
-                const float power = pair_exp2_arg(A.z, A.w, B.x, dx, dy);   // exp2 domain, see conic_to_exp2
-                const float alpha = fminf(ALPHA_MAX, B.y * __builtin_amdgcn_exp2f(power));
-                const bool ok = power <= 0.0f && alpha >= ALPHA_MIN;
-                const float test_T = T * (1.0f - alpha);
-                const bool stop = ok && test_T < T_EPS;
-                const bool upd = ok != stop;   // stop implies ok
-                const float w = upd ? alpha * T : 0.0f;
-                float col[C];
-                load_cols<C>(rec[slot], col);
+            if (__ballot(cur != 0u) == 0ull) break;
+            // branch-free from here: a lane without a candidate evaluates the neutral instance
+            const int j = __builtin_ctz(cur | 0x80000000u);
+            const uint32_t slot = cur != 0u ? (uint32_t)(h * 32 + j) : (uint32_t)CH;
+            cur &= cur - 1u;
+            const float4 A = rec[slot].a, B = rec[slot].b;
+            float col[C];
+            load_cols<C>(rec[slot], col);
+            const float dx = A.x - pxf, dy = A.y - pyf;
+            const float power = pair_exp2_arg(A.z, A.w, B.x, dx, dy);   // exp2 domain, see conic_to_exp2
+            const float alpha = fminf(ALPHA_MAX, B.y * __builtin_amdgcn_exp2f(power));
+            const bool ok = power <= 0.0f && alpha >= ALPHA_MIN;
+            const float test_T = T * (1.0f - alpha);
+            const bool stop = ok && test_T < T_EPS;
+            const bool upd = ok != stop;   // stop implies ok
+            const float w = upd ? alpha * T : 0.0f;
 #pragma unroll
-                for (int ch = 0; ch < C; ch++) Cc[ch] += col[ch] * w;
-                T = upd ? test_T : T;
-                last = upd ? c0 + (uint32_t)slot + 1u : last;
-                bl |= (upd ? 1u : 0u) << j;
-                if (stop) { done = true; active = false; }
-            }
+            for (int ch = 0; ch < C; ch++) Cc[ch] += col[ch] * w;
+            T = upd ? test_T : T;
+            last = upd ? c0 + slot + 1u : last;
+            bl |= (upd ? 1u : 0u) << j;
+            // a pixel that terminates drops the rest of its candidates; the words it never reached hold no blended instance
+            done = done || stop;
+            nz_zero = stop ? (nz | (nw != 0u ? 1u << nh : 0u)) : nz_zero;
+            nz = stop ? 0u : nz;
+            nw = stop ? 0u : nw;
+            cur = stop ? 0u : cur;
         }
-        if (keep_masks) {
-            // a pixel that terminated inside the chunk: its current word keeps what was blended, the words it never
-            // reached hold no blended instance
-            if (h >= 0) mk[wave][h][lane] = __builtin_bitreverse32(bl);
-            while (__ballot(nz != 0u) != 0ull) {
-                if (nz != 0u) { mk[wave][__builtin_ctz(nz)][lane] = 0u; nz &= nz - 1u; }
+        if (keep) {
+            while (__ballot(nz_zero != 0u) != 0ull) {
+                if (nz_zero != 0u) { mk[wave][__builtin_ctz(nz_zero)][lane] = 0u; nz_zero &= nz_zero - 1u; }
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -180,7 +234,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         for (int ch = 0; ch < C; ch++) out_color[ch * HW + pix] = Cc[ch] + T * bg[ch];
         // a tile with more than one segment: the first unit's snapshot slot (never used as a boundary) keeps the
         // final (T, C), from which the backward derives "colour behind a boundary" = C_final - C_snap
-        if (keep_masks && n > (uint32_t)SEG) store_snapshot<C>(snap + ((size_t)unit0 * 256 + pix_in_tile) * SV, T, Cc);
+        if (keep && n > (uint32_t)SNAP_SEG) store_snapshot<C>(snap + ((size_t)unit0 * 256 + pix_in_tile) * SV, T, Cc);
     }
     if (trace && lane == 0) {   // last wave to finish wins the end stamp
         if (wave == 0) trace[2 * blockIdx.x] = t_start;

@@ -92,16 +92,23 @@ inline ImageState carve_image(void* base, int W, int H)
 // instances actually blended after it.
 constexpr int SEG = 64;
 
-// List positions staged in LDS at a time by the blend kernels (gsr_blend_fwd.hip / gsr_blend_bwd.hip).  A wave's trip
-// count per chunk is the largest per-pixel count within the chunk, so longer chunks mean fewer trips (config C: 45 trips
-// per 8x8 block at 256, 36 at 512) at the price of LDS = resident workgroups.
+// List positions staged in LDS at a time by the forward blend (gsr_blend_fwd.hip).  A wave's trip count per chunk is
+// the largest per-pixel candidate count within the chunk, so longer chunks mean fewer trips (config C: 45 trips per 8x8
+// block at 256, 36 at 512; measured 0.088 -> 0.071 ms) at the price of LDS = resident workgroups.
 #ifndef GSR_FWD_CHUNK
-#define GSR_FWD_CHUNK 256
+#define GSR_FWD_CHUNK 512
 #endif
-#ifndef GSR_BWD_CHUNK
-#define GSR_BWD_CHUNK 256
+constexpr int FWD_CHUNK = GSR_FWD_CHUNK;
+// The backward blend treats each (tile, SNAP_SEG list positions, 8x8 block) as an independent unit (bounded size: the
+// dispatcher can balance them and nothing carries a long serial chain).  A pixel that blended instances beyond its unit
+// resumes from a snapshot of its running (T, C): the forward blend stores one whenever a pixel moves on to a word of a
+// new segment -- its state before the first candidate of that segment, which is also its state at every segment
+// boundary it skipped since its last word.
+#ifndef GSR_SNAP_SEG
+#define GSR_SNAP_SEG 64
 #endif
-constexpr int FWD_CHUNK = GSR_FWD_CHUNK, BWD_CHUNK = GSR_BWD_CHUNK;
+constexpr int SNAP_SEG = GSR_SNAP_SEG;
+static_assert(SNAP_SEG % 64 == 0 && FWD_CHUNK % SNAP_SEG == 0, "segments are whole mask units and divide a chunk");
 
 // Channel count of a render: 3 = the reference's NUM_CHANNELS (cuda_rasterizer/config.h:15); 6 = two targets
 // sharing geometry, blended in one walk; 4 = RGB + one scalar target.  A snapshot is (T, C[0..C-1]) padded to whole float4s.
@@ -585,19 +592,11 @@ __device__ __forceinline__ void for_each_tile_aggregated(ushort4 rect, float px,
 // backward must round identically), then the colour channels padded to whole float4s.  48 B (C = 3, 4) / 64 B (C = 6).
 template <int C> struct __attribute__((aligned(16))) BlendRec { float4 a, b; float col[(C + 3) / 4 * 4]; };
 template <int C>
-__device__ __forceinline__ void store_rec(BlendRec<C>& r, float4 a, float4 b, uint32_t gid, const float* __restrict__ feats)
+__device__ __forceinline__ void store_rec(BlendRec<C>& r, float4 a, float4 b, uint32_t gid, const float (&colour)[C])
 {
     float col[(C + 3) / 4 * 4];
 #pragma unroll
-    for (int ch = C; ch < (C + 3) / 4 * 4; ch++) col[ch] = 0.f;
-    if constexpr (C % 2 == 0) {   // rows of an even channel count are 8-byte aligned
-        const float2* pf = reinterpret_cast<const float2*>(feats + (size_t)C * gid);
-#pragma unroll
-        for (int ch = 0; ch < C; ch += 2) { const float2 v = pf[ch / 2]; col[ch] = v.x; col[ch + 1] = v.y; }
-    } else {
-#pragma unroll
-        for (int ch = 0; ch < C; ch++) col[ch] = feats[(size_t)C * gid + ch];
-    }
+    for (int ch = 0; ch < (C + 3) / 4 * 4; ch++) col[ch] = ch < C ? colour[ch < C ? ch : 0] : 0.f;
     float a2 = a.z, b2 = a.w, c2 = b.x;
     conic_to_exp2(a2, b2, c2);
     r.a = make_float4(a.x, a.y, a2, b2);
