@@ -57,11 +57,12 @@ def algorithmic_bytes(P, R, W, H, M=0):
         "tile_scan_kernel": T * 16,
         # key-emit reads 20 per Gaussian, key+value write 12 per instance
         "scatter_kernel": P * 20 + R * 12,
-        # per-tile depth sort + per-pixel candidate masks: one logical sort pass (read + write) 24 + range detect 8 per
-        # instance (the mask words themselves are this library's own intermediate: no algorithmic bytes)
-        "tile_sort_mask_kernel": R * 32,
-        # list fetch 28 + colour 12 per instance; 20 B written per pixel; ranges read
-        "blend_fwd_kernel": R * 40 + N * 20 + T * 8,
+        # lists of up to 2 048 entries (every tile of this workload) are sorted INSIDE blend_fwd; this stage only times the
+        # kernels for longer lists and carries no bytes of its own here
+        "tile_sort_kernel": 0,
+        # one logical sort pass (read + write) 24 + range detect 8 per instance, then list fetch 28 + colour 12 per
+        # instance; 20 B written per pixel; ranges read
+        "blend_fwd_kernel": R * 72 + N * 20 + T * 8,
         "zero_fill": P * (108 + 12 * M),
         # fetch 40 + one reduced 9-float flush 36 per instance; 20 B read per pixel; ranges read
         "blend_bwd_kernel": R * 76 + N * 20 + T * 8,

@@ -28,7 +28,7 @@ thread_local uint32_t* g_pinned = nullptr;   // pinned, device-mapped landing pa
 enum Stage { ST_PREPROCESS = 0, ST_TILE_SCAN, ST_SCATTER, ST_TILE_SORT, ST_BLEND_FWD, ST_ZERO_FILL, ST_BLEND_BWD,
              ST_GEOM_BWD, ST_LOSS, ST_PRODUCERS, ST_OPTIM, ST_COUNT };
 const char* const kStageNames[ST_COUNT] = {"preprocess_kernel", "tile_scan_kernel", "scatter_kernel",
-                                           "tile_sort_mask_kernel", "blend_fwd_kernel", "zero_fill", "blend_bwd_kernel",
+                                           "tile_sort_kernel", "blend_fwd_kernel", "zero_fill", "blend_bwd_kernel",
                                            "geom_bwd_kernel", "loss_kernels", "producer_kernels", "optimizer_kernels"};
 struct Rec { int stage; hipEvent_t a, b; };
 // Process-wide (PyTorch runs backward on its own autograd thread), guarded by a mutex.
@@ -327,6 +327,7 @@ int forward_stage2_impl(int P, int R, int max_tile_instances, int num_segments, 
     if (num_segments < 0) num_segments = -num_segments;
     if (R > 0 && num_segments == 0) return fail_msg("gsr_forward_stage2: num_segments of stage 1 is required (it sizes the binning buffer)");
     BinState b = carve_bin(binning_buffer, R > 0 ? R : 0, num_segments, C);
+    bool sort_in_blend = false;
     if (R > 0) {
         {
             Scope sc(ST_SCATTER, st);
@@ -335,19 +336,17 @@ int forward_stage2_impl(int P, int R, int max_tile_instances, int num_segments, 
         GSR_CHECK_LAUNCH("scatter_kernel");
         {
             Scope sc(ST_TILE_SORT, st);
-            const char* e_fuse = getenv("GSR_SORT_WITH_MASKS");   // read per call (tools/ab_env.py); "0": separate sort kernel
+            const char* e_fuse = getenv("GSR_SORT_IN_BLEND");   // read per call (tools/ab_env.py); "0": separate sort kernel
             const bool fuse = !(e_fuse && e_fuse[0] == '0');
-            const uint32_t maxc = (uint32_t)(max_tile_instances > 0 ? max_tile_instances : 0);
-            const bool sort_with_masks = launch_tile_sort(W, H, R, maxc, im, b, fuse, st);
-            launch_tile_masks(W, H, num_segments, maxc, sort_with_masks, g, im, b, st);
+            sort_in_blend = launch_tile_sort(W, H, R, (uint32_t)(max_tile_instances > 0 ? max_tile_instances : 0), im, b, fuse, st);
         }
-        GSR_CHECK_LAUNCH("tile_sort_mask_kernel");
+        GSR_CHECK_LAUNCH("tile_sort_kernel");
     }
     const float* feats = colors_precomp ? colors_precomp : g.rgb;
     {
         Scope sc(ST_BLEND_FWD, st);
         launch_blend_fwd(C, W, H, background, feats, g, im, b, out_color, !forward_only, grad_scratch,
-                         grad_scratch ? gsr_grad_scratch_bytes(P > 0 ? P : 0) : 0, counters, st);
+                         grad_scratch ? gsr_grad_scratch_bytes(P > 0 ? P : 0) : 0, counters, sort_in_blend, st);
     }
     GSR_CHECK_LAUNCH("blend_fwd_kernel");
     return 0;

@@ -359,7 +359,7 @@ tile_sort_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ 
     }
 }
 
-// (the register-resident bitonic sort lives in gsr_sort.h: tile_sort_mask_kernel runs it in front of its masks)
+// (the register-resident bitonic sort lives in gsr_sort.h: blend_fwd runs it in front of its walk)
 
 __global__ void __launch_bounds__(256)
 tile_sort_reg_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ order, const uint64_t* __restrict__ keys,
@@ -392,7 +392,7 @@ tile_sort_big_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
     else sort_tile_in_registers<16>(s, gk, out, n, 16384u);
 }
 
-bool launch_tile_sort(int W, int H, int R, uint32_t max_count, ImageState im, BinState b, bool mask_sorts_small, hipStream_t st)
+bool launch_tile_sort(int W, int H, int R, uint32_t max_count, ImageState im, BinState b, bool blend_sorts_small, hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);
     bool left_small = false;
@@ -404,8 +404,8 @@ bool launch_tile_sort(int W, int H, int R, uint32_t max_count, ImageState im, Bi
     }
     static const bool lds_sort = getenv("GSR_SORT_LDS") != nullptr;   // A/B switch: the LDS network for every tile
     if (lds_sort) tile_sort_kernel<2048, 0, false><<<t.T, 256, 2048 * 8, st>>>(im.ranges, im.order, b.keys, b.point_list);
-    // tile_sort_mask_kernel sorts each of these lists right before it builds the tile's masks (gsr_mask.hip)
-    else if (mask_sorts_small) left_small = true;
+    // the forward blend sorts each of these lists right before walking it
+    else if (blend_sorts_small) left_small = true;
     else tile_sort_reg_kernel<<<t.T, 256, 0, st>>>(im.ranges, im.order, b.keys, b.point_list);
     if (max_count > 2048 && !lds_sort) {
         // the longest lists sit at the front of `order` (32-entry length classes, snake within bands of 256): every tile

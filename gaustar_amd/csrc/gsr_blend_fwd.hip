@@ -31,6 +31,8 @@
 // walk, 4 = RGB + one scalar target -- alpha, T, termination and n_contrib do not depend on colour, so channels 0-2 /
 // 3-5 are bit-identical to two separate 3-channel renders.
 #include "gsr_internal.h"
+#include "gsr_mask.h"
+#include "gsr_sort.h"
 #include <cstdlib>
 
 namespace gsr {
@@ -38,7 +40,8 @@ namespace gsr {
 template <int C, int CH>
 __global__ void __launch_bounds__(256)
 blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ order,
-                 const uint32_t* __restrict__ point_list, const float4* __restrict__ g0, const float4* __restrict__ g1,
+                 uint32_t* point_list, const uint64_t* __restrict__ sort_keys, const float4* __restrict__ g0,
+                 const float4* __restrict__ g1,
                  const float* __restrict__ feats, const float* __restrict__ bg, float* __restrict__ out_color,
                  float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ seg_off,
                  uint2* __restrict__ masks, float4* __restrict__ snap, float4* __restrict__ zero_ptr, uint32_t zero_n,
@@ -57,8 +60,14 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     constexpr int NH = CH / 32;                                       // 32-bit mask words per lane and chunk
     constexpr int PT = CH / 256;                                      // list positions per thread and chunk
     static_assert(CH % 256 == 0 && NH <= 32, "a chunk is a whole number of 256-thread fetch rounds; nz is one dword");
-    __shared__ R rec[CH + 1];                                         // slot CH: the neutral instance
-    __shared__ uint32_t mk[4][NH][64];                                // [wave][word][lane]
+    // LDS: rec[CH] | mk[block][word][lane]; the sort in front of the walk (below) uses the same bytes for its cross-wave
+    // stages.  C = 3 at CH = 512: exactly 40 KB, four workgroups per CU.
+    constexpr size_t REC_BYTES = sizeof(R) * CH, MK_BYTES = sizeof(uint32_t) * 4 * NH * 64;
+    constexpr size_t LDS_BYTES = REC_BYTES + MK_BYTES > 2048 * 8 ? REC_BYTES + MK_BYTES : 2048 * 8;
+    static_assert(REC_BYTES % 16 == 0, "mask words follow the records");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    R* const rec = reinterpret_cast<R*>(smem);
+    uint32_t (*mk)[NH][64] = reinterpret_cast<uint32_t(*)[NH][64]>(smem + REC_BYTES);
     const int tile = (int)order[blockIdx.x];
     // Second side job (fused forward): this tile's eight shard counters and eight scatter cursors live in a library-owned
     // block that has to be all zero again for the next view's preprocess; scatter, their last reader, is done.
@@ -76,21 +85,23 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     const uint2 rg = ranges[tile];
     const uint32_t n = rg.y - rg.x;
     const uint32_t unit0 = seg_off[tile], n_units = (n + 63u) >> 6;
+    // Depth sort of this tile's list, right here (lists up to 2 048 entries; longer ones were sorted by tile_sort_big_kernel
+    // before this launch).  As a kernel of its own the sort is latency-bound (key loads, cross-lane exchanges, barriers:
+    // 25 us at a fraction of the vector ALU) and the blend then starts from a cold chip; inside the blend kernel one
+    // tile's sort overlaps the other resident tiles' blending, and the sorted ids are read back while still in L2.
+    if (sort_keys != nullptr) {
+        if (n >= 1u && n <= 2048u) sort_small_tile(reinterpret_cast<uint64_t*>(smem), sort_keys + rg.x, point_list + rg.x, n);
+        __syncthreads();   // ids visible to the four waves; the sort's LDS is free
+    }
     const uint32_t* list = point_list + rg.x;
     uint2* const my_masks = masks + ((size_t)unit0 * 4 + wave) * 64 + lane;   // + 256 per unit
+    const TransposeConsts tc(lane);
 
     // The kernel's span is its longest tile (a pixel's walk is serial), and co-resident waves share a SIMD's issue slots:
     // long lists get issue priority so that they do not also run at 1/7 speed (0.088 -> 0.084 ms on config C).
     if (n > 1024u) __builtin_amdgcn_s_setprio(3);
     else if (n > 704u) __builtin_amdgcn_s_setprio(2);
     else if (n > 448u) __builtin_amdgcn_s_setprio(1);
-    if (threadIdx.x == 0) {   // neutral instance: opacity 0 never passes the alpha test; lanes without a candidate read it
-        rec[CH].a = make_float4(0.f, 0.f, 0.f, 0.f);
-        rec[CH].b = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int ch = 0; ch < (C + 3) / 4 * 4; ch++) rec[CH].col[ch] = 0.f;
-    }
-
     float T = 1.0f;
     float Cc[C];
 #pragma unroll
@@ -104,7 +115,6 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     uint32_t gid_nxt[PT];
     float4 a_nxt[PT], b_nxt[PT];
     float col_nxt[PT][C];
-    uint2 m_nxt[NH / 2];
     const auto fetch_ids = [&](uint32_t c0) {
 #pragma unroll
         for (int q = 0; q < PT; q++) {
@@ -116,6 +126,10 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
 #pragma unroll
         for (int q = 0; q < PT; q++) {
             const uint32_t gid = gid_nxt[q];
+            a_nxt[q] = make_float4(0.f, 0.f, 1.f, 0.f);
+            b_nxt[q] = make_float4(1.f, 0.f, -1.f, 0.f);   // tau = -1: no instance
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) col_nxt[q][ch] = 0.f;
             if (gid != 0xffffffffu) {
                 a_nxt[q] = g0[gid];
                 b_nxt[q] = g1[gid];
@@ -130,15 +144,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             }
         }
     };
-    const auto fetch_masks = [&](uint32_t c0) {
-#pragma unroll
-        for (int w = 0; w < NH / 2; w++) {
-            m_nxt[w] = make_uint2(0u, 0u);
-            if ((c0 >> 6) + w < n_units) m_nxt[w] = my_masks[(size_t)((c0 >> 6) + w) * 256];
-        }
-    };
     fetch_ids(0);
-    fetch_masks(0);
     fetch_records();
     uint32_t gid_cur[PT];
 #pragma unroll
@@ -148,24 +154,34 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     for (uint32_t c0 = 0; c0 < n; c0 += CH) {
         // every pixel of the tile saturated: stop (also the barrier that frees the LDS of the previous chunk)
         if (__syncthreads_or(!done) == 0) break;
-        // ---- park the chunk's records; request the next chunk's
+        // ---- park the chunk's records and reduce them to per-pixel candidate words (gsr_mask.h): this wave holds, per
+        // fetch round q, the 64 instances of unit 4 q + wave of the chunk, one per lane
 #pragma unroll
-        for (int q = 0; q < PT; q++)
-            if (gid_cur[q] != 0xffffffffu) store_rec<C>(rec[q * 256 + threadIdx.x], a_nxt[q], b_nxt[q], gid_cur[q], col_nxt[q]);
-        const uint32_t u_lo = c0 >> 6;
-        uint32_t nz = 0;
-#pragma unroll
-        for (int w = 0; w < NH / 2; w++) {
-            const uint2 m = done ? make_uint2(0u, 0u) : m_nxt[w];
-            mk[wave][2 * w][lane] = m.x;
-            mk[wave][2 * w + 1][lane] = m.y;
-            nz |= (m.x != 0u ? 1u : 0u) << (2 * w) | (m.y != 0u ? 1u : 0u) << (2 * w + 1);
+        for (int q = 0; q < PT; q++) {
+            // (positions past the end of the list park zeros: a lane without a candidate reads some slot of its current
+            // word and multiplies it by a zero weight -- the slot has to hold finite numbers)
+            store_rec<C>(rec[q * 256 + threadIdx.x], a_nxt[q], b_nxt[q], gid_cur[q], col_nxt[q]);
+            if (c0 + q * 256 + wave * 64 < n) {   // (wave-uniform) the unit exists
+                const int hw = 2 * (4 * q + wave);
+                unit_masks(a_nxt[q], b_nxt[q], tx * TILE, ty * TILE, tc,
+                           [&](int blk, uint32_t lo, uint32_t hi) { mk[blk][hw][lane] = lo; mk[blk][hw + 1][lane] = hi; });
+            }
         }
+        const uint32_t u_lo = c0 >> 6;
 #pragma unroll
         for (int q = 0; q < PT; q++) gid_cur[q] = gid_nxt[q];
         fetch_records();
-        fetch_masks(c0 + CH);
         fetch_ids(c0 + 2 * CH);
+        __syncthreads();
+        // which of this pixel's words are non-empty (a pixel that is done consumes none: its words become zeros)
+        uint32_t nz = 0;
+#pragma unroll
+        for (int hh = 0; hh < NH; hh++) {
+            if (c0 + 32u * hh < n) {
+                if (done) mk[wave][hh][lane] = 0u;
+                else nz |= (mk[wave][hh][lane] != 0u ? 1u : 0u) << hh;
+            }
+        }
         __syncthreads();
         // ---- the walk: every lane through its own candidates.  (h, cur) = the word being consumed and its remaining
         // bits, bl = the bits of it that were blended, (nh, nw) = the next non-empty word, already read.
@@ -188,9 +204,10 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                 }
             }
             if (__ballot(cur != 0u) == 0ull) break;
-            // branch-free from here: a lane without a candidate evaluates the neutral instance
+            // branch-free from here: a lane without a candidate evaluates some record of its current word and drops it
+            const bool act = cur != 0u;
             const int j = __builtin_ctz(cur | 0x80000000u);
-            const uint32_t slot = cur != 0u ? (uint32_t)(h * 32 + j) : (uint32_t)CH;
+            const uint32_t slot = (uint32_t)(h * 32 + j);
             cur &= cur - 1u;
             const float4 A = rec[slot].a, B = rec[slot].b;
             float col[C];
@@ -198,7 +215,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             const float dx = A.x - pxf, dy = A.y - pyf;
             const float power = pair_exp2_arg(A.z, A.w, B.x, dx, dy);   // exp2 domain, see conic_to_exp2
             const float alpha = fminf(ALPHA_MAX, B.y * __builtin_amdgcn_exp2f(power));
-            const bool ok = power <= 0.0f && alpha >= ALPHA_MIN;
+            const bool ok = act && power <= 0.0f && alpha >= ALPHA_MIN;
             const float test_T = T * (1.0f - alpha);
             const bool stop = ok && test_T < T_EPS;
             const bool upd = ok != stop;   // stop implies ok
@@ -245,10 +262,11 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
 template <int C>
 static void launch_fwd_c(int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
                          float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, uint32_t* counters,
-                         hipStream_t st)
+                         bool sort_small, hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);
-    blend_fwd_kernel<C, FWD_CHUNK><<<t.T, 256, 0, st>>>(W, H, t.gx, im.ranges, im.order, b.point_list, g.g0, g.g1, feats, bg,
+    blend_fwd_kernel<C, FWD_CHUNK><<<t.T, 256, 0, st>>>(W, H, t.gx, im.ranges, im.order, b.point_list,
+                                                        sort_small ? b.keys : nullptr, g.g0, g.g1, feats, bg,
                                                         out_color, im.final_T, im.n_contrib, im.seg_off, b.masks,
                                                         keep_masks ? b.snap : nullptr, static_cast<float4*>(zero_ptr),
                                                         (uint32_t)(zero_bytes / 16), counters,
@@ -257,11 +275,11 @@ static void launch_fwd_c(int W, int H, const float* bg, const float* feats, Geom
 
 void launch_blend_fwd(int C, int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
                       float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, uint32_t* counters,
-                      hipStream_t st)
+                      bool sort_small, hipStream_t st)
 {
-    if (C == 6) launch_fwd_c<6>(W, H, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, st);
-    else if (C == 4) launch_fwd_c<4>(W, H, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, st);
-    else launch_fwd_c<3>(W, H, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, st);
+    if (C == 6) launch_fwd_c<6>(W, H, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, sort_small, st);
+    else if (C == 4) launch_fwd_c<4>(W, H, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, sort_small, st);
+    else launch_fwd_c<3>(W, H, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, sort_small, st);
 }
 
 }  // namespace gsr

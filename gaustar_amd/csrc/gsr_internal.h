@@ -187,10 +187,8 @@ void launch_preprocess(int P, int D, int M, const float* means3D, const float* s
                        hipStream_t st);
 void launch_tile_scan(ImageState im, int T, uint32_t* host_totals, uint32_t host_seq, hipStream_t st);
 void launch_scatter(int P, int W, int H, GeomState g, ImageState im, BinState b, hipStream_t st);
-// -> true if lists of up to 2 048 entries were left for tile_sort_mask_kernel to sort (gsr_mask.hip, gsr_sort.h)
-bool launch_tile_sort(int W, int H, int R, uint32_t max_count, ImageState im, BinState b, bool mask_sorts_small, hipStream_t st);
-// per-tile depth sort (lists up to 2 048 entries, if sort_here) + per-pixel candidate masks of every unit (gsr_mask.hip)
-void launch_tile_masks(int W, int H, int U, uint32_t max_count, bool sort_here, GeomState g, ImageState im, BinState b, hipStream_t st);
+// -> true if lists of up to 2 048 entries were left for the forward blend to sort (gsr_sort.h)
+bool launch_tile_sort(int W, int H, int R, uint32_t max_count, ImageState im, BinState b, bool blend_sorts_small, hipStream_t st);
 // Launch positions [0, front_of_order(R, T)) of `order` hold every tile with 2 017 or more entries: they all fall into
 // length class 0, which sits at the front, there are at most R / 2017 of them, and the snake only permutes within
 // bands of 256.  Kernels that only concern such tiles are launched over this prefix instead of all T tiles.
@@ -200,7 +198,8 @@ inline int front_of_order(int R, int T)
     return (int)(bound < (long long)T ? bound : (long long)T);
 }
 void launch_blend_fwd(int C, int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
-                      float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, uint32_t* counters, hipStream_t st);
+                      float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, uint32_t* counters, bool sort_small,
+                      hipStream_t st);
 void launch_blend_bwd(int C, int W, int H, int U, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
                       const float* dL_dpix, float* grad_acc, hipStream_t st);
 void launch_geom_bwd(int P, int D, int M, const float* means3D, const float* shs, const float* scales,

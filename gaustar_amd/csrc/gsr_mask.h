@@ -1,4 +1,4 @@
-// gsr_mask.hip -- per-pixel CANDIDATE MASKS of a tile's depth-sorted list, and the per-tile depth sort in front of them.
+// gsr_mask.h -- per-pixel CANDIDATE MASKS of a tile's depth-sorted list (device code shared with gsr_blend_fwd.hip).
 //
 // Why.  The reference's renderCUDA (DGR/cuda_rasterizer/forward.cu:261-374, backward.cu:399-557) feeds every pixel of a
 // 16x16 tile every instance of the tile's list.  GauSTAR's surface splats are ~3.6 px in radius: of the (instance, pixel)
@@ -21,9 +21,12 @@
 // (v_permlane32_swap, byte permutes, nibble/pair/bit swaps with lane ^ s) turns "instance-major" into "pixel-major":
 // 27 vector instructions per block instead of 64 ballots.  ~500 instructions per unit, all 64 lanes busy.
 //
-// Layout: masks[(unit * 4 + block) * 64 + lane] = uint2 {positions 0-31, positions 32-63} of the unit, block = 2*by + bx,
-// lane = 8*(y - block_y0) + (x - block_x0).  The forward blend overwrites each word it consumes with the bits it
-// actually blended (per half bit-reversed, see gsr_blend_fwd.hip); the backward walks only those.
+// The forward blend calls unit_masks() on the records of a chunk while it parks them in LDS (lane = instance, one unit
+// per wave and fetch round) and consumes the words from LDS; what it writes to global memory,
+// masks[(unit * 4 + block) * 64 + lane] = uint2 {positions 0-31, positions 32-63} with block = 2*by + bx and
+// lane = 8*(y - block_y0) + (x - block_x0), are the bits it actually BLENDED (per half bit-reversed): the backward
+// blend finds its snapshots through them.
+#pragma once
 #include "gsr_internal.h"
 #include "gsr_sort.h"
 
@@ -70,14 +73,12 @@ __device__ __forceinline__ void transpose64(uint32_t& lo, uint32_t& hi, const Tr
     lo = x[0]; hi = x[1];
 }
 
-// Candidate masks of one unit (64 consecutive list positions of one tile); called by one whole wave.
-__device__ __forceinline__ void unit_masks(int lane, uint32_t k, uint32_t n, const uint32_t* __restrict__ list,
-                                           const float4* __restrict__ g0, const float4* __restrict__ g1, int tile_x0,
-                                           int tile_y0, const TransposeConsts& tc, uint2* __restrict__ out)
+// Candidate masks of one unit (64 consecutive list positions of one tile); called by one whole wave, lane = instance
+// with its geometry records a = {x, y, conic a, conic b}, b = {conic c, opacity, tau, -} (tau < 0: no instance here).
+// out(block, lo, hi): lane = pixel of the block, (hi:lo) = its 64-bit word over the unit's positions.
+template <class Out>
+__device__ __forceinline__ void unit_masks(float4 a, float4 b, int tile_x0, int tile_y0, const TransposeConsts& tc, Out out)
 {
-    // ---- lane = instance k of the list
-    float4 a = make_float4(0.f, 0.f, 1.f, 0.f), b = make_float4(1.f, 0.f, -1.f, 0.f);
-    if (k < n) { const uint32_t gid = list[k]; a = g0[gid]; b = g1[gid]; }
     const float ca = a.z, cb = a.w, cc = b.x, tau = b.z;
     // f <= tau along the pixel row Y (relative to the splat):  X in [(-bY - sqrt D) / a, (-bY + sqrt D) / a],
     // D = 2 a tau - (a c - b^2) Y^2.  Every rounding is pushed outwards: D is inflated by 2^-12 of its largest term (the
@@ -116,66 +117,8 @@ __device__ __forceinline__ void unit_masks(int lane, uint32_t k, uint32_t n, con
         const int p0 = (blk >> 1) * 4;
         uint32_t lo = __builtin_amdgcn_perm(pk[p0 + 1], pk[p0], sel), hi = __builtin_amdgcn_perm(pk[p0 + 3], pk[p0 + 2], sel);
         transpose64(lo, hi, tc);
-        out[blk * 64 + lane] = make_uint2(lo, hi);
+        out(blk, lo, hi);
     }
-}
-
-// One workgroup per tile (launch order = `order`, longest lists first): depth-sort the tile's bucket (lists of up to
-// 2 048 entries; longer ones were sorted by tile_sort_big_kernel / tile_sort_kernel before this launch and get their masks
-// from tile_mask_kernel), then the four waves share the tile's units.  Fused because the sort alone is latency-bound
-// (key loads, cross-lane exchanges, barriers) while the mask arithmetic is pure vector ALU work: resident tiles overlap.
-__global__ void __launch_bounds__(256)
-tile_sort_mask_kernel(int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ order,
-                      const uint32_t* __restrict__ seg_off, const uint64_t* __restrict__ keys,
-                      uint32_t* __restrict__ point_list, const float4* __restrict__ g0, const float4* __restrict__ g1,
-                      uint2* __restrict__ masks, int sort_here)
-{
-    __shared__ uint64_t s[2048];
-    const int tile = (int)order[blockIdx.x];
-    const uint2 rg = ranges[tile];
-    const uint32_t n = rg.y - rg.x;
-    if (n == 0 || n > 2048u) return;
-    uint32_t* list = point_list + rg.x;
-    if (sort_here) {
-        sort_small_tile(s, keys + rg.x, list, n);
-        __syncthreads();   // the sorted ids are visible to the four waves
-    }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const TransposeConsts tc(lane);
-    const uint32_t unit0 = seg_off[tile], n_units = (n + 63u) >> 6;
-    const int tx = tile % gx, ty = tile / gx;
-    for (uint32_t u = (uint32_t)wave; u < n_units; u += 4u)
-        unit_masks(lane, u * 64u + (uint32_t)lane, n, list, g0, g1, tx * TILE, ty * TILE, tc,
-                   masks + (size_t)(unit0 + u) * 256);
-}
-
-// Unit-parallel variant for the tiles above 2 048 entries (close-up views): one wave per unit, so that a 12 000-entry
-// tile is 188 independent waves instead of one workgroup's serial loop.
-__global__ void __launch_bounds__(64)
-tile_mask_kernel(int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ seg_off,
-                 const uint32_t* __restrict__ unit_tile, const uint32_t* __restrict__ point_list,
-                 const float4* __restrict__ g0, const float4* __restrict__ g1, uint2* __restrict__ masks)
-{
-    const uint32_t unit = blockIdx.x;
-    const int tile = (int)unit_tile[unit];
-    const uint2 rg = ranges[tile];
-    const uint32_t n = rg.y - rg.x;
-    if (n <= 2048u) return;
-    const int lane = threadIdx.x;
-    const TransposeConsts tc(lane);
-    const int tx = tile % gx, ty = tile / gx;
-    unit_masks(lane, (unit - seg_off[tile]) * 64u + (uint32_t)lane, n, point_list + rg.x, g0, g1, tx * TILE, ty * TILE, tc,
-               masks + (size_t)unit * 256);
-}
-
-void launch_tile_masks(int W, int H, int U, uint32_t max_count, bool sort_here, GeomState g, ImageState im, BinState b, hipStream_t st)
-{
-    const Tiles t = tiles_of(W, H);
-    if (U <= 0) return;
-    tile_sort_mask_kernel<<<t.T, 256, 0, st>>>(t.gx, im.ranges, im.order, im.seg_off, b.keys, b.point_list, g.g0, g.g1,
-                                               b.masks, sort_here ? 1 : 0);
-    if (max_count > 2048u)
-        tile_mask_kernel<<<U, 64, 0, st>>>(t.gx, im.ranges, im.seg_off, b.unit_tile, b.point_list, g.g0, g.g1, b.masks);
 }
 
 }  // namespace gsr

@@ -1,8 +1,7 @@
-"""Dev tool (GPU): the per-pixel mask words of gsr_mask.hip / gsr_blend_fwd.hip against a numpy restatement.
-
-  candidates (forward-only render leaves them in place): must be a SUPERSET of the pairs that pass the reference's
-  tests  power <= 0 and alpha >= 1/255  (forward.cu:335-343), and tight (reports candidates per passing pair);
-  blended (training-mode forward): must equal the pairs the reference's control flow blends, per pixel.
+"""Dev tool (GPU): the per-pixel mask words the forward blend leaves behind (gsr_mask.h / gsr_blend_fwd.hip) against a
+numpy restatement of the reference's control flow (forward.cu:306-363): the blended-instance words of a training-mode
+forward must equal, per pixel, the pairs the reference blends.  (The candidate words themselves live only in LDS; they
+were checked the same way when they still went through global memory: superset, 1.006 candidates per passing pair.)
 
 usage: python tests/devtools/check_masks.py [smoke|A|C] [view]
 """
@@ -75,14 +74,11 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "smoke"
     view = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     gs, cam, bg = build(which, view)
-    fo = render(gs, cam, bg, need_backward=False)
     tr = render(gs, cam, bg, need_backward=True)
-    assert np.array_equal(fo["color"], tr["color"])
-    W, H = fo["W"], fo["H"]
+    W, H = tr["W"], tr["H"]
     gx = (W + 15) // 16
-    ranges, lst, m2, co = fo["ranges"], fo["list"], fo["m2"], fo["co"]
-    cand = unpack(fo["masks"], False)     # [U, 4, 64 lanes, 64 positions]
-    blen = unpack(tr["masks"], True)
+    ranges, lst, m2, co = tr["ranges"], tr["list"], tr["m2"], tr["co"]
+    blen = unpack(tr["masks"], True)      # [U, 4, 64 lanes, 64 positions]
     yy, xx = np.arange(256) // 16, np.arange(256) % 16
     blk = (yy // 8) * 2 + xx // 8
     lane = (yy % 8) * 8 + xx % 8
@@ -90,7 +86,7 @@ def main():
     if len(tiles) > 400:
         tiles = np.random.default_rng(1).choice(tiles, 400, replace=False)
     unit0 = np.concatenate([[0], np.cumsum((ranges[:, 1] - ranges[:, 0] + 63) // 64)])
-    n_ok = n_cand = n_missing = n_bl_ref = n_bl_diff = 0
+    n_ok = n_bl_ref = n_bl_diff = 0
     for t in tiles:
         a, b = ranges[t]
         ids = lst[a:b]; n = len(ids)
@@ -102,12 +98,7 @@ def main():
         alpha = np.minimum(0.99, co[ids, 3:4] * np.exp(power))
         ok = (power <= 0) & (alpha >= 1 / 255)
         nu = (n + 63) // 64
-        c = cand[unit0[t]:unit0[t] + nu][:, blk, lane, :]            # [nu, 256, 64]
-        c = c.transpose(0, 2, 1).reshape(nu * 64, 256)[:n]           # [n, 256]
-        n_ok += int((ok & inside[None]).sum()); n_cand += int((c & inside[None]).sum())
-        # pairs within an ulp of a threshold may legitimately differ between exp implementations: only count clear misses
-        clear = (power <= -1e-5) & (co[ids, 3:4] * np.exp(power) >= (1 / 255) * 1.0001)
-        n_missing += int((clear & ~c & inside[None]).sum())
+        n_ok += int((ok & inside[None]).sum())
         # reference control flow per pixel
         Tt = np.ones(256, np.float32); done = ~inside.copy(); blended = np.zeros((n, 256), bool)
         for k in range(n):
@@ -128,10 +119,8 @@ def main():
         valid = np.arange(n)[:, None] < nc_t[None]       # words behind n_contrib are undefined
         bm = bm & valid
         n_bl_ref += int(blended.sum()); n_bl_diff += int((bm != blended).sum())
-    print(f"{which}: tiles {len(tiles)}  passing pairs {n_ok}  candidates {n_cand} ({n_cand / max(n_ok, 1):.3f} per passing pair)  "
-          f"clearly-passing pairs missing from the masks: {n_missing}")
-    print(f"blended pairs (numpy) {n_bl_ref}; differing bits vs the forward's words: {n_bl_diff}")
-    assert n_missing == 0
+    print(f"{which}: tiles {len(tiles)}  pairs passing the alpha test {n_ok}  blended pairs (numpy) {n_bl_ref}; "
+          f"differing bits vs the forward's words: {n_bl_diff}")
     assert n_bl_diff <= max(4, n_bl_ref // 100000)
 
 
