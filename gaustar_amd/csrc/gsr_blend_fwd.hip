@@ -56,17 +56,18 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         const uint32_t i0 = blockIdx.x * per, i1 = min(zero_n, i0 + per);
         for (uint32_t i = i0 + threadIdx.x; i < i1; i += 256u) zero_ptr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    using R = BlendRec<C>;
     constexpr int NH = CH / 32;                                       // 32-bit mask words per lane and chunk
     constexpr int PT = CH / 256;                                      // list positions per thread and chunk
     static_assert(CH % 256 == 0 && NH <= 32, "a chunk is a whole number of 256-thread fetch rounds; nz is one dword");
-    // LDS: rec[CH] | mk[block][word][lane]; the sort in front of the walk (below) uses the same bytes for its cross-wave
-    // stages.  C = 3 at CH = 512: exactly 40 KB, four workgroups per CU.
-    constexpr size_t REC_BYTES = sizeof(R) * CH, MK_BYTES = sizeof(uint32_t) * 4 * NH * 64;
+    // LDS: ga[CH] | gb[CH] | gc[CH] (the staged instances, see store_rec) | mk[block][word][lane]; the sort in front of
+    // the walk (below) uses the same bytes for its cross-wave stages.  C = 3 at CH = 512: 34 KB, four workgroups per CU.
+    constexpr size_t GC_BYTES = (sizeof(RecTail<C>) * CH + 15) / 16 * 16;
+    constexpr size_t REC_BYTES = 32 * CH + GC_BYTES, MK_BYTES = sizeof(uint32_t) * 4 * NH * 64;
     constexpr size_t LDS_BYTES = REC_BYTES + MK_BYTES > 2048 * 8 ? REC_BYTES + MK_BYTES : 2048 * 8;
-    static_assert(REC_BYTES % 16 == 0, "mask words follow the records");
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
-    R* const rec = reinterpret_cast<R*>(smem);
+    float4* const ga = reinterpret_cast<float4*>(smem);
+    float4* const gb = ga + CH;
+    RecTail<C>* const gc = reinterpret_cast<RecTail<C>*>(smem + 32 * CH);
     uint32_t (*mk)[NH][64] = reinterpret_cast<uint32_t(*)[NH][64]>(smem + REC_BYTES);
     const int tile = (int)order[blockIdx.x];
     // Second side job (fused forward): this tile's eight shard counters and eight scatter cursors live in a library-owned
@@ -82,19 +83,20 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     const int pix_in_tile = 16 * (py - ty * TILE) + (px - tx * TILE);
     const bool keep = snap != nullptr;   // a backward pass may follow
 
+    // (wave-uniform values are pinned to scalar registers: the per-chunk bookkeeping below then runs on the scalar unit)
     const uint2 rg = ranges[tile];
-    const uint32_t n = rg.y - rg.x;
-    const uint32_t unit0 = seg_off[tile], n_units = (n + 63u) >> 6;
+    const uint32_t list0 = __builtin_amdgcn_readfirstlane(rg.x);
+    const uint32_t n = __builtin_amdgcn_readfirstlane(rg.y - rg.x);
+    const uint32_t unit0 = __builtin_amdgcn_readfirstlane(seg_off[tile]);
     // Depth sort of this tile's list, right here (lists up to 2 048 entries; longer ones were sorted by tile_sort_big_kernel
     // before this launch).  As a kernel of its own the sort is latency-bound (key loads, cross-lane exchanges, barriers:
     // 25 us at a fraction of the vector ALU) and the blend then starts from a cold chip; inside the blend kernel one
     // tile's sort overlaps the other resident tiles' blending, and the sorted ids are read back while still in L2.
     if (sort_keys != nullptr) {
-        if (n >= 1u && n <= 2048u) sort_small_tile(reinterpret_cast<uint64_t*>(smem), sort_keys + rg.x, point_list + rg.x, n);
+        if (n >= 1u && n <= 2048u) sort_small_tile(reinterpret_cast<uint64_t*>(smem), sort_keys + list0, point_list + list0, n);
         __syncthreads();   // ids visible to the four waves; the sort's LDS is free
     }
-    const uint32_t* list = point_list + rg.x;
-    uint2* const my_masks = masks + ((size_t)unit0 * 4 + wave) * 64 + lane;   // + 256 per unit
+    const uint32_t* list = point_list + list0;
     const TransposeConsts tc(lane);
 
     // The kernel's span is its longest tile (a pixel's walk is serial), and co-resident waves share a SIMD's issue slots:
@@ -146,72 +148,78 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     };
     fetch_ids(0);
     fetch_records();
-    uint32_t gid_cur[PT];
-#pragma unroll
-    for (int q = 0; q < PT; q++) gid_cur[q] = gid_nxt[q];
     fetch_ids(CH);
 
     for (uint32_t c0 = 0; c0 < n; c0 += CH) {
         // every pixel of the tile saturated: stop (also the barrier that frees the LDS of the previous chunk)
         if (__syncthreads_or(!done) == 0) break;
         // ---- park the chunk's records and reduce them to per-pixel candidate words (gsr_mask.h): this wave holds, per
-        // fetch round q, the 64 instances of unit 4 q + wave of the chunk, one per lane
+        // fetch round q, the 64 instances of unit 4 q + wave of the chunk, one per lane.  The words go to LDS for the
+        // walk and, when a backward pass may follow, to global memory: the backward's units find their snapshots by them.
+        const uint32_t u_lo = c0 >> 6;
 #pragma unroll
         for (int q = 0; q < PT; q++) {
             // (positions past the end of the list park zeros: a lane without a candidate reads some slot of its current
             // word and multiplies it by a zero weight -- the slot has to hold finite numbers)
-            store_rec<C>(rec[q * 256 + threadIdx.x], a_nxt[q], b_nxt[q], gid_cur[q], col_nxt[q]);
+            store_rec<C>(ga, gb, gc, q * 256 + threadIdx.x, a_nxt[q], b_nxt[q], col_nxt[q]);
             if (c0 + q * 256 + wave * 64 < n) {   // (wave-uniform) the unit exists
                 const int hw = 2 * (4 * q + wave);
-                unit_masks(a_nxt[q], b_nxt[q], tx * TILE, ty * TILE, tc,
-                           [&](int blk, uint32_t lo, uint32_t hi) { mk[blk][hw][lane] = lo; mk[blk][hw + 1][lane] = hi; });
+                uint2* const gm = masks + ((size_t)(unit0 + u_lo + 4 * q + wave) * 4) * 64 + lane;
+                unit_masks(a_nxt[q], b_nxt[q], tx * TILE, ty * TILE, tc, [&](int blk, uint32_t lo, uint32_t hi) {
+                    mk[blk][hw][lane] = lo;
+                    mk[blk][hw + 1][lane] = hi;
+                    if (keep) gm[blk * 64] = make_uint2(lo, hi);
+                });
             }
         }
-        const uint32_t u_lo = c0 >> 6;
-#pragma unroll
-        for (int q = 0; q < PT; q++) gid_cur[q] = gid_nxt[q];
         fetch_records();
         fetch_ids(c0 + 2 * CH);
         __syncthreads();
-        // which of this pixel's words are non-empty (a pixel that is done consumes none: its words become zeros)
+        // which of this pixel's words are non-empty (a pixel that is done consumes none)
         uint32_t nz = 0;
 #pragma unroll
-        for (int hh = 0; hh < NH; hh++) {
-            if (c0 + 32u * hh < n) {
-                if (done) mk[wave][hh][lane] = 0u;
-                else nz |= (mk[wave][hh][lane] != 0u ? 1u : 0u) << hh;
-            }
-        }
-        __syncthreads();
+        for (int hh = 0; hh < NH; hh++)
+            if (c0 + 32u * hh < n) nz |= (mk[wave][hh][lane] != 0u ? 1u : 0u) << hh;
+        nz = done ? 0u : nz;
         // ---- the walk: every lane through its own candidates.  (h, cur) = the word being consumed and its remaining
-        // bits, bl = the bits of it that were blended, (nh, nw) = the next non-empty word, already read.
-        uint32_t cur = 0, bl = 0, nw = 0, nz_zero = 0;
+        // bits, (nh, nw) = the next non-empty word, read one step ahead, nz = the non-empty words behind it.  Everything
+        // but the snapshot store is branch-free: lanes need a new word in different trips, and a conditional block that
+        // almost every trip enters for a few lanes costs more than selects for all.
+        uint32_t cur = 0, nw = 0;
         int h = 0, nh = 0;
-        bool started = false;
-        if (nz != 0u) { nh = __builtin_ctz(nz); nz &= nz - 1u; nw = mk[wave][nh][lane]; }
+        if (nz != 0u) { nh = __builtin_ctz(nz); nw = mk[wave][nh][lane]; nz &= nz - 1u; }
         while (true) {
-            if (cur == 0u && (nw != 0u || started)) {
-                if (started) mk[wave][h][lane] = __builtin_bitreverse32(bl);   // the word just finished: what was blended
-                started = nw != 0u;
-                h = nh; cur = nw; bl = 0u; nw = 0u;
-                if (nz != 0u) { nh = __builtin_ctz(nz); nz &= nz - 1u; nw = mk[wave][nh][lane]; }
+            const bool need = cur == 0u;
+            cur = need ? nw : cur;
+            h = need ? nh : h;
+            if (keep) {
                 // first word of a new segment: the running (T, C) is the pixel's state at the segment's boundary (and at
                 // every boundary it skipped) -- what the backward blend's units resume from (gsr_blend_bwd.hip)
                 const uint32_t seg_new = (c0 + (uint32_t)h * 32u) / (uint32_t)SNAP_SEG;
-                if (keep && started && seg_new != seg_cur) {
+                if (need && cur != 0u && seg_new != seg_cur) {
                     seg_cur = seg_new;
                     store_snapshot<C>(snap + ((size_t)(unit0 + seg_new * (SNAP_SEG / 64)) * 256 + pix_in_tile) * SV, T, Cc);
                 }
             }
+            {   // refill the look-ahead slot (reads a word every trip; consumed only by lanes that needed one)
+                const int t = __builtin_ctz(nz | 0x80000000u) & (NH - 1);
+                const uint32_t wnext = mk[wave][t][lane];
+                nw = need ? (nz != 0u ? wnext : 0u) : nw;
+                nh = need ? t : nh;
+                nz = need ? (nz & (nz - 1u)) : nz;
+            }
             if (__ballot(cur != 0u) == 0ull) break;
-            // branch-free from here: a lane without a candidate evaluates some record of its current word and drops it
+            // a lane without a candidate evaluates some record of its current word and drops it
             const bool act = cur != 0u;
             const int j = __builtin_ctz(cur | 0x80000000u);
             const uint32_t slot = (uint32_t)(h * 32 + j);
             cur &= cur - 1u;
-            const float4 A = rec[slot].a, B = rec[slot].b;
+            const float4 A = ga[slot], B = gb[slot];
+            const RecTail<C> K = gc[slot];
             float col[C];
-            load_cols<C>(rec[slot], col);
+            col[0] = B.z; col[1] = B.w;
+#pragma unroll
+            for (int ch = 2; ch < C; ch++) col[ch] = K.c[ch - 2];
             const float dx = A.x - pxf, dy = A.y - pyf;
             const float power = pair_exp2_arg(A.z, A.w, B.x, dx, dy);   // exp2 domain, see conic_to_exp2
             const float alpha = fminf(ALPHA_MAX, B.y * __builtin_amdgcn_exp2f(power));
@@ -224,22 +232,11 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             for (int ch = 0; ch < C; ch++) Cc[ch] += col[ch] * w;
             T = upd ? test_T : T;
             last = upd ? c0 + slot + 1u : last;
-            bl |= (upd ? 1u : 0u) << j;
-            // a pixel that terminates drops the rest of its candidates; the words it never reached hold no blended instance
+            // a pixel that terminates drops the rest of its candidates
             done = done || stop;
-            nz_zero = stop ? (nz | (nw != 0u ? 1u << nh : 0u)) : nz_zero;
-            nz = stop ? 0u : nz;
-            nw = stop ? 0u : nw;
             cur = stop ? 0u : cur;
-        }
-        if (keep) {
-            while (__ballot(nz_zero != 0u) != 0ull) {
-                if (nz_zero != 0u) { mk[wave][__builtin_ctz(nz_zero)][lane] = 0u; nz_zero &= nz_zero - 1u; }
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int w = 0; w < NH / 2; w++)
-                if (u_lo + w < n_units) my_masks[(size_t)(u_lo + w) * 256] = make_uint2(mk[wave][2 * w][lane], mk[wave][2 * w + 1][lane]);
+            nw = stop ? 0u : nw;
+            nz = stop ? 0u : nz;
         }
     }
     if (inside) {

@@ -586,35 +586,26 @@ __device__ __forceinline__ void for_each_tile_aggregated(ushort4 rect, float px,
     while (w.next_round(v)) f(v.tile, v.is_leader, v.group, v.rank, v.leader_lane);
 }
 
-// LDS record of one staged list instance, shared by the blend kernels: a = {x, y, conic a, conic b} and
-// b = {conic c, opacity, Gaussian id (uint bits), -} with the conic in the exp2 domain (conic_to_exp2: the forward and the
-// backward must round identically), then the colour channels padded to whole float4s.  48 B (C = 3, 4) / 64 B (C = 6).
-template <int C> struct __attribute__((aligned(16))) BlendRec { float4 a, b; float col[(C + 3) / 4 * 4]; };
+// LDS image of the list instances the forward blend has staged (gsr_blend_fwd.hip), structure-of-arrays so that a
+// pixel gathers an instance with two 16-byte reads and one short one:
+//   ga[i] = {x, y, conic a, conic b},  gb[i] = {conic c, opacity, colour 0, colour 1},  gc[i] = colour 2 ..
+// with the conic in the exp2 domain (conic_to_exp2: the forward and the backward must round identically).
+// 36 B per instance for three channels (40 for four, 48 for six).
+template <int C> struct RecTail { float c[C - 2]; };
+template <> struct __attribute__((aligned(8))) RecTail<4> { float c[2]; };
+template <> struct __attribute__((aligned(16))) RecTail<6> { float c[4]; };
 template <int C>
-__device__ __forceinline__ void store_rec(BlendRec<C>& r, float4 a, float4 b, uint32_t gid, const float (&colour)[C])
+__device__ __forceinline__ void store_rec(float4* __restrict__ ga, float4* __restrict__ gb, RecTail<C>* __restrict__ gc, int i, float4 a,
+                                          float4 b, const float (&colour)[C])
 {
-    float col[(C + 3) / 4 * 4];
-#pragma unroll
-    for (int ch = 0; ch < (C + 3) / 4 * 4; ch++) col[ch] = ch < C ? colour[ch < C ? ch : 0] : 0.f;
     float a2 = a.z, b2 = a.w, c2 = b.x;
     conic_to_exp2(a2, b2, c2);
-    r.a = make_float4(a.x, a.y, a2, b2);
-    r.b = make_float4(c2, b.y, __uint_as_float(gid), 0.f);
+    ga[i] = make_float4(a.x, a.y, a2, b2);
+    gb[i] = make_float4(c2, b.y, colour[0], colour[1]);
+    RecTail<C> t;
 #pragma unroll
-    for (int v = 0; v < (C + 3) / 4; v++)
-        reinterpret_cast<float4*>(r.col)[v] = make_float4(col[4 * v], col[4 * v + 1], col[4 * v + 2], col[4 * v + 3]);
-}
-template <int C>
-__device__ __forceinline__ void load_cols(const BlendRec<C>& r, float (&c)[C])
-{
-#pragma unroll
-    for (int v = 0; v < (C + 3) / 4; v++) {
-        const float4 q = reinterpret_cast<const float4*>(r.col)[v];
-        if (4 * v < C) c[4 * v < C ? 4 * v : 0] = q.x;
-        if (4 * v + 1 < C) c[4 * v + 1 < C ? 4 * v + 1 : 0] = q.y;
-        if (4 * v + 2 < C) c[4 * v + 2 < C ? 4 * v + 2 : 0] = q.z;
-        if (4 * v + 3 < C) c[4 * v + 3 < C ? 4 * v + 3 : 0] = q.w;
-    }
+    for (int ch = 2; ch < C; ch++) t.c[ch - 2] = colour[ch];
+    gc[i] = t;
 }
 
 // Snapshot record of one pixel: float4s {T, C0, C1, C2}, {C3, C4, C5, 0}, ...
