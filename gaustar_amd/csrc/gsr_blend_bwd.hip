@@ -185,20 +185,24 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         const int pidx = 16 * (py - ty * TILE) + (px - tx * TILE);
         float Ts, Tf, cs[C], cf[C];
         // The forward stored a snapshot whenever the pixel moved on to a word of a new segment (gsr_blend_fwd.hip); the
-        // first segment behind this unit in which the pixel blended anything has one, and nothing was blended between
-        // this unit's far end and that segment, so it is the state at list position s1.  (Words up to the one holding
-        // the pixel's last contributor are defined.)
+        // first segment behind this unit in which the pixel has a candidate at all has one, and nothing was blended
+        // between this unit's far end and that segment, so it is the state at list position s1.  Almost always that is
+        // the very next segment: its snapshot is requested together with its mask words, and only a pixel whose words
+        // there are empty walks on.
         uint32_t useg = unit + UPS;
         const uint32_t u_end = unit0 + (uint32_t)(n + 63) / 64u;
-        while (true) {
+        const auto words_of = [&](uint32_t u) {
             uint32_t any = 0;
 #pragma unroll
             for (int w = 0; w < UPS; w++)
-                if (useg + w < u_end) { const uint2 m = masks[((size_t)(useg + w) * 4 + wave) * 64 + lane]; any |= m.x | m.y; }
-            if (any != 0u || useg + UPS >= u_end) break;
-            useg += UPS;
-        }
+                if (u + w < u_end) { const uint2 m = masks[((size_t)(u + w) * 4 + wave) * 64 + lane]; any |= m.x | m.y; }
+            return any;
+        };
         load_snapshot<C>(snap + ((size_t)useg * 256 + pidx) * SV, Ts, cs);
+        if (words_of(useg) == 0u) {
+            do { useg += UPS; } while (useg + UPS < u_end && words_of(useg) == 0u);
+            load_snapshot<C>(snap + ((size_t)useg * 256 + pidx) * SV, Ts, cs);
+        }
         load_snapshot<C>(snap + ((size_t)unit0 * 256 + pidx) * SV, Tf, cf);   // final (T, C) kept in the tile's first slot
         const float inv = __builtin_amdgcn_rcpf(Ts);
         T = Ts;

@@ -42,17 +42,15 @@ for case in range(N):
             nflip = int((hip["radii"] != st["radii"]).sum())
             assert nflip <= 2, f"radii differ in {nflip} entries"
             flips += nflip
-            parity.check_image(hip["color"][:3], st["color"]); parity.check_image(hip["color"][3:], st2["color"])
-            parity.check_grad(hip["dL_dcolors"][:, :3], g["dL_dcolors"]); parity.check_grad(hip["dL_dcolors"][:, 3:], g2["dL_dcolors"])
+            io, go = dict(max_outlier_frac=2e-4), dict(max_outlier_frac=1e-3)   # random scenes: threshold-flip allowance
+            parity.check_image(hip["color"][:3], st["color"], **io); parity.check_image(hip["color"][3:], st2["color"], **io)
+            parity.check_grad(hip["dL_dcolors"][:, :3], g["dL_dcolors"], **go); parity.check_grad(hip["dL_dcolors"][:, 3:], g2["dL_dcolors"], **go)
             for k in ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dmeans2D"):
-                parity.check_grad(hip[k], np.asarray(g[k], np.float64).reshape(hip[k].shape) + np.asarray(g2[k], np.float64).reshape(hip[k].shape), k)
+                parity.check_grad(hip[k], np.asarray(g[k], np.float64).reshape(hip[k].shape) + np.asarray(g2[k], np.float64).reshape(hip[k].shape), k, **go)
         else:
             hip = parity.run_hip(kw, dpix)
-            nflip = int((hip["radii"] != st["radii"]).sum())
-            assert nflip <= 2, f"radii differ in {nflip} entries"     # ceil(3 sigma) on values one ulp apart (CPU sqrtf vs device)
-            flips += nflip
-            hip["radii"] = st["radii"]
-            parity.compare_hip_to(hip, st["color"], st["radii"], g, what=f"case {case}")
+            flips += int((hip["radii"] != st["radii"]).sum())   # assert_radii: only ceil(3 sigma) flips at an integer boundary
+            parity.compare_hip_to(hip, st["color"], st["radii"], g, what=f"case {case}", kw=kw, max_radii_flips=2, strict=False)
     except AssertionError as e:
         # One (pixel, Gaussian) pair sitting within an ulp of a hard threshold (alpha >= 1/255, T < 1e-4) may fall on the other
         # side of it here than in the oracle -- the two evaluate the exponent with different roundings.  It shows as ONE or

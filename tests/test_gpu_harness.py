@@ -75,7 +75,10 @@ def test_render_matches_oracle_composition(loose, in_rasterizer, hip_lib):
     else:
         kw.update(shs=None, colors_precomp=po.points_rgb(pts, torch.from_numpy(cam.campos)[None], sh, 4).numpy(), sh_degree=0)
     st, _ = parity.run_oracle(kw)
-    parity.check_image(img.detach().permute(2, 0, 1).cpu().numpy(), st["color"], "harness image vs oracle composition", tol=2e-4)
+    # the two compositions feed the rasterizer inputs that differ by rounding (HIP producers vs the torch restatement):
+    # a (pixel, Gaussian) pair next to a blend threshold may flip, hence the threshold-flip allowance of parity.py here
+    parity.check_image(img.detach().permute(2, 0, 1).cpu().numpy(), st["color"], "harness image vs oracle composition", tol=2e-4,
+                       max_outlier_frac=2e-4)
 
 
 def test_fused_rgb_depth_equals_the_two_reference_style_renders(hip_lib):

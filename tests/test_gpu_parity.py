@@ -103,9 +103,8 @@ def test_hip_matches_oracle_seeded(seed, P, W, H, deg):
     dpix = rng.normal(size=(3, H, W)).astype(np.float32)
     st, g = parity.run_oracle(kw, dpix)
     hip = parity.run_hip(kw, dpix)
-    assert (hip["radii"] != st["radii"]).sum() <= 1
-    hip["radii"] = st["radii"]
-    parity.compare_hip_to(hip, st["color"], st["radii"], g, what=f"seed{seed}")
+    # random scenes: the threshold-flip allowance of parity.py applies (not needed so far; reported in the log)
+    parity.compare_hip_to(hip, st["color"], st["radii"], g, what=f"seed{seed}", kw=kw, max_radii_flips=1, strict=False)
 
 
 def test_config_A_against_oracle():
@@ -116,9 +115,7 @@ def test_config_A_against_oracle():
     dpix = np.random.default_rng(0).normal(size=(3, cam.H, cam.W)).astype(np.float32)
     st, g = parity.run_oracle(kw, dpix)
     hip = parity.run_hip(kw, dpix)
-    assert (hip["radii"] != st["radii"]).sum() <= 1
-    hip["radii"] = st["radii"]
-    parity.compare_hip_to(hip, st["color"], st["radii"], g, what="config A")
+    parity.compare_hip_to(hip, st["color"], st["radii"], g, what="config A", kw=kw, max_radii_flips=1)
 
 
 # ------------------------------------------------------------------ (3) the reference build itself, full sizes
@@ -153,9 +150,11 @@ def test_full_size_configs_against_reference_build(cfg):
     g = rr.backward(dpix)
     hip = parity.run_hip(kw, dpix)
     radii = radii.cpu().numpy()
-    assert (hip["radii"] != radii).sum() <= max(2, gs.P // 100_000), "radii differ beyond ulp-level ceil() flips"
-    hip["radii"] = radii
-    parity.compare_hip_to(hip, color.cpu().numpy(), radii, {k: v.cpu().numpy() for k, v in g.items()}, what=cfg)
+    # full size: a few dozen threshold-flip elements of millions (parity.FULL_*_OUTLIERS); radii may differ only by
+    # ceil(3 sigma) flips at an integer boundary
+    parity.compare_hip_to(hip, color.cpu().numpy(), radii, {k: v.cpu().numpy() for k, v in g.items()}, what=cfg, kw=kw,
+                          max_radii_flips=max(2, gs.P // 100_000), strict=False, img_outliers=parity.FULL_IMG_OUTLIERS,
+                          grad_outliers=parity.FULL_GRAD_OUTLIERS)
 
 
 def test_mark_visible_matches_reference_build():
@@ -282,7 +281,7 @@ def test_long_tile_lists_use_the_big_lds_sort():
 
 
 # ------------------------------------------------------------------ robustness: sizes, streams, extremes
-def _compare_with_ref_or_oracle(kw, dpix, what, radii_slack=1):
+def _compare_with_ref_or_oracle(kw, dpix, what, radii_slack=1, full_size=False):
     from oracle import ref
     hip = parity.run_hip(kw, dpix)
     if ref.available():
@@ -293,9 +292,8 @@ def _compare_with_ref_or_oracle(kw, dpix, what, radii_slack=1):
     else:
         st, g = parity.run_oracle(kw, dpix)
         color, radii = st["color"], st["radii"]
-    assert (hip["radii"] != radii).sum() <= radii_slack
-    hip["radii"] = radii
-    parity.compare_hip_to(hip, color, radii, g, what=what)
+    loose = dict(strict=False, img_outliers=parity.FULL_IMG_OUTLIERS, grad_outliers=parity.FULL_GRAD_OUTLIERS) if full_size else {}
+    parity.compare_hip_to(hip, color, radii, g, what=what, kw=kw, max_radii_flips=radii_slack, **loose)
 
 
 def test_4k_image_many_tiles():
@@ -306,7 +304,7 @@ def test_4k_image_many_tiles():
     cam = scene.look_at_camera((0.2, 0.1, -4.0), (0, 0, 0), 3840, 2160, fovx=0.9, znear=0.01)
     kw = _kw(gs, cam, np.array([0.1, 0.2, 0.3], np.float32))
     dpix = rng.normal(size=(3, cam.H, cam.W)).astype(np.float32)
-    _compare_with_ref_or_oracle(kw, dpix, "4k")
+    _compare_with_ref_or_oracle(kw, dpix, "4k", full_size=True)
 
 
 @pytest.mark.parametrize("W,H", [(1, 1), (17, 33), (16, 16), (250, 9)])
