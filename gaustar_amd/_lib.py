@@ -36,6 +36,7 @@ SIGNATURES = {
                                   c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float,
                                   c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p,
                                   POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), c_void_p]),
+    "gsr_release_stream_state": (c_int, [c_void_p]),
     "gsr_forward": (c_int, [ALLOC_FN, ALLOC_FN, ALLOC_FN, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int,
                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, POINTER(c_int),

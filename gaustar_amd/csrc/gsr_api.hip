@@ -108,11 +108,19 @@ namespace {
 // (device, stream) that the forward blend -- the last kernel of the forward, one workgroup per tile -- hands back zeroed.
 // `clean` is host-side bookkeeping of that invariant: it is dropped while a call is in flight and only restored once the
 // cleaning kernel has been launched (or the block has been re-filled), so any failure in between costs one fill later.
-struct Counters { uint32_t* base = nullptr; size_t words = 0; bool clean = false; };
+// `busy` makes a block exclusive to ONE call from acquire_counters() until its stage 2 has been launched (or the call
+// has bailed out): a second host thread rendering on the same stream meanwhile gets nullptr and falls back to the
+// counters in its own image buffer (one fill per view) instead of interleaving its preprocess with this call's scatter.
+struct Counters { uint32_t* base = nullptr; size_t words = 0; bool clean = false; std::atomic<bool> busy{false}; };
 std::mutex g_cnt_mu;
 std::map<std::pair<int, hipStream_t>, Counters> g_cnt;
 
-// -> a zeroed block of at least `words` uint32 for (current device, st), marked in flight; nullptr: use the image buffer
+struct CountersLease {   // releases the block on every way out of gsr_forward_fused
+    Counters* c;
+    ~CountersLease() { if (c) c->busy.store(false, std::memory_order_release); }
+};
+
+// -> a zeroed block of at least `words` uint32 for (current device, st), marked in flight and busy; nullptr: use the image buffer
 Counters* acquire_counters(hipStream_t st, size_t words)
 {
     const char* e_own = getenv("GSR_OWN_COUNTERS");   // read per call: tools/ab_env.py flips it inside one process
@@ -124,13 +132,18 @@ Counters* acquire_counters(hipStream_t st, size_t words)
         std::lock_guard<std::mutex> lk(g_cnt_mu);
         c = &g_cnt[std::make_pair(dev, st)];   // std::map: the address stays valid
     }
+    if (c->busy.exchange(true, std::memory_order_acquire)) return nullptr;   // another thread's call owns it right now
     if (c->words < words) {
         if (c->base) { (void)hipStreamSynchronize(st); (void)hipFree(c->base); }
         c->base = nullptr; c->words = 0; c->clean = false;
-        if (hipMalloc((void**)&c->base, 4 * words) != hipSuccess) { (void)hipGetLastError(); c->base = nullptr; return nullptr; }
+        if (hipMalloc((void**)&c->base, 4 * words) != hipSuccess) {
+            (void)hipGetLastError(); c->base = nullptr; c->busy.store(false); return nullptr;
+        }
         c->words = words;
     }
-    if (!c->clean && hipMemsetAsync(c->base, 0, 4 * c->words, st) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (!c->clean && hipMemsetAsync(c->base, 0, 4 * c->words, st) != hipSuccess) {
+        (void)hipGetLastError(); c->busy.store(false); return nullptr;
+    }
     c->clean = false;   // in flight
     return c;
 }
@@ -264,6 +277,7 @@ int gsr_forward_fused(int P, int D, int M, int num_channels, int need_backward, 
     const bool sane = W > 0 && H > 0 && (long long)tiles_of(W > 0 ? W : 1, H > 0 ? H : 1).T <= 256ll * 1024 && image_buffer && P > 0;
     const size_t cnt_words = sane ? 2 * (size_t)shard_stride(tiles_of(W, H).T) * NSHARD : 0;
     Counters* own = sane ? acquire_counters(st, cnt_words) : nullptr;
+    CountersLease lease{own};
     const int rc = forward_stage1_impl(P, D, M, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
                                        cov3D_precomp, viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, prefiltered,
                                        radii, geom_buffer, image_buffer, num_rendered, max_tile_instances, num_segments,
@@ -651,6 +665,21 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
     if (!means3D || !viewmatrix || !present) return fail_msg("gsr_mark_visible: required pointer is null");
     launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
     GSR_CHECK_LAUNCH("mark_visible_kernel");
+    return 0;
+}
+
+int gsr_release_stream_state(gsr_stream_t stream)
+{
+    g_err.clear();
+    hipStream_t st = (hipStream_t)stream;
+    int dev = 0;
+    GSR_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_cnt_mu);
+    auto it = g_cnt.find(std::make_pair(dev, st));
+    if (it == g_cnt.end()) return 0;
+    if (it->second.busy.exchange(true)) return fail_msg("gsr_release_stream_state: a forward on this stream is in flight");
+    if (it->second.base) { GSR_CHECK(hipStreamSynchronize(st)); GSR_CHECK(hipFree(it->second.base)); }
+    g_cnt.erase(it);
     return 0;
 }
 

@@ -362,8 +362,12 @@ depth_finalize_kernel(int n_wg, const float* __restrict__ partials, float depth_
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        out[0] = (float)((double)depth_factor * (r[0][0] / r[1][0]));   // 0/0 = nan, like torch's mean of an empty selection
-        out[1] = (float)((double)mask_factor * (r[2][0] / r[3][0]));
+        // A factor of exactly 0 means "term absent": the reference only adds the depth term after depth_loss_from and the
+        // mask term after mask_loss_from (refine.py:634-660), so a view without foreground (or background) pixels must
+        // not turn a disabled term into 0 * (0/0) = nan.  An ENABLED term over an empty selection is nan, like torch's
+        // mean of an empty selection.
+        out[0] = depth_factor == 0.f ? 0.f : (float)((double)depth_factor * (r[0][0] / r[1][0]));
+        out[1] = mask_factor == 0.f ? 0.f : (float)((double)mask_factor * (r[2][0] / r[3][0]));
         out[2] = (float)r[1][0];
         out[3] = (float)r[3][0];
     }
@@ -378,7 +382,8 @@ depth_grad_kernel(int H, int W, const float* __restrict__ pred, long long psy, l
     const int yy = (int)blockIdx.y, xx = (int)(blockIdx.x * 256 + threadIdx.x);   // grid = (ceil(W / 256), H): no division
     if (xx >= W) return;
     const float p = pred[yy * psy + xx * psx], g = gt[yy * gsy + xx * gsx];
-    const float cf = depth_factor / stats[2], cb = mask_factor / stats[3];
+    const float cf = depth_factor == 0.f ? 0.f : depth_factor / stats[2];   // a disabled term has no gradient (not 0/0)
+    const float cb = mask_factor == 0.f ? 0.f : mask_factor / stats[3];
     float v = 0.f;
     if (g < max_depth) { const float d = p - g; v = cf * (d > 0.f ? 1.f : d < 0.f ? -1.f : 0.f); }
     else if (g > max_depth) { const float d = p - max_depth; v = cb * (d > 0.f ? 1.f : d < 0.f ? -1.f : 0.f); }

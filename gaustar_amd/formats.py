@@ -187,7 +187,9 @@ def load_sugar_checkpoint(path: str, map_location="cpu") -> Dict:
     arguments of gaustar_amd.producers.mesh_bound_gaussians / points_rgb, from a `{iter}.pt` written by
     SuGaR.save_model (sugar_model.py:1313-1318)."""
     import torch
-    ckpt = torch.load(path, map_location=map_location, weights_only=False)
+    # weights_only: a checkpoint is tensors plus plain containers / numbers (state_dict, train_losses, epoch, iteration,
+    # optimizer_state_dict); nothing in it needs the unpickler to run code
+    ckpt = torch.load(path, map_location=map_location, weights_only=True)
     sd = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
     missing = [k for k in SUGAR_KEYS if k not in sd]
     if missing:

@@ -16,6 +16,16 @@ import torch
 from . import _lib
 
 
+def _bump_version(p: torch.Tensor) -> None:
+    """The kernel writes through data_ptr(), behind autograd's back: count it as the in-place update it is, so that
+    version-keyed caches (harness.SurfaceGaussians._geometry) and autograd's saved-tensor checks see the step."""
+    inc = getattr(torch.autograd.graph, "increment_version", None)
+    if inc is not None:
+        inc(p)
+    else:
+        torch._C._increment_version(p)
+
+
 class Adam(torch.optim.Optimizer):
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
                  amsgrad: bool = False):
@@ -55,4 +65,5 @@ class Adam(torch.optim.Optimizer):
                         ctypes.c_void_p(st["exp_avg"].data_ptr()), ctypes.c_void_p(st["exp_avg_sq"].data_ptr()), lr, float(b1),
                         float(b2), eps, int(st["step"].item()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
                         "gsr_adam_step")
+                _bump_version(p)
         return loss

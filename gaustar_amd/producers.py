@@ -159,5 +159,26 @@ def mesh_bound_gaussians(verts: torch.Tensor, faces: torch.Tensor, bary_coords: 
     for the backward.  Arguments are the model's `_points`, `_surface_mesh_faces`,
     `surface_triangle_bary_coords` ([G,3] or [G,3,1]), `_scales`, `_quaternions` (the 2-D rotation),
     `surface_mesh_thickness`, `min_gaussian_scale`, `max_gaussian_scale`, and the loose-bind `_delta_t`, `_delta_r`."""
+    _check_faces(faces, int(verts.shape[0]))
     return _MeshGaussians.apply(verts, faces, bary_coords, raw_scales, raw_complex, float(thickness), min_scale,
                                 max_scale, delta_t, delta_r)
+
+
+_FACES_CHECKED: dict = {}   # (data_ptr, numel, version) -> number of vertices the indices were checked against
+
+
+def _check_faces(faces: torch.Tensor, n_verts: int) -> None:
+    """A face index outside [0, V) would read out of bounds in the forward kernel and ADD out of bounds in the backward
+    (silent corruption; the reference's `self._points[self._surface_mesh_faces]` raises).  Checked once per faces tensor
+    (one device reduction), then remembered until the tensor is modified."""
+    if faces.numel() == 0:
+        return
+    key = (faces.data_ptr(), faces.numel(), faces._version)
+    if _FACES_CHECKED.get(key) == n_verts:
+        return
+    lo, hi = int(faces.min()), int(faces.max())
+    if lo < 0 or hi >= n_verts:
+        raise IndexError(f"faces hold vertex indices in [{lo}, {hi}] but there are {n_verts} vertices")
+    if len(_FACES_CHECKED) > 64:
+        _FACES_CHECKED.clear()
+    _FACES_CHECKED[key] = n_verts

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 from typing import NamedTuple
 
 import torch
@@ -96,6 +97,7 @@ def _require_gpu(t: torch.Tensor, what: str):
 # --------------------------------------------------------------------------------------------
 # device index -> bytes of binning scratch to hand gsr_forward_fused up front (1.25x the largest need seen so far)
 _BINNING_HINT: dict = {}
+_HINT_LOCK = threading.Lock()   # trainer thread + evaluation thread may render on one device
 _FUSED = os.environ.get("GSR_FUSED_FORWARD", "1") != "0"   # 0: always stage 1, allocate exactly, stage 2
 
 
@@ -135,7 +137,8 @@ def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rot
         # (x1.25): the library then goes from the stage-1 read-back straight into the stage-2 launches, and the GPU does
         # not idle while Python allocates and re-enters.  First view, or a guess that turns out too small: blended = 0,
         # and stage 2 runs below over an exactly sized buffer (the reference's order of events, rasterize_points.cu:82-112).
-        hint = _BINNING_HINT.get(dev.index, 0) if _FUSED else 0
+        with _HINT_LOCK:
+            hint = _BINNING_HINT.get(dev.index, 0) if _FUSED else 0
         binning = torch.empty(hint, **byte_opts)
         # The backward's accumulation table rides along (callers that will run a backward pass a list as scratch_box):
         # the forward blend clears it on the side, and the backward skips its own fill.
@@ -151,10 +154,11 @@ def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rot
         if scratch is not None and blended.value:
             scratch_box.append(scratch)   # cleared by the forward blend: good for exactly one backward
         need = int(lib.gsr_binning_bytes_mt(R.value, nseg.value, C))
-        if need * 5 // 4 > hint:
-            _BINNING_HINT[dev.index] = (need * 5 // 4 + (1 << 20) - 1) >> 20 << 20
-        elif need * 2 < hint:   # far too generous (one close-up view long ago): come down 10 % per call
-            _BINNING_HINT[dev.index] = max(need * 5 // 4, hint * 9 // 10 + (1 << 20) - 1) >> 20 << 20
+        with _HINT_LOCK:
+            if need * 5 // 4 > hint:
+                _BINNING_HINT[dev.index] = max(_BINNING_HINT.get(dev.index, 0), (need * 5 // 4 + (1 << 20) - 1) >> 20 << 20)
+            elif need * 2 < hint:   # far too generous (one close-up view long ago): come down 10 % per call
+                _BINNING_HINT[dev.index] = max(need * 5 // 4, hint * 9 // 10 + (1 << 20) - 1) >> 20 << 20
         if not blended.value:
             # forward-only renders hand stage 2 the NEGATED segment count: no per-segment snapshots are written (gsr.h)
             nseg2 = nseg.value if need_backward else -nseg.value

@@ -66,8 +66,11 @@ class ForwardSweep:
         self._cam_cache = {}
 
     def _cam(self, cam):
-        key = id(cam)
-        if key not in self._cam_cache:   # per-camera matrices are uploaded once (the reference re-uploads per call)
+        # per-camera matrices are uploaded once (the reference re-uploads per call).  Keyed by the matrices' bytes, not by
+        # id(cam): ids of transient camera objects are reused after collection, and an edited camera must not hit.
+        key = (np.asarray(cam.viewmatrix, np.float32).tobytes(), np.asarray(cam.projmatrix, np.float32).tobytes(),
+               np.asarray(cam.campos, np.float32).tobytes())
+        if key not in self._cam_cache:
             dev = self.means3D.device
             t = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
             self._cam_cache[key] = (t(cam.viewmatrix), t(cam.projmatrix), t(cam.campos))

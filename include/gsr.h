@@ -11,9 +11,14 @@
  * tensor, DGR/rasterize_points.cu:94-111).
  *
  * Ownership (as DGR/rasterize_points.cu:68-78): the caller owns every buffer including
- * the three scratch buffers; the library keeps no state between calls, so backward
- * re-derives its view of the scratch from (P, R, W, H) alone
- * (DGR/cuda_rasterizer/rasterizer_impl.cu:371-373).
+ * the three scratch buffers, and backward re-derives its view of the scratch from
+ * (P, R, W, H) alone (DGR/cuda_rasterizer/rasterizer_impl.cu:371-373).  The library itself
+ * holds: per calling thread, a 64-byte pinned landing pad for the stage-1 totals and the
+ * last error message; process-wide, a pool of HIP events for gsr_profile_*; and -- only
+ * once gsr_forward_fused has been used -- one block of tile counters (<= 1 MB) per
+ * (device, stream), exclusive to one call at a time (a concurrent call on the same
+ * stream falls back to counters in its own image buffer) and freed by
+ * gsr_release_stream_state().  Nothing else persists between calls.
  *
  * Every function returns 0 on success, non-zero on failure; gsr_last_error() then
  * holds a message for the calling thread.
@@ -111,6 +116,10 @@ int gsr_forward_fused(int P, int D, int M, int num_channels, int need_backward, 
                       int prefiltered, const float* background, int* radii, void* geom_buffer, void* image_buffer,
                       void* binning_buffer, size_t binning_capacity, void* grad_scratch, float* out_color,
                       int* num_rendered, int* max_tile_instances, int* num_segments, int* blended, gsr_stream_t stream);
+
+/* Frees what the library keeps for (current device, stream) -- the tile-counter block of gsr_forward_fused -- e.g.
+ * before the stream is destroyed.  Fails if a gsr_forward_fused on that stream is in flight on another thread. */
+int gsr_release_stream_state(gsr_stream_t stream);
 
 /* One-call forward with the reference's allocator-callback shape.  Replaces
  * CudaRasterizer::Rasterizer::forward (DGR/cuda_rasterizer/rasterizer.h:31-55).

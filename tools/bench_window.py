@@ -1,0 +1,91 @@
+"""tools/bench_window.py [--frames F] [--iters I] [--level L] -- the shape of BASELINE.json configs[4] (train_seq.py over a
+tracking window: per frame, refine the mesh-bound Gaussians against that frame's images, then carry them to the next
+frame, train_seq.py:101-244 / gaustar_trainers/refine.py:529-841) assembled from this package only:
+
+  per frame:   ground truth = renders of a deformed + recoloured copy of the surface (synthetic)
+  per iteration (refine.py:538-794):  camera = dist.shard_views(...) (one seeded permutation per epoch, as :534),
+               harness.SurfaceGaussians -> one 4-channel render (RGB + depth-as-colour) -> l1 + dssim + masked depth L1
+               -> backward -> gaustar_amd.optim.Adam.step()
+  between frames: the optimised parameters are kept (the tracker's warm start), the optimiser state is rebuilt.
+
+Not included (out of scope): mesh regularisers (pytorch3d), topology update (Open3D),
+flow warp.  Prints iterations/s over all frames and the loss at the start / end of every frame."""
+import argparse, json, os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gaustar_amd import GaussianRasterizer, dist as gdist, harness, losses, optim, producers, scene
+
+MAX_DEPTH = 10.0
+
+
+def render4(model, ncam, bg4):
+    settings, view, campos = model._settings(ncam, bg4, 0)
+    pts = model.points
+    colors4 = producers.points_rgb_depth(pts, campos, model.sh_coordinates, model.sh_levels, view, depth_channels=1)
+    img, _ = GaussianRasterizer(settings)(means3D=pts, means2D=torch.zeros_like(pts), opacities=model.strengths,
+                                          colors_precomp=colors4, scales=model.scaling, rotations=model.quaternions)
+    return img
+
+
+def run(a):
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(0)
+    v, f = scene.icosphere(a.level, scene.SUBJECT_RADIUS, scene.SUBJECT_CENTER)
+    verts, faces = torch.from_numpy(v).float().to(dev), torch.from_numpy(f).long().to(dev)
+    model = harness.SurfaceGaussians(verts, faces, 6, 3).to(dev)
+    N = model.n_points
+    with torch.no_grad():
+        model._sh_coordinates_dc.copy_(torch.rand(N, 1, 3, device=dev, generator=g) * 2 - 1)
+    edge = float((verts[faces[:, 0]] - verts[faces[:, 1]]).norm(dim=-1).mean())
+    cams = scene.ring_cameras(5, 32, a.width, a.height, focal_px=1200.0 * a.width / 1920.0)[:a.cameras]
+    ncams = [harness.nerf_camera_from_scene(c) for c in cams]
+    bg4 = torch.tensor([0.0, 1.0, 0.0, MAX_DEPTH], device=dev)
+    target = harness.SurfaceGaussians(verts, faces, 6, 3).to(dev)
+    target.load_state_dict(model.state_dict())
+    frames, n_it = [], 0
+    pts_start = model.points.detach().clone()
+    t_total = 0.0
+    for fi in range(a.frames):
+        with torch.no_grad():   # the subject moves and changes colour from frame to frame
+            target._points.add_(0.25 * edge * torch.randn(verts.shape, device=dev, generator=g))
+            target._sh_coordinates_dc.add_(0.2 * torch.randn(N, 1, 3, device=dev, generator=g))
+            gts = []
+            for nc in ncams:
+                img = render4(target, nc, bg4)
+                d = img[3].clone()
+                d[d >= MAX_DEPTH - 1e-3] = 2 * MAX_DEPTH
+                gts.append((img[:3].clone(), d))
+        opt = optim.Adam([{"params": [model._points], "lr": 2e-4},
+                          {"params": [model._sh_coordinates_dc, model._sh_coordinates_rest], "lr": 5e-3},
+                          {"params": [model._scales, model._quaternions, model.all_densities], "lr": 5e-3}], eps=1e-15)
+        hist = []
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for it in range(a.iters):
+            ci = gdist.shard_views(len(ncams), fi * a.iters + it, 0, 1)
+            opt.zero_grad(set_to_none=True)
+            img = render4(model, ncams[ci], bg4)
+            loss = losses.rgb_depth_loss(img, gts[ci][0], gts[ci][1], MAX_DEPTH, 0.2, 1.0, 0.5)
+            loss.backward()
+            opt.step()
+            hist.append(loss.detach())
+        torch.cuda.synchronize(); t_total += time.perf_counter() - t0
+        n_it += a.iters
+        k = max(1, min(5, a.iters // 4))
+        frames.append({"loss_first": round(float(torch.stack(hist[:k]).mean()), 5), "loss_last": round(float(torch.stack(hist[-k:]).mean()), 5)})
+    moved = float((model.points.detach() - pts_start).abs().max())
+    return {"gaussians": N, "image": [a.width, a.height], "cameras": len(ncams), "frames": frames, "iterations": n_it,
+            "iterations_per_s": round(n_it / t_total, 1), "ms_per_iteration": round(t_total / n_it * 1e3, 3),
+            "geometry_moved": moved}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=3); ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--level", type=int, default=6); ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080); ap.add_argument("--cameras", type=int, default=160)
+    print(json.dumps(run(ap.parse_args())))
+
+
+if __name__ == "__main__":
+    main()
