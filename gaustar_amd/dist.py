@@ -130,16 +130,27 @@ def shard_views(num_views: int, step: int, rank_: int | None = None, world: int 
 
 
 class GradAllReducer:
-    """Flatten -> all-reduce(SUM) -> / world -> scatter back, in fixed-size buckets.
+    """Bucketed SUM all-reduce (then / world) of parameter gradients, OVERLAPPED with the backward pass.
 
-    `params` are the tensors whose `.grad` the optimiser will consume (the param groups of
-    SuGaROptimizer, sugar_optimizer.py:67-87).  Parameters whose grad is None on this rank (a
-    Gaussian set no pixel of this view touched) contribute zeros, so every rank issues identical
-    collectives."""
+    `params` are the tensors whose `.grad` the optimiser will consume (the param groups of SuGaROptimizer,
+    sugar_optimizer.py:67-87), listed in the order their gradients become final during backward (for
+    harness.SurfaceGaussians: `grad_ready_order()`).  Consecutive parameters share a flat bucket of at most
+    `bucket_bytes`.  With `overlap`, every parameter carries a post-accumulate-grad hook: the moment the last
+    gradient of a bucket has been accumulated, the bucket is flattened and its all-reduce is issued asynchronously
+    (RCCL runs it on its own stream) while autograd goes on with the rest of the backward -- the SH coefficients'
+    53 MB travel while the mesh producers' backward and the remaining kernels still run.  Calling the reducer (right
+    before `optimizer.step()`, the place of sugar_optimizer.py:99-101) issues whatever has not been issued, waits,
+    divides by the world size and re-points every `p.grad` at its slice of the flat buffer (no copy back).
 
-    def __init__(self, params: Iterable[torch.Tensor], bucket_bytes: int = 32 << 20, average: bool = True):
+    Parameters whose grad is None on this rank (a Gaussian set no pixel of this view touched) contribute zeros, so
+    every rank issues identical collectives in identical order.  The views stay valid until the next backward;
+    callers that keep gradients across steps must clone them."""
+
+    def __init__(self, params: Iterable[torch.Tensor], bucket_bytes: int = 32 << 20, average: bool = True,
+                 overlap: bool = True, run_at_world_size_1: bool = False):
         self.params: List[torch.Tensor] = [p for p in params]
         self.average = average
+        self.solo = bool(run_at_world_size_1)   # tests: issue the collectives even when there is nobody to talk to
         self.buckets: List[List[torch.Tensor]] = []
         cur, cur_bytes = [], 0
         for p in self.params:
@@ -152,66 +163,99 @@ class GradAllReducer:
         if cur:
             self.buckets.append(cur)
         self._flat: List[torch.Tensor] = []
+        self._bucket_of = {id(p): bi for bi, bucket in enumerate(self.buckets) for p in bucket}
+        self._ready = [0] * len(self.buckets)          # gradients accumulated since the last call, per bucket
+        self._works: List = [None] * len(self.buckets)  # in-flight collectives
+        self._fast = [False] * len(self.buckets)
+        self._hooks = []
+        self.issued_early = 0                          # buckets whose all-reduce started during backward (last step)
+        if overlap:
+            for p in self.params:
+                if p.requires_grad and hasattr(p, "register_post_accumulate_grad_hook"):
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     def payload_bytes(self) -> int:
         return sum(p.numel() for p in self.params) * 4
 
+    def close(self) -> None:
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    # ------------------------------------------------------------------ internals
+    def _on_grad(self, p: torch.Tensor) -> None:
+        if world_size() == 1 and not self.solo:
+            return
+        bi = self._bucket_of[id(p)]
+        self._ready[bi] += 1
+        # issue in bucket order only (every rank must enqueue the same sequence of collectives): a later bucket that
+        # completes first waits for its predecessors
+        while True:
+            nxt = next((i for i, w in enumerate(self._works) if w is None), None)
+            if nxt is None or self._ready[nxt] < sum(1 for q in self.buckets[nxt] if q.requires_grad):
+                break
+            self._issue(nxt)
+            self.issued_early += 1
+
+    @torch.no_grad()
+    def _issue(self, bi: int) -> None:
+        bucket = self.buckets[bi]
+        n = sum(p.numel() for p in bucket)
+        dev = bucket[0].device
+        if bi >= len(self._flat) or self._flat[bi].numel() != n or self._flat[bi].device != dev:
+            flat = torch.empty(n, dtype=torch.float32, device=dev)
+            while len(self._flat) <= bi:
+                self._flat.append(flat)
+            self._flat[bi] = flat
+        flat = self._flat[bi]
+        all_there = all(p.grad is not None and p.grad.dtype == torch.float32 for p in bucket)
+        self._fast[bi] = all_there
+        if all_there:
+            # a gradient that already is a view of this buffer (kept from the last call) must not alias the output
+            parts = [(p.grad.clone() if p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() else p.grad).reshape(-1)
+                     for p in bucket]
+            torch.cat(parts, out=flat)
+        else:
+            off = 0
+            for p in bucket:
+                k = p.numel()
+                if p.grad is None:
+                    flat[off:off + k].zero_()
+                else:
+                    flat[off:off + k].copy_(p.grad.reshape(-1))
+                off += k
+        # SUM + one divide kernel on every backend: gloo has no AVG, and a 12 us kernel is not worth a second code path
+        self._works[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+
     @torch.no_grad()
     def __call__(self) -> None:
-        """After this call every p.grad holds the mean (or sum) over ranks.  Fast path (all grads present): ONE
-        torch.cat per bucket into a persistent flat buffer, an in-place all-reduce, one divide, and p.grad re-pointed at views of the flat buffer -- no copy back.  The views stay valid until the
-        next call; callers that keep gradients across steps must clone them."""
+        """After this call every p.grad holds the mean (or sum) over ranks."""
         ws = world_size()
-        if ws == 1:
+        if ws == 1 and not self.solo:
             return
-        # SUM + one divide kernel on every backend: gloo has no AVG, and the RCCL AVG path cannot be exercised on the
-        # single-GPU boxes this is developed on -- a 12 us kernel is not worth an untested collective.
-        use_avg = False
-        works = []
-        fast = []
+        early = sum(1 for w in self._works if w is not None)
+        for bi in range(len(self.buckets)):
+            if self._works[bi] is None:
+                self._issue(bi)
         for bi, bucket in enumerate(self.buckets):
-            n = sum(p.numel() for p in bucket)
-            dev = bucket[0].device
-            if bi >= len(self._flat) or self._flat[bi].numel() != n or self._flat[bi].device != dev:
-                flat = torch.empty(n, dtype=torch.float32, device=dev)
-                if bi < len(self._flat):
-                    self._flat[bi] = flat
-                else:
-                    self._flat.append(flat)
+            self._works[bi].wait()
             flat = self._flat[bi]
-            all_there = all(p.grad is not None and p.grad.dtype == torch.float32 for p in bucket)
-            fast.append(all_there)
-            if all_there:
-                # a gradient that already is a view of this buffer (kept from the last call) must not alias the output
-                parts = [(p.grad.clone() if p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() else p.grad).reshape(-1)
-                         for p in bucket]
-                torch.cat(parts, out=flat)
-            else:
-                off = 0
-                for p in bucket:
-                    k = p.numel()
-                    if p.grad is None:
-                        flat[off:off + k].zero_()
-                    else:
-                        flat[off:off + k].copy_(p.grad.reshape(-1))
-                    off += k
-            works.append(dist.all_reduce(flat, op=dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM, async_op=True))
-        for bi, bucket in enumerate(self.buckets):
-            works[bi].wait()
-            flat = self._flat[bi]
-            if self.average and not use_avg:
+            if self.average:
                 flat.div_(ws)
             off = 0
             for p in bucket:
                 k = p.numel()
                 g = flat[off:off + k].view_as(p)
-                if fast[bi] or p.grad is None:
-                    p.grad = g if fast[bi] else g.clone()
+                if self._fast[bi] or p.grad is None:
+                    p.grad = g if self._fast[bi] else g.clone()
                 else:
                     p.grad.copy_(g)
                 off += k
+        self.issued_early = early
+        self._ready = [0] * len(self.buckets)
+        self._works = [None] * len(self.buckets)
 
 
 def allreduce_grads(params: Sequence[torch.Tensor], average: bool = True) -> None:
-    """One-shot convenience wrapper (builds the buckets every call)."""
-    GradAllReducer(params, average=average)()
+    """One-shot convenience wrapper (builds the buckets every call; no overlap)."""
+    GradAllReducer(params, average=average, overlap=False)()

@@ -141,6 +141,17 @@ class SurfaceGaussians(nn.Module):
                 m._delta_t.copy_(ckpt["delta_t"]); m._delta_r.copy_(ckpt["delta_r"])
         return m
 
+    def grad_ready_order(self):
+        """The optimiser's parameters (sugar_optimizer.py:67-87) in the order their gradients become final in the backward
+        of a render: the rasterizer's backward feeds the SH producer's backward first (`_sh_coordinates_*`, 70 % of the
+        bytes) and `all_densities` (one sigmoid), then the mesh producer's backward (`_points`, `_scales`,
+        `_quaternions`, `_delta_*`).  dist.GradAllReducer buckets in this order and starts a bucket's all-reduce as soon
+        as its last gradient lands."""
+        ps = [self._sh_coordinates_rest, self._sh_coordinates_dc, self.all_densities, self._scales, self._quaternions]
+        if self._loose_bind:
+            ps += [self._delta_t, self._delta_r]
+        return ps + [self._points]
+
     # -------------------------------------------------------------------------------- the reference's properties
     @property
     def device(self):

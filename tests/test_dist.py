@@ -64,6 +64,51 @@ def test_grad_allreduce_gloo_world2():
     assert len(set(v0) | set(v1)) == 160        # one epoch of 80 steps x 2 ranks covers all 160 cameras
 
 
+def _overlap_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from gaustar_amd import dist as gd
+    gd.init_from_env("gloo")
+    # four parameters in the order their gradients become final; buckets of <= 2 parameters
+    params = [torch.nn.Parameter(torch.zeros(3000)) for _ in range(4)]
+    red = gd.GradAllReducer(params, bucket_bytes=24_000, average=True)
+    assert len(red.buckets) == 2
+    seen = []
+    ok = True
+    for step in range(3):
+        for p in params:
+            p.grad = None
+        # autograd accumulates in the reverse order of use: params[0]'s gradient lands first
+        loss = sum((i + 1) * (rank + 1) * p.sum() for i, p in reversed(list(enumerate(params))))
+        h = params[3].register_hook(lambda g: seen.append(sum(1 for w in red._works if w is not None)))
+        loss.backward()
+        h.remove()
+        red()
+        ok = ok and red.issued_early >= 1            # the first bucket left while backward was still running
+        ok = ok and all(torch.allclose(p.grad, torch.full_like(p, 1.5 * (i + 1))) for i, p in enumerate(params))
+    q.put((rank, ok, seen))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_buckets_leave_during_backward_gloo_world2():
+    """Hook-driven overlap: the bucket of the gradients that become final first is all-reduced while autograd still
+    computes the rest; results equal the plain average on both ranks, step after step (flat buffers are re-used)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    # when the LAST parameter's gradient arrived, the first bucket's collective was already in flight
+    assert all(s and s[-1] >= 1 for _, _, s in res), res
+
+
 def test_single_process_is_a_noop():
     from gaustar_amd import dist as gd
     p = torch.zeros(4, requires_grad=True)

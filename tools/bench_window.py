@@ -29,7 +29,12 @@ def render4(model, ncam, bg4):
 
 
 def run(a):
-    dev = torch.device("cuda:0")
+    # torchrun: one process per GPU, one camera per rank per iteration, parameter gradients averaged over the ranks right
+    # before the optimiser step (gaustar_amd.dist; GSR_BENCH_BACKEND=gloo lets ranks share a GPU for tests)
+    backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")
+    rank, world, local = gdist.init_from_env(backend)
+    dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
+    torch.cuda.set_device(dev)
     g = torch.Generator(device=dev).manual_seed(0)
     v, f = scene.icosphere(a.level, scene.SUBJECT_RADIUS, scene.SUBJECT_CENTER)
     verts, faces = torch.from_numpy(v).float().to(dev), torch.from_numpy(f).long().to(dev)
@@ -56,25 +61,35 @@ def run(a):
                 d = img[3].clone()
                 d[d >= MAX_DEPTH - 1e-3] = 2 * MAX_DEPTH
                 gts.append((img[:3].clone(), d))
+        reducer = gdist.GradAllReducer(model.grad_ready_order()) if world > 1 else None
         opt = optim.Adam([{"params": [model._points], "lr": 2e-4},
                           {"params": [model._sh_coordinates_dc, model._sh_coordinates_rest], "lr": 5e-3},
                           {"params": [model._scales, model._quaternions, model.all_densities], "lr": 5e-3}], eps=1e-15)
         hist = []
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for it in range(a.iters):
-            ci = gdist.shard_views(len(ncams), fi * a.iters + it, 0, 1)
+            ci = gdist.shard_views(len(ncams), fi * a.iters + it, rank, world)
             opt.zero_grad(set_to_none=True)
             img = render4(model, ncams[ci], bg4)
             loss = losses.rgb_depth_loss(img, gts[ci][0], gts[ci][1], MAX_DEPTH, 0.2, 1.0, 0.5)
             loss.backward()
+            if reducer is not None:
+                reducer()                      # the hook in front of sugar_optimizer.py:99-101
             opt.step()
             hist.append(loss.detach())
+        if reducer is not None:
+            early, payload = reducer.issued_early, reducer.payload_bytes()
+            reducer.close()
         torch.cuda.synchronize(); t_total += time.perf_counter() - t0
         n_it += a.iters
         k = max(1, min(5, a.iters // 4))
         frames.append({"loss_first": round(float(torch.stack(hist[:k]).mean()), 5), "loss_last": round(float(torch.stack(hist[-k:]).mean()), 5)})
     moved = float((model.points.detach() - pts_start).abs().max())
-    return {"gaussians": N, "image": [a.width, a.height], "cameras": len(ncams), "frames": frames, "iterations": n_it,
+    if world > 1:
+        torch.distributed.barrier()
+    extra = {} if world == 1 else {"world": world, "allreduce_payload_MB": round(payload / 1e6, 1), "buckets_issued_during_backward": early,
+                                  "views_per_iteration": world}
+    return {**extra, "gaussians": N, "image": [a.width, a.height], "cameras": len(ncams), "frames": frames, "iterations": n_it,
             "iterations_per_s": round(n_it / t_total, 1), "ms_per_iteration": round(t_total / n_it * 1e3, 3),
             "geometry_moved": moved}
 
@@ -84,7 +99,11 @@ def main():
     ap.add_argument("--frames", type=int, default=3); ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--level", type=int, default=6); ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080); ap.add_argument("--cameras", type=int, default=160)
-    print(json.dumps(run(ap.parse_args())))
+    r = run(ap.parse_args())
+    if gdist.rank() == 0:
+        print(json.dumps(r))
+    if gdist.world_size() > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
