@@ -236,3 +236,28 @@ def test_mesh_bound_gaussians_other_counts_per_face(G, hip_lib):
     for name, a, b in zip(("verts", "raw_scales", "raw_complex", "delta_t", "delta_r"), g1, g0):
         err = np.abs(a.numpy().astype(np.float64) - b.numpy()).max() / max(np.abs(b.numpy()).max(), 1e-30)
         assert err < 2e-4, f"G={G} {name}: normalised max error {err:.3e}"
+
+
+def test_hip_mesh_producer_against_scipy_float64(hip_lib):
+    """The fused HIP producer (gsr_mesh_gaussians) against the independent float64 numpy + scipy construction of
+    tests/crosscheck.py -- a cross-check, not a pin: pytorch3d, whose conventions the reference calls, is absent here."""
+    import crosscheck
+    from gaustar_amd import harness, producers, scene
+    rng = np.random.default_rng(12)
+    v, f = scene.icosphere(3, 0.9, (0.0, 1.2, 0.0))
+    G = 6
+    N = len(f) * G
+    bary = np.asarray(harness.BARY_COORDS[G], np.float64)
+    raw_scales = rng.normal(-5.0, 0.3, (N, 2)); raw_complex = rng.normal(size=(N, 2))
+    delta_t = 1e-3 * rng.normal(size=(N, 3)); delta_r = np.array([1.0, 0, 0, 0]) + 0.05 * rng.normal(size=(N, 4))
+    dev = torch.device("cuda:0")
+    t = lambda x: None if x is None else torch.from_numpy(np.asarray(x, np.float32)).to(dev)
+    for dt, dr in ((None, None), (delta_t, delta_r)):
+        pts, scl, quat = producers.mesh_bound_gaussians(t(v), torch.from_numpy(f).long().to(dev), t(bary), t(raw_scales), t(raw_complex),
+                                                        3e-6, None, None, t(dt), t(dr))
+        p64, s64, R64 = crosscheck.mesh_frames_f64(v, f, bary, raw_scales, raw_complex, 3e-6, dt, dr)
+        np.testing.assert_allclose(pts.cpu().numpy(), p64, atol=2e-6)
+        np.testing.assert_allclose(scl.cpu().numpy(), s64, rtol=2e-6)
+        q = quat.cpu().numpy().astype(np.float64)
+        np.testing.assert_allclose(np.linalg.norm(q, axis=1), 1.0, atol=1e-6)
+        np.testing.assert_allclose(crosscheck.quat_wxyz_to_matrix(q), R64, atol=5e-6)

@@ -65,3 +65,40 @@ def test_render_from_ply_and_cameras_json(tmp_path, hip_lib):
     b = parity.run_hip(mk(cams[1], dict(means3D=gs.means3D, opacities=gs.opacities, shs=gs.shs, scales=gs.scales, rotations=gs.rotations)))
     assert (a["radii"] != b["radii"]).sum() <= 2
     parity.check_image(a["color"], b["color"], "ply + cameras.json vs in-memory", tol=2e-4)
+
+
+def test_three_pass_sweep_against_reference_build(hip_lib):
+    """The per-camera renders of detect_topo_err / forward_rendering_and_mesh_update (gaustar_trainers/refined_mesh.py:733-775)
+    at config-C size, one rig camera: (1) RGB with IN-KERNEL SH of degree 2 (compute_color_in_rasterizer=True,
+    sugar_model.py:1207-1209), (2) depth-as-colour with bg = max depth, (3) the same with `use_solid_surface` scales
+    (sugar_model.py:1230-1232) -- each run through the reference's own kernels (oracle/_ref/libgsr_ref.so) -- against
+    sweep.ForwardSweep: passes 1 + 2 as ONE 4-channel forward with colours from the fused SH producer, pass 3 as
+    render_depth(cam, scales=...)."""
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref/libgsr_ref.so did not travel to this box")
+    from gaustar_amd import scene, sweep
+    gs, cams, _bg = scene.config_C()
+    cam = cams[37]
+    rng = np.random.default_rng(9)
+    sh = np.concatenate([rng.uniform(-1.5, 1.5, (gs.P, 1, 3)), rng.uniform(-0.3, 0.3, (gs.P, 8, 3))], 1).astype(np.float32)
+    max_depth = 10.0
+    fs = sweep.ForwardSweep(_t(gs.means3D), _t(gs.opacities), _t(gs.scales), _t(gs.rotations), sh=_t(sh), sh_levels=3,
+                            max_depth=max_depth)
+    rgb, depth = fs.render_rgb_depth(cam)
+    solid = _t(gs.scales).clone()
+    solid[..., 1:] = torch.maximum(solid[..., 1:].mean(), solid[..., 1:])            # sugar_model.py:1230-1232
+    sdepth = fs.render_depth(cam, scales=solid)
+
+    common = dict(means3D=gs.means3D, opacities=gs.opacities, view=cam.viewmatrix, proj=cam.projmatrix, campos=cam.campos, W=cam.W,
+                  H=cam.H, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, rotations=gs.rotations)
+    rr = ref.RefRasterizer()
+    c1, _, _ = rr.forward(bg=np.array([0.0, 1.0, 0.0], np.float32), shs=sh, sh_degree=2, scales=gs.scales, **common)
+    dcol = scene.view_depth_colors(gs, cam)
+    c2, _, _ = rr.forward(bg=np.full(3, max_depth, np.float32), colors_precomp=dcol, scales=gs.scales, **common)
+    c3, _, _ = rr.forward(bg=np.full(3, max_depth, np.float32), colors_precomp=dcol, scales=solid.cpu().numpy(), **common)
+    full = dict(max_outlier_frac=parity.FULL_IMG_OUTLIERS)
+    parity.check_image(rgb.permute(2, 0, 1).cpu().numpy(), c1.cpu().numpy(), "sweep pass 1: RGB, in-kernel SH deg 2", **full)
+    parity.check_image(depth.cpu().numpy(), c2[0].cpu().numpy(), "sweep pass 2: depth", **full)
+    parity.check_image(sdepth.cpu().numpy(), c3[0].cpu().numpy(), "sweep pass 3: solid-surface depth", **full)
+    assert float((sdepth < max_depth - 1e-3).float().mean()) >= float((depth < max_depth - 1e-3).float().mean())   # larger splats cover more

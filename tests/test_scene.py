@@ -74,3 +74,33 @@ def test_mesh_binding_properties():
     np.testing.assert_allclose(col0, n6, atol=1e-5)
     assert np.allclose(gs.scales[:, 0], 3.5e-6) and (gs.scales[:, 1] == gs.scales[:, 2]).all()
     assert gs.opacities.min() >= 0.8 and gs.opacities.max() <= 0.99
+
+
+def test_mesh_bound_producer_oracle_against_scipy_float64():
+    """Cross-check (not a pin, see tests/crosscheck.py): oracle/producers_oracle.mesh_bound_gaussians -- torch float32 with the
+    restated pytorch3d matrix_to_quaternion -- against an independent float64 numpy + scipy construction: same points,
+    same scaling, and the same ROTATION (quaternions compared through R(q) and, up to sign, against scipy's from_matrix)."""
+    import torch
+    import crosscheck
+    from gaustar_amd import harness, scene
+    from oracle import producers_oracle as po
+    rng = np.random.default_rng(11)
+    v, f = scene.icosphere(2, 0.9, (0.0, 1.2, 0.0))
+    G = 6
+    N = len(f) * G
+    bary = np.asarray(harness.BARY_COORDS[G], np.float64)
+    raw_scales = rng.normal(-5.0, 0.3, (N, 2)); raw_complex = rng.normal(size=(N, 2))
+    delta_t = 1e-3 * rng.normal(size=(N, 3)); delta_r = np.array([1.0, 0, 0, 0]) + 0.05 * rng.normal(size=(N, 4))
+    for dt, dr in ((None, None), (delta_t, delta_r)):
+        t = lambda x: None if x is None else torch.from_numpy(np.asarray(x, np.float32))
+        pts, scl, quat = po.mesh_bound_gaussians(t(v), torch.from_numpy(f).long(), t(bary), t(raw_scales), t(raw_complex), 3e-6, None, None,
+                                                 t(dt), t(dr))
+        p64, s64, R64 = crosscheck.mesh_frames_f64(v, f, bary, raw_scales, raw_complex, 3e-6, dt, dr)
+        np.testing.assert_allclose(pts.numpy(), p64, atol=2e-6)
+        np.testing.assert_allclose(scl.numpy(), s64, rtol=2e-6)
+        q = quat.numpy().astype(np.float64)
+        np.testing.assert_allclose(np.linalg.norm(q, axis=1), 1.0, atol=1e-6)
+        np.testing.assert_allclose(crosscheck.quat_wxyz_to_matrix(q), R64, atol=5e-6)
+        qs = crosscheck.quats_from_matrices_scipy(R64)
+        sign = np.sign(np.sum(q * qs, axis=1, keepdims=True))
+        np.testing.assert_allclose(q, sign * qs, atol=5e-6)
