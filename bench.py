@@ -41,6 +41,16 @@ from gaustar_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib,
 from gaustar_amd import dist as gdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+N_SIMD, CLOCK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMDs; a wave64 vector instruction occupies its SIMD for 4 cycles
+
+
+def csrc_sha256():
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gaustar_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
 
 
 def algorithmic_bytes(P, R, W, H, M=0):
@@ -222,13 +232,26 @@ def main():
                              "GBps": round(per_kernel_b.get(nme, 0) / launches_per_step / (mean_ms * 1e-3) / 1e9, 1)}
         dom = max(kern, key=lambda k: kern[k]["ms_per_launch"] * kern[k]["launches_per_step"])
         ach = kern[dom]["GBps"]
-        traffic = None
+        # HBM traffic and instruction counts come from rocprofv3 PMC passes (separate runs, tools/pmc.sh ->
+        # profiles/pmc_latest.json), which carries a hash of gaustar_amd/csrc: counters of other kernels than the ones
+        # timed here are dropped (null), never reported stale.
+        traffic, valu = None, None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_file):
             try:
-                traffic = json.load(open(pmc_file)).get(dom, {}).get("hbm_bytes_per_launch")
+                pmc = json.load(open(pmc_file))
+                if pmc.get("_csrc_sha256") == csrc_sha256() and dom in pmc:
+                    traffic = pmc[dom].get("hbm_bytes_per_launch")
+                    vi = pmc[dom].get("valu_insts")
+                    if vi:
+                        # secondary roofline: vector-ALU issue.  frac = share of the chip's VALU issue
+                        # slots the kernel's own vector instructions occupy while it runs
+                        t_s = kern[dom]["ms_per_launch"] * 1e-3
+                        valu = {"insts_per_launch": int(vi), "issue_cycles_per_simd": round(vi * 4 / N_SIMD, 1),
+                                "frac": round(vi * 4 / N_SIMD / (t_s * CLOCK_HZ), 4), "unit": "wave64 VALU instructions",
+                                "salu_insts_per_launch": pmc[dom].get("salu_insts")}
             except Exception:
-                traffic = None
+                traffic, valu = None, None
         path_gbs = total_b / (ms_per_step * 1e-3) / 1e9 if world == 1 else total_b * world / (ms_per_step * 1e-3) / 1e9
         out = {
             "metric": "views/sec fwd+bwd @1920x1080, 500k Gaussians; HBM GB/s vs roofline",
@@ -241,7 +264,7 @@ def main():
                        "gaussians": gs.P, "width": W, "height": H, "views_per_step": world,
                        "num_rendered_mean": R_mean, "parallelism": f"view-parallel x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "valu": valu,
                          "path_alg_bytes_per_view": int(total_b), "path_achieved": round(path_gbs, 1),
                          "path_frac": round(path_gbs / HBM_PEAK_GBS / world, 5),
                          "instrumented_ms_per_step": round(dt_prof / args.steps * 1e3, 4), "kernels": kern},

@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(256)
 tile_sort_reg_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ order, const uint64_t* __restrict__ keys,
                      uint32_t* __restrict__ point_list)
 {
-    __shared__ uint64_t s[2048];
+    __shared__ uint64_t s[2 * SORT_SMALL_CAP];
     const uint2 rg = ranges[order[blockIdx.x]];
     const uint32_t n = rg.y - rg.x;
     if (n == 0 || n > 2048u) return;     // longer lists: tile_sort_kernel<16384, 2048, true>

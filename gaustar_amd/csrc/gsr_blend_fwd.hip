@@ -63,7 +63,8 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     // the walk (below) uses the same bytes for its cross-wave stages.  C = 3 at CH = 512: 34 KB, four workgroups per CU.
     constexpr size_t GC_BYTES = (sizeof(RecTail<C>) * CH + 15) / 16 * 16;
     constexpr size_t REC_BYTES = 32 * CH + GC_BYTES, MK_BYTES = sizeof(uint32_t) * 4 * NH * 64;
-    constexpr size_t LDS_BYTES = REC_BYTES + MK_BYTES > 2048 * 8 ? REC_BYTES + MK_BYTES : 2048 * 8;
+    constexpr size_t SORT_BYTES = 2 * SORT_SMALL_CAP * 8;
+    constexpr size_t LDS_BYTES = REC_BYTES + MK_BYTES > SORT_BYTES ? REC_BYTES + MK_BYTES : SORT_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     float4* const ga = reinterpret_cast<float4*>(smem);
     float4* const gb = ga + CH;
@@ -162,7 +163,11 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             // (positions past the end of the list park zeros: a lane without a candidate reads some slot of its current
             // word and multiplies it by a zero weight -- the slot has to hold finite numbers)
             store_rec<C>(ga, gb, gc, q * 256 + threadIdx.x, a_nxt[q], b_nxt[q], col_nxt[q]);
+#ifdef GSR_EXP_NOMASK
+            if (false) {
+#else
             if (c0 + q * 256 + wave * 64 < n) {   // (wave-uniform) the unit exists
+#endif
                 const int hw = 2 * (4 * q + wave);
                 uint2* const gm = masks + ((size_t)(unit0 + u_lo + 4 * q + wave) * 4) * 64 + lane;
                 unit_masks(a_nxt[q], b_nxt[q], tx * TILE, ty * TILE, tc, [&](int blk, uint32_t lo, uint32_t hi) {
@@ -188,6 +193,9 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         uint32_t cur = 0, nw = 0;
         int h = 0, nh = 0;
         if (nz != 0u) { nh = __builtin_ctz(nz); nw = mk[wave][nh][lane]; nz &= nz - 1u; }
+#ifdef GSR_EXP_NOWALK
+        nz = 0; nw = 0;
+#endif
         while (true) {
             const bool need = cur == 0u;
             cur = need ? nw : cur;

@@ -7,7 +7,8 @@
 
 namespace gsr {
 
-// ---- register-resident bitonic sort for buckets of up to 2 048 keys (every tile of a typical view).
+// ---- register-resident bitonic sort (tiles of 2 049 .. 16 384 keys: tile_sort_big_kernel; its cross-lane stage also sorts
+// the 64-key runs of the merge sort below).
 // The LDS network above moves 32 bytes through LDS per compare-exchange; with eight workgroups per CU that
 // traffic, not the comparisons, bounded the kernel.  Here every thread keeps E consecutive keys in registers
 // (blocked layout, 256 threads, E = 2 / 4 / 8 for 512 / 1 024 / 2 048 padded keys):
@@ -106,7 +107,75 @@ __device__ __forceinline__ void sort_tile_in_registers(uint64_t* __restrict__ s,
         if (e0 + r < n) out[e0 + r] = (uint32_t)v[r];
 }
 
-// One tile of 1 .. 2 048 keys, 256 threads, s = 2 048 x 8 bytes of LDS (used by the cross-wave stages only).
+// ---- merge sort for buckets of up to 2 048 keys (every tile of a typical view), 256 threads.
+// The register network above costs O(log^2 n) compare-exchanges PER KEY (55 stages for 1 024 padded keys, 66 for 2 048) and
+// pads n to a power of two; measured inside the forward blend it was the largest single consumer of issue slots (10.6 M vector
+// + 10.5 M scalar instructions per 1080p view, 34 us on the critical path of a 1 300-entry tile).  Here:
+//   1. every wave sorts runs of 64 keys in registers (one key per lane, the 21 cross-lane stages of the network above);
+//   2. log2(n / 64) merge levels through LDS (two buffers, ping-pong): a thread owns E consecutive OUTPUT positions of its
+//      pair of runs, finds where they start in the two inputs with one binary search along the merge path (keys are
+//      unique: depth bits << 32 | Gaussian id), and merges E keys sequentially.  ~135 instructions per thread and level.
+// No padding beyond the last run: runs are clipped to n.
+constexpr uint32_t SORT_SMALL_CAP = 2048;                       // keys; the caller provides 2 * SORT_SMALL_CAP * 8 bytes of LDS
+
+template <uint32_t K, uint32_t J>
+__device__ __forceinline__ void run64_stages(uint64_t (&v)[1], int lane)
+{
+    cross_lane_stage<1, (int)J>(v, (uint32_t)lane, K, lane);
+    if constexpr (J > 1) run64_stages<K, J / 2>(v, lane);
+    else if constexpr (K < 64) run64_stages<K * 2, K>(v, lane);
+}
+
+template <int E>
+__device__ __forceinline__ void sort_tile_merge(uint64_t* __restrict__ s, const uint64_t* __restrict__ gk,
+                                                uint32_t* __restrict__ out, uint32_t n)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint64_t* A = s;
+    uint64_t* B = s + SORT_SMALL_CAP;
+    const uint32_t n_runs = (n + 63u) >> 6;
+    for (uint32_t r = wave; r < n_runs; r += 4u) {
+        const uint32_t i = r * 64u + lane;
+        uint64_t v[1] = {i < n ? gk[i] : ~0ull};
+        run64_stages<2, 1>(v, (int)lane);
+        A[i] = v[0];
+    }
+    __syncthreads();
+    const uint32_t o0 = tid * (uint32_t)E;                       // this thread's output positions [o0, o0 + E) on every level
+    for (uint32_t len = 64u; len < n; len <<= 1) {
+        uint64_t res[E];
+        if (o0 < n) {
+            const uint32_t base = o0 & ~(2u * len - 1u);        // E divides 2 len: the E outputs lie in one pair of runs
+            const uint32_t la = min(len, n - base);
+            const uint32_t lb = base + len < n ? min(len, n - base - len) : 0u;
+            const uint64_t* a = A + base;
+            const uint64_t* b = A + base + len;
+            const uint32_t d = o0 - base;
+            uint32_t lo = d > lb ? d - lb : 0u, hi = min(d, la);
+            while (lo < hi) {                                   // merge path: how many of the first d outputs come from a
+                const uint32_t mid = (lo + hi) >> 1;
+                if (a[mid] < b[d - 1u - mid]) lo = mid + 1u; else hi = mid;
+            }
+            uint32_t ai = lo, bi = d - lo;
+            uint64_t ka = ai < la ? a[ai] : ~0ull, kb = bi < lb ? b[bi] : ~0ull;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const bool take_a = bi >= lb || (ai < la && ka < kb);
+                res[e] = take_a ? ka : kb;
+                if (take_a) { ai++; ka = ai < la ? a[ai] : ~0ull; }
+                else { bi++; kb = bi < lb ? b[bi] : ~0ull; }
+            }
+#pragma unroll
+            for (int e = 0; e < E; e++)
+                if (o0 + (uint32_t)e < n) B[o0 + e] = res[e];
+        }
+        __syncthreads();                                        // level done: B complete, nobody reads A any more
+        uint64_t* t = A; A = B; B = t;
+    }
+    for (uint32_t i = tid; i < n; i += 256u) out[i] = (uint32_t)A[i];
+}
+
+// One tile of 1 .. 2 048 keys, 256 threads, s = 2 * SORT_SMALL_CAP * 8 bytes of LDS.
 // Must be called by all 256 threads of the workgroup (it contains workgroup barriers).
 __device__ __forceinline__ void sort_small_tile(uint64_t* __restrict__ s, const uint64_t* __restrict__ gk,
                                                 uint32_t* __restrict__ out, uint32_t n)
@@ -115,11 +184,9 @@ __device__ __forceinline__ void sort_small_tile(uint64_t* __restrict__ s, const 
         if (threadIdx.x == 0) out[0] = (uint32_t)gk[0];
         return;
     }
-    uint32_t np2 = 2;
-    while (np2 < n) np2 <<= 1;
-    if (np2 <= 512u) sort_tile_in_registers<2>(s, gk, out, n, np2);
-    else if (np2 == 1024u) sort_tile_in_registers<4>(s, gk, out, n, np2);
-    else sort_tile_in_registers<8>(s, gk, out, n, np2);
+    if (n <= 512u) sort_tile_merge<2>(s, gk, out, n);
+    else if (n <= 1024u) sort_tile_merge<4>(s, gk, out, n);
+    else sort_tile_merge<8>(s, gk, out, n);
 }
 
 }  // namespace gsr

@@ -1,10 +1,10 @@
-"""Generate tests/golden/cameras_ref.json + cameras_ref.npz by IMPORTING the reference's own camera code
+"""Generate tests/golden/formats_cameras_ref.json + formats_cameras_ref.npz by IMPORTING the reference's own camera code
 (runs only where /root/reference exists; the fixtures -- data only -- are committed):
 
-  * cameras_ref.json is written by the reference's writer, camera_to_JSON
+  * formats_cameras_ref.json is written by the reference's writer, camera_to_JSON
     (gaussian_splatting/utils/camera_utils.py:70-89), from duck-typed cameras (R, T, FovX, FovY, width, height,
     image_name -- the attributes it reads);
-  * cameras_ref.npz holds, per camera, the matrices the reference's reader side builds from such an entry
+  * formats_cameras_ref.npz holds, per camera, the matrices the reference's reader side builds from such an entry
     (gaustar_scene/cameras.py:55-69 -> GSCamera, gaussian_splatting/scene/cameras.py:56-59): world_view =
     getWorld2View2(R, T)^T, full_proj = world_view @ getProjectionMatrix(0.01, 100, fovx, fovy)^T, camera centre --
     computed with the reference's getWorld2View2 / getProjectionMatrix / focal2fov (utils/graphics_utils.py).
@@ -51,7 +51,7 @@ def main():
             height = int(rng.integers(200, 1200))
             image_name = f"img_{(7 * i) % 6:04d}"     # not in id order: the reader sorts by name (cameras.py:37)
         entries.append(camera_to_JSON(i, Duck))
-    with open(os.path.join(HERE, "cameras_ref.json"), "w") as f:
+    with open(os.path.join(HERE, "formats_cameras_ref.json"), "w") as f:
         json.dump(entries, f)
     # the reader side (cameras.py:35-78), sorted by img_name
     for e in sorted(entries, key=lambda x: x["img_name"]):
@@ -66,8 +66,8 @@ def main():
         exp["view_t"].append(view_t.numpy()); exp["full_t"].append(full_t.numpy())
         exp["campos"].append(view_t.inverse()[3, :3].numpy())
         exp["tanfov"].append([np.tan(fovx * 0.5), np.tan(fovy * 0.5)]); exp["size"].append([e["width"], e["height"]])
-    np.savez(os.path.join(HERE, "cameras_ref.npz"), **{k: np.asarray(v) for k, v in exp.items()})
-    print("wrote cameras_ref.json / cameras_ref.npz:", len(entries), "cameras")
+    np.savez(os.path.join(HERE, "formats_cameras_ref.npz"), **{k: np.asarray(v) for k, v in exp.items()})
+    print("wrote formats_cameras_ref.json / formats_cameras_ref.npz:", len(entries), "cameras")
 
 
 if __name__ == "__main__":

@@ -117,15 +117,15 @@ def test_sugar_checkpoint_round_trip(tmp_path):
 
 
 def test_cameras_json_written_by_the_reference():
-    """tests/golden/cameras_ref.json was written by the reference's camera_to_JSON (camera_utils.py:70-89) and
-    cameras_ref.npz holds what the reference's reader + GSCamera build from it (tests/golden/make_formats_golden.py):
+    """tests/golden/formats_cameras_ref.json was written by the reference's camera_to_JSON (camera_utils.py:70-89) and
+    formats_cameras_ref.npz holds what the reference's reader + GSCamera build from it (tests/golden/make_formats_golden.py):
     formats.load_cameras_json must reproduce those matrices, and formats.camera_to_json_entry must write the
     reference's entries back."""
     import json
     from gaustar_amd import formats
     g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-    cams = formats.load_cameras_json(os.path.join(g, "cameras_ref.json"), znear=0.01, zfar=100.0)
-    z = np.load(os.path.join(g, "cameras_ref.npz"))
+    cams = formats.load_cameras_json(os.path.join(g, "formats_cameras_ref.json"), znear=0.01, zfar=100.0)
+    z = np.load(os.path.join(g, "formats_cameras_ref.npz"))
     assert len(cams) == len(z["view_t"]) == 6
     assert [c.name for c in cams] == sorted(c.name for c in cams)          # sorted by img_name like cameras.py:37
     for i, c in enumerate(cams):
@@ -134,7 +134,7 @@ def test_cameras_json_written_by_the_reference():
         np.testing.assert_allclose(c.campos, z["campos"][i], rtol=0, atol=5e-6)
         np.testing.assert_allclose([c.tanfovx, c.tanfovy], z["tanfov"][i], rtol=1e-6)
         assert [c.W, c.H] == z["size"][i].tolist()
-    ref_entries = {e["img_name"]: e for e in json.load(open(os.path.join(g, "cameras_ref.json")))}
+    ref_entries = {e["img_name"]: e for e in json.load(open(os.path.join(g, "formats_cameras_ref.json")))}
     for c in cams:
         ours, ref = formats.camera_to_json_entry(c.uid, c, c.name), ref_entries[c.name]
         assert ours["id"] == ref["id"] and ours["width"] == ref["width"] and ours["height"] == ref["height"]

@@ -6,7 +6,7 @@ HBM bytes per launch follow MI355X_MICROARCH.md's HBM section: FETCH_SIZE and WR
 so it is doubled.  Calibration on a kernel of known traffic in this very run (geom_bwd_kernel: 124 B read and
 92 B written per Gaussian, 491 520 Gaussians) confirms both: 2*FETCH_SIZE = 61.1 MB vs 60.9 MB expected,
 WRITE_SIZE = 45.2 MB vs 45.2 MB expected."""
-import json, os, re, sys
+import hashlib, json, os, re, sys
 
 tag, name = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -38,13 +38,21 @@ for l in pmc.splitlines():
         kern.setdefault(cur, {})
     elif cur and "mean" in l:
         p = l.split()
-        kern[cur][p[0]] = kern[cur].get(p[0], 0.0) + float(p[2]) if p[0] in kern[cur] and cur == "tile_sort_kernel" else float(p[2])
+        kern[cur][p[0]] = float(p[2])
 res = {}
 for k, c in kern.items():
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         res[k] = {"hbm_bytes_per_launch": int((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024),
                   "fetch_size_kib": c["FETCH_SIZE"], "write_size_kib": c["WRITE_SIZE"],
-                  "valu_insts": c.get("SQ_INSTS_VALU"), "atomic_requests": c.get("TCC_EA0_ATOMIC_sum")}
+                  "valu_insts": c.get("SQ_INSTS_VALU"), "salu_insts": c.get("SQ_INSTS_SALU"), "lds_insts": c.get("SQ_INSTS_LDS"),
+                  "lds_bank_conflict_cycles": c.get("SQ_LDS_BANK_CONFLICT"), "lds_active_cycles": c.get("SQ_ACTIVE_INST_LDS"),
+                  "atomic_requests": c.get("TCC_EA0_ATOMIC_sum")}
 res["_source"] = f"profiles/{name}_pmc.txt (2*FETCH_SIZE + WRITE_SIZE, KiB; see tools/summarize_profiles.py)"
+# the counters describe THESE kernels: bench.py drops them (traffic = null) once gaustar_amd/csrc has changed
+h = hashlib.sha256()
+csrc = os.path.join(root, "gaustar_amd", "csrc")
+for f in sorted(os.listdir(csrc)):
+    h.update(f.encode()); h.update(open(os.path.join(csrc, f), "rb").read())
+res["_csrc_sha256"] = h.hexdigest()
 json.dump(res, open(os.path.join(dst, "pmc_latest.json"), "w"), indent=1)
 print(json.dumps(res, indent=1)[:1500])
