@@ -8,14 +8,15 @@
 // per tile over the whole list and issues 9 global float atomicAdds per contributing (pixel, Gaussian) pair
 // (backward.cu:523, :545-554).  Here
 //
-//  * the work unit is a (tile, SEGMENT of SEG list positions, 8x8 pixel block) triple, one wave64 each.
+//  * the work unit is a (tile, SEGMENT of 64 list positions, 8x8 pixel block) triple, one wave64 each.
 //    A pixel whose last contributor lies beyond the segment starts from the forward pass's snapshot at the
 //    segment's far boundary: T = T_snap, accum_rec = (C_final - C_snap) / T_snap -- exactly the state the
 //    reference's back-to-front recurrence has at that list position; a pixel that ends inside the segment
 //    starts from (T_final, 0) like the reference; a pixel that ended before it is idle.  Units have bounded
 //    size, so the dispatcher can balance them and nothing carries a 1 600-instance serial chain;
-//  * lane i fetches instance i of the segment; instances that cannot reach alpha >= 1/255 inside the block
-//    (exact test, block_min_half_quad) never enter the LDS queue;
+//  * which instances of the segment the block needs comes from the forward's per-pixel candidate words (gsr_mask.h):
+//    the OR over the block's pixels of (word AND "positions this pixel replays").  Only those are fetched (lane i
+//    takes position i) and queued in LDS -- no geometric test is repeated here;
 //  * for a queued instance every lane evaluates its pixel and produces just TWO numbers,
 //    w = alpha*T and r = G*dL_dalpha.  Everything the gradients need is a sum over the block's pixels of w or r
 //    times a per-pixel constant:   sum w*dL_dpix_{r,g,b}   and   sum r*{1, x, y, x^2, xy, y^2}  (x, y = pixel
@@ -99,8 +100,7 @@ constexpr int GRP = GSR_BWD_GRP;   // instances per MFMA group: A-operand rows 0
 constexpr int RSTRIDE = 68;     // floats per row of the r|w table: 64 pixels + 4 (16-byte aligned, spreads banks)
 
 constexpr int BSEG = SNAP_SEG;
-static_assert(BSEG % 64 == 0, "a unit is a whole number of 64-instance fetch batches");
-constexpr int UPS = BSEG / 64;   // 64-entry mask units per backward unit
+static_assert(BSEG == 64, "a unit is one 64-instance fetch batch (the forward's mask words have that granularity)");
 
 template <int C>
 __global__ void __launch_bounds__(64)
@@ -139,9 +139,6 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     if (blockIdx.x >= full * 4u) { unit = blockIdx.x >> 2; wave_sel = blockIdx.x & 3u; }   // ragged tail: plain map
     const int tile = (int)unit_tile[unit];
     const uint32_t unit0 = seg_off[tile];
-    // unit ids count 64-entry segments (the granularity of the mask words); a backward unit spans UPS of them and is
-    // worked by the first one's workgroups
-    if ((unit - unit0) % UPS != 0u) return;
     const int s0 = (int)(unit - unit0) * 64;           // this unit covers list positions [s0, s1)
     const int wave = (int)wave_sel, lane = threadIdx.x;
     const int tx = tile % gx, ty = tile / gx;
@@ -149,7 +146,7 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     const int px = sx + (lane & 7), py = sy + (lane >> 3);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
-    const float bx0 = (float)sx, bx1 = (float)(sx + SUB - 1), by0 = (float)sy, by1 = (float)(sy + SUB - 1);
+    const float bx0 = (float)sx, by0 = (float)sy;
 
     const uint2 rg = ranges[tile];
     const int n = (int)(rg.y - rg.x);
@@ -160,6 +157,11 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     const size_t HW = (size_t)H * W;
     const float T_final = inside ? final_T[pix] : 0.f;
     const int my_last = inside ? (int)n_contrib[pix] : 0;   // 1-based position of the last contributor
+    // this pixel's candidate word over the unit's 64 positions, from the forward (gsr_mask.h); the forward's lanes are
+    // the block's pixels in the same row-major order as here
+    const uint2* const my_words = masks + ((size_t)unit * 4 + wave) * 64 + lane;   // + 256 per unit
+    uint2 word = make_uint2(0u, 0u);
+    if (my_last > s0) word = my_words[0];
     float dp[C];
     float bg_dot_dpixel = 0.f;
 #pragma unroll
@@ -189,18 +191,12 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         // between this unit's far end and that segment, so it is the state at list position s1.  Almost always that is
         // the very next segment: its snapshot is requested together with its mask words, and only a pixel whose words
         // there are empty walks on.
-        uint32_t useg = unit + UPS;
+        uint32_t useg = unit + 1u;
         const uint32_t u_end = unit0 + (uint32_t)(n + 63) / 64u;
-        const auto words_of = [&](uint32_t u) {
-            uint32_t any = 0;
-#pragma unroll
-            for (int w = 0; w < UPS; w++)
-                if (u + w < u_end) { const uint2 m = masks[((size_t)(u + w) * 4 + wave) * 64 + lane]; any |= m.x | m.y; }
-            return any;
-        };
+        const auto words_of = [&](uint32_t u) { const uint2 w_ = my_words[(size_t)(u - unit) * 256]; return w_.x | w_.y; };
         load_snapshot<C>(snap + ((size_t)useg * 256 + pidx) * SV, Ts, cs);
         if (words_of(useg) == 0u) {
-            do { useg += UPS; } while (useg + UPS < u_end && words_of(useg) == 0u);
+            do { useg++; } while (useg + 1u < u_end && words_of(useg) == 0u);
             load_snapshot<C>(snap + ((size_t)useg * 256 + pidx) * SV, Ts, cs);
         }
         load_snapshot<C>(snap + ((size_t)unit0 * 256 + pidx) * SV, Tf, cf);   // final (T, C) kept in the tile's first slot
@@ -210,19 +206,20 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         for (int ch = 0; ch < C; ch++) acc[ch] = (cf[ch] - cs[ch]) * inv;
     }
 
-    // Nothing behind the deepest position any pixel of this wave replays can matter.  In every segment but a
-    // pixel's last one that is simply the segment end (one ballot); only otherwise reduce.
-    int wave_hi;
-    if (__ballot(my_last >= s1) != 0ull) {
-        wave_hi = s1;
-    } else
+    // Which of the unit's positions ANY pixel of the block replays: the OR over the lanes of (candidate word AND
+    // "positions below this pixel's limit").  No geometric test is repeated here, and only these instances are fetched.
     {
-        wave_hi = my_lim;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) wave_hi = max(wave_hi, __shfl_xor(wave_hi, d, 64));
-        wave_hi = __builtin_amdgcn_readfirstlane(wave_hi);
+        const int lim = my_lim - s0;                         // <= 64; <= 0: nothing
+        word.x &= lim >= 32 ? 0xffffffffu : lim > 0 ? (1u << lim) - 1u : 0u;
+        word.y &= lim >= 64 ? 0xffffffffu : lim > 32 ? (1u << (lim - 32)) - 1u : 0u;
     }
-    if (wave_hi <= s0) return;
+    uint32_t olo = word.x, ohi = word.y;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { olo |= (uint32_t)__shfl_xor((int)olo, d, 64); ohi |= (uint32_t)__shfl_xor((int)ohi, d, 64); }
+    const unsigned long long kany = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)ohi) << 32) |
+                                    (uint32_t)__builtin_amdgcn_readfirstlane((int)olo);
+    if (kany == 0ull) return;
+    const int wave_hi = s0 + 64 - __builtin_clzll(kany);   // one past the deepest queued position
 
     // The unit is walked back to front in batches of 64 list positions; lane l of a batch takes position hi-1-l
     // (queue order == back-to-front order).
@@ -264,11 +261,10 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     }
     __builtin_amdgcn_wave_barrier();
 
-    for (int hi = wave_hi; hi > s0; hi -= 64) {
-    const int k = hi - 1 - lane;
-    const FetchedB<C> cur = fetch_instance_b<C>(k, s0, list, g0, g1, feats);
-    const bool keep = block_min_half_quad(cur.a.z, cur.a.w, cur.b.x, bx0 - cur.a.x, bx1 - cur.a.x, by0 - cur.a.y,
-                                          by1 - cur.a.y) <= cur.b.z;
+    {
+    const int k = wave_hi - 1 - lane;
+    const bool keep = k >= s0 && ((kany >> ((k - s0) & 63)) & 1ull) != 0ull;
+    const FetchedB<C> cur = fetch_instance_b<C>(k, keep ? k : k + 1, list, g0, g1, feats);
     const unsigned long long m = __ballot(keep);
     const int cnt_all = __popcll(m);
     // The queue holds QCAP of the batch's up to 64 kept instances at a time (LDS per workgroup decides how many units are
