@@ -359,7 +359,8 @@ int forward_stage2_impl(int P, int R, int max_tile_instances, int num_segments, 
     const float* feats = colors_precomp ? colors_precomp : g.rgb;
     {
         Scope sc(ST_BLEND_FWD, st);
-        launch_blend_fwd(C, W, H, background, feats, g, im, b, out_color, !forward_only, grad_scratch,
+        launch_blend_fwd(C, W, H, num_segments, (uint32_t)(max_tile_instances > 0 ? max_tile_instances : 0), background, feats, g, im, b,
+                         out_color, !forward_only, grad_scratch,
                          grad_scratch ? gsr_grad_scratch_bytes(P > 0 ? P : 0) : 0, counters, sort_in_blend, st);
     }
     GSR_CHECK_LAUNCH("blend_fwd_kernel");

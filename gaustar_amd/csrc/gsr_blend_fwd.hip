@@ -37,6 +37,8 @@
 
 namespace gsr {
 
+constexpr uint32_t LONG_LIST = 2048;   // lists above this get their candidate words from tile_mask_kernel (below)
+
 template <int C, int CH>
 __global__ void __launch_bounds__(256)
 blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ order,
@@ -99,6 +101,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     }
     const uint32_t* list = point_list + list0;
     const TransposeConsts tc(lane);
+    const bool words_ready = n > LONG_LIST;   // (wave-uniform) candidate words already in global memory
 
     // The kernel's span is its longest tile (a pixel's walk is serial), and co-resident waves share a SIMD's issue slots:
     // long lists get issue priority so that they do not also run at 1/7 speed (0.088 -> 0.084 ms on config C).
@@ -163,18 +166,25 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             // (positions past the end of the list park zeros: a lane without a candidate reads some slot of its current
             // word and multiplies it by a zero weight -- the slot has to hold finite numbers)
             store_rec<C>(ga, gb, gc, q * 256 + threadIdx.x, a_nxt[q], b_nxt[q], col_nxt[q]);
-#ifdef GSR_EXP_NOMASK
-            if (false) {
-#else
             if (c0 + q * 256 + wave * 64 < n) {   // (wave-uniform) the unit exists
-#endif
                 const int hw = 2 * (4 * q + wave);
                 uint2* const gm = masks + ((size_t)(unit0 + u_lo + 4 * q + wave) * 4) * 64 + lane;
-                unit_masks(a_nxt[q], b_nxt[q], tx * TILE, ty * TILE, tc, [&](int blk, uint32_t lo, uint32_t hi) {
-                    mk[blk][hw][lane] = lo;
-                    mk[blk][hw + 1][lane] = hi;
-                    if (keep) gm[blk * 64] = make_uint2(lo, hi);
-                });
+                if (words_ready) {
+                    // long list: tile_mask_kernel has produced the words, one wave per unit, before this launch -- a
+                    // 12 000-entry tile would otherwise spend its time on 184 units' worth of interval solves, serially
+#pragma unroll
+                    for (int blk = 0; blk < 4; blk++) {
+                        const uint2 m = gm[blk * 64];
+                        mk[blk][hw][lane] = m.x;
+                        mk[blk][hw + 1][lane] = m.y;
+                    }
+                } else {
+                    unit_masks(a_nxt[q], b_nxt[q], tx * TILE, ty * TILE, tc, [&](int blk, uint32_t lo, uint32_t hi) {
+                        mk[blk][hw][lane] = lo;
+                        mk[blk][hw + 1][lane] = hi;
+                        if (keep) gm[blk * 64] = make_uint2(lo, hi);
+                    });
+                }
             }
         }
         fetch_records();
@@ -193,9 +203,6 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         uint32_t cur = 0, nw = 0;
         int h = 0, nh = 0;
         if (nz != 0u) { nh = __builtin_ctz(nz); nw = mk[wave][nh][lane]; nz &= nz - 1u; }
-#ifdef GSR_EXP_NOWALK
-        nz = 0; nw = 0;
-#endif
         while (true) {
             const bool need = cur == 0u;
             cur = need ? nw : cur;
@@ -264,12 +271,35 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     }
 }
 
+// Candidate words of the tiles above LONG_LIST entries (close-up views), one wave per unit: a 12 000-entry tile is 188
+// independent waves here instead of 47 serial mask phases of its forward workgroup.
+__global__ void __launch_bounds__(64)
+tile_mask_kernel(int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ seg_off,
+                 const uint32_t* __restrict__ unit_tile, const uint32_t* __restrict__ point_list,
+                 const float4* __restrict__ g0, const float4* __restrict__ g1, uint2* __restrict__ masks)
+{
+    const uint32_t unit = blockIdx.x;
+    const int tile = (int)unit_tile[unit];
+    const uint2 rg = ranges[tile];
+    const uint32_t n = rg.y - rg.x;
+    if (n <= LONG_LIST) return;
+    const int lane = threadIdx.x;
+    const TransposeConsts tc(lane);
+    const uint32_t k = (unit - seg_off[tile]) * 64u + (uint32_t)lane;
+    float4 a = make_float4(0.f, 0.f, 1.f, 0.f), b = make_float4(1.f, 0.f, -1.f, 0.f);   // tau = -1: no instance
+    if (k < n) { const uint32_t gid = point_list[rg.x + k]; a = g0[gid]; b = g1[gid]; }
+    uint2* const gm = masks + (size_t)unit * 256 + lane;
+    unit_masks(a, b, (tile % gx) * TILE, (tile / gx) * TILE, tc, [&](int blk, uint32_t lo, uint32_t hi) { gm[blk * 64] = make_uint2(lo, hi); });
+}
+
 template <int C>
-static void launch_fwd_c(int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
-                         float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, uint32_t* counters,
+static void launch_fwd_c(int W, int H, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im,
+                         BinState b, float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, uint32_t* counters,
                          bool sort_small, hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);
+    if (max_count > LONG_LIST && U > 0)   // (such lists were sorted by the big-sort kernels before: launch_tile_sort)
+        tile_mask_kernel<<<U, 64, 0, st>>>(t.gx, im.ranges, im.seg_off, b.unit_tile, b.point_list, g.g0, g.g1, b.masks);
     blend_fwd_kernel<C, FWD_CHUNK><<<t.T, 256, 0, st>>>(W, H, t.gx, im.ranges, im.order, b.point_list,
                                                         sort_small ? b.keys : nullptr, g.g0, g.g1, feats, bg,
                                                         out_color, im.final_T, im.n_contrib, im.seg_off, b.masks,
@@ -278,13 +308,13 @@ static void launch_fwd_c(int W, int H, const float* bg, const float* feats, Geom
                                                         (uint32_t)shard_stride(t.T), g_trace);
 }
 
-void launch_blend_fwd(int C, int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
-                      float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, uint32_t* counters,
+void launch_blend_fwd(int C, int W, int H, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im,
+                      BinState b, float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, uint32_t* counters,
                       bool sort_small, hipStream_t st)
 {
-    if (C == 6) launch_fwd_c<6>(W, H, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, sort_small, st);
-    else if (C == 4) launch_fwd_c<4>(W, H, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, sort_small, st);
-    else launch_fwd_c<3>(W, H, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, sort_small, st);
+    if (C == 6) launch_fwd_c<6>(W, H, U, max_count, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, sort_small, st);
+    else if (C == 4) launch_fwd_c<4>(W, H, U, max_count, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, sort_small, st);
+    else launch_fwd_c<3>(W, H, U, max_count, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, sort_small, st);
 }
 
 }  // namespace gsr

@@ -197,9 +197,9 @@ inline int front_of_order(int R, int T)
     const long long bound = ((long long)(R > 0 ? R : 0) / 2017 + 1 + 255) / 256 * 256;
     return (int)(bound < (long long)T ? bound : (long long)T);
 }
-void launch_blend_fwd(int C, int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
-                      float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, uint32_t* counters, bool sort_small,
-                      hipStream_t st);
+void launch_blend_fwd(int C, int W, int H, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im,
+                      BinState b, float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, uint32_t* counters,
+                      bool sort_small, hipStream_t st);
 void launch_blend_bwd(int C, int W, int H, int U, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
                       const float* dL_dpix, float* grad_acc, hipStream_t st);
 void launch_geom_bwd(int P, int D, int M, const float* means3D, const float* shs, const float* scales,
