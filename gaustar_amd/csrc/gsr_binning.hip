@@ -231,18 +231,20 @@ __global__ void __launch_bounds__(256)
 scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __restrict__ g0,
                const float4* __restrict__ g1, const float* __restrict__ depth, uint32_t* __restrict__ tile_cursor,
                uint64_t* __restrict__ keys, int T, const uint32_t* __restrict__ seg_off,
-               uint32_t* __restrict__ unit_tile, const uint32_t* __restrict__ tile_count,
+               uint4* __restrict__ unit_info, const uint32_t* __restrict__ tile_count,
                const uint2* __restrict__ ranges)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int shard = (int)(blockIdx.x & (NSHARD - 1));
     const size_t Tp = shard_stride(T);
-    // side job of the first T threads: expand the per-tile segment counts into the unit -> tile table
-    // (it lives in the binning buffer, which did not exist yet when the scan kernel ran; read by tile_mask_kernel)
+    // side job of the first T threads: expand the per-tile segment counts into the unit table -- everything a unit of
+    // the backward blend (or of tile_mask_kernel) has to know about its tile in ONE 16-byte load instead of a chain of
+    // three (it lives in the binning buffer, which did not exist yet when the scan kernel ran)
     if (idx < T) {
         const uint32_t u0 = seg_off[idx], u1 = seg_off[idx + 1];
-        for (uint32_t u = u0; u < u1; u++) unit_tile[u] = (uint32_t)idx;
+        const uint2 rg = ranges[idx];
+        for (uint32_t u = u0; u < u1; u++) unit_info[u] = make_uint4((uint32_t)idx, rg.x, rg.y - rg.x, u0);
     }
     ushort4 r = make_ushort4(0, 0, 0, 0);
     float4 a = make_float4(0.f, 0.f, 1.f, 0.f), b = make_float4(1.f, 0.f, -1.f, 0.f);
@@ -281,7 +283,7 @@ void launch_scatter(int P, int W, int H, GeomState g, ImageState im, BinState b,
     const Tiles t = tiles_of(W, H);
     const int n = P > t.T ? P : t.T;
     scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(P, t.gx, g.rect, g.g0, g.g1, g.depth, im.tile_cursor, b.keys, t.T,
-                                                    im.seg_off, b.unit_tile, im.tile_count, im.ranges);
+                                                    im.seg_off, b.unit_info, im.tile_count, im.ranges);
 }
 
 // ---- per-tile bitonic sort of 64-bit keys in LDS.

@@ -40,6 +40,7 @@
 #include "gsr_internal.h"
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 namespace gsr {
 
@@ -59,33 +60,25 @@ template <int C> struct SlotLayout {
     static_assert(MOM0 + NM <= FLOATS, "moments must fit the slot");
 };
 
-template <int C> struct FetchedB { float4 a, b; float col[C]; uint32_t gid; };
-
-template <int C>
-__device__ __forceinline__ FetchedB<C> fetch_instance_b(int k, int k_min, const uint32_t* __restrict__ list,
-                                                        const float4* __restrict__ g0, const float4* __restrict__ g1,
-                                                        const float* __restrict__ feats)
+// A queue slot is read with explicit ds_read_b128 (uniform address): left to the compiler the colour words are read
+// inside the conditional "live" block, where the full LDS latency is exposed once per live pair, and nothing can be
+// requested one pair ahead across the branches.  lds_wait() is the matching s_waitcnt; the operands tie the uses to it,
+// and the "memory" clobber keeps the compiler's own LDS stores (queue fill, moments) on their side of a request.
+__device__ __forceinline__ uint32_t lds_byte_address(const void* p) { return (uint32_t)(size_t)p; }   // low half of the flat address
+template <int VECS> struct SlotRegs { f32x4 v[VECS]; };
+template <int VECS, int OFF>   // OFF: compile-time byte offset from `addr` (one address register serves a whole group)
+__device__ __forceinline__ void lds_request(SlotRegs<VECS>& r, uint32_t addr)
 {
-    FetchedB<C> f;
-    f.a = make_float4(0.f, 0.f, 1.f, 0.f);
-    f.b = make_float4(1.f, 0.f, -1.f, 0.f);   // tau = -1: never kept
-#pragma unroll
-    for (int ch = 0; ch < C; ch++) f.col[ch] = 0.f;
-    f.gid = 0;
-    if (k >= k_min) {
-        f.gid = list[k];
-        f.a = g0[f.gid];
-        f.b = g1[f.gid];
-        if constexpr (C % 2 == 0) {
-            const float2* pf = reinterpret_cast<const float2*>(feats + (size_t)C * f.gid);
-#pragma unroll
-            for (int ch = 0; ch < C; ch += 2) { const float2 v = pf[ch / 2]; f.col[ch] = v.x; f.col[ch + 1] = v.y; }
-        } else {
-#pragma unroll
-            for (int ch = 0; ch < C; ch++) f.col[ch] = feats[(size_t)C * f.gid + ch];
-        }
-    }
-    return f;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r.v[0]) : "v"(addr), "n"(OFF) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r.v[1]) : "v"(addr), "n"(OFF + 16) : "memory");
+    if constexpr (VECS > 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r.v[2]) : "v"(addr), "n"(OFF + 32) : "memory");
+    if constexpr (VECS > 3) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r.v[3]) : "v"(addr), "n"(OFF + 48) : "memory");
+}
+template <int VECS>
+__device__ __forceinline__ void lds_wait(SlotRegs<VECS>& r)
+{
+    if constexpr (VECS == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]), "+v"(r.v[3]));
 }
 
 __device__ __forceinline__ void atomic_add_f32(float* p, float v)
@@ -96,6 +89,12 @@ __device__ __forceinline__ void atomic_add_f32(float* p, float v)
 #ifndef GSR_BWD_GRP
 #define GSR_BWD_GRP 8
 #endif
+template <int... I, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
 constexpr int GRP = GSR_BWD_GRP;   // instances per MFMA group: A-operand rows 0..GRP-1 carry their r, the next GRP rows their w
 constexpr int RSTRIDE = 68;     // floats per row of the r|w table: 64 pixels + 4 (16-byte aligned, spreads banks)
 
@@ -103,11 +102,10 @@ constexpr int BSEG = SNAP_SEG;
 static_assert(BSEG == 64, "a unit is one 64-instance fetch batch (the forward's mask words have that granularity)");
 
 template <int C>
-__global__ void __launch_bounds__(64)
-blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ seg_off,
-                 const uint32_t* __restrict__ unit_tile, const float4* __restrict__ snap, const uint2* __restrict__ masks,
-                 const uint32_t* __restrict__ point_list, const float4* __restrict__ g0,
-                 const float4* __restrict__ g1, const float* __restrict__ feats, const float* __restrict__ bg,
+__device__ __forceinline__ void
+blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const float4* __restrict__ snap,
+                 const uint2* __restrict__ masks, const uint32_t* __restrict__ point_list, const float4* __restrict__ rec_a,
+                 const float4* __restrict__ rec_b, const RecTail<C>* __restrict__ rec_c, const float* __restrict__ bg,
                  const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
                  const float* __restrict__ dL_dpix, float* __restrict__ grad_acc, uint64_t* __restrict__ trace)
 {
@@ -115,6 +113,7 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     constexpr int SF = L::FLOATS, NM = L::NM, MOM0 = L::MOM0, SV = snap_vecs(C);
     static_assert(NM <= 16 && NM <= GRAD_RS, "moment columns must fit one MFMA tile and one record");
     static_assert((C + 1) * 64 <= 2 * GRP * RSTRIDE, "dL_dpix staging must fit the r|w table");
+    static_assert(L::VECS == 3 || L::VECS == 4, "slot reads are written for three or four float4");
     const uint64_t t_start = trace ? wall_clock64() : 0;
 #ifndef GSR_BWD_QCAP
 #define GSR_BWD_QCAP 32
@@ -126,7 +125,7 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     float* const Wm = Rm + GRP * RSTRIDE;
     // one wave64 per workgroup: unit = (tile, segment), wave = 8x8 block of the tile.
     // XCD-aware placement: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the
-    // naive map (unit = id / 4) would put the four blocks of a unit -- which gather the SAME instance records -- on
+    // naive map (unit = id / 4) would put the four blocks of a unit -- which read the SAME instance records -- on
     // four different L2s.  Instead the four blocks of a unit take four consecutive slots of ONE XCD.
     // Units of one tile are consecutive and also share their pixels' dL_dpix / T / n_contrib and the tile's final
     // snapshot, so an XCD takes RUNS of 8 consecutive units: of every 64 units, XCD x owns [8x, 8x + 8).
@@ -137,8 +136,16 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     uint32_t wave_sel = slot & 3u;
     const uint32_t full = (n_units >> 6) << 6;            // units covered by complete groups of 64
     if (blockIdx.x >= full * 4u) { unit = blockIdx.x >> 2; wave_sel = blockIdx.x & 3u; }   // ragged tail: plain map
-    const int tile = (int)unit_tile[unit];
-    const uint32_t unit0 = seg_off[tile];
+    // Everything the unit has to know about its tile in one (scalar) load; then EVERY vector load of the unit's head is
+    // requested before the first one is waited for -- pixel state, candidate words of this unit and the next, the two
+    // snapshots a resuming pixel needs, and the unit's 64 instance records, which the forward left in list order
+    // (rec_a/b/c).  As a chain (unit -> tile -> ranges -> n_contrib -> words -> snapshot; words -> list -> id -> geometry)
+    // the head of a unit was six dependent trips to memory, a third of a unit's life, with nothing to issue meanwhile.
+    const uint4 info = unit_info[unit];
+    const int tile = (int)info.x;
+    const uint32_t list0 = info.y;
+    const int n = (int)info.z;
+    const uint32_t unit0 = info.w;
     const int s0 = (int)(unit - unit0) * 64;           // this unit covers list positions [s0, s1)
     const int wave = (int)wave_sel, lane = threadIdx.x;
     const int tx = tile % gx, ty = tile / gx;
@@ -147,28 +154,44 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
     const float bx0 = (float)sx, by0 = (float)sy;
-
-    const uint2 rg = ranges[tile];
-    const int n = (int)(rg.y - rg.x);
     const int s1 = min(s0 + BSEG, n);
-    const uint32_t* list = point_list + rg.x;
+    const bool has_next = s1 < n;                       // (uniform) the tile has a unit behind this one
+    const bool multi = n > BSEG;                        // (uniform) the tile's first snapshot slot holds the final (T, C)
 
     const size_t pix = (size_t)W * py + px;
     const size_t HW = (size_t)H * W;
     const float T_final = inside ? final_T[pix] : 0.f;
     const int my_last = inside ? (int)n_contrib[pix] : 0;   // 1-based position of the last contributor
+    float dp[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) dp[ch] = inside ? dL_dpix[ch * HW + pix] : 0.f;
     // this pixel's candidate word over the unit's 64 positions, from the forward (gsr_mask.h); the forward's lanes are
     // the block's pixels in the same row-major order as here
     const uint2* const my_words = masks + ((size_t)unit * 4 + wave) * 64 + lane;   // + 256 per unit
-    uint2 word = make_uint2(0u, 0u);
-    if (my_last > s0) word = my_words[0];
-    float dp[C];
+    uint2 word = my_words[0];
+    const uint2 word_next = has_next ? my_words[256] : make_uint2(0u, 0u);
+    const int pidx = 16 * (py - ty * TILE) + (px - tx * TILE);
+    float Ts = 1.f, Tf = 0.f, cs[C], cf[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) cs[ch] = cf[ch] = 0.f;
+    if (has_next) load_snapshot<C>(snap + ((size_t)(unit + 1u) * 256 + pidx) * SV, Ts, cs);
+    if (multi) load_snapshot<C>(snap + ((size_t)unit0 * 256 + pidx) * SV, Tf, cf);   // final (T, C) kept in the tile's first slot
+    // lane l holds list position s0 + 63 - l (queue order == back-to-front order)
+    const int k = s0 + 63 - lane;
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+    RecTail<C> rc;
+#pragma unroll
+    for (int ch = 2; ch < C; ch++) rc.c[ch - 2] = 0.f;
+    uint32_t gid = 0;
+    if (k < n) {
+        ra = rec_a[list0 + k];
+        rb = rec_b[list0 + k];
+        rc = rec_c[list0 + k];
+        gid = point_list[list0 + k];
+    }
     float bg_dot_dpixel = 0.f;
 #pragma unroll
-    for (int ch = 0; ch < C; ch++) {
-        dp[ch] = inside ? dL_dpix[ch * HW + pix] : 0.f;
-        bg_dot_dpixel += bg[ch] * dp[ch];
-    }
+    for (int ch = 0; ch < C; ch++) bg_dot_dpixel += bg[ch] * dp[ch];
 
     // Per-pixel start state at the far end of the segment.
     float T = T_final;
@@ -184,22 +207,17 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     if (my_last > s1) {
         // the pixel blended instances beyond this segment: resume from the forward's snapshot taken before
         // list position s1.  accum_rec at that point = colour composited behind s1, seen from s1.
-        const int pidx = 16 * (py - ty * TILE) + (px - tx * TILE);
-        float Ts, Tf, cs[C], cf[C];
         // The forward stored a snapshot whenever the pixel moved on to a word of a new segment (gsr_blend_fwd.hip); the
         // first segment behind this unit in which the pixel has a candidate at all has one, and nothing was blended
         // between this unit's far end and that segment, so it is the state at list position s1.  Almost always that is
-        // the very next segment: its snapshot is requested together with its mask words, and only a pixel whose words
-        // there are empty walks on.
-        uint32_t useg = unit + 1u;
-        const uint32_t u_end = unit0 + (uint32_t)(n + 63) / 64u;
-        const auto words_of = [&](uint32_t u) { const uint2 w_ = my_words[(size_t)(u - unit) * 256]; return w_.x | w_.y; };
-        load_snapshot<C>(snap + ((size_t)useg * 256 + pidx) * SV, Ts, cs);
-        if (words_of(useg) == 0u) {
+        // the very next segment (requested above); only a pixel whose words there are empty walks on.
+        if ((word_next.x | word_next.y) == 0u) {
+            uint32_t useg = unit + 1u;
+            const uint32_t u_end = unit0 + (uint32_t)(n + 63) / 64u;
+            const auto words_of = [&](uint32_t u) { const uint2 w_ = my_words[(size_t)(u - unit) * 256]; return w_.x | w_.y; };
             do { useg++; } while (useg + 1u < u_end && words_of(useg) == 0u);
             load_snapshot<C>(snap + ((size_t)useg * 256 + pidx) * SV, Ts, cs);
         }
-        load_snapshot<C>(snap + ((size_t)unit0 * 256 + pidx) * SV, Tf, cf);   // final (T, C) kept in the tile's first slot
         const float inv = __builtin_amdgcn_rcpf(Ts);
         T = Ts;
 #pragma unroll
@@ -218,11 +236,18 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     for (int d = 32; d > 0; d >>= 1) { olo |= (uint32_t)__shfl_xor((int)olo, d, 64); ohi |= (uint32_t)__shfl_xor((int)ohi, d, 64); }
     const unsigned long long kany = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)ohi) << 32) |
                                     (uint32_t)__builtin_amdgcn_readfirstlane((int)olo);
+#ifdef GSR_TRACE_DETAIL
+    const uint64_t t_head = wall_clock64();
+    if (trace && lane == 0 && kany == 0ull) {
+        uint64_t* tw = trace + ((size_t)unit * 4 + wave) * 4;
+        tw[0] = t_start; tw[1] = t_head; tw[2] = t_head;
+        tw[3] = ((uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
+#endif
     if (kany == 0ull) return;
-    const int wave_hi = s0 + 64 - __builtin_clzll(kany);   // one past the deepest queued position
-
-    // The unit is walked back to front in batches of 64 list positions; lane l of a batch takes position hi-1-l
-    // (queue order == back-to-front order).
+#ifdef GSR_ABL_EARLY
+    if (T != 77.f) { if (acc[0] + ra.x + rb.y + rc.c[0] == 78.f) grad_acc[gid] = T; return; }
+#endif
 
     // B operand of the contraction, constant over the unit.  MFMA step t (0..15) consumes the four pixels
     // p = 16*kap + t, kap = 0..3; in the B operand lane l carries row kap = l >> 4, column col = l & 15.
@@ -262,9 +287,7 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     __builtin_amdgcn_wave_barrier();
 
     {
-    const int k = wave_hi - 1 - lane;
-    const bool keep = k >= s0 && ((kany >> ((k - s0) & 63)) & 1ull) != 0ull;
-    const FetchedB<C> cur = fetch_instance_b<C>(k, keep ? k : k + 1, list, g0, g1, feats);
+    const bool keep = ((kany >> (63 - lane)) & 1ull) != 0ull;
     const unsigned long long m = __ballot(keep);
     const int cnt_all = __popcll(m);
     // The queue holds QCAP of the batch's up to 64 kept instances at a time (LDS per workgroup decides how many units are
@@ -274,47 +297,61 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     const int slot = __popcll(m & ((1ull << lane) - 1ull)) - q0;
     if (keep && slot >= 0 && slot < QCAP) {
         float4* qs = reinterpret_cast<float4*>(&qf[slot * SF]);
-        float a2 = cur.a.z, b2 = cur.a.w, c2 = cur.b.x;
-        conic_to_exp2(a2, b2, c2);   // exp2-domain conic, the same roundings as the forward's slots
-        qs[0] = make_float4(cur.a.x, cur.a.y, __uint_as_float(cur.gid), a2);
-        qs[1] = make_float4(b2, c2, cur.b.y, __uint_as_float((uint32_t)k));
+        float col[C];
+        col[0] = rb.z; col[1] = rb.w;
+#pragma unroll
+        for (int ch = 2; ch < C; ch++) col[ch] = rc.c[ch - 2];
+        qs[0] = make_float4(ra.x, ra.y, __uint_as_float(gid), ra.z);      // the conic is already in the exp2 domain
+        qs[1] = make_float4(ra.w, rb.x, rb.y, __uint_as_float((uint32_t)k));
 #pragma unroll
         for (int v = 2; v < L::VECS; v++) {
             const int c0 = 4 * (v - 2);
-            qs[v] = make_float4(c0 < C ? cur.col[c0 < C ? c0 : 0] : 0.f, c0 + 1 < C ? cur.col[c0 + 1 < C ? c0 + 1 : 0] : 0.f,
-                                c0 + 2 < C ? cur.col[c0 + 2 < C ? c0 + 2 : 0] : 0.f,
-                                c0 + 3 < C ? cur.col[c0 + 3 < C ? c0 + 3 : 0] : 0.f);
+            qs[v] = make_float4(c0 < C ? col[c0 < C ? c0 : 0] : 0.f, c0 + 1 < C ? col[c0 + 1 < C ? c0 + 1 : 0] : 0.f,
+                                c0 + 2 < C ? col[c0 + 2 < C ? c0 + 2 : 0] : 0.f,
+                                c0 + 3 < C ? col[c0 + 3 < C ? c0 + 3 : 0] : 0.f);
         }
     }
     __builtin_amdgcn_wave_barrier();
 
+#ifdef GSR_ABL_NOLOOP
+    if (T != 77.f) { if (qf[lane] == 78.f) grad_acc[gid] = T; return; }
+#endif
     unsigned long long touched = 0ull;
+    const uint32_t q_base = lds_byte_address(qf);
     for (int g0i = 0; g0i < cnt; g0i += GRP) {
-        // ---- vector ALU: w and r of GRP instances for this lane's pixel, parked row-wise in LDS
-#pragma unroll
-        for (int jj = 0; jj < GRP; jj++) {
+        // ---- vector ALU: w and r of GRP instances for this lane's pixel, parked row-wise in LDS.  The slot of the
+        // group's first instance is requested here, every further one while its predecessor is being evaluated.
+        SlotRegs<L::VECS> nxt;
+        const uint32_t q_grp = q_base + (uint32_t)(g0i * SF * 4);
+        lds_request<L::VECS, 0>(nxt, q_grp);
+        static_for<GRP>([&](auto JJ) {
+            constexpr int jj = decltype(JJ)::value;
             const int j = g0i + jj;
             float r = 0.f, w = 0.f;
+            // Request and wait sit in straight-line code, outside the (uniform) j < cnt branch: registers with a load in
+            // flight must not cross a control-flow merge, where the compiler may copy them -- reading them before the
+            // data have landed.  Likewise the wait is on the requested registers themselves, the copy comes after it.
+            // (Slot j + 1 < QCAP exists in LDS; past the end of the queue it holds stale numbers nobody uses.)
+            lds_wait(nxt);
+            const SlotRegs<L::VECS> cur = nxt;
+            if constexpr (jj + 1 < GRP) lds_request<L::VECS, (jj + 1) * SF * 4>(nxt, q_grp);
             if (j < cnt) {
-                const float4* qs = reinterpret_cast<const float4*>(&qf[j * SF]);
-                const float4 A = qs[0], B = qs[1];
+                const float4 A = make_float4(cur.v[0][0], cur.v[0][1], cur.v[0][2], cur.v[0][3]);
+                const float4 B = make_float4(cur.v[1][0], cur.v[1][1], cur.v[1][2], cur.v[1][3]);
                 float cc[C];
 #pragma unroll
-                for (int v = 2; v < L::VECS; v++) {
-                    const float4 kv = qs[v];
-                    const int c0 = 4 * (v - 2);
-                    if (c0 < C) cc[c0 < C ? c0 : 0] = kv.x;
-                    if (c0 + 1 < C) cc[c0 + 1 < C ? c0 + 1 : 0] = kv.y;
-                    if (c0 + 2 < C) cc[c0 + 2 < C ? c0 + 2 : 0] = kv.z;
-                    if (c0 + 3 < C) cc[c0 + 3 < C ? c0 + 3 : 0] = kv.w;
-                }
+                for (int ch = 0; ch < C; ch++) cc[ch] = cur.v[2 + ch / 4][ch % 4];
                 const int pos = (int)__float_as_uint(B.w);
                 const float dx = A.x - pxf, dy = A.y - pyf;
                 const float power = pair_exp2_arg(A.w, B.x, B.y, dx, dy);
                 const float G = __builtin_amdgcn_exp2f(power);
                 const float alpha = fminf(ALPHA_MAX, B.z * G);
                 const bool live = pos < my_lim && power <= 0.0f && alpha >= ALPHA_MIN;
+#ifdef GSR_ABL_NOLIVE
+                if (power == 77.f) {
+#else
                 if (__ballot(live) != 0ull) {
+#endif
                     touched |= 1ull << j;
                     if (live) {
                         // accum_rec' = alpha c + (1 - alpha) accum_rec written as accum_rec + alpha (c - accum_rec):
@@ -336,7 +373,7 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             }
             Rm[jj * RSTRIDE + lane] = r;
             Wm[jj * RSTRIDE + lane] = w;
-        }
+        });
         __builtin_amdgcn_wave_barrier();
         // ---- matrix pipe: [16 rows = r and w of GRP instances] x [64 pixels] . [64 pixels x 16 columns].
         // A operand: lane l carries table row (l & 15) and, for step t, pixel 16*kap + t -> its 16 steps are
@@ -395,10 +432,41 @@ blend_bwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     __builtin_amdgcn_wave_barrier();   // the queue is rewritten by the next chunk / batch
     }   // chunks of the batch
     }   // batches of the unit
+#ifdef GSR_TRACE_DETAIL
+    if (trace && lane == 0) {
+        uint64_t* tw = trace + ((size_t)unit * 4 + wave) * 4;
+        tw[0] = t_start; tw[1] = t_head; tw[2] = wall_clock64();
+        tw[3] = ((uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
+    return;
+#endif
     if (trace && lane == 0) {   // last wave to finish wins the end stamp (monotone clock, max via atomic)
         if (wave == 0) trace[2 * unit] = t_start;
         atomicMax((unsigned long long*)&trace[2 * unit + 1], (unsigned long long)wall_clock64());
     }
+}
+
+template <int C>
+__global__ void __launch_bounds__(64)
+blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, const float4* __restrict__ snap,
+                 const uint2* __restrict__ masks, const uint32_t* __restrict__ point_list, const float4* __restrict__ rec_a,
+                 const float4* __restrict__ rec_b, const RecTail<C>* __restrict__ rec_c, const float* __restrict__ bg,
+                 const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+                 const float* __restrict__ dL_dpix, float* __restrict__ grad_acc, uint64_t* __restrict__ trace)
+{
+    blend_bwd_unit<C>(W, H, gx, unit_info, snap, masks, point_list, rec_a, rec_b, rec_c, bg, final_T, n_contrib, dL_dpix, grad_acc, trace);
+}
+// Three channels: the register allocator is told to stay within six waves per SIMD (80 registers; left alone it takes 82
+// and the kernel runs five: 0.141 vs 0.131 ms on config C).  Four and six channels would have to spill for that and lose.
+template <>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8)))
+blend_bwd_kernel<3>(int W, int H, int gx, const uint4* __restrict__ unit_info, const float4* __restrict__ snap,
+                    const uint2* __restrict__ masks, const uint32_t* __restrict__ point_list, const float4* __restrict__ rec_a,
+                    const float4* __restrict__ rec_b, const RecTail<3>* __restrict__ rec_c, const float* __restrict__ bg,
+                    const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+                    const float* __restrict__ dL_dpix, float* __restrict__ grad_acc, uint64_t* __restrict__ trace)
+{
+    blend_bwd_unit<3>(W, H, gx, unit_info, snap, masks, point_list, rec_a, rec_b, rec_c, bg, final_T, n_contrib, dL_dpix, grad_acc, trace);
 }
 
 void launch_blend_bwd(int C, int W, int H, int U, const float* bg, const float* feats, GeomState g, ImageState im,
@@ -411,8 +479,9 @@ void launch_blend_bwd(int C, int W, int H, int U, const float* bg, const float* 
     uint64_t* tr = g_trace ? g_trace + 2 * (size_t)t.T : nullptr;
     const auto go = [&](auto tag) {
         constexpr int CC = decltype(tag)::value;
-        blend_bwd_kernel<CC><<<4 * U, 64, pad, st>>>(W, H, t.gx, im.ranges, im.seg_off, b.unit_tile, b.snap, b.masks, b.point_list,
-                                                     g.g0, g.g1, feats, bg, im.final_T, im.n_contrib, dL_dpix, grad_acc, tr);
+        blend_bwd_kernel<CC><<<4 * U, 64, pad, st>>>(W, H, t.gx, b.unit_info, b.snap, b.masks, b.point_list, b.rec_a, b.rec_b,
+                                                     static_cast<const RecTail<CC>*>(b.rec_c), bg, im.final_T, im.n_contrib,
+                                                     dL_dpix, grad_acc, tr);
     };
     if (C == 6) go(std::integral_constant<int, 6>{});
     else if (C == 4) go(std::integral_constant<int, 4>{});

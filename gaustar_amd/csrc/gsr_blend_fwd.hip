@@ -46,7 +46,8 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                  const float4* __restrict__ g1,
                  const float* __restrict__ feats, const float* __restrict__ bg, float* __restrict__ out_color,
                  float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ seg_off,
-                 uint2* __restrict__ masks, float4* __restrict__ snap, float4* __restrict__ zero_ptr, uint32_t zero_n,
+                 uint2* __restrict__ masks, float4* __restrict__ snap, float4* __restrict__ rec_a, float4* __restrict__ rec_b,
+                 RecTail<C>* __restrict__ rec_c, float4* __restrict__ zero_ptr, uint32_t zero_n,
                  uint32_t* __restrict__ counters, uint32_t counters_tp, uint64_t* __restrict__ trace)
 {
     const uint64_t t_start = trace ? wall_clock64() : 0;
@@ -61,7 +62,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     constexpr int NH = CH / 32;                                       // 32-bit mask words per lane and chunk
     constexpr int PT = CH / 256;                                      // list positions per thread and chunk
     static_assert(CH % 256 == 0 && NH <= 32, "a chunk is a whole number of 256-thread fetch rounds; nz is one dword");
-    // LDS: ga[CH] | gb[CH] | gc[CH] (the staged instances, see store_rec) | mk[block][word][lane]; the sort in front of
+    // LDS: ga[CH] | gb[CH] | gc[CH] (the staged instances, see make_rec) | mk[block][word][lane]; the sort in front of
     // the walk (below) uses the same bytes for its cross-wave stages.  C = 3 at CH = 512: 34 KB, four workgroups per CU.
     constexpr size_t GC_BYTES = (sizeof(RecTail<C>) * CH + 15) / 16 * 16;
     constexpr size_t REC_BYTES = 32 * CH + GC_BYTES, MK_BYTES = sizeof(uint32_t) * 4 * NH * 64;
@@ -165,7 +166,20 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         for (int q = 0; q < PT; q++) {
             // (positions past the end of the list park zeros: a lane without a candidate reads some slot of its current
             // word and multiplies it by a zero weight -- the slot has to hold finite numbers)
-            store_rec<C>(ga, gb, gc, q * 256 + threadIdx.x, a_nxt[q], b_nxt[q], col_nxt[q]);
+            const InstRec<C> rec = make_rec<C>(a_nxt[q], b_nxt[q], col_nxt[q]);
+            ga[q * 256 + threadIdx.x] = rec.a;
+            gb[q * 256 + threadIdx.x] = rec.b;
+            gc[q * 256 + threadIdx.x] = rec.t;
+            if (keep) {
+                // the backward's units read their 64 records as three contiguous rows instead of gathering them again
+                // through list -> id -> geometry state (a chain of three dependent trips to memory at the head of a unit)
+                const uint32_t k = c0 + q * 256 + threadIdx.x;
+                if (k < n) {
+                    rec_a[list0 + k] = rec.a;
+                    rec_b[list0 + k] = rec.b;
+                    rec_c[list0 + k] = rec.t;
+                }
+            }
             if (c0 + q * 256 + wave * 64 < n) {   // (wave-uniform) the unit exists
                 const int hw = 2 * (4 * q + wave);
                 uint2* const gm = masks + ((size_t)(unit0 + u_lo + 4 * q + wave) * 4) * 64 + lane;
@@ -274,20 +288,19 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
 // Candidate words of the tiles above LONG_LIST entries (close-up views), one wave per unit: a 12 000-entry tile is 188
 // independent waves here instead of 47 serial mask phases of its forward workgroup.
 __global__ void __launch_bounds__(64)
-tile_mask_kernel(int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ seg_off,
-                 const uint32_t* __restrict__ unit_tile, const uint32_t* __restrict__ point_list,
+tile_mask_kernel(int gx, const uint4* __restrict__ unit_info, const uint32_t* __restrict__ point_list,
                  const float4* __restrict__ g0, const float4* __restrict__ g1, uint2* __restrict__ masks)
 {
     const uint32_t unit = blockIdx.x;
-    const int tile = (int)unit_tile[unit];
-    const uint2 rg = ranges[tile];
-    const uint32_t n = rg.y - rg.x;
+    const uint4 info = unit_info[unit];   // {tile, first entry, entries, first unit}
+    const int tile = (int)info.x;
+    const uint32_t n = info.z;
     if (n <= LONG_LIST) return;
     const int lane = threadIdx.x;
     const TransposeConsts tc(lane);
-    const uint32_t k = (unit - seg_off[tile]) * 64u + (uint32_t)lane;
+    const uint32_t k = (unit - info.w) * 64u + (uint32_t)lane;
     float4 a = make_float4(0.f, 0.f, 1.f, 0.f), b = make_float4(1.f, 0.f, -1.f, 0.f);   // tau = -1: no instance
-    if (k < n) { const uint32_t gid = point_list[rg.x + k]; a = g0[gid]; b = g1[gid]; }
+    if (k < n) { const uint32_t gid = point_list[info.y + k]; a = g0[gid]; b = g1[gid]; }
     uint2* const gm = masks + (size_t)unit * 256 + lane;
     unit_masks(a, b, (tile % gx) * TILE, (tile / gx) * TILE, tc, [&](int blk, uint32_t lo, uint32_t hi) { gm[blk * 64] = make_uint2(lo, hi); });
 }
@@ -299,11 +312,12 @@ static void launch_fwd_c(int W, int H, int U, uint32_t max_count, const float* b
 {
     const Tiles t = tiles_of(W, H);
     if (max_count > LONG_LIST && U > 0)   // (such lists were sorted by the big-sort kernels before: launch_tile_sort)
-        tile_mask_kernel<<<U, 64, 0, st>>>(t.gx, im.ranges, im.seg_off, b.unit_tile, b.point_list, g.g0, g.g1, b.masks);
+        tile_mask_kernel<<<U, 64, 0, st>>>(t.gx, b.unit_info, b.point_list, g.g0, g.g1, b.masks);
     blend_fwd_kernel<C, FWD_CHUNK><<<t.T, 256, 0, st>>>(W, H, t.gx, im.ranges, im.order, b.point_list,
                                                         sort_small ? b.keys : nullptr, g.g0, g.g1, feats, bg,
                                                         out_color, im.final_T, im.n_contrib, im.seg_off, b.masks,
-                                                        keep_masks ? b.snap : nullptr, static_cast<float4*>(zero_ptr),
+                                                        keep_masks ? b.snap : nullptr, b.rec_a, b.rec_b,
+                                                        static_cast<RecTail<C>*>(b.rec_c), static_cast<float4*>(zero_ptr),
                                                         (uint32_t)(zero_bytes / 16), counters,
                                                         (uint32_t)shard_stride(t.T), g_trace);
 }

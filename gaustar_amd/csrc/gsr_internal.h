@@ -116,10 +116,15 @@ __host__ __device__ constexpr int snap_vecs(int C) { return (C + 4) / 4; }
 __host__ __device__ constexpr bool channels_ok(int C) { return C == 3 || C == 4 || C == 6; }
 constexpr int GRAD_RS = 12;  // floats per record of the backward accumulation table: 6 geometric moments + C <= 6 colours
 
+__host__ __device__ constexpr size_t rec_tail_bytes(int C) { return C == 6 ? 16 : C == 4 ? 8 : 4; }   // == sizeof(RecTail<C>)
+
 struct BinState {            // per instance / per segment
     uint64_t* keys;          // [R] (depth_bits << 32) | gaussian, bucketed by tile, unsorted within the bucket
     uint32_t* point_list;    // [R] gaussian ids, tile-major, depth-ascending, ties by ascending id
-    uint32_t* unit_tile;     // [U] tile of segment (unit) u; its segment index is u - seg_off[tile]
+    float4* rec_a;           // [R] the forward's staged instance records in list order (make_rec: {x, y, a', b'},
+    float4* rec_b;           // [R] {c', opacity, colour 0, colour 1}, conic in the exp2 domain), written by blend_fwd
+    void* rec_c;             // [R] RecTail<C>: colours 2 .. C-1       for the backward's units (contiguous reads)
+    uint4* unit_info;        // [U] {tile, first list entry of the tile, entries of the tile, first unit of the tile}
     uint2* masks;            // [U][4 blocks][64 lanes] per-pixel 64-bit words over the unit's 64 list positions
                              // {positions 0-31, positions 32-63}; block = 2*by + bx, lane = 8*(y % 8) + (x % 8)
     float4* snap;            // [U][256][snap_vecs(C)] per-pixel {T, C0, C1, ...} BEFORE the first instance of segment
@@ -129,12 +134,16 @@ struct BinState {            // per instance / per segment
 };
 inline BinState carve_bin(void* base, int R, int U, int C = 3)
 {
+    // (everything up to and including `masks` sits at offsets that do not depend on C: the debug exports carve with C = 3)
     BinState s; size_t o = 0; char* b = (char*)base;
     s.keys = (uint64_t*)(b + o); o = align_up(o + 8 * (size_t)R);
     s.point_list = (uint32_t*)(b + o); o = align_up(o + 4 * (size_t)R);
-    s.unit_tile = (uint32_t*)(b + o); o = align_up(o + 4 * (size_t)U);
+    s.rec_a = (float4*)(b + o); o = align_up(o + 16 * (size_t)R);
+    s.rec_b = (float4*)(b + o); o = align_up(o + 16 * (size_t)R);
+    s.unit_info = (uint4*)(b + o); o = align_up(o + 16 * (size_t)U);
     s.masks = (uint2*)(b + o); o = align_up(o + sizeof(uint2) * 256 * (size_t)U);
     s.snap = (float4*)(b + o); o = align_up(o + sizeof(float4) * 256 * (size_t)snap_vecs(C) * (size_t)U);
+    s.rec_c = (void*)(b + o); o = align_up(o + rec_tail_bytes(C) * (size_t)R);
     s.bytes = o + 256;
     return s;
 }
@@ -594,18 +603,19 @@ __device__ __forceinline__ void for_each_tile_aggregated(ushort4 rect, float px,
 template <int C> struct RecTail { float c[C - 2]; };
 template <> struct __attribute__((aligned(8))) RecTail<4> { float c[2]; };
 template <> struct __attribute__((aligned(16))) RecTail<6> { float c[4]; };
+static_assert(sizeof(RecTail<3>) == rec_tail_bytes(3) && sizeof(RecTail<4>) == rec_tail_bytes(4) && sizeof(RecTail<6>) == rec_tail_bytes(6), "");
+template <int C> struct InstRec { float4 a, b; RecTail<C> t; };
 template <int C>
-__device__ __forceinline__ void store_rec(float4* __restrict__ ga, float4* __restrict__ gb, RecTail<C>* __restrict__ gc, int i, float4 a,
-                                          float4 b, const float (&colour)[C])
+__device__ __forceinline__ InstRec<C> make_rec(float4 a, float4 b, const float (&colour)[C])
 {
     float a2 = a.z, b2 = a.w, c2 = b.x;
     conic_to_exp2(a2, b2, c2);
-    ga[i] = make_float4(a.x, a.y, a2, b2);
-    gb[i] = make_float4(c2, b.y, colour[0], colour[1]);
-    RecTail<C> t;
+    InstRec<C> r;
+    r.a = make_float4(a.x, a.y, a2, b2);
+    r.b = make_float4(c2, b.y, colour[0], colour[1]);
 #pragma unroll
-    for (int ch = 2; ch < C; ch++) t.c[ch - 2] = colour[ch];
-    gc[i] = t;
+    for (int ch = 2; ch < C; ch++) r.t.c[ch - 2] = colour[ch];
+    return r;
 }
 
 // Snapshot record of one pixel: float4s {T, C0, C1, C2}, {C3, C4, C5, 0}, ...

@@ -1,0 +1,64 @@
+"""Dev tool: per-WAVE timeline of blend_bwd on one view of config C, from a build with -DGSR_TRACE_DETAIL
+(python -m gaustar_amd.build --variant trace -DGSR_TRACE_DETAIL; GSR_LIB_PATH=.../libgsr_hip_trace.so).
+Per wave: start, end of the unit's head (all loads landed, keep-set known), end; plus HW_ID / XCC_ID."""
+import ctypes, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch
+from gaustar_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib, scene
+from gaustar_amd import rasterizer as R
+
+cam_i = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+gs, cams, bg = scene.config_C()
+cam = cams[cam_i]
+dev = torch.device("cuda:0")
+t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
+lib = _lib.load()
+W, H = cam.W, cam.H
+T = ((W + 15) // 16) * ((H + 15) // 16)
+m3, m2, op = t(gs.means3D).requires_grad_(True), torch.zeros(gs.P, 3, device=dev, requires_grad=True), t(gs.opacities).requires_grad_(True)
+cols, sc, rot = t(gs.colors_precomp).requires_grad_(True), t(gs.scales).requires_grad_(True), t(gs.rotations).requires_grad_(True)
+s = GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, t(bg), 1.0, t(cam.viewmatrix), t(cam.projmatrix), 0, t(cam.campos), False, False)
+rast = GaussianRasterizer(s)
+dp = torch.randn(3, H, W, device=dev)
+for _ in range(3):
+    c, r = rast(m3, m2, op, None, cols, sc, rot, None); c.backward(dp)
+e = torch.Tensor([])
+out = R.rasterize_gaussians_native(t(bg), m3.detach(), cols.detach(), op.detach(), sc.detach(), rot.detach(), 1.0, e,
+                                   t(cam.viewmatrix), t(cam.projmatrix), cam.tanfovx, cam.tanfovy, H, W, e, 0, t(cam.campos), False, False)
+Rn, _, _, geom, binning, img, maxc, U = out
+trace = torch.zeros(2 * T + 16 * U, dtype=torch.int64, device=dev)
+lib.gsr_debug_set_trace(ctypes.c_void_p(trace.data_ptr()))
+c, r = rast(m3, m2, op, None, cols, sc, rot, None); c.backward(dp)
+torch.cuda.synchronize()
+lib.gsr_debug_set_trace(None)
+tr = trace.cpu().numpy()[2 * T:].reshape(4 * U, 4)
+ok = tr[:, 0] > 0
+st, hd, en = (tr[ok, i].astype(np.float64) / 100.0 for i in range(3))   # microseconds (100 MHz clock)
+hw = tr[ok, 3]
+t0 = st.min(); st -= t0; hd -= t0; en -= t0
+span = en.max()
+print(f"waves {ok.sum()} of {4 * U}; span {span:.1f} us")
+print("head (start -> loads landed) us  p10/p50/p90/p99:", [round(float(np.percentile(hd - st, q)), 2) for q in (10, 50, 90, 99)])
+body = en - hd
+live = body > 0
+print(f"waves with work {live.sum()}; body us p10/p50/p90/p99:", [round(float(np.percentile(body[live], q)), 2) for q in (10, 50, 90, 99)])
+print(f"sum head {np.sum(hd - st):.0f} us, sum body {body.sum():.0f} us; mean waves in head {np.sum(hd - st) / span:.0f}, in body {body.sum() / span:.0f}")
+# per SIMD: how many of its resident waves are in the head phase at a time (sampled)
+simd = ((hw >> 32) & 0xf) * 4096 + ((hw >> 13) & 7) * 512 + ((hw >> 8) & 0xf) * 8 + ((hw >> 4) & 3)   # xcc, se, cu, simd
+ids = np.unique(simd)
+print("distinct (xcc, se, cu, simd):", len(ids))
+ts = np.linspace(0.1 * span, 0.9 * span, 41)
+frac = []
+hist = np.zeros(10, int)
+for sid in ids[:: max(1, len(ids) // 128)]:
+    m = simd == sid
+    for tt in ts:
+        inhead = np.sum((st[m] <= tt) & (hd[m] > tt)); inbody = np.sum((hd[m] <= tt) & (en[m] > tt))
+        hist[min(9, inhead)] += 1
+        frac.append((inhead, inbody))
+frac = np.array(frac)
+print("per SIMD sample: mean waves in head %.2f, in body %.2f" % (frac[:, 0].mean(), frac[:, 1].mean()))
+print("histogram of #waves in head per SIMD sample:", hist.tolist())
+print("histogram of #waves in body per SIMD sample:", np.bincount(frac[:, 1], minlength=8).tolist())

@@ -64,14 +64,16 @@ def test_scratch_sizes(hip_lib):
     i = hip_lib.gsr_image_bytes(1920, 1080)
     assert 8 * 1920 * 1080 <= i <= 8 * 1920 * 1080 + (8 + 64 + 12) * 8160 + 8192   # ranges, 2x8 shard counters, order, seg_off, totals
     assert hip_lib.gsr_grad_scratch_bytes(500_000) == 48 * 500_000 + 256
+    # per instance: 8 B key + 4 B id + the forward's 36-byte record in list order (16 + 16 + 4)
     b = hip_lib.gsr_binning_bytes(1_000_000, 0)
-    assert 12_000_000 <= b <= 12_000_000 + 2048
-    # per unit: unit table entry + one 64-bit mask word and one snapshot per pixel of the tile
-    assert hip_lib.gsr_binning_bytes(1_000_000, 1000) - b == 1000 * (4 + 256 * 8 + 256 * 16) + 96
+    assert 48_000_000 <= b <= 48_000_000 + 4096
+    # per unit: 16-byte unit table entry + one 64-bit mask word and one snapshot per pixel of the tile
+    assert hip_lib.gsr_binning_bytes(1_000_000, 1000) - b == 1000 * (16 + 256 * 8 + 256 * 16) + 128   # (+ alignment of the unit table)
     assert hip_lib.gsr_geom_bytes(0) > 0 and hip_lib.gsr_binning_bytes(0, 0) > 0
     # multi-target: 3 channels = the plain size; 6 channels double the per-pixel snapshot (two float4 instead of one)
     assert hip_lib.gsr_binning_bytes_mt(1_000_000, 1000, 3) == hip_lib.gsr_binning_bytes(1_000_000, 1000)
-    assert hip_lib.gsr_binning_bytes_mt(1_000_000, 1000, 6) - hip_lib.gsr_binning_bytes(1_000_000, 1000) == 1000 * 256 * 16
+    # (and its record tail carries four more colours: 16 instead of 4 bytes per instance)
+    assert hip_lib.gsr_binning_bytes_mt(1_000_000, 1000, 6) - hip_lib.gsr_binning_bytes(1_000_000, 1000) == 1000 * 256 * 16 + 12_000_000
 
 
 def test_validation_errors_without_gpu(hip_lib):
