@@ -81,6 +81,26 @@ __device__ __forceinline__ void lds_wait(SlotRegs<VECS>& r)
     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]), "+v"(r.v[3]));
 }
 
+// OR over the 64 lanes of a wave, returned as a scalar: the classic DPP ladder (three row shifts of the input, two masked
+// row shifts, two row broadcasts -- seven fused v_or_b32_dpp) and one v_readlane of lane 63, instead of six
+// ds_bpermute round trips.
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t x)
+{
+    const auto dpp = [](uint32_t v, auto ctrl, auto row_mask, auto bank_mask) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, decltype(row_mask)::value,
+                                                     decltype(bank_mask)::value, true);
+    };
+    using std::integral_constant;
+    uint32_t v = x | dpp(x, integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{});   // row_shr:1
+    v |= dpp(x, integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{});               // row_shr:2
+    v |= dpp(x, integral_constant<int, 0x113>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{});               // row_shr:3
+    v |= dpp(v, integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xe>{});               // row_shr:4
+    v |= dpp(v, integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xc>{});               // row_shr:8
+    v |= dpp(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{}, integral_constant<int, 0xf>{});               // row_bcast:15
+    v |= dpp(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{}, integral_constant<int, 0xf>{});               // row_bcast:31
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 __device__ __forceinline__ void atomic_add_f32(float* p, float v)
 {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -112,7 +132,6 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     using L = SlotLayout<C>;
     constexpr int SF = L::FLOATS, NM = L::NM, MOM0 = L::MOM0, SV = snap_vecs(C);
     static_assert(NM <= 16 && NM <= GRAD_RS, "moment columns must fit one MFMA tile and one record");
-    static_assert((C + 1) * 64 <= 2 * GRP * RSTRIDE, "dL_dpix staging must fit the r|w table");
     static_assert(L::VECS == 3 || L::VECS == 4, "slot reads are written for three or four float4");
     const uint64_t t_start = trace ? wall_clock64() : 0;
 #ifndef GSR_BWD_QCAP
@@ -231,11 +250,7 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
         word.x &= lim >= 32 ? 0xffffffffu : lim > 0 ? (1u << lim) - 1u : 0u;
         word.y &= lim >= 64 ? 0xffffffffu : lim > 32 ? (1u << (lim - 32)) - 1u : 0u;
     }
-    uint32_t olo = word.x, ohi = word.y;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { olo |= (uint32_t)__shfl_xor((int)olo, d, 64); ohi |= (uint32_t)__shfl_xor((int)ohi, d, 64); }
-    const unsigned long long kany = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)ohi) << 32) |
-                                    (uint32_t)__builtin_amdgcn_readfirstlane((int)olo);
+    const unsigned long long kany = ((unsigned long long)wave_or_u32(word.y) << 32) | wave_or_u32(word.x);
 #ifdef GSR_TRACE_DETAIL
     const uint64_t t_head = wall_clock64();
     if (trace && lane == 0 && kany == 0ull) {
@@ -245,43 +260,37 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     }
 #endif
     if (kany == 0ull) return;
-#ifdef GSR_ABL_EARLY
-    if (T != 77.f) { if (acc[0] + ra.x + rb.y + rc.c[0] == 78.f) grad_acc[gid] = T; return; }
-#endif
 
     // B operand of the contraction, constant over the unit.  MFMA step t (0..15) consumes the four pixels
     // p = 16*kap + t, kap = 0..3; in the B operand lane l carries row kap = l >> 4, column col = l & 15.
     // Columns 0..5: {1, x, y, x^2, xy, y^2} of pixel p relative to the block centre (used by the r rows);
     // columns 6..6+C-1: dL_dpix of pixel p per channel (used by the w rows; staged through LDS once).
     const int kap = lane >> 4, col = lane & 15;
+    // Every column is staged as a row of 64 floats [pixel] in the (not yet used) r|w table, then each lane reads the 16
+    // pixels of ITS column with four ds_read_b128: rows 0..5 the monomials of the lane's own pixel (exact small
+    // half-integers), row 6 + ch = dL_dpix channel ch, one all-zero row for the unused columns.  (Forming the monomials
+    // per (lane, step) in registers took 90 vector instructions per wave.)
+    static_assert((6 + C + 1) * 64 <= 2 * GRP * RSTRIDE, "B-operand staging must fit the r|w table");
+    {
+        const float xr = (float)(lane & 7) - 3.5f, yr = (float)(lane >> 3) - 3.5f;
+        Rm[0 * 64 + lane] = 1.0f;
+        Rm[1 * 64 + lane] = xr;
+        Rm[2 * 64 + lane] = yr;
+        Rm[3 * 64 + lane] = xr * xr;
+        Rm[4 * 64 + lane] = xr * yr;
+        Rm[5 * 64 + lane] = yr * yr;
 #pragma unroll
-    for (int ch = 0; ch < C; ch++) Rm[ch * 64 + lane] = dp[ch];   // [channel][pixel]
-    Rm[C * 64 + lane] = 0.f;                                      // extra all-zero channel for the unused columns
+        for (int ch = 0; ch < C; ch++) Rm[(6 + ch) * 64 + lane] = dp[ch];
+        Rm[(6 + C) * 64 + lane] = 0.f;
+    }
     __builtin_amdgcn_wave_barrier();
     float Bf[16];
     {
-        // spatial monomial of this lane's column as  base(y) + x*slope(y) + x^2*quad : x is a compile-time constant
-        // per step, y takes two values per lane; all products are exact (small half-integers), one term non-zero
-        const float ya = (float)(2 * kap) - 3.5f, yb = ya + 1.0f;
-        const float quad = col == 3 ? 1.0f : 0.0f;
-        const float base_a = col == 0 ? 1.0f : col == 2 ? ya : col == 5 ? ya * ya : 0.0f;
-        const float base_b = col == 0 ? 1.0f : col == 2 ? yb : col == 5 ? yb * yb : 0.0f;
-        const float slope_a = col == 1 ? 1.0f : col == 4 ? ya : 0.0f;
-        const float slope_b = col == 1 ? 1.0f : col == 4 ? yb : 0.0f;
-        const int ch = (col >= 6 && col < 6 + C) ? col - 6 : C;
-        const float4* pd = reinterpret_cast<const float4*>(&Rm[ch * 64 + 16 * kap]);
-        const bool spatial = col < 6;
+        const float4* pd = reinterpret_cast<const float4*>(&Rm[(col < 6 + C ? col : 6 + C) * 64 + 16 * kap]);
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) {
             const float4 v = pd[qd];
-            const float dv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int t = 4 * qd + u;
-                const float xr = (float)(t & 7) - 3.5f;
-                const float sp = fmaf(xr * xr, quad, fmaf(xr, t < 8 ? slope_a : slope_b, t < 8 ? base_a : base_b));
-                Bf[t] = spatial ? sp : dv[u];
-            }
+            Bf[4 * qd] = v.x; Bf[4 * qd + 1] = v.y; Bf[4 * qd + 2] = v.z; Bf[4 * qd + 3] = v.w;
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -313,11 +322,13 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     }
     __builtin_amdgcn_wave_barrier();
 
-#ifdef GSR_ABL_NOLOOP
-    if (T != 77.f) { if (qf[lane] == 78.f) grad_acc[gid] = T; return; }
-#endif
     unsigned long long touched = 0ull;
     const uint32_t q_base = lds_byte_address(qf);
+    // where this lane's four accumulator registers go: rows 4 kap .. 4 kap + 3 of the D tile = instances (row & 7)
+    static_assert(GRP == 8, "the write-back below assumes rows 0-7 = r, 8-15 = w");
+    const int wb_row0 = 4 * (kap & 1);
+    const bool wb_take = kap < 2 ? col < 6 : (col >= 6 && col < NM);
+    float* const wb_ptr = &qf[wb_row0 * SF + MOM0 + col];
     for (int g0i = 0; g0i < cnt; g0i += GRP) {
         // ---- vector ALU: w and r of GRP instances for this lane's pixel, parked row-wise in LDS.  The slot of the
         // group's first instance is requested here, every further one while its predecessor is being evaluated.
@@ -347,11 +358,7 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
                 const float G = __builtin_amdgcn_exp2f(power);
                 const float alpha = fminf(ALPHA_MAX, B.z * G);
                 const bool live = pos < my_lim && power <= 0.0f && alpha >= ALPHA_MIN;
-#ifdef GSR_ABL_NOLIVE
-                if (power == 77.f) {
-#else
                 if (__ballot(live) != 0ull) {
-#endif
                     touched |= 1ull << j;
                     if (live) {
                         // accum_rec' = alpha c + (1 - alpha) accum_rec written as accum_rec + alpha (c - accum_rec):
@@ -396,11 +403,13 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
         }
         // D layout: lane l, register i -> operand row 4*(l >> 4) + i, column l & 15.
         // rows 0..7: r of instance row, columns 0..5 = spatial sums; rows 8..15: w of instance row-8, columns 6..6+C-1.
+        // (wb_take / wb_row0 / wb_ptr are per-lane constants of the wave, see above)
+        if (wb_take) {
+            float* const dst = wb_ptr + g0i * SF;
+            const int left = cnt - g0i - wb_row0;     // instances of this group at or behind the lane's first row
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int row = 4 * kap + i, inst = g0i + (row & (GRP - 1));
-            const bool take = row < GRP ? col < 6 : (row < 2 * GRP && col >= 6 && col < NM);
-            if (take && inst < cnt) qf[inst * SF + MOM0 + col] = acc0[i] + acc1[i];
+            for (int i = 0; i < 4; i++)
+                if (i < left) dst[i * SF] = acc0[i] + acc1[i];
         }
         __builtin_amdgcn_wave_barrier();
     }
