@@ -101,11 +101,29 @@ def build_workload(device, rank):
     return gs, cams, bg, params, means2D, rasters, dpix
 
 
-def one_step(step, rank, world, params, means2D, rasters, dpix, reducer):
+# Gradient payload of one optimiser step in the reference loop (the param groups of sugar_optimizer.py:67-87 at
+# config C): `_points` 3 floats per mesh vertex + 39 floats per Gaussian (SH dc 3 + rest 24, density 1, scales 2,
+# quaternions 2, delta_t 3, delta_r 4) = 77 MB.  This step produces the 14 floats per Gaussian of the rasterizer's inputs;
+# the rest stands for what the producers' backward turns them into.  Its gradient only becomes final AFTER the
+# rasterizer's backward (it is downstream of it), so its buckets are issued behind the real ones: no overlap is claimed.
+MESH_VERTICES = 40962          # icosphere level 6
+FLOATS_PER_GAUSSIAN = 39
+RASTER_INPUT_FLOATS = 14
+
+
+def optimiser_payload_standin(P, device):
+    n = 3 * MESH_VERTICES + (FLOATS_PER_GAUSSIAN - RASTER_INPUT_FLOATS) * P
+    t = torch.zeros(n, dtype=torch.float32, device=device)
+    return t, torch.zeros_like(t)
+
+
+def one_step(step, rank, world, params, means2D, rasters, dpix, reducer, standin=None):
     r = rasters[(step * world + rank) % len(rasters)]
     for p in params.values():
         p.grad = None
     means2D.grad = None
+    if standin is not None:
+        standin[0].grad = standin[1]   # a fresh (here: constant) gradient every step, as autograd would leave it
     color, radii = r(means3D=params["means3D"], means2D=means2D, opacities=params["opacities"],
                      colors_precomp=params["colors"], scales=params["scales"], rotations=params["rotations"])
     color.backward(dpix)
@@ -186,8 +204,9 @@ def main():
     lib = _lib.load()
 
     gs, cams, bg, params, means2D, rasters, dpix = build_workload(device, rank)
-    reducer = gdist.GradAllReducer(list(params.values())) if world > 1 else None
-    step = lambda s: one_step(s, rank, world, params, means2D, rasters, dpix, reducer)
+    standin = optimiser_payload_standin(gs.P, device) if world > 1 else None
+    reducer = gdist.GradAllReducer(list(params.values()) + [standin[0]]) if world > 1 else None
+    step = lambda s: one_step(s, rank, world, params, means2D, rasters, dpix, reducer, standin)
 
     for s in range(args.warmup):
         step(s)
@@ -260,7 +279,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "config C: 491520 mesh-bound surface Gaussians (icosphere level 6, 6/face), "
                                    "160-camera rig @1920x1080, colours precomputed (M=0), one view per GPU per step, "
-                                   "fwd+bwd" + (", + RCCL all-reduce of 27.5 MB input gradients" if world > 1 else ""),
+                                   "fwd+bwd" + ((", + all-reduce of the reference loop's %.0f MB optimiser-gradient payload (27.5 MB of it this "
+                                                 "step's input gradients, overlapped with the end of the backward; the rest a "
+                                                 "stand-in issued after it)" % (reducer.payload_bytes() / 1e6)) if world > 1 else ""),
                        "gaussians": gs.P, "width": W, "height": H, "views_per_step": world,
                        "num_rendered_mean": R_mean, "parallelism": f"view-parallel x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -270,6 +291,9 @@ def main():
                          "instrumented_ms_per_step": round(dt_prof / args.steps * 1e3, 4), "kernels": kern},
         }
         out["config"]["host_cpus_pinned"] = len(pinned)
+        if world > 1:
+            out["config"]["allreduce_payload_MB"] = round(reducer.payload_bytes() / 1e6, 1)
+            out["config"]["allreduce_buckets_issued_during_backward"] = reducer.issued_early
         if world == 1 and not args.no_cpu_baseline:
             try:   # the CPU baseline gets every core the process started with
                 for tid in os.listdir("/proc/self/task"):

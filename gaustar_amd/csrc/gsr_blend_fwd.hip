@@ -7,24 +7,25 @@
 //
 // What differs is who looks at what.  The reference (and round 1 of this library) walks the list in LOCK STEP: all
 // pixels of a block evaluate the same instance.  For GauSTAR's ~3.6 px surface splats that leaves 10 of 64 lanes with
-// anything to do.  Here each pixel walks ITS OWN candidates: gsr_mask.hip has reduced "which instances of this
-// 64-entry segment can reach alpha >= 1/255 at this pixel" to one 64-bit word per (segment, pixel), and a lane just
-// iterates the set bits of its words (v_ffbl_b32, clear lowest bit) -- different lanes of a wave are at different list
-// positions at the same time; what they share is the tile's instance records, staged in LDS CH entries at a time and
-// gathered per lane (ds_read_b128 with per-lane addresses).  A wave's trip count is the LARGEST per-pixel candidate
-// count of its 8x8 block (config C: ~36 - 46 per block depending on CH, against ~160 lock-step instance visits), and
-// every trip has ~70 % of its lanes live.
+// anything to do.  Here each pixel walks ITS OWN candidates: gsr_mask.h reduces "which instances of this 64-entry unit
+// can reach alpha >= 1/255 at this pixel" to one 64-bit word per (unit, pixel), and a lane just iterates the set bits
+// of its words (v_ffbl_b32, clear lowest bit) -- different lanes of a wave are at different list positions at the same
+// time; what they share is the tile's instance records, staged in LDS CH entries at a time and gathered per lane
+// (ds_read_b128 with per-lane addresses).  A wave's trip count is the LARGEST per-pixel candidate count of its 8x8 block
+// (config C: ~36 per block and chunk, against ~160 lock-step instance visits), and ~70 % of a trip's lanes are live.
 //
 //  * workgroup = tile (16x16 pixels, launch order = `order`, longest lists first), wave = 8x8 block, lane = pixel;
-//  * per chunk of CH list positions: 256 threads park the chunk's records (position, exp2-domain conic, opacity,
-//    colour) in LDS; every wave copies its pixels' mask words into LDS (a lane needs word h of ITS sequence: dynamic per
-//    lane, hence memory not registers) keeping a bit summary of the non-empty ones, so that an exhausted word is
-//    replaced in one step, never by a scan over empty words;
-//  * the walk is a single loop: [replace an exhausted word] -> lowest set bit -> gather -> the reference's tests -> blend;
-//  * every word a lane consumes is written back holding the bits it actually BLENDED (bit-reversed per 32-bit half:
-//    the backward pass iterates them with the same v_ffbl, highest position first), untouched words of a terminated
-//    pixel are cleared, and the wave streams its words back to global memory, coalesced.  The backward needs nothing
-//    else from the forward but final_T and n_contrib: no per-segment snapshots (55 MB per view in round 1).
+//  * the tile's list is depth-sorted right here first (gsr_sort.h; lists above 2 048 entries by their own kernels);
+//  * per chunk of CH list positions: 256 threads park the chunk's records (make_rec: exp2-domain conic, opacity,
+//    colour) in LDS -- and, when a backward pass may follow, in global memory in list order (rec_a/b/c) --; every wave
+//    turns the 64 instances it just parked per fetch round into the candidate words of all four blocks (row interval
+//    solve + 64x64 bit transpose, gsr_mask.h), to LDS for the walk and to global memory for the backward; a bit
+//    summary of a lane's non-empty words lets an exhausted word be replaced in one step, never by a scan;
+//  * the walk is a single branch-free loop: [replace an exhausted word] -> lowest set bit -> gather -> the reference's
+//    tests -> blend;
+//  * whenever a pixel moves on to a word of a new 64-entry segment its running (T, C) is stored as that segment's
+//    snapshot: the state the backward's units resume from (gsr_blend_bwd.hip); the tile's first snapshot slot keeps
+//    the final (T, C).
 //
 // Template over the number of colour channels C: 3 is the reference's NUM_CHANNELS (cuda_rasterizer/config.h:15);
 // 6 renders TWO targets that share geometry (GauSTAR's RGB + depth-as-colour passes, refine.py:552 and :607) in one

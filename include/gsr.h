@@ -176,11 +176,12 @@ int gsr_debug_export(int P, int R, int num_segments, int W, int H, const void* g
                      const void* image_buffer, float* means2D, float* conic_opacity, float* depths, float* rgb,
                      uint32_t* tile_ranges, uint32_t* point_list, float* final_T, uint32_t* n_contrib,
                      gsr_stream_t stream);
-/* Same for the per-pixel mask words of the binning buffer: masks [num_segments][4][64] uint64 -- unit (= 64-entry
+/* Same for the per-pixel candidate words of the binning buffer: masks [num_segments][4][64] uint64 -- unit (= 64-entry
  * segment of a tile's list; units of a tile are consecutive, tiles in index order), 8x8 block 2*by + bx of the tile, pixel
- * 8*(y % 8) + (x % 8) of the block.  After a forward that a backward may follow, bit (31 - i) of the low dword <=> list
- * position 64*segment + i was blended into that pixel, bit (31 - i) of the high dword <=> position 64*segment + 32 + i
- * (words behind a pixel's n_contrib are undefined).  No reference counterpart. */
+ * 8*(y % 8) + (x % 8) of the block.  Bit i of a word <=> the instance at list position 64*segment + i CAN reach
+ * alpha >= 1/255 at that pixel (a conservative superset of what the pixel blends; bits of positions past the end of the
+ * list are zero).  Words of segments the forward never reached (every pixel of the tile saturated before) are undefined.
+ * No reference counterpart. */
 int gsr_debug_export_masks(int R, int num_segments, const void* binning_buffer, uint64_t* masks, gsr_stream_t stream);
 
 /* ---- Producers of rasterizer inputs.

@@ -74,6 +74,8 @@ def test_bench_two_ranks_over_gloo():
     d = _torchrun(["bench.py", "--gpus", "2", "--steps", "8", "--warmup", "2", "--no-cpu-baseline"], {})
     assert d["n_gpus"] == 2 and d["steps"] == 8 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["views_per_step"] == 2 and "roofline" in d
+    # the exchange is the reference loop's optimiser payload (3 floats per mesh vertex + 39 per Gaussian)
+    assert abs(d["config"]["allreduce_payload_MB"] - (3 * 40962 + 39 * 491520) * 4 / 1e6) < 0.1
 
 
 def test_refinement_window_two_ranks_over_gloo():

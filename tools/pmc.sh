@@ -12,6 +12,7 @@ PASSES=(
  "FETCH_SIZE GRBM_GUI_ACTIVE"
  "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"
  "TCC_EA0_ATOMIC_sum TCC_ATOMIC_sum"
+ "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_INSTS_BRANCH"
 )
 i=0
 for P in "${PASSES[@]}"; do
