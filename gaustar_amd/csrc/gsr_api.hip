@@ -188,12 +188,19 @@ int forward_stage1_impl(int P, int D, int M, const float* means3D, const float* 
         GSR_CHECK(hipMemsetAsync(im.tile_count, 0,
                                  (size_t)((char*)(im.tile_cursor + shard_stride(t.T) * NSHARD) - (char*)im.tile_count), st));
     }
+    // Token of this view (never 0, unique in the process): a preprocess workgroup that cannot record all of its instances
+    // stores it in totals[4], the scan stores it in totals[5], and scatter walks the tiles again iff the two are equal.
+    // No word has to be cleared between views, and a stale or uninitialised totals[4] can only select the slower path.
+    static std::atomic<uint32_t> g_view_token{0};
+    uint32_t view_token = ++g_view_token;
+    if (view_token == 0) view_token = ++g_view_token;
     if (P > 0) {
         GeomState g = carve_geom(geom_buffer, P);
         {
             Scope sc(ST_PREPROCESS, st);
             launch_preprocess(P, D, M, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
-                              cov3D_precomp, viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, radii, g, im, st);
+                              cov3D_precomp, viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, radii, g, im, view_token,
+                              st);
         }
         GSR_CHECK_LAUNCH("preprocess_kernel");
     }
@@ -209,7 +216,7 @@ int forward_stage1_impl(int P, int D, int M, const float* means3D, const float* 
     const uint32_t seq = ++g_pinned_seq ? g_pinned_seq : ++g_pinned_seq;   // never 0 (the pad's initial value)
     {
         Scope sc(ST_TILE_SCAN, st);
-        launch_tile_scan(im, t.T, g_pinned, seq, st);
+        launch_tile_scan(im, t.T, g_pinned, seq, view_token, st);
     }
     GSR_CHECK_LAUNCH("tile_scan_kernel");
     if (spin) {

@@ -45,7 +45,7 @@ template <int PER>
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges,
                  uint32_t* __restrict__ totals, uint32_t* __restrict__ host_totals, uint32_t host_seq,
-                 uint32_t* __restrict__ order, uint32_t* __restrict__ seg_off)
+                 uint32_t* __restrict__ order, uint32_t* __restrict__ seg_off, uint32_t view_token)
 {
     static_assert((NSHARD & (NSHARD - 1)) == 0, "shard = workgroup index & (NSHARD - 1)");
     __shared__ uint32_t wave_sum[16];
@@ -171,6 +171,7 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
         totals[1] = gmax;
         totals[2] = (uint32_t)T - empty;
         totals[3] = total_seg;
+        totals[5] = view_token;   // scatter compares it with totals[4] (set by a preprocess workgroup that ran out of room)
         // The host's copy goes straight into its pinned, device-mapped landing pad -- no separate device-to-host copy
         // (a 5 us blit kernel plus its dispatch) -- followed by the call's sequence number with system-scope release:
         // the host polls that word (gsr_forward_stage1) and starts launching stage 2 while this kernel still builds
@@ -215,24 +216,29 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
     }
 }
 
-void launch_tile_scan(ImageState im, int T, uint32_t* host_totals, uint32_t host_seq, hipStream_t st)
+void launch_tile_scan(ImageState im, int T, uint32_t* host_totals, uint32_t host_seq, uint32_t view_token, hipStream_t st)
 {
     if (T <= 8 * 1024)          // up to 1920x1088: counts stay in registers
-        tile_scan_kernel<8><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.totals, host_totals, host_seq, im.order, im.seg_off);
+        tile_scan_kernel<8><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.totals, host_totals, host_seq, im.order, im.seg_off, view_token);
     else                        // any larger grid (gsr_forward_stage1 caps T at 262 144 = 8k x 8k)
-        tile_scan_kernel<0><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.totals, host_totals, host_seq, im.order, im.seg_off);
+        tile_scan_kernel<0><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.totals, host_totals, host_seq, im.order, im.seg_off, view_token);
 }
 
-// One thread per Gaussian: claim a slot in every reachable tile's bucket and store the sort key.  Walks exactly
-// the tiles preprocess counted (same stored inputs, same contraction-free test) with the same wave
-// aggregation: the wave's leader for a tile reserves popcount(mask) slots with ONE returning atomic and
-// every lane of the mask takes its own slot by prefix popcount.
+// Every (Gaussian, tile) instance's sort key goes to its slot of the tile's bucket.  Workgroup b serves the 256 Gaussians
+// preprocess workgroup b looked at.  Normally those left RECORDS {gaussian, depth bits, table slot, offset} and a table
+// {tile, first rank of the workgroup's span within (tile, shard)} (gsr_preprocess.hip): 256 threads turn the table into
+// absolute bucket positions (tile start + counts of the lower shards + first rank), then it is one load and one store per
+// record -- no tile walk, no atomics.  A view in which some workgroup ran out of table or record space carries its own
+// token in totals[4]: then every workgroup walks exactly the tiles preprocess counted (same stored inputs, same
+// contraction-free test, same wave aggregation) and claims slots with one returning atomic per (wave, tile) on the shard's
+// cursor, every lane of the group taking its own by prefix popcount.
 __global__ void __launch_bounds__(256)
 scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __restrict__ g0,
                const float4* __restrict__ g1, const float* __restrict__ depth, uint32_t* __restrict__ tile_cursor,
                uint64_t* __restrict__ keys, int T, const uint32_t* __restrict__ seg_off,
                uint4* __restrict__ unit_info, const uint32_t* __restrict__ tile_count,
-               const uint2* __restrict__ ranges)
+               const uint2* __restrict__ ranges, const uint4* __restrict__ wg_recs, const uint2* __restrict__ wg_tab,
+               const uint32_t* __restrict__ wg_nrec, const uint32_t* __restrict__ totals)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -245,6 +251,34 @@ scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __
         const uint32_t u0 = seg_off[idx], u1 = seg_off[idx + 1];
         const uint2 rg = ranges[idx];
         for (uint32_t u = u0; u < u1; u++) unit_info[u] = make_uint4((uint32_t)idx, rg.x, rg.y - rg.x, u0);
+    }
+    if (totals[4] != totals[5]) {   // (uniform) every preprocess workgroup of this view recorded all of its instances
+        if ((size_t)blockIdx.x * 256 >= (size_t)P) return;
+        __shared__ uint32_t slot_base[WG_TAB_SLOTS];
+        static_assert(WG_TAB_SLOTS == 256, "one thread per table slot");
+        const uint2 e = wg_tab[(size_t)blockIdx.x * WG_TAB_SLOTS + threadIdx.x];
+        if (e.x != 0xffffffffu) {
+            // all seven lower-shard counts are requested together (a loop with `if (s < shard)` compiles to dependent trips)
+            uint32_t cnt[NSHARD - 1];
+            const uint32_t start = ranges[e.x].x;
+#pragma unroll
+            for (int s_ = 0; s_ < NSHARD - 1; s_++) cnt[s_] = tile_count[s_ * Tp + e.x];
+            uint32_t base = start + e.y;
+#pragma unroll
+            for (int s_ = 0; s_ < NSHARD - 1; s_++) base += s_ < shard ? cnt[s_] : 0u;
+            slot_base[threadIdx.x] = base;
+        }
+        __syncthreads();
+        // every wave takes the records of the preprocess wave at its position (its quarter of the array)
+        constexpr uint32_t WAVE_CAP = WG_REC_CAP / 4;
+        const uint32_t wv = threadIdx.x >> 6;
+        const uint32_t nr = wg_nrec[blockIdx.x * 4 + wv];
+        const uint4* const recs = wg_recs + (size_t)blockIdx.x * WG_REC_CAP + (size_t)wv * WAVE_CAP;
+        for (uint32_t i = lane; i < nr; i += 64u) {
+            const uint4 r = recs[i];
+            keys[slot_base[r.z] + r.w] = ((uint64_t)r.y << 32) | r.x;
+        }
+        return;
     }
     ushort4 r = make_ushort4(0, 0, 0, 0);
     float4 a = make_float4(0.f, 0.f, 1.f, 0.f), b = make_float4(1.f, 0.f, -1.f, 0.f);
@@ -283,7 +317,8 @@ void launch_scatter(int P, int W, int H, GeomState g, ImageState im, BinState b,
     const Tiles t = tiles_of(W, H);
     const int n = P > t.T ? P : t.T;
     scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(P, t.gx, g.rect, g.g0, g.g1, g.depth, im.tile_cursor, b.keys, t.T,
-                                                    im.seg_off, b.unit_info, im.tile_count, im.ranges);
+                                                    im.seg_off, b.unit_info, im.tile_count, im.ranges, g.wg_recs, g.wg_tab,
+                                                    g.wg_nrec, im.totals);
 }
 
 // ---- per-tile bitonic sort of 64-bit keys in LDS.

@@ -33,8 +33,15 @@ struct GeomState {           // per Gaussian
     float* depth;            // view-space z (sort key)
     ushort4* rect;           // tile rect {min_x, min_y, max_x, max_y} actually binned (empty => no instances)
     float* rgb;              // SH-evaluated colours [P,3] (SH mode only, but always carved)
+    // What preprocess workgroup b (256 Gaussians) leaves for scatter: its (Gaussian, tile) instances as records
+    // {gaussian, depth bits, slot of the tile in the workgroup's table, position inside the workgroup's span of that tile}
+    // and the table {tile, first rank of the workgroup's span within (tile, shard)} -- see gsr_preprocess.hip.
+    uint4* wg_recs;          // [ceil(P / 256)][4 waves][WG_REC_CAP / 4]
+    uint2* wg_tab;           // [ceil(P / 256)][WG_TAB_SLOTS]
+    uint32_t* wg_nrec;       // [ceil(P / 256)][4] records each wave produced (more than its quarter: the view is flagged)
     size_t bytes;
 };
+constexpr int WG_REC_CAP = 1024, WG_TAB_SLOTS = 256;
 inline GeomState carve_geom(void* base, int P)
 {
     GeomState s; size_t o = 0; char* b = (char*)base;
@@ -43,6 +50,10 @@ inline GeomState carve_geom(void* base, int P)
     s.depth = (float*)(b + o); o = align_up(o + sizeof(float) * (size_t)P);
     s.rect = (ushort4*)(b + o); o = align_up(o + sizeof(ushort4) * (size_t)P);
     s.rgb = (float*)(b + o); o = align_up(o + sizeof(float) * 3 * (size_t)P);
+    const size_t nwg = ((size_t)P + 255) / 256;
+    s.wg_recs = (uint4*)(b + o); o = align_up(o + sizeof(uint4) * WG_REC_CAP * nwg);
+    s.wg_tab = (uint2*)(b + o); o = align_up(o + sizeof(uint2) * WG_TAB_SLOTS * nwg);
+    s.wg_nrec = (uint32_t*)(b + o); o = align_up(o + 16 * nwg);
     s.bytes = o + 256;
     return s;
 }
@@ -64,7 +75,9 @@ struct ImageState {          // per pixel / per tile
     uint2* ranges;           // [T] {start, end} into point_list
     uint32_t* tile_count;    // [NSHARD][Tp] instances per (shard, tile) (atomics in preprocess), Tp = shard_stride(T)
     uint32_t* tile_cursor;   // [NSHARD][Tp] scatter cursors: a tile's bucket is the concatenation of its shards
-    uint32_t* totals;        // [4] {R, max tile count, number of non-empty tiles, U = number of list segments}
+    uint32_t* totals;        // [8] {R, max tile count, number of non-empty tiles, U = number of list segments,
+                             //      token of the view whose preprocess could not record every instance (scatter then
+                             //      walks the tiles again), token of the current view, -, -}
     uint32_t* order;         // [T] tile ids, longest instance lists first (32-entry buckets), empty tiles last:
                              // the blockIdx -> tile map of the per-tile kernels (longest-processing-time-first
                              // dispatch evens out the very uneven per-tile work of a surface seen in perspective)
@@ -80,7 +93,7 @@ inline ImageState carve_image(void* base, int W, int H)
     s.ranges = (uint2*)(b + o); o = align_up(o + 8 * T);
     s.tile_count = (uint32_t*)(b + o); o = align_up(o + 4 * shard_stride((int)T) * NSHARD);
     s.tile_cursor = (uint32_t*)(b + o); o = align_up(o + 4 * shard_stride((int)T) * NSHARD);
-    s.totals = (uint32_t*)(b + o); o = align_up(o + 16);
+    s.totals = (uint32_t*)(b + o); o = align_up(o + 32);
     s.order = (uint32_t*)(b + o); o = align_up(o + 4 * T);
     s.seg_off = (uint32_t*)(b + o); o = align_up(o + 4 * (T + 1));
     s.bytes = o + 256;
@@ -192,9 +205,9 @@ struct Camera {              // passed by value to kernels (lands in SGPRs / ker
 void launch_preprocess(int P, int D, int M, const float* means3D, const float* shs, const float* colors_precomp,
                        const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                        const float* cov3D_precomp, const float* view, const float* proj, const float* campos, int W,
-                       int H, float tan_fovx, float tan_fovy, int* radii, GeomState g, ImageState im,
+                       int H, float tan_fovx, float tan_fovy, int* radii, GeomState g, ImageState im, uint32_t view_token,
                        hipStream_t st);
-void launch_tile_scan(ImageState im, int T, uint32_t* host_totals, uint32_t host_seq, hipStream_t st);
+void launch_tile_scan(ImageState im, int T, uint32_t* host_totals, uint32_t host_seq, uint32_t view_token, hipStream_t st);
 void launch_scatter(int P, int W, int H, GeomState g, ImageState im, BinState b, hipStream_t st);
 // -> true if lists of up to 2 048 entries were left for the forward blend to sort (gsr_sort.h)
 bool launch_tile_sort(int W, int H, int R, uint32_t max_count, ImageState im, BinState b, bool blend_sorts_small, hipStream_t st);

@@ -23,11 +23,15 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
                   const float* __restrict__ proj, const float* __restrict__ campos, int W, int H, float tan_fovx,
                   float tan_fovy, float focal_x, float focal_y, int gx, int gy, int* __restrict__ radii,
                   float4* __restrict__ g0, float4* __restrict__ g1, float* __restrict__ depth,
-                  ushort4* __restrict__ rect, float* __restrict__ rgb, uint32_t* __restrict__ tile_count)
+                  ushort4* __restrict__ rect, float* __restrict__ rgb, uint32_t* __restrict__ tile_count,
+                  uint4* __restrict__ wg_recs, uint2* __restrict__ wg_tab, uint32_t* __restrict__ wg_nrec,
+                  uint32_t* __restrict__ totals, uint32_t view_token)
 {
-    constexpr int AGG_SLOTS = 256;
+    constexpr int AGG_SLOTS = WG_TAB_SLOTS;
     __shared__ uint32_t agg_key[AGG_SLOTS], agg_cnt[AGG_SLOTS];
+    __shared__ uint32_t tab_full;   // set by the first group that finds no slot: later groups do not probe at all
     for (int i = threadIdx.x; i < AGG_SLOTS; i += blockDim.x) { agg_key[i] = 0xffffffffu; agg_cnt[i] = 0u; }
+    if (threadIdx.x == 0) tab_full = 0u;
     __syncthreads();
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -45,6 +49,7 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
     int out_radius = 0;
     ushort4 out_rect = make_ushort4(0, 0, 0, 0);
     float px = 0.f, py = 0.f, conic_a = 1.f, conic_b = 0.f, conic_c = 1.f, tau = -1.f;
+    float my_depth = 0.f;
 
     if (valid) {
         const Vec3 p = load3(means3D, idx);
@@ -124,6 +129,7 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
                     g0[idx] = make_float4(px, py, conic_a, conic_b);
                     g1[idx] = make_float4(conic_c, op, tau, 0.0f);
                     depth[idx] = view_z;
+                    my_depth = view_z;
                     out_rect = make_ushort4((unsigned short)rx0, (unsigned short)ry0, (unsigned short)rx1,
                                             (unsigned short)ry1);
                 }
@@ -136,34 +142,71 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
     // The wave-level groups are merged once more per WORKGROUP in a small LDS table (open addressing on the tile id)
     // before they reach memory: the 256 Gaussians of a workgroup are neighbours on the mesh and hit the same dozen
     // tiles from all four waves and in every round, and the memory-side atomics are what bounds this kernel
-    // (31.6 us with, 15.3 us without them).  A group that finds no slot within 8 probes goes to memory directly.
+    // (31.6 us with, 15.3 us without them).
+    // The same table hands every instance its PLACE: the LDS counter of the tile's slot, read back by the group's leader,
+    // is the group's offset inside the workgroup's span of that tile; the workgroup's one memory atomic per slot returns
+    // where that span starts within (tile, shard).  Instances leave as records {gaussian, depth bits, slot, offset} --
+    // complete the moment they are formed; each wave fills its own quarter of the workgroup's record array, a running
+    // count in a scalar register -- and the table follows at the end: scatter then is one store per record instead of a
+    // second tile walk with returning atomics (28 -> 13 us).  A workgroup whose table or record array does not suffice (close-ups: hundreds of tiles per
+    // workgroup) marks the VIEW with its token: counting stays exact, and scatter falls back to walking the tiles.
     uint32_t* const my_row = tile_count + (size_t)(blockIdx.x & (NSHARD - 1)) * shard_stride(gx * gy);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    constexpr uint32_t WAVE_CAP = WG_REC_CAP / 4;
+    uint4* const wave_recs = wg_recs + (size_t)blockIdx.x * WG_REC_CAP + (size_t)(threadIdx.x >> 6) * WAVE_CAP;
+    uint32_t n_wave = 0;   // (wave-uniform) records of this wave so far
     for_each_tile_aggregated(out_rect, px, py, conic_a, conic_b, conic_c, tau, gx, lane,
-                             [&](int tile, bool is_leader, int group, int, int) {
+                             [&](int tile, bool is_leader, int group, int rank, int leader_lane) {
+                                 uint32_t slot = 0xffffffffu, off0 = 0u;
                                  if (is_leader) {
-                                     uint32_t h = (uint32_t)tile & (AGG_SLOTS - 1);
-                                     bool placed = false;
-                                     for (int probe = 0; probe < 8 && !placed; probe++) {
+                                     // (multiplicative hash: a workgroup's ~90 tiles are runs of consecutive ids in rows gx
+                                     // apart, which `tile & 255` folds onto each other into long probe chains)
+                                     uint32_t h = ((uint32_t)tile * 0x9E3779B1u) >> 24;
+                                     static_assert(AGG_SLOTS == 256, "hash keeps the top 8 bits");
+                                     const int max_probe = tab_full ? 0 : 24;
+                                     for (int probe = 0; probe < max_probe && slot == 0xffffffffu; probe++) {
                                          const uint32_t prev = atomicCAS(&agg_key[h], 0xffffffffu, (uint32_t)tile);
                                          if (prev == 0xffffffffu || prev == (uint32_t)tile) {
-                                             atomicAdd(&agg_cnt[h], (uint32_t)group);
-                                             placed = true;
+                                             off0 = atomicAdd(&agg_cnt[h], (uint32_t)group);
+                                             slot = h;
                                          } else {
                                              h = (h + 1) & (AGG_SLOTS - 1);
                                          }
                                      }
-                                     if (!placed) atomicAdd(&my_row[tile], (uint32_t)group);
+                                     if (slot == 0xffffffffu) {   // table full around this hash: count directly, flag the view
+                                         atomicAdd(&my_row[tile], (uint32_t)group);
+                                         tab_full = 1u;
+                                         totals[4] = view_token;
+                                     }
                                  }
+                                 slot = (uint32_t)__shfl((int)slot, leader_lane, 64);
+                                 off0 = (uint32_t)__shfl((int)off0, leader_lane, 64);
+                                 const unsigned long long act = __ballot(tile >= 0);
+                                 if (tile >= 0) {
+                                     const uint32_t pos = n_wave + (uint32_t)__popcll(act & lt);
+                                     if (pos < WAVE_CAP)
+                                         wave_recs[pos] = make_uint4((uint32_t)idx, __float_as_uint(my_depth), slot, off0 + (uint32_t)rank);
+                                 }
+                                 n_wave += (uint32_t)__popcll(act);
                              });
+    if (lane == 0) {
+        wg_nrec[blockIdx.x * 4 + (threadIdx.x >> 6)] = n_wave;
+        if (n_wave > WAVE_CAP) totals[4] = view_token;
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < AGG_SLOTS; i += blockDim.x)
-        if (agg_key[i] != 0xffffffffu) atomicAdd(&my_row[agg_key[i]], agg_cnt[i]);
+    uint2* const tab = wg_tab + (size_t)blockIdx.x * WG_TAB_SLOTS;
+    for (int i = threadIdx.x; i < AGG_SLOTS; i += blockDim.x) {
+        uint2 e = make_uint2(0xffffffffu, 0u);
+        if (agg_key[i] != 0xffffffffu) e = make_uint2(agg_key[i], atomicAdd(&my_row[agg_key[i]], agg_cnt[i]));
+        tab[i] = e;
+    }
 }
 
 void launch_preprocess(int P, int D, int M, const float* means3D, const float* shs, const float* colors_precomp,
                        const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                        const float* cov3D_precomp, const float* view, const float* proj, const float* campos, int W,
-                       int H, float tan_fovx, float tan_fovy, int* radii, GeomState g, ImageState im, hipStream_t st)
+                       int H, float tan_fovx, float tan_fovy, int* radii, GeomState g, ImageState im, uint32_t view_token,
+                       hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);
     const float focal_y = H / (2.0f * tan_fovy), focal_x = W / (2.0f * tan_fovx);   // rasterizer_impl.cu:222-223
@@ -171,7 +214,8 @@ void launch_preprocess(int P, int D, int M, const float* means3D, const float* s
     preprocess_kernel<<<(P + 255) / 256, 256, lds, st>>>(P, D, M, means3D, shs, colors_precomp, opacities, scales,
                                                        scale_modifier, rotations, cov3D_precomp, view, proj, campos, W,
                                                        H, tan_fovx, tan_fovy, focal_x, focal_y, t.gx, t.gy, radii,
-                                                       g.g0, g.g1, g.depth, g.rect, g.rgb, im.tile_count);
+                                                       g.g0, g.g1, g.depth, g.rect, g.rgb, im.tile_count, g.wg_recs, g.wg_tab,
+                                                       g.wg_nrec, im.totals, view_token);
 }
 
 // rasterizer_impl.cu:54-66 (checkFrustum): present = view-space z > 0.2.
