@@ -57,6 +57,7 @@ template <int C> struct SlotLayout {
     static constexpr int IN_FLOATS = (8 + C + 3) / 4 * 4, OUT_FLOATS = (MOM0 + NM + 3) / 4 * 4;
     static constexpr int FLOATS = IN_FLOATS > OUT_FLOATS ? IN_FLOATS : OUT_FLOATS;   // C = 4: 12 in, 13 out -> 16
     static constexpr int VECS = FLOATS / 4;
+    static constexpr int IN_VECS = IN_FLOATS / 4;   // what the pair loop reads of a slot (C = 4: three of its four float4)
     static_assert(MOM0 + NM <= FLOATS, "moments must fit the slot");
 };
 
@@ -132,7 +133,7 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     using L = SlotLayout<C>;
     constexpr int SF = L::FLOATS, NM = L::NM, MOM0 = L::MOM0, SV = snap_vecs(C);
     static_assert(NM <= 16 && NM <= GRAD_RS, "moment columns must fit one MFMA tile and one record");
-    static_assert(L::VECS == 3 || L::VECS == 4, "slot reads are written for three or four float4");
+    static_assert(L::IN_VECS == 3 || L::IN_VECS == 4, "slot reads are written for three or four float4");
     const uint64_t t_start = trace ? wall_clock64() : 0;
 #ifndef GSR_BWD_QCAP
 #define GSR_BWD_QCAP 32
@@ -332,9 +333,9 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     for (int g0i = 0; g0i < cnt; g0i += GRP) {
         // ---- vector ALU: w and r of GRP instances for this lane's pixel, parked row-wise in LDS.  The slot of the
         // group's first instance is requested here, every further one while its predecessor is being evaluated.
-        SlotRegs<L::VECS> nxt;
+        SlotRegs<L::IN_VECS> nxt;
         const uint32_t q_grp = q_base + (uint32_t)(g0i * SF * 4);
-        lds_request<L::VECS, 0>(nxt, q_grp);
+        lds_request<L::IN_VECS, 0>(nxt, q_grp);
         static_for<GRP>([&](auto JJ) {
             constexpr int jj = decltype(JJ)::value;
             const int j = g0i + jj;
@@ -344,8 +345,8 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
             // data have landed.  Likewise the wait is on the requested registers themselves, the copy comes after it.
             // (Slot j + 1 < QCAP exists in LDS; past the end of the queue it holds stale numbers nobody uses.)
             lds_wait(nxt);
-            const SlotRegs<L::VECS> cur = nxt;
-            if constexpr (jj + 1 < GRP) lds_request<L::VECS, (jj + 1) * SF * 4>(nxt, q_grp);
+            const SlotRegs<L::IN_VECS> cur = nxt;
+            if constexpr (jj + 1 < GRP) lds_request<L::IN_VECS, (jj + 1) * SF * 4>(nxt, q_grp);
             if (j < cnt) {
                 const float4 A = make_float4(cur.v[0][0], cur.v[0][1], cur.v[0][2], cur.v[0][3]);
                 const float4 B = make_float4(cur.v[1][0], cur.v[1][1], cur.v[1][2], cur.v[1][3]);
@@ -466,17 +467,22 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
     blend_bwd_unit<C>(W, H, gx, unit_info, snap, masks, point_list, rec_a, rec_b, rec_c, bg, final_T, n_contrib, dL_dpix, grad_acc, trace);
 }
 // Three channels: the register allocator is told to stay within six waves per SIMD (80 registers; left alone it takes 82
-// and the kernel runs five: 0.141 vs 0.131 ms on config C).  Four and six channels would have to spill for that and lose.
-template <>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8)))
-blend_bwd_kernel<3>(int W, int H, int gx, const uint4* __restrict__ unit_info, const float4* __restrict__ snap,
-                    const uint2* __restrict__ masks, const uint32_t* __restrict__ point_list, const float4* __restrict__ rec_a,
-                    const float4* __restrict__ rec_b, const RecTail<3>* __restrict__ rec_c, const float* __restrict__ bg,
-                    const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-                    const float* __restrict__ dL_dpix, float* __restrict__ grad_acc, uint64_t* __restrict__ trace)
-{
-    blend_bwd_unit<3>(W, H, gx, unit_info, snap, masks, point_list, rec_a, rec_b, rec_c, bg, final_T, n_contrib, dL_dpix, grad_acc, trace);
-}
+// and the kernel runs five: 0.141 vs 0.131 ms on config C).  Six channels (104 registers) would have to spill 20 and lose.
+#define GSR_BWD_SPECIALISE(CH, WAVES)                                                                                          \
+    template <>                                                                                                               \
+    __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))                                      \
+    blend_bwd_kernel<CH>(int W, int H, int gx, const uint4* __restrict__ unit_info, const float4* __restrict__ snap,          \
+                         const uint2* __restrict__ masks, const uint32_t* __restrict__ point_list,                            \
+                         const float4* __restrict__ rec_a, const float4* __restrict__ rec_b,                                  \
+                         const RecTail<CH>* __restrict__ rec_c, const float* __restrict__ bg,                                 \
+                         const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,                           \
+                         const float* __restrict__ dL_dpix, float* __restrict__ grad_acc, uint64_t* __restrict__ trace)       \
+    {                                                                                                                         \
+        blend_bwd_unit<CH>(W, H, gx, unit_info, snap, masks, point_list, rec_a, rec_b, rec_c, bg, final_T, n_contrib,         \
+                           dL_dpix, grad_acc, trace);                                                                         \
+    }
+GSR_BWD_SPECIALISE(3, 6)
+GSR_BWD_SPECIALISE(4, 6)   // 92 registers left alone; held at 80 it spills four and still wins (iteration 0.780 -> 0.757 ms)
 
 void launch_blend_bwd(int C, int W, int H, int U, const float* bg, const float* feats, GeomState g, ImageState im,
                       BinState b, const float* dL_dpix, float* grad_acc, hipStream_t st)

@@ -97,6 +97,11 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     // before this launch).  As a kernel of its own the sort is latency-bound (key loads, cross-lane exchanges, barriers:
     // 25 us at a fraction of the vector ALU) and the blend then starts from a cold chip; inside the blend kernel one
     // tile's sort overlaps the other resident tiles' blending, and the sorted ids are read back while still in L2.
+    // The kernel's span is its longest tile (a pixel's walk is serial), and co-resident waves share a SIMD's issue slots:
+    // long lists get issue priority -- from their sort on -- so that they do not also run at 1/7 speed.
+    if (n > 1024u) __builtin_amdgcn_s_setprio(3);
+    else if (n > 704u) __builtin_amdgcn_s_setprio(2);
+    else if (n > 448u) __builtin_amdgcn_s_setprio(1);
     if (sort_keys != nullptr) {
         if (n >= 1u && n <= 2048u) sort_small_tile(reinterpret_cast<uint64_t*>(smem), sort_keys + list0, point_list + list0, n);
         __syncthreads();   // ids visible to the four waves; the sort's LDS is free
@@ -105,11 +110,6 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     const TransposeConsts tc(lane);
     const bool words_ready = n > LONG_LIST;   // (wave-uniform) candidate words already in global memory
 
-    // The kernel's span is its longest tile (a pixel's walk is serial), and co-resident waves share a SIMD's issue slots:
-    // long lists get issue priority so that they do not also run at 1/7 speed (0.088 -> 0.084 ms on config C).
-    if (n > 1024u) __builtin_amdgcn_s_setprio(3);
-    else if (n > 704u) __builtin_amdgcn_s_setprio(2);
-    else if (n > 448u) __builtin_amdgcn_s_setprio(1);
     float T = 1.0f;
     float Cc[C];
 #pragma unroll
