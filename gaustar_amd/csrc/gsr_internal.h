@@ -572,18 +572,23 @@ struct TileWalker {
                                           int gx_, int lane_)
         : rect(r), px(px_), py(py_), ca(ca_), cb(cb_), cc(cc_), tau(tau_), gx(gx_), lane(lane_), tx(r.x), ty(r.y),
           more(r.z > r.x && r.w > r.y && tau_ >= 0.0f) {}
-    // One round: every lane advances to its next reachable tile (or none), lanes are grouped by tile id.
-    // Returns false (wave-uniformly) when no lane has a tile left; v.tile < 0 for lanes without one.
-    __device__ __forceinline__ bool next_round(TileVisit& v)
+    // This lane's next reachable tile, or -1.
+    __device__ __forceinline__ int next_tile()
     {
-        int cur = -1;
         while (more) {
             const float X0 = (float)(tx * TILE) - px, Y0 = (float)(ty * TILE) - py;
             const bool hit = block_min_half_quad(ca, cb, cc, X0, X0 + (float)(TILE - 1), Y0, Y0 + (float)(TILE - 1)) <= tau;
             const int id = ty * gx + tx;
             if (++tx == rect.z) { tx = rect.x; if (++ty == rect.w) more = false; }
-            if (hit) { cur = id; break; }
+            if (hit) return id;
         }
+        return -1;
+    }
+    // One round: every lane advances to its next reachable tile (or none), lanes are grouped by tile id.
+    // Returns false (wave-uniformly) when no lane has a tile left; v.tile < 0 for lanes without one.
+    __device__ __forceinline__ bool next_round(TileVisit& v)
+    {
+        const int cur = next_tile();
         unsigned long long active = __ballot(cur >= 0);
         v.tile = cur; v.is_leader = false; v.group = 0; v.rank = 0; v.leader_lane = lane;
         if (active == 0ull) return false;

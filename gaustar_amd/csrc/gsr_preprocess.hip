@@ -155,40 +155,38 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
     constexpr uint32_t WAVE_CAP = WG_REC_CAP / 4;
     uint4* const wave_recs = wg_recs + (size_t)blockIdx.x * WG_REC_CAP + (size_t)(threadIdx.x >> 6) * WAVE_CAP;
     uint32_t n_wave = 0;   // (wave-uniform) records of this wave so far
-    for_each_tile_aggregated(out_rect, px, py, conic_a, conic_b, conic_c, tau, gx, lane,
-                             [&](int tile, bool is_leader, int group, int rank, int leader_lane) {
-                                 uint32_t slot = 0xffffffffu, off0 = 0u;
-                                 if (is_leader) {
-                                     // (multiplicative hash: a workgroup's ~90 tiles are runs of consecutive ids in rows gx
-                                     // apart, which `tile & 255` folds onto each other into long probe chains)
-                                     uint32_t h = ((uint32_t)tile * 0x9E3779B1u) >> 24;
-                                     static_assert(AGG_SLOTS == 256, "hash keeps the top 8 bits");
-                                     const int max_probe = tab_full ? 0 : 24;
-                                     for (int probe = 0; probe < max_probe && slot == 0xffffffffu; probe++) {
-                                         const uint32_t prev = atomicCAS(&agg_key[h], 0xffffffffu, (uint32_t)tile);
-                                         if (prev == 0xffffffffu || prev == (uint32_t)tile) {
-                                             off0 = atomicAdd(&agg_cnt[h], (uint32_t)group);
-                                             slot = h;
-                                         } else {
-                                             h = (h + 1) & (AGG_SLOTS - 1);
-                                         }
-                                     }
-                                     if (slot == 0xffffffffu) {   // table full around this hash: count directly, flag the view
-                                         atomicAdd(&my_row[tile], (uint32_t)group);
-                                         tab_full = 1u;
-                                         totals[4] = view_token;
-                                     }
-                                 }
-                                 slot = (uint32_t)__shfl((int)slot, leader_lane, 64);
-                                 off0 = (uint32_t)__shfl((int)off0, leader_lane, 64);
-                                 const unsigned long long act = __ballot(tile >= 0);
-                                 if (tile >= 0) {
-                                     const uint32_t pos = n_wave + (uint32_t)__popcll(act & lt);
-                                     if (pos < WAVE_CAP)
-                                         wave_recs[pos] = make_uint4((uint32_t)idx, __float_as_uint(my_depth), slot, off0 + (uint32_t)rank);
-                                 }
-                                 n_wave += (uint32_t)__popcll(act);
-                             });
+    // (No wave-level grouping of the lanes by tile here: with the LDS table in front of memory every lane simply takes its
+    // own place with one returning LDS atomic -- same-address lanes serialise inside that one instruction, which is far
+    // cheaper than the ballot loop that used to elect a leader per distinct tile.)
+    TileWalker walker(out_rect, px, py, conic_a, conic_b, conic_c, tau, gx, lane);
+    while (true) {
+        const int tile = walker.next_tile();
+        const unsigned long long act = __ballot(tile >= 0);
+        if (act == 0ull) break;
+        if (tile >= 0) {
+            uint32_t slot = 0xffffffffu, off = 0u;
+            // (multiplicative hash: a workgroup's ~90 tiles are runs of consecutive ids in rows gx apart, which
+            // `tile & 255` folds onto each other into long probe chains)
+            uint32_t h = ((uint32_t)tile * 0x9E3779B1u) >> 24;
+            static_assert(AGG_SLOTS == 256, "hash keeps the top 8 bits");
+            const int max_probe = tab_full ? 0 : 24;
+            for (int probe = 0; probe < max_probe; probe++) {
+                const uint32_t prev = atomicCAS(&agg_key[h], 0xffffffffu, (uint32_t)tile);
+                if (prev == 0xffffffffu || prev == (uint32_t)tile) { slot = h; break; }
+                h = (h + 1) & (AGG_SLOTS - 1);
+            }
+            if (slot != 0xffffffffu) {
+                off = atomicAdd(&agg_cnt[slot], 1u);
+            } else {   // table full around this hash: count directly, flag the view
+                atomicAdd(&my_row[tile], 1u);
+                tab_full = 1u;
+                totals[4] = view_token;
+            }
+            const uint32_t pos = n_wave + (uint32_t)__popcll(act & lt);
+            if (pos < WAVE_CAP) wave_recs[pos] = make_uint4((uint32_t)idx, __float_as_uint(my_depth), slot, off);
+        }
+        n_wave += (uint32_t)__popcll(act);
+    }
     if (lane == 0) {
         wg_nrec[blockIdx.x * 4 + (threadIdx.x >> 6)] = n_wave;
         if (n_wave > WAVE_CAP) totals[4] = view_token;
