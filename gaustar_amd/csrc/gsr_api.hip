@@ -352,7 +352,7 @@ int forward_stage2_impl(int P, int R, int max_tile_instances, int num_segments, 
     if (R > 0) {
         {
             Scope sc(ST_SCATTER, st);
-            launch_scatter(P, W, H, g, im, b, st);
+            launch_scatter(P, W, H, (uint32_t)(max_tile_instances > 0 ? max_tile_instances : 0), g, im, b, st);
         }
         GSR_CHECK_LAUNCH("scatter_kernel");
         {
@@ -366,7 +366,7 @@ int forward_stage2_impl(int P, int R, int max_tile_instances, int num_segments, 
     const float* feats = colors_precomp ? colors_precomp : g.rgb;
     {
         Scope sc(ST_BLEND_FWD, st);
-        launch_blend_fwd(C, W, H, num_segments, (uint32_t)(max_tile_instances > 0 ? max_tile_instances : 0), background, feats, g, im, b,
+        launch_blend_fwd(C, W, H, R > 0 ? R : 0, num_segments, (uint32_t)(max_tile_instances > 0 ? max_tile_instances : 0), background, feats, g, im, b,
                          out_color, !forward_only, grad_scratch,
                          grad_scratch ? gsr_grad_scratch_bytes(P > 0 ? P : 0) : 0, counters, sort_in_blend, st);
     }

@@ -171,6 +171,7 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
         totals[1] = gmax;
         totals[2] = (uint32_t)T - empty;
         totals[3] = total_seg;
+        totals[6] = 0u;           // scatter counts the parts of long lists here
         totals[5] = view_token;   // scatter compares it with totals[4] (set by a preprocess workgroup that ran out of room)
         // The host's copy goes straight into its pinned, device-mapped landing pad -- no separate device-to-host copy
         // (a 5 us blit kernel plus its dispatch) -- followed by the call's sequence number with system-scope release:
@@ -238,7 +239,8 @@ scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __
                uint64_t* __restrict__ keys, int T, const uint32_t* __restrict__ seg_off,
                uint4* __restrict__ unit_info, const uint32_t* __restrict__ tile_count,
                const uint2* __restrict__ ranges, const uint4* __restrict__ wg_recs, const uint2* __restrict__ wg_tab,
-               const uint32_t* __restrict__ wg_nrec, const uint32_t* __restrict__ totals)
+               const uint32_t* __restrict__ wg_nrec, uint32_t* __restrict__ totals, uint2* __restrict__ part_list,
+               uint32_t split_n)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -251,6 +253,13 @@ scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __
         const uint32_t u0 = seg_off[idx], u1 = seg_off[idx + 1];
         const uint2 rg = ranges[idx];
         for (uint32_t u = u0; u < u1; u++) unit_info[u] = make_uint4((uint32_t)idx, rg.x, rg.y - rg.x, u0);
+        // ... and list the parts (one forward chunk each) of a list the forward blends in parts (gsr_blend_fwd.hip)
+        const uint32_t n = rg.y - rg.x;
+        if (n > split_n) {
+            const uint32_t np = (n + (uint32_t)FWD_CHUNK - 1u) / (uint32_t)FWD_CHUNK;
+            const uint32_t at = atomicAdd(&totals[6], np);
+            for (uint32_t k = 0; k < np; k++) part_list[at + k] = make_uint2((uint32_t)idx, k * (uint32_t)FWD_CHUNK);
+        }
     }
     if (totals[4] != totals[5]) {   // (uniform) every preprocess workgroup of this view recorded all of its instances
         if ((size_t)blockIdx.x * 256 >= (size_t)P) return;
@@ -312,13 +321,13 @@ scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __
                              });
 }
 
-void launch_scatter(int P, int W, int H, GeomState g, ImageState im, BinState b, hipStream_t st)
+void launch_scatter(int P, int W, int H, uint32_t max_count, GeomState g, ImageState im, BinState b, hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);
     const int n = P > t.T ? P : t.T;
     scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(P, t.gx, g.rect, g.g0, g.g1, g.depth, im.tile_cursor, b.keys, t.T,
                                                     im.seg_off, b.unit_info, im.tile_count, im.ranges, g.wg_recs, g.wg_tab,
-                                                    g.wg_nrec, im.totals);
+                                                    g.wg_nrec, im.totals, b.part_list, split_threshold(max_count));
 }
 
 // ---- per-tile bitonic sort of 64-bit keys in LDS.

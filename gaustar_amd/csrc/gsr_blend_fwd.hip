@@ -38,9 +38,16 @@
 
 namespace gsr {
 
-constexpr uint32_t LONG_LIST = 2048;   // lists above this get their candidate words from tile_mask_kernel (below)
 
-template <int C, int CH>
+// MODE 0: one workgroup per tile (launch order = `order`).  Lists up to LONG_LIST entries are sorted and walked here, front
+// to back.  A longer list -- a surface seen edge-on stacks thousands of thin splats onto a tile without saturating it, and
+// a pixel's walk is serial: 11 787 entries took one workgroup 514 us -- has been walked before this launch in PARTS of one
+// chunk (MODE 1, one workgroup per part, every part starting from T = 1, C = 0): this workgroup only COMBINES them in
+// order, T_in C_in -> C_in + T_in C_part, T_in T_part per pixel, re-basing the part's per-unit snapshots the same way.
+// A part is folded in like that only for pixels that cannot have terminated inside it -- the product of ALL its (1 - alpha)
+// keeps T above 1e-4 (then every prefix does) and the part itself did not stop -- the others walk that one chunk again
+// with their true state, exactly as a short list would (a pixel terminates once, so at most one chunk per pixel).
+template <int C, int CH, int MODE>
 __global__ void __launch_bounds__(256)
 blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ order,
                  uint32_t* point_list, const uint64_t* __restrict__ sort_keys, const float4* __restrict__ g0,
@@ -48,14 +55,17 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                  const float* __restrict__ feats, const float* __restrict__ bg, float* __restrict__ out_color,
                  float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ seg_off,
                  uint2* __restrict__ masks, float4* __restrict__ snap, float4* __restrict__ rec_a, float4* __restrict__ rec_b,
-                 RecTail<C>* __restrict__ rec_c, float4* __restrict__ zero_ptr, uint32_t zero_n,
-                 uint32_t* __restrict__ counters, uint32_t counters_tp, uint64_t* __restrict__ trace)
+                 RecTail<C>* __restrict__ rec_c, const uint2* __restrict__ part_list, const uint32_t* __restrict__ totals,
+                 float4* __restrict__ part_fin, uint32_t* __restrict__ part_last, uint32_t split_n, bool keep,
+                 float4* __restrict__ zero_ptr,
+                 uint32_t zero_n, uint32_t* __restrict__ counters, uint32_t counters_tp, uint64_t* __restrict__ trace)
 {
     const uint64_t t_start = trace ? wall_clock64() : 0;
+    if constexpr (MODE == 1) { if (blockIdx.x >= totals[6]) return; }   // parts of this view (scatter_kernel lists them)
     // Side job: the backward's accumulation table (48 B per Gaussian) has to be zero before blend_bwd runs.  When the
     // caller hands it over at forward time every workgroup clears its slice here instead of a separate fill (a 5 us blit
     // plus its dispatch) in front of the backward.
-    if (zero_ptr != nullptr) {
+    if (MODE == 0 && zero_ptr != nullptr) {
         const uint32_t per = (zero_n + gridDim.x - 1u) / gridDim.x;
         const uint32_t i0 = blockIdx.x * per, i1 = min(zero_n, i0 + per);
         for (uint32_t i = i0 + threadIdx.x; i < i1; i += 256u) zero_ptr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -67,17 +77,25 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     // the walk (below) uses the same bytes for its cross-wave stages.  C = 3 at CH = 512: 34 KB, four workgroups per CU.
     constexpr size_t GC_BYTES = (sizeof(RecTail<C>) * CH + 15) / 16 * 16;
     constexpr size_t REC_BYTES = 32 * CH + GC_BYTES, MK_BYTES = sizeof(uint32_t) * 4 * NH * 64;
-    constexpr size_t SORT_BYTES = 2 * SORT_SMALL_CAP * 8;
+    constexpr size_t SORT_BYTES = MODE == 0 ? 2 * SORT_SMALL_CAP * 8 : 0;
     constexpr size_t LDS_BYTES = REC_BYTES + MK_BYTES > SORT_BYTES ? REC_BYTES + MK_BYTES : SORT_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     float4* const ga = reinterpret_cast<float4*>(smem);
     float4* const gb = ga + CH;
     RecTail<C>* const gc = reinterpret_cast<RecTail<C>*>(smem + 32 * CH);
     uint32_t (*mk)[NH][64] = reinterpret_cast<uint32_t(*)[NH][64]>(smem + REC_BYTES);
-    const int tile = (int)order[blockIdx.x];
+    uint32_t part_c0 = 0;
+    int tile;
+    if constexpr (MODE == 0) {
+        tile = (int)order[blockIdx.x];
+    } else {
+        const uint2 part = part_list[blockIdx.x];
+        tile = (int)part.x;
+        part_c0 = __builtin_amdgcn_readfirstlane(part.y);
+    }
     // Second side job (fused forward): this tile's eight shard counters and eight scatter cursors live in a library-owned
     // block that has to be all zero again for the next view's preprocess; scatter, their last reader, is done.
-    if (counters != nullptr && threadIdx.x < 2 * NSHARD)
+    if (MODE == 0 && counters != nullptr && threadIdx.x < 2 * NSHARD)
         counters[(size_t)threadIdx.x * counters_tp + tile] = 0u;      // rows 0-7: counts, rows 8-15: cursors ([16][Tp])
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tx = tile % gx, ty = tile / gx;
@@ -86,13 +104,14 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     const float pxf = (float)px, pyf = (float)py;
     constexpr int SV = snap_vecs(C);
     const int pix_in_tile = 16 * (py - ty * TILE) + (px - tx * TILE);
-    const bool keep = snap != nullptr;   // a backward pass may follow
+    const bool snaps = keep && snap != nullptr;   // a backward pass may follow
 
     // (wave-uniform values are pinned to scalar registers: the per-chunk bookkeeping below then runs on the scalar unit)
     const uint2 rg = ranges[tile];
     const uint32_t list0 = __builtin_amdgcn_readfirstlane(rg.x);
     const uint32_t n = __builtin_amdgcn_readfirstlane(rg.y - rg.x);
     const uint32_t unit0 = __builtin_amdgcn_readfirstlane(seg_off[tile]);
+    const bool long_list = n > split_n;   // (wave-uniform) blended in parts: split_n = LONG_LIST in views that split at all
     // Depth sort of this tile's list, right here (lists up to 2 048 entries; longer ones were sorted by tile_sort_big_kernel
     // before this launch).  As a kernel of its own the sort is latency-bound (key loads, cross-lane exchanges, barriers:
     // 25 us at a fraction of the vector ALU) and the blend then starts from a cold chip; inside the blend kernel one
@@ -102,13 +121,14 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     if (n > 1024u) __builtin_amdgcn_s_setprio(3);
     else if (n > 704u) __builtin_amdgcn_s_setprio(2);
     else if (n > 448u) __builtin_amdgcn_s_setprio(1);
-    if (sort_keys != nullptr) {
-        if (n >= 1u && n <= 2048u) sort_small_tile(reinterpret_cast<uint64_t*>(smem), sort_keys + list0, point_list + list0, n);
-        __syncthreads();   // ids visible to the four waves; the sort's LDS is free
+    if constexpr (MODE == 0) {
+        if (sort_keys != nullptr) {
+            if (n >= 1u && n <= 2048u) sort_small_tile(reinterpret_cast<uint64_t*>(smem), sort_keys + list0, point_list + list0, n);
+            __syncthreads();   // ids visible to the four waves; the sort's LDS is free
+        }
     }
     const uint32_t* list = point_list + list0;
     const TransposeConsts tc(lane);
-    const bool words_ready = n > LONG_LIST;   // (wave-uniform) candidate words already in global memory
 
     float T = 1.0f;
     float Cc[C];
@@ -116,7 +136,9 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     for (int ch = 0; ch < C; ch++) Cc[ch] = 0.f;
     uint32_t last = 0;
     bool done = !inside;
-    uint32_t seg_cur = 0;   // segment (SNAP_SEG list positions) of the word this pixel consumed last
+    // segment (SNAP_SEG list positions) of the word this pixel consumed last.  A part that is not the tile's first starts
+    // "nowhere": the first word of ANY of its units, the first one included, opens a segment and leaves a snapshot
+    uint32_t seg_cur = (MODE == 1 && part_c0 != 0u) ? 0xffffffffu : 0u;
 
     // Two-stage software pipeline over the dependent gather (list -> id -> records): ids are fetched two chunks ahead,
     // records and mask words one chunk ahead, so no global-memory latency sits between a chunk's barrier and its walk.
@@ -152,16 +174,11 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             }
         }
     };
-    fetch_ids(0);
-    fetch_records();
-    fetch_ids(CH);
-
-    for (uint32_t c0 = 0; c0 < n; c0 += CH) {
-        // every pixel of the tile saturated: stop (also the barrier that frees the LDS of the previous chunk)
-        if (__syncthreads_or(!done) == 0) break;
-        // ---- park the chunk's records and reduce them to per-pixel candidate words (gsr_mask.h): this wave holds, per
-        // fetch round q, the 64 instances of unit 4 q + wave of the chunk, one per lane.  The words go to LDS for the
-        // walk and, when a backward pass may follow, to global memory: the backward's units find their snapshots by them.
+    // ---- park the chunk's records (held in a_nxt / b_nxt / col_nxt) and reduce them to per-pixel candidate words
+    // (gsr_mask.h): this wave holds, per fetch round q, the 64 instances of unit 4 q + wave of the chunk, one per lane.
+    // The words go to LDS for the walk and, when a backward pass may follow (or the chunk is a part: the combining
+    // workgroup reads them), to global memory.  words_known: the part has left them there already.
+    const auto park = [&](uint32_t c0, bool words_known, bool words_out, bool recs_out) {
         const uint32_t u_lo = c0 >> 6;
 #pragma unroll
         for (int q = 0; q < PT; q++) {
@@ -171,7 +188,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             ga[q * 256 + threadIdx.x] = rec.a;
             gb[q * 256 + threadIdx.x] = rec.b;
             gc[q * 256 + threadIdx.x] = rec.t;
-            if (keep) {
+            if (recs_out) {
                 // the backward's units read their 64 records as three contiguous rows instead of gathering them again
                 // through list -> id -> geometry state (a chain of three dependent trips to memory at the head of a unit)
                 const uint32_t k = c0 + q * 256 + threadIdx.x;
@@ -184,9 +201,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             if (c0 + q * 256 + wave * 64 < n) {   // (wave-uniform) the unit exists
                 const int hw = 2 * (4 * q + wave);
                 uint2* const gm = masks + ((size_t)(unit0 + u_lo + 4 * q + wave) * 4) * 64 + lane;
-                if (words_ready) {
-                    // long list: tile_mask_kernel has produced the words, one wave per unit, before this launch -- a
-                    // 12 000-entry tile would otherwise spend its time on 184 units' worth of interval solves, serially
+                if (words_known) {
 #pragma unroll
                     for (int blk = 0; blk < 4; blk++) {
                         const uint2 m = gm[blk * 64];
@@ -197,32 +212,34 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                     unit_masks(a_nxt[q], b_nxt[q], tx * TILE, ty * TILE, tc, [&](int blk, uint32_t lo, uint32_t hi) {
                         mk[blk][hw][lane] = lo;
                         mk[blk][hw + 1][lane] = hi;
-                        if (keep) gm[blk * 64] = make_uint2(lo, hi);
+                        if (words_out) gm[blk * 64] = make_uint2(lo, hi);
                     });
                 }
             }
         }
-        fetch_records();
-        fetch_ids(c0 + 2 * CH);
-        __syncthreads();
-        // which of this pixel's words are non-empty (a pixel that is done consumes none)
+    };
+    // which of this pixel's words of the parked chunk are non-empty
+    const auto nonempty_words = [&](uint32_t c0) {
         uint32_t nz = 0;
 #pragma unroll
         for (int hh = 0; hh < NH; hh++)
             if (c0 + 32u * hh < n) nz |= (mk[wave][hh][lane] != 0u ? 1u : 0u) << hh;
-        nz = done ? 0u : nz;
-        // ---- the walk: every lane through its own candidates.  (h, cur) = the word being consumed and its remaining
-        // bits, (nh, nw) = the next non-empty word, read one step ahead, nz = the non-empty words behind it.  Everything
-        // but the snapshot store is branch-free: lanes need a new word in different trips, and a conditional block that
-        // almost every trip enters for a few lanes costs more than selects for all.
+        return nz;
+    };
+    // ---- the walk: every lane through its own candidates of the parked chunk.  (h, cur) = the word being consumed and its
+    // remaining bits, (nh, nw) = the next non-empty word, read one step ahead, nz = the non-empty words behind it.
+    // Everything but the snapshot store is branch-free: lanes need a new word in different trips, and a conditional block
+    // that almost every trip enters for a few lanes costs more than selects for all.  Returns whether the pixel stopped.
+    const auto walk = [&](uint32_t c0, uint32_t nz) {
         uint32_t cur = 0, nw = 0;
         int h = 0, nh = 0;
+        bool stopped = false;
         if (nz != 0u) { nh = __builtin_ctz(nz); nw = mk[wave][nh][lane]; nz &= nz - 1u; }
         while (true) {
             const bool need = cur == 0u;
             cur = need ? nw : cur;
             h = need ? nh : h;
-            if (keep) {
+            if (snaps || MODE == 1) {   // (a part always leaves them: the combining workgroup finds its way by them)
                 // first word of a new segment: the running (T, C) is the pixel's state at the segment's boundary (and at
                 // every boundary it skipped) -- what the backward blend's units resume from (gsr_blend_bwd.hip)
                 const uint32_t seg_new = (c0 + (uint32_t)h * 32u) / (uint32_t)SNAP_SEG;
@@ -263,10 +280,196 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             T = upd ? test_T : T;
             last = upd ? c0 + slot + 1u : last;
             // a pixel that terminates drops the rest of its candidates
-            done = done || stop;
+            stopped = stopped || stop;
             cur = stop ? 0u : cur;
             nw = stop ? 0u : nw;
             nz = stop ? 0u : nz;
+        }
+        return stopped;
+    };
+    // where a part of this tile keeps its per-pixel result: parts are numbered (first unit / 8) + (first list entry of
+    // the tile / LONG_LIST) -- increasing along a tile, and strictly increasing from one long tile to the next, whose
+    // list starts more than LONG_LIST entries later; at most U / 8 + R / LONG_LIST + 1
+    const auto part_slot = [&](uint32_t c0) {
+        return ((size_t)((unit0 + (c0 >> 6)) / 8u + list0 / LONG_LIST) * 256 + (size_t)pix_in_tile);
+    };
+
+    if constexpr (MODE == 1) {
+        // ---- one part: chunk [part_c0, part_c0 + CH) from T = 1, C = 0
+        fetch_ids(part_c0);
+        fetch_records();
+        park(part_c0, false, true, true);   // (words and records always: the combining workgroup may need them)
+        __syncthreads();
+        const bool stopped = walk(part_c0, done ? 0u : nonempty_words(part_c0));
+        const size_t ps = part_slot(part_c0);
+        store_snapshot<C>(part_fin + ps * SV, T, Cc);
+        part_last[ps] = last | (stopped ? 0x80000000u : 0u);
+        return;
+    } else if (long_list) {
+        // ---- combine the parts, in list order.  Phase A, all pixels in step: a part the pixel certainly passes through is
+        // folded in; at the first one it may not, the pixel PARKS with its state at that part's start.
+        const float thr = T_EPS * 1.001f;   // (0.1 % of slack for the rounding of the products: a borderline pixel parks)
+        // re-base the snapshot a part left for this pixel in `unit` (relative to the part's start) on the state (T, Cc)
+        const auto rebase = [&](uint32_t unit) {
+            float4* const sp = snap + ((size_t)unit * 256 + pix_in_tile) * SV;
+            float Ts, cs[C];
+            load_snapshot<C>(sp, Ts, cs);
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) cs[ch] = Cc[ch] + T * cs[ch];
+            store_snapshot<C>(sp, T * Ts, cs);
+        };
+        const auto words_of = [&](uint32_t unit) { return masks[((size_t)unit * 4 + wave) * 64 + lane]; };
+        bool parked = false;
+        uint32_t park_c0 = 0, park_lp = 0;
+        float park_Tp = 1.f;
+        for (uint32_t c0 = 0; c0 < n; c0 += CH) {
+            if (__syncthreads_or(!done && !parked) == 0) break;
+            if (done || parked) continue;
+            const size_t ps = part_slot(c0);
+            float Tp, Cp[C];
+            load_snapshot<C>(part_fin + ps * SV, Tp, Cp);
+            const uint32_t lp = part_last[ps];
+            if ((lp & 0x80000000u) != 0u || T * Tp < thr) {   // the pixel may terminate inside this part
+                parked = true; park_c0 = c0; park_lp = lp; park_Tp = Tp;
+                continue;
+            }
+            if (snaps) {
+                // (the pixel left a snapshot in every unit in which it has a candidate; the tile's very first slot is not
+                // a boundary, see below)
+#pragma unroll
+                for (int uu = 0; uu < CH / 64; uu++) {
+                    if (c0 + 64u * uu < n && (c0 != 0u || uu != 0)) {
+                        const uint32_t unit = unit0 + (c0 >> 6) + uu;
+                        const uint2 wd = words_of(unit);
+                        if ((wd.x | wd.y) != 0u) rebase(unit);
+                    }
+                }
+            }
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) Cc[ch] += T * Cp[ch];
+            T *= Tp;
+            last = (lp & 0x7fffffffu) != 0u ? (lp & 0x7fffffffu) : last;
+        }
+        // Phase B, every parked pixel on its own (they sit in different parts; no barrier from here on): the units of its
+        // part that it certainly passes through are folded in one by one -- the state a unit ends in is the snapshot of the
+        // next unit with a candidate, or the part's result -- and from the first one it may not pass it walks its candidates
+        // exactly, records and words gathered from memory, until it terminates (a borderline pixel that does not after all
+        // simply walks on, through the rest of the list).
+        if (parked) {
+            const uint32_t u_part = unit0 + (park_c0 >> 6);
+            const uint32_t n_units = min((uint32_t)(CH / 64), (n - park_c0 + 63u) / 64u);
+            // a part that stopped has valid snapshots only up to the unit of its last contributor
+            const uint32_t trust = (park_lp & 0x80000000u) ? (((park_lp & 0x7fffffffu) != 0u ? (park_lp & 0x7fffffffu) - 1u - park_c0 : 0u) >> 6)
+                                                          : 0xffffffffu;
+            const float T_in = T;
+            float C_in[C];
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) C_in[ch] = Cc[ch];
+            uint32_t uw = n_units;   // first unit (of the part) the pixel walks exactly
+            int pass_hi = -1;        // deepest unit of the part it passes through
+            for (uint32_t uu = 0; uu < n_units; uu++) {
+                const uint2 wd = words_of(u_part + uu);
+                if ((wd.x | wd.y) == 0u) continue;
+                // local state at the end of this unit
+                float Te = park_Tp;
+                bool have_end = (park_lp & 0x80000000u) == 0u;
+                for (uint32_t u2 = uu + 1; u2 < n_units; u2++) {
+                    const uint2 w2 = words_of(u_part + u2);
+                    if ((w2.x | w2.y) != 0u) {
+                        float ce[C];
+                        load_snapshot<C>(snap + ((size_t)(u_part + u2) * 256 + pix_in_tile) * SV, Te, ce);
+                        have_end = u2 <= trust;
+                        break;
+                    }
+                }
+                if (uu < trust && have_end && T_in * Te >= thr) {
+                    // passes through: the unit's own snapshot becomes absolute
+                    if (snaps && (park_c0 != 0u || uu != 0u)) rebase(u_part + uu);   // (T, Cc still hold the part's start state)
+                    pass_hi = (int)uu;
+                    continue;
+                }
+                uw = uu;
+                break;
+            }
+            // the pixel blended the units it passed through: its last contributor so far is the deepest candidate of those
+            // units that passes the alpha test (no running state needed for that; the words are tight, so the first look
+            // almost always hits)
+            for (int uu = pass_hi; uu >= 0; uu--) {
+                const uint2 wd = words_of(u_part + (uint32_t)uu);
+                bool found = false;
+                for (int half = 1; half >= 0 && !found; half--) {
+                    uint32_t bits = half ? wd.y : wd.x;
+                    while (bits != 0u) {
+                        const int bpos = 31 - __builtin_clz(bits);
+                        bits &= ~(1u << bpos);
+                        const uint32_t k = park_c0 + 64u * (uint32_t)uu + 32u * (uint32_t)half + (uint32_t)bpos;
+                        const float4 A = rec_a[list0 + k], B = rec_b[list0 + k];
+                        const float dx = A.x - pxf, dy = A.y - pyf;
+                        const float power = pair_exp2_arg(A.z, A.w, B.x, dx, dy);
+                        const float alpha = fminf(ALPHA_MAX, B.y * __builtin_amdgcn_exp2f(power));
+                        if (power <= 0.0f && alpha >= ALPHA_MIN) { last = k + 1u; found = true; break; }
+                    }
+                }
+                if (found) break;
+            }
+            // state at the start of unit uw: the part's start state carried through the unit's own (relative) snapshot
+            if (uw < n_units) {
+                if (park_c0 != 0u || uw != 0u) {
+                    float Ts, cs[C];
+                    load_snapshot<C>(snap + ((size_t)(u_part + uw) * 256 + pix_in_tile) * SV, Ts, cs);
+#pragma unroll
+                    for (int ch = 0; ch < C; ch++) Cc[ch] = C_in[ch] + T_in * cs[ch];
+                    T = T_in * Ts;
+                }
+                // (the tile's first unit has no snapshot: the pixel's state there is the start state)
+            }
+            // exact walk from unit uw of the part to termination
+            const uint32_t u_end = unit0 + (n + 63u) / 64u;
+            for (uint32_t unit = u_part + uw; unit < u_end && !done; unit++) {
+                const uint2 wd = words_of(unit);
+                if ((wd.x | wd.y) == 0u) continue;
+                if (snaps && unit != unit0) store_snapshot<C>(snap + ((size_t)unit * 256 + pix_in_tile) * SV, T, Cc);
+                const uint32_t k0 = (unit - unit0) * 64u;
+                for (int half = 0; half < 2 && !done; half++) {
+                    uint32_t bits = half ? wd.y : wd.x;
+                    while (bits != 0u) {
+                        const uint32_t k = k0 + 32u * half + (uint32_t)__builtin_ctz(bits);
+                        bits &= bits - 1u;
+                        const float4 A = rec_a[list0 + k], B = rec_b[list0 + k];
+                        const RecTail<C> K = rec_c[list0 + k];
+                        float col[C];
+                        col[0] = B.z; col[1] = B.w;
+#pragma unroll
+                        for (int ch = 2; ch < C; ch++) col[ch] = K.c[ch - 2];
+                        const float dx = A.x - pxf, dy = A.y - pyf;
+                        const float power = pair_exp2_arg(A.z, A.w, B.x, dx, dy);
+                        const float alpha = fminf(ALPHA_MAX, B.y * __builtin_amdgcn_exp2f(power));
+                        if (power > 0.0f || alpha < ALPHA_MIN) continue;
+                        const float test_T = T * (1.0f - alpha);
+                        if (test_T < T_EPS) { done = true; break; }
+                        const float w = alpha * T;
+#pragma unroll
+                        for (int ch = 0; ch < C; ch++) Cc[ch] += col[ch] * w;
+                        T = test_T;
+                        last = k + 1u;
+                    }
+                }
+            }
+        }
+    } else {
+        fetch_ids(0);
+        fetch_records();
+        fetch_ids(CH);
+        for (uint32_t c0 = 0; c0 < n; c0 += CH) {
+            // every pixel of the tile saturated: stop (also the barrier that frees the LDS of the previous chunk)
+            if (__syncthreads_or(!done) == 0) break;
+            park(c0, false, snaps, snaps);
+            fetch_records();
+            fetch_ids(c0 + 2 * CH);
+            __syncthreads();
+            // (a pixel that is done consumes no words)
+            const bool stopped = walk(c0, done ? 0u : nonempty_words(c0));
+            done = done || stopped;
         }
     }
     if (inside) {
@@ -278,7 +481,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         for (int ch = 0; ch < C; ch++) out_color[ch * HW + pix] = Cc[ch] + T * bg[ch];
         // a tile with more than one segment: the first unit's snapshot slot (never used as a boundary) keeps the
         // final (T, C), from which the backward derives "colour behind a boundary" = C_final - C_snap
-        if (keep && n > (uint32_t)SNAP_SEG) store_snapshot<C>(snap + ((size_t)unit0 * 256 + pix_in_tile) * SV, T, Cc);
+        if (snaps && n > (uint32_t)SNAP_SEG) store_snapshot<C>(snap + ((size_t)unit0 * 256 + pix_in_tile) * SV, T, Cc);
     }
     if (trace && lane == 0) {   // last wave to finish wins the end stamp
         if (wave == 0) trace[2 * blockIdx.x] = t_start;
@@ -286,50 +489,33 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     }
 }
 
-// Candidate words of the tiles above LONG_LIST entries (close-up views), one wave per unit: a 12 000-entry tile is 188
-// independent waves here instead of 47 serial mask phases of its forward workgroup.
-__global__ void __launch_bounds__(64)
-tile_mask_kernel(int gx, const uint4* __restrict__ unit_info, const uint32_t* __restrict__ point_list,
-                 const float4* __restrict__ g0, const float4* __restrict__ g1, uint2* __restrict__ masks)
-{
-    const uint32_t unit = blockIdx.x;
-    const uint4 info = unit_info[unit];   // {tile, first entry, entries, first unit}
-    const int tile = (int)info.x;
-    const uint32_t n = info.z;
-    if (n <= LONG_LIST) return;
-    const int lane = threadIdx.x;
-    const TransposeConsts tc(lane);
-    const uint32_t k = (unit - info.w) * 64u + (uint32_t)lane;
-    float4 a = make_float4(0.f, 0.f, 1.f, 0.f), b = make_float4(1.f, 0.f, -1.f, 0.f);   // tau = -1: no instance
-    if (k < n) { const uint32_t gid = point_list[info.y + k]; a = g0[gid]; b = g1[gid]; }
-    uint2* const gm = masks + (size_t)unit * 256 + lane;
-    unit_masks(a, b, (tile % gx) * TILE, (tile / gx) * TILE, tc, [&](int blk, uint32_t lo, uint32_t hi) { gm[blk * 64] = make_uint2(lo, hi); });
-}
-
 template <int C>
-static void launch_fwd_c(int W, int H, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im,
+static void launch_fwd_c(int W, int H, int R, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im,
                          BinState b, float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, uint32_t* counters,
                          bool sort_small, hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);
-    if (max_count > LONG_LIST && U > 0)   // (such lists were sorted by the big-sort kernels before: launch_tile_sort)
-        tile_mask_kernel<<<U, 64, 0, st>>>(t.gx, b.unit_info, b.point_list, g.g0, g.g1, b.masks);
-    blend_fwd_kernel<C, FWD_CHUNK><<<t.T, 256, 0, st>>>(W, H, t.gx, im.ranges, im.order, b.point_list,
-                                                        sort_small ? b.keys : nullptr, g.g0, g.g1, feats, bg,
-                                                        out_color, im.final_T, im.n_contrib, im.seg_off, b.masks,
-                                                        keep_masks ? b.snap : nullptr, b.rec_a, b.rec_b,
-                                                        static_cast<RecTail<C>*>(b.rec_c), static_cast<float4*>(zero_ptr),
-                                                        (uint32_t)(zero_bytes / 16), counters,
-                                                        (uint32_t)shard_stride(t.T), g_trace);
+    // (lists above 2 048 entries were sorted by the big-sort kernels before: launch_tile_sort; scatter_kernel listed the parts)
+    const uint32_t split_n = split_threshold(max_count);
+    if (split_n != 0xffffffffu && U > 0)
+        blend_fwd_kernel<C, FWD_CHUNK, 1><<<(unsigned)part_capacity(R, U), 256, 0, st>>>(
+            W, H, t.gx, im.ranges, im.order, b.point_list, nullptr, g.g0, g.g1, feats, bg, out_color, im.final_T, im.n_contrib,
+            im.seg_off, b.masks, b.snap, b.rec_a, b.rec_b, static_cast<RecTail<C>*>(b.rec_c), b.part_list, im.totals, b.part_fin,
+            b.part_last, split_n, keep_masks, nullptr, 0u, nullptr, 0u, nullptr);
+    blend_fwd_kernel<C, FWD_CHUNK, 0><<<t.T, 256, 0, st>>>(
+        W, H, t.gx, im.ranges, im.order, b.point_list, sort_small ? b.keys : nullptr, g.g0, g.g1, feats, bg, out_color, im.final_T,
+        im.n_contrib, im.seg_off, b.masks, b.snap, b.rec_a, b.rec_b, static_cast<RecTail<C>*>(b.rec_c), b.part_list, im.totals,
+        b.part_fin, b.part_last, split_n, keep_masks, static_cast<float4*>(zero_ptr), (uint32_t)(zero_bytes / 16), counters,
+        (uint32_t)shard_stride(t.T), g_trace);
 }
 
-void launch_blend_fwd(int C, int W, int H, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im,
+void launch_blend_fwd(int C, int W, int H, int R, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im,
                       BinState b, float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, uint32_t* counters,
                       bool sort_small, hipStream_t st)
 {
-    if (C == 6) launch_fwd_c<6>(W, H, U, max_count, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, sort_small, st);
-    else if (C == 4) launch_fwd_c<4>(W, H, U, max_count, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, sort_small, st);
-    else launch_fwd_c<3>(W, H, U, max_count, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, sort_small, st);
+    if (C == 6) launch_fwd_c<6>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, sort_small, st);
+    else if (C == 4) launch_fwd_c<4>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, sort_small, st);
+    else launch_fwd_c<3>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, sort_small, st);
 }
 
 }  // namespace gsr

@@ -77,7 +77,7 @@ struct ImageState {          // per pixel / per tile
     uint32_t* tile_cursor;   // [NSHARD][Tp] scatter cursors: a tile's bucket is the concatenation of its shards
     uint32_t* totals;        // [8] {R, max tile count, number of non-empty tiles, U = number of list segments,
                              //      token of the view whose preprocess could not record every instance (scatter then
-                             //      walks the tiles again), token of the current view, -, -}
+                             //      walks the tiles again), token of the current view, number of parts of long lists, -}
     uint32_t* order;         // [T] tile ids, longest instance lists first (32-entry buckets), empty tiles last:
                              // the blockIdx -> tile map of the per-tile kernels (longest-processing-time-first
                              // dispatch evens out the very uneven per-tile work of a surface seen in perspective)
@@ -140,11 +140,31 @@ struct BinState {            // per instance / per segment
     uint4* unit_info;        // [U] {tile, first list entry of the tile, entries of the tile, first unit of the tile}
     uint2* masks;            // [U][4 blocks][64 lanes] per-pixel 64-bit words over the unit's 64 list positions
                              // {positions 0-31, positions 32-63}; block = 2*by + bx, lane = 8*(y % 8) + (x % 8)
+    uint2* part_list;        // [part_capacity] {tile, first list position} of every part of a list above 2 048 entries
+    uint32_t* part_last;     // [part_capacity][256] a part's per-pixel last contributor (bit 31: the part stopped)
+    float4* part_fin;        // [part_capacity][256][snap_vecs(C)] a part's per-pixel {T, C...} from T = 1, C = 0
     float4* snap;            // [U][256][snap_vecs(C)] per-pixel {T, C0, C1, ...} BEFORE the first instance of segment
                              // u (u not the first segment of its tile; that slot holds the FINAL {T, C...} when the
                              // tile has more than one segment); pixel index = 16*(y - tile_y0) + (x - tile_x0)
     size_t bytes;
 };
+// Lists above LONG_LIST entries are blended in parts of one forward chunk (gsr_blend_fwd.hip); part_capacity bounds their
+// number.  (GSR_LONG_LIST: a build with a huge value walks every list serially -- the comparison build of the tests' tools.)
+#ifndef GSR_LONG_LIST
+#define GSR_LONG_LIST 2048
+#endif
+constexpr uint32_t LONG_LIST = GSR_LONG_LIST;
+static_assert(LONG_LIST >= 2048, "lists up to 2 048 entries are sorted inside the forward kernel, whole");
+__host__ __device__ inline size_t part_capacity(int R, int U) { return (size_t)U / 8 + (size_t)R / 2048 + 2; }
+// Splitting costs a launch in front of the forward blend (its parts run before any tile does), so a view splits only if
+// its longest list would otherwise hold the kernel up -- above SPLIT_FROM entries -- and then every list above LONG_LIST
+// is split; 0xffffffff: nothing is.  (Config B's two 2 100-entry tiles are faster left alone: 0.116 vs 0.144 ms.)
+constexpr uint32_t SPLIT_FROM = 4096;
+inline uint32_t split_threshold(uint32_t max_count)
+{
+    static const uint32_t from = getenv("GSR_SPLIT_FROM") ? (uint32_t)atoi(getenv("GSR_SPLIT_FROM")) : SPLIT_FROM;   // (tests: 0)
+    return max_count > from && max_count > LONG_LIST ? LONG_LIST : 0xffffffffu;
+}
 inline BinState carve_bin(void* base, int R, int U, int C = 3)
 {
     // (everything up to and including `masks` sits at offsets that do not depend on C: the debug exports carve with C = 3)
@@ -155,6 +175,10 @@ inline BinState carve_bin(void* base, int R, int U, int C = 3)
     s.rec_b = (float4*)(b + o); o = align_up(o + 16 * (size_t)R);
     s.unit_info = (uint4*)(b + o); o = align_up(o + 16 * (size_t)U);
     s.masks = (uint2*)(b + o); o = align_up(o + sizeof(uint2) * 256 * (size_t)U);
+    const size_t np = part_capacity(R, U);
+    s.part_list = (uint2*)(b + o); o = align_up(o + sizeof(uint2) * np);
+    s.part_last = (uint32_t*)(b + o); o = align_up(o + 4 * 256 * np);
+    s.part_fin = (float4*)(b + o); o = align_up(o + sizeof(float4) * 256 * (size_t)snap_vecs(C) * np);
     s.snap = (float4*)(b + o); o = align_up(o + sizeof(float4) * 256 * (size_t)snap_vecs(C) * (size_t)U);
     s.rec_c = (void*)(b + o); o = align_up(o + rec_tail_bytes(C) * (size_t)R);
     s.bytes = o + 256;
@@ -208,7 +232,7 @@ void launch_preprocess(int P, int D, int M, const float* means3D, const float* s
                        int H, float tan_fovx, float tan_fovy, int* radii, GeomState g, ImageState im, uint32_t view_token,
                        hipStream_t st);
 void launch_tile_scan(ImageState im, int T, uint32_t* host_totals, uint32_t host_seq, uint32_t view_token, hipStream_t st);
-void launch_scatter(int P, int W, int H, GeomState g, ImageState im, BinState b, hipStream_t st);
+void launch_scatter(int P, int W, int H, uint32_t max_count, GeomState g, ImageState im, BinState b, hipStream_t st);
 // -> true if lists of up to 2 048 entries were left for the forward blend to sort (gsr_sort.h)
 bool launch_tile_sort(int W, int H, int R, uint32_t max_count, ImageState im, BinState b, bool blend_sorts_small, hipStream_t st);
 // Launch positions [0, front_of_order(R, T)) of `order` hold every tile with 2 017 or more entries: they all fall into
@@ -219,7 +243,7 @@ inline int front_of_order(int R, int T)
     const long long bound = ((long long)(R > 0 ? R : 0) / 2017 + 1 + 255) / 256 * 256;
     return (int)(bound < (long long)T ? bound : (long long)T);
 }
-void launch_blend_fwd(int C, int W, int H, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im,
+void launch_blend_fwd(int C, int W, int H, int R, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im,
                       BinState b, float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, uint32_t* counters,
                       bool sort_small, hipStream_t st);
 void launch_blend_bwd(int C, int W, int H, int U, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,

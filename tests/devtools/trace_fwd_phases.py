@@ -9,7 +9,9 @@ import torch
 from gaustar_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib, scene
 
 cam_i = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-gs, cams, bg = scene.config_C()
+cfg = sys.argv[2] if len(sys.argv) > 2 else "C"
+gs, cams, bg = getattr(scene, "config_" + cfg)()
+cams = cams if isinstance(cams, (list, tuple)) else [cams]
 cam = cams[cam_i]
 dev = torch.device("cuda:0")
 t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
@@ -17,7 +19,8 @@ lib = _lib.load()
 W, H = cam.W, cam.H
 T = ((W + 15) // 16) * ((H + 15) // 16)
 m3, m2, op = t(gs.means3D).requires_grad_(True), torch.zeros(gs.P, 3, device=dev, requires_grad=True), t(gs.opacities).requires_grad_(True)
-cols, sc, rot = t(gs.colors_precomp).requires_grad_(True), t(gs.scales).requires_grad_(True), t(gs.rotations).requires_grad_(True)
+cols_np = gs.colors_precomp if gs.colors_precomp is not None else np.random.default_rng(0).random((gs.P, 3), dtype=np.float32)
+cols, sc, rot = t(cols_np).requires_grad_(True), t(gs.scales).requires_grad_(True), t(gs.rotations).requires_grad_(True)
 s = GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, t(bg), 1.0, t(cam.viewmatrix), t(cam.projmatrix), 0, t(cam.campos), False, False)
 rast = GaussianRasterizer(s)
 for _ in range(3):

@@ -384,6 +384,51 @@ print("LONG_PATH_OK")
     assert r.returncode == 0 and "LONG_PATH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+def test_lists_blended_in_parts():
+    """Lists above 2 048 entries in a view that splits (GSR_SPLIT_FROM=0 makes every such view split; by default only views
+    with a list above 4 096 entries do): the forward blends them in independent parts of one chunk and a combining
+    workgroup folds the parts together, pixels that may terminate inside a part walking their unit exactly
+    (gsr_blend_fwd.hip).  Translucent stacks (nobody terminates), opaque ones (everybody does, in different parts), and a
+    mix; 3 and 6 channels; against the oracle, and the no-grad forward must stay bit-identical to the differentiable one."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.getcwd(), "tests")); sys.path.insert(0, os.getcwd())
+import parity
+from gaustar_amd import scene, GaussianRasterizationSettings, GaussianRasterizer
+for seed, opac, P in ((1, (0.004, 0.02), 9000), (2, (0.3, 0.99), 9000), (3, (0.01, 0.6), 12000)):
+    rng = np.random.default_rng(seed)
+    gs = scene.random_gaussians(P, rng, scale_range=(0.02, 0.06), box=((-0.12, 0.12), (-0.1, 0.1), (-0.5, 0.5)))
+    gs.opacities[:] = rng.uniform(*opac, (gs.P, 1)).astype(np.float32)
+    cam = scene.look_at_camera((0.05, 0.0, -4.0), (0, 0, 0), 80, 64, fovx=0.5, znear=0.01)
+    kw = dict(means3D=gs.means3D, opacities=gs.opacities, view=cam.viewmatrix, proj=cam.projmatrix, campos=cam.campos, W=cam.W, H=cam.H,
+              tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=np.array([0.3, 0.1, 0.6], np.float32), shs=None, colors_precomp=gs.colors_precomp,
+              scales=gs.scales, rotations=gs.rotations, cov3D_precomp=None, sh_degree=0, scale_modifier=1.0)
+    dpix = rng.normal(size=(3, cam.H, cam.W)).astype(np.float32)
+    st, g = parity.run_oracle(kw, dpix)
+    longest = int((st["ranges"][:, 1] - st["ranges"][:, 0]).max())
+    assert longest > 2048 + 512, longest
+    hip = parity.run_hip(kw, dpix)
+    parity.compare_hip_to(hip, st["color"], st["radii"], g, what="parts seed %d (longest list %d)" % (seed, longest))
+    # no-grad forward == differentiable forward, bit for bit
+    dev = torch.device("cuda:0")
+    t = lambda x, rg=False: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev).requires_grad_(rg)
+    s = GaussianRasterizationSettings(cam.H, cam.W, cam.tanfovx, cam.tanfovy, t(kw["bg"]), 1.0, t(cam.viewmatrix), t(cam.projmatrix), 0,
+                                      t(cam.campos), False, False)
+    args = dict(means2D=torch.zeros(gs.P, 3, device=dev), colors_precomp=t(gs.colors_precomp), scales=t(gs.scales), rotations=t(gs.rotations))
+    img_g, _ = GaussianRasterizer(s)(means3D=t(gs.means3D, True), opacities=t(gs.opacities, True), **args)
+    with torch.no_grad():
+        img_n, _ = GaussianRasterizer(s)(means3D=t(gs.means3D), opacities=t(gs.opacities), **args)
+    assert torch.equal(img_g.detach(), img_n), "forward-only render differs"
+print("PARTS_OK")
+'''
+    env = dict(os.environ, GSR_SPLIT_FROM="0")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "PARTS_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
+
+
 def test_hostile_inputs_neither_hang_nor_fault():
     """NaN / Inf / huge / degenerate parameters (tests/devtools/fuzz_inputs.py) must come back from forward + backward:
     no hang, no device fault.  (Values are garbage in the reference too and are not compared.)"""

@@ -49,3 +49,17 @@ for name, arr in (("fwd", tr[:2 * T].reshape(T, 2)), ("bwd", tr[2 * T:].reshape(
     conc = [(np.minimum(en[ok], b) - np.maximum(st[ok], a)).clip(0).sum() / (b - a) for a, b in zip(edges[:-1], edges[1:])]
     print("   concurrency per decile:", [int(c_) for c_ in conc])
     print("   duration percentiles (us) p50/p90/p99/max:", [round(float(np.percentile(dur[ok], q)), 1) for q in (50, 90, 99, 100)])
+# the slowest forward workgroups: launch slot, duration, list length of their tile
+e2 = torch.Tensor([])
+rng_t = torch.zeros(T, 2, dtype=torch.int32, device=dev); pl_t = torch.zeros(max(Rn, 1), dtype=torch.int32, device=dev)
+P_ = gs.P
+m2_ = torch.zeros(P_, 2, device=dev); co_ = torch.zeros(P_, 4, device=dev); fT_ = torch.zeros(H, W, device=dev); nc_ = torch.zeros(H, W, dtype=torch.int32, device=dev)
+pp = lambda x: ctypes.c_void_p(x.data_ptr())
+_lib.check(lib.gsr_debug_export(P_, Rn, 1, W, H, pp(geom), pp(binning), pp(img), pp(m2_), pp(co_), None, None, pp(rng_t), pp(pl_t), pp(fT_), pp(nc_), None), "export")
+torch.cuda.synchronize()
+rg = rng_t.cpu().numpy().astype(np.int64); lens = rg[:, 1] - rg[:, 0]
+order = np.argsort(-lens, kind="stable")      # approximately the launch order (32-entry buckets, snake)
+fw = tr[:2 * T].reshape(T, 2); dur = fw[:, 1] - fw[:, 0]
+top = np.argsort(-dur)[:8]
+print("slowest forward slots (slot, us, list length of the tile at that rank of the length order):", [(int(s_), round(float(dur[s_]), 1), int(lens[order[s_]])) for s_ in top])
+print("deepest n_contrib per tile of the longest lists:", [(int(lens[t_]), int(nc_.cpu().numpy()[(t_ // ((W + 15) // 16)) * 16:(t_ // ((W + 15) // 16)) * 16 + 16, (t_ % ((W + 15) // 16)) * 16:(t_ % ((W + 15) // 16)) * 16 + 16].max())) for t_ in order[:8]])
