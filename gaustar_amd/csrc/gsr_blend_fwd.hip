@@ -329,19 +329,35 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             float Tp, Cp[C];
             load_snapshot<C>(part_fin + ps * SV, Tp, Cp);
             const uint32_t lp = part_last[ps];
+            // (the candidate words of the part's units are requested with its result: one trip to memory instead of two)
+            constexpr int NU = CH / 64;
+            uint2 wd[NU];
+            const uint32_t u_first = unit0 + (c0 >> 6);
+#pragma unroll
+            for (int uu = 0; uu < NU; uu++)
+                wd[uu] = (snaps && c0 + 64u * uu < n && (c0 != 0u || uu != 0)) ? words_of(u_first + uu) : make_uint2(0u, 0u);
             if ((lp & 0x80000000u) != 0u || T * Tp < thr) {   // the pixel may terminate inside this part
                 parked = true; park_c0 = c0; park_lp = lp; park_Tp = Tp;
                 continue;
             }
             if (snaps) {
-                // (the pixel left a snapshot in every unit in which it has a candidate; the tile's very first slot is not
-                // a boundary, see below)
+                // re-base the part's snapshots (the pixel left one in every unit in which it has a candidate; the tile's very
+                // first slot is not a boundary, see below).  All snapshots are requested together, then the stores: as eight
+                // dependent word -> snapshot -> store chains this loop cost 6 us per part.
+                float Ts[NU], cs[NU][C];
 #pragma unroll
-                for (int uu = 0; uu < CH / 64; uu++) {
-                    if (c0 + 64u * uu < n && (c0 != 0u || uu != 0)) {
-                        const uint32_t unit = unit0 + (c0 >> 6) + uu;
-                        const uint2 wd = words_of(unit);
-                        if ((wd.x | wd.y) != 0u) rebase(unit);
+                for (int uu = 0; uu < NU; uu++) {
+                    Ts[uu] = 0.f;
+#pragma unroll
+                    for (int ch = 0; ch < C; ch++) cs[uu][ch] = 0.f;
+                    if ((wd[uu].x | wd[uu].y) != 0u) load_snapshot<C>(snap + ((size_t)(u_first + uu) * 256 + pix_in_tile) * SV, Ts[uu], cs[uu]);
+                }
+#pragma unroll
+                for (int uu = 0; uu < NU; uu++) {
+                    if ((wd[uu].x | wd[uu].y) != 0u) {
+#pragma unroll
+                        for (int ch = 0; ch < C; ch++) cs[uu][ch] = Cc[ch] + T * cs[uu][ch];
+                        store_snapshot<C>(snap + ((size_t)(u_first + uu) * 256 + pix_in_tile) * SV, T * Ts[uu], cs[uu]);
                     }
                 }
             }
