@@ -359,7 +359,7 @@ int forward_stage2_impl(int P, int R, int max_tile_instances, int num_segments, 
             Scope sc(ST_TILE_SORT, st);
             const char* e_fuse = getenv("GSR_SORT_IN_BLEND");   // read per call (tools/ab_env.py); "0": separate sort kernel
             const bool fuse = !(e_fuse && e_fuse[0] == '0');
-            sort_in_blend = launch_tile_sort(W, H, R, (uint32_t)(max_tile_instances > 0 ? max_tile_instances : 0), im, b, fuse, st);
+            sort_in_blend = launch_tile_sort(W, H, R, num_segments, (uint32_t)(max_tile_instances > 0 ? max_tile_instances : 0), im, b, fuse, st);
         }
         GSR_CHECK_LAUNCH("tile_sort_kernel");
     }

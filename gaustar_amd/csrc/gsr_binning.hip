@@ -438,7 +438,73 @@ tile_sort_big_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
     else sort_tile_in_registers<16>(s, gk, out, n, 16384u);
 }
 
-bool launch_tile_sort(int W, int H, int R, uint32_t max_count, ImageState im, BinState b, bool blend_sorts_small, hipStream_t st)
+// ---- lists of a view that blends its long lists in parts (gsr_blend_fwd.hip; scatter_kernel has listed the parts): a merge
+// sort over memory instead of one padded bitonic network per list -- the network of the longest list's padded size ran for
+// EVERY list above 2 048 entries (config D: 155 us for 16 384 padded keys), and above 16 384 keys it fell back to global
+// memory.  Runs of 2 048 keys are sorted in LDS (the forward's merge sort) by the workgroup of every fourth part; then
+// ceil(log2(n / 2 048)) passes, one launch each, merge neighbouring runs: a part's workgroup produces ITS 512 output
+// positions, every thread finding where its two outputs start in the two input runs by a binary search along the merge
+// path (keys are unique).  The passes ping-pong between two buffers; the last one leaves the ids in point_list.
+__global__ void __launch_bounds__(256)
+long_sort_runs_kernel(const uint2* __restrict__ part_list, const uint32_t* __restrict__ totals, const uint2* __restrict__ ranges,
+                      const uint64_t* __restrict__ keys, uint64_t* __restrict__ dst)
+{
+    if (blockIdx.x >= totals[6]) return;
+    const uint2 part = part_list[blockIdx.x];
+    if ((part.y & (SORT_SMALL_CAP - 1u)) != 0u) return;
+    const uint2 rg = ranges[part.x];
+    const uint32_t n = rg.y - rg.x, m = min(SORT_SMALL_CAP, n - part.y);
+    __shared__ __attribute__((aligned(16))) uint64_t s[2 * SORT_SMALL_CAP];
+    const uint64_t* gk = keys + rg.x + part.y;
+    uint64_t* out = dst + rg.x + part.y;
+    if (m == 1u) { if (threadIdx.x == 0) out[0] = gk[0]; return; }
+    if (m <= 512u) sort_tile_merge<2>(s, gk, nullptr, m, out);
+    else if (m <= 1024u) sort_tile_merge<4>(s, gk, nullptr, m, out);
+    else sort_tile_merge<8>(s, gk, nullptr, m, out);
+}
+
+__global__ void __launch_bounds__(256)
+long_sort_merge_kernel(const uint2* __restrict__ part_list, const uint32_t* __restrict__ totals, const uint2* __restrict__ ranges,
+                       const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, uint32_t* __restrict__ ids_out, uint32_t len)
+{
+    if (blockIdx.x >= totals[6]) return;
+    const uint2 part = part_list[blockIdx.x];
+    const uint2 rg = ranges[part.x];
+    const uint32_t n = rg.y - rg.x;
+    const uint32_t o0 = part.y + 2u * threadIdx.x;   // a part is FWD_CHUNK = 512 positions: two outputs per thread
+    static_assert(FWD_CHUNK == 512, "two outputs per thread of a 256-thread workgroup");
+    if (o0 >= n) return;
+    const uint32_t base = o0 & ~(2u * len - 1u);
+    const uint32_t la = min(len, n - base);
+    const uint32_t lb = base + len < n ? min(len, n - base - len) : 0u;
+    const uint64_t* a = src + rg.x + base;
+    const uint64_t* b = a + len;
+    const uint32_t d = o0 - base;
+    uint32_t lo = d > lb ? d - lb : 0u, hi = min(d, la);
+    while (lo < hi) {   // merge path: how many of the first d outputs come from a
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] < b[d - 1u - mid]) lo = mid + 1u; else hi = mid;
+    }
+    uint32_t ai = lo, bi = d - lo;
+    uint64_t ka = ai < la ? a[ai] : ~0ull, kb = bi < lb ? b[bi] : ~0ull;
+    uint64_t res[2];
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const bool take_a = bi >= lb || (ai < la && ka < kb);
+        res[e] = take_a ? ka : kb;
+        if (take_a) { ai++; ka = ai < la ? a[ai] : ~0ull; }
+        else { bi++; kb = bi < lb ? b[bi] : ~0ull; }
+    }
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        if (o0 + (uint32_t)e < n) {
+            dst[rg.x + o0 + e] = res[e];
+            if (ids_out != nullptr) ids_out[rg.x + o0 + e] = (uint32_t)res[e];
+        }
+    }
+}
+
+bool launch_tile_sort(int W, int H, int R, int U, uint32_t max_count, ImageState im, BinState b, bool blend_sorts_small, hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);
     bool left_small = false;
@@ -453,7 +519,21 @@ bool launch_tile_sort(int W, int H, int R, uint32_t max_count, ImageState im, Bi
     // the forward blend sorts each of these lists right before walking it
     else if (blend_sorts_small) left_small = true;
     else tile_sort_reg_kernel<<<t.T, 256, 0, st>>>(im.ranges, im.order, b.keys, b.point_list);
-    if (max_count > 2048 && !lds_sort) {
+    const bool in_parts = split_threshold(max_count) != 0xffffffffu && !lds_sort;
+    if (in_parts) {
+        uint64_t* bufs[2] = {reinterpret_cast<uint64_t*>(b.rec_a), reinterpret_cast<uint64_t*>(b.rec_a) + (size_t)R};   // (free until the forward)
+        const unsigned grid = (unsigned)part_capacity(R, U);
+        long_sort_runs_kernel<<<grid, 256, 0, st>>>(b.part_list, im.totals, im.ranges, b.keys, bufs[0]);
+        int cur = 0;
+        for (uint32_t len = SORT_SMALL_CAP; len < max_count; len <<= 1) {
+            const bool last = (len << 1) >= max_count || (len << 1) == 0u;
+            long_sort_merge_kernel<<<grid, 256, 0, st>>>(b.part_list, im.totals, im.ranges, bufs[cur], bufs[cur ^ 1],
+                                                         last ? b.point_list : nullptr, len);
+            cur ^= 1;
+            if (last) break;
+        }
+    }
+    if (max_count > 2048 && !lds_sort && !in_parts) {
         // the longest lists sit at the front of `order` (32-entry length classes, snake within bands of 256): every tile
         // above 2 048 entries is within the first few bands, but the kernel checks each tile's length itself anyway
         static bool attr_big = false;
@@ -466,7 +546,7 @@ bool launch_tile_sort(int W, int H, int R, uint32_t max_count, ImageState im, Bi
         uint32_t np2 = 4096; while (np2 < cap) np2 <<= 1;
         tile_sort_big_kernel<<<front_of_order(R, t.T), 1024, (size_t)np2 * 8, st>>>(im.ranges, im.order, b.keys, b.point_list);
     }
-    if (max_count > 16384 || (lds_sort && max_count > 2048)) {
+    if ((max_count > 16384 && !in_parts) || (lds_sort && max_count > 2048)) {
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_kernel<16384, 2048, true>),

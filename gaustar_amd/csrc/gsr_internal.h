@@ -234,7 +234,7 @@ void launch_preprocess(int P, int D, int M, const float* means3D, const float* s
 void launch_tile_scan(ImageState im, int T, uint32_t* host_totals, uint32_t host_seq, uint32_t view_token, hipStream_t st);
 void launch_scatter(int P, int W, int H, uint32_t max_count, GeomState g, ImageState im, BinState b, hipStream_t st);
 // -> true if lists of up to 2 048 entries were left for the forward blend to sort (gsr_sort.h)
-bool launch_tile_sort(int W, int H, int R, uint32_t max_count, ImageState im, BinState b, bool blend_sorts_small, hipStream_t st);
+bool launch_tile_sort(int W, int H, int R, int U, uint32_t max_count, ImageState im, BinState b, bool blend_sorts_small, hipStream_t st);
 // Launch positions [0, front_of_order(R, T)) of `order` hold every tile with 2 017 or more entries: they all fall into
 // length class 0, which sits at the front, there are at most R / 2017 of them, and the snake only permutes within
 // bands of 256.  Kernels that only concern such tiles are launched over this prefix instead of all T tiles.

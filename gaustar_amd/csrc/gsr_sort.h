@@ -126,9 +126,10 @@ __device__ __forceinline__ void run64_stages(uint64_t (&v)[1], int lane)
     else if constexpr (K < 64) run64_stages<K * 2, K>(v, lane);
 }
 
+// (out: the sorted Gaussian ids; out_keys, if given instead: the sorted keys themselves -- runs of a longer list)
 template <int E>
 __device__ __forceinline__ void sort_tile_merge(uint64_t* __restrict__ s, const uint64_t* __restrict__ gk,
-                                                uint32_t* __restrict__ out, uint32_t n)
+                                                uint32_t* __restrict__ out, uint32_t n, uint64_t* __restrict__ out_keys = nullptr)
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint64_t* A = s;
@@ -172,7 +173,8 @@ __device__ __forceinline__ void sort_tile_merge(uint64_t* __restrict__ s, const 
         __syncthreads();                                        // level done: B complete, nobody reads A any more
         uint64_t* t = A; A = B; B = t;
     }
-    for (uint32_t i = tid; i < n; i += 256u) out[i] = (uint32_t)A[i];
+    if (out_keys != nullptr) { for (uint32_t i = tid; i < n; i += 256u) out_keys[i] = A[i]; }
+    else { for (uint32_t i = tid; i < n; i += 256u) out[i] = (uint32_t)A[i]; }
 }
 
 // One tile of 1 .. 2 048 keys, 256 threads, s = 2 * SORT_SMALL_CAP * 8 bytes of LDS.

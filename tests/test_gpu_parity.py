@@ -398,9 +398,10 @@ import numpy as np, torch
 sys.path.insert(0, os.path.join(os.getcwd(), "tests")); sys.path.insert(0, os.getcwd())
 import parity
 from gaustar_amd import scene, GaussianRasterizationSettings, GaussianRasterizer
-for seed, opac, P in ((1, (0.004, 0.02), 9000), (2, (0.3, 0.99), 9000), (3, (0.01, 0.6), 12000)):
+for seed, opac, P, half in ((1, (0.004, 0.02), 9000, 0.12), (2, (0.3, 0.99), 9000, 0.12), (3, (0.01, 0.6), 12000, 0.12),
+                            (4, (0.004, 0.01), 20000, 0.02)):     # (the last: one list above 16 384 entries -- four merge passes)
     rng = np.random.default_rng(seed)
-    gs = scene.random_gaussians(P, rng, scale_range=(0.02, 0.06), box=((-0.12, 0.12), (-0.1, 0.1), (-0.5, 0.5)))
+    gs = scene.random_gaussians(P, rng, scale_range=(0.02, 0.06), box=((-half, half), (-half, half), (-0.5, 0.5)))
     gs.opacities[:] = rng.uniform(*opac, (gs.P, 1)).astype(np.float32)
     cam = scene.look_at_camera((0.05, 0.0, -4.0), (0, 0, 0), 80, 64, fovx=0.5, znear=0.01)
     kw = dict(means3D=gs.means3D, opacities=gs.opacities, view=cam.viewmatrix, proj=cam.projmatrix, campos=cam.campos, W=cam.W, H=cam.H,
@@ -409,7 +410,7 @@ for seed, opac, P in ((1, (0.004, 0.02), 9000), (2, (0.3, 0.99), 9000), (3, (0.0
     dpix = rng.normal(size=(3, cam.H, cam.W)).astype(np.float32)
     st, g = parity.run_oracle(kw, dpix)
     longest = int((st["ranges"][:, 1] - st["ranges"][:, 0]).max())
-    assert longest > 2048 + 512, longest
+    assert longest > (16384 if seed == 4 else 2048 + 512), longest
     hip = parity.run_hip(kw, dpix)
     parity.compare_hip_to(hip, st["color"], st["radii"], g, what="parts seed %d (longest list %d)" % (seed, longest))
     # no-grad forward == differentiable forward, bit for bit
