@@ -178,8 +178,10 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     const bool has_next = s1 < n;                       // (uniform) the tile has a unit behind this one
     const bool multi = n > BSEG;                        // (uniform) the tile's first snapshot slot holds the final (T, C)
 
-    const size_t pix = (size_t)W * py + px;
-    const size_t HW = (size_t)H * W;
+    // (32-bit element indices on uniform base pointers: the loads take an SGPR base + a VGPR offset instead of 64-bit
+    // vector address arithmetic; gsr_forward_stage1 caps the image at 8k x 8k, so channel * H * W + pixel fits)
+    const uint32_t pix = (uint32_t)W * (uint32_t)py + (uint32_t)px;
+    const uint32_t HW = (uint32_t)H * (uint32_t)W;
     const float T_final = inside ? final_T[pix] : 0.f;
     const int my_last = inside ? (int)n_contrib[pix] : 0;   // 1-based position of the last contributor
     float dp[C];
@@ -187,15 +189,15 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     for (int ch = 0; ch < C; ch++) dp[ch] = inside ? dL_dpix[ch * HW + pix] : 0.f;
     // this pixel's candidate word over the unit's 64 positions, from the forward (gsr_mask.h); the forward's lanes are
     // the block's pixels in the same row-major order as here
-    const uint2* const my_words = masks + ((size_t)unit * 4 + wave) * 64 + lane;   // + 256 per unit
+    const uint2* const my_words = masks + ((size_t)unit * 4 + wave) * 64 + (uint32_t)lane;   // + 256 per unit
     uint2 word = my_words[0];
     const uint2 word_next = has_next ? my_words[256] : make_uint2(0u, 0u);
     const int pidx = 16 * (py - ty * TILE) + (px - tx * TILE);
     float Ts = 1.f, Tf = 0.f, cs[C], cf[C];
 #pragma unroll
     for (int ch = 0; ch < C; ch++) cs[ch] = cf[ch] = 0.f;
-    if (has_next) load_snapshot<C>(snap + ((size_t)(unit + 1u) * 256 + pidx) * SV, Ts, cs);
-    if (multi) load_snapshot<C>(snap + ((size_t)unit0 * 256 + pidx) * SV, Tf, cf);   // final (T, C) kept in the tile's first slot
+    if (has_next) load_snapshot<C>(snap + (size_t)(unit + 1u) * 256 * SV + (uint32_t)(pidx * SV), Ts, cs);
+    if (multi) load_snapshot<C>(snap + (size_t)unit0 * 256 * SV + (uint32_t)(pidx * SV), Tf, cf);   // final (T, C) kept in the tile's first slot
     // lane l holds list position s0 + 63 - l (queue order == back-to-front order)
     const int k = s0 + 63 - lane;
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
@@ -204,10 +206,11 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     for (int ch = 2; ch < C; ch++) rc.c[ch - 2] = 0.f;
     uint32_t gid = 0;
     if (k < n) {
-        ra = rec_a[list0 + k];
-        rb = rec_b[list0 + k];
-        rc = rec_c[list0 + k];
-        gid = point_list[list0 + k];
+        const uint32_t kl = (uint32_t)(63 - lane);   // (uniform base list0 + s0, lane offset)
+        ra = (rec_a + list0 + s0)[kl];
+        rb = (rec_b + list0 + s0)[kl];
+        rc = (rec_c + list0 + s0)[kl];
+        gid = (point_list + list0 + s0)[kl];
     }
     float bg_dot_dpixel = 0.f;
 #pragma unroll
@@ -323,7 +326,6 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     }
     __builtin_amdgcn_wave_barrier();
 
-    unsigned long long touched = 0ull;
     const uint32_t q_base = lds_byte_address(qf);
     // where this lane's four accumulator registers go: rows 4 kap .. 4 kap + 3 of the D tile = instances (row & 7)
     static_assert(GRP == 8, "the write-back below assumes rows 0-7 = r, 8-15 = w");
@@ -360,7 +362,6 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
                 const float alpha = fminf(ALPHA_MAX, B.z * G);
                 const bool live = pos < my_lim && power <= 0.0f && alpha >= ALPHA_MIN;
                 if (__ballot(live) != 0ull) {
-                    touched |= 1ull << j;
                     if (live) {
                         // accum_rec' = alpha c + (1 - alpha) accum_rec written as accum_rec + alpha (c - accum_rec):
                         // the difference is needed for dL_dalpha anyway (one fma per channel instead of mul + fma);
@@ -417,7 +418,8 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
 
     // ---- lane = queued instance: re-centre the spatial sums on the splat (dx = x_splat - x_pixel), in place:
     // {sum r, sum r dx, sum r dy, sum r dx^2, sum r dx dy, sum r dy^2}; the colour moments stay as they are.
-    if (lane < cnt && ((touched >> lane) & 1ull)) {
+    // (every queued instance is flushed: 99.4 % of them have a live pixel, the others add zeros)
+    if (lane < cnt) {
         float* rw = &qf[lane * SF];
         const float m0 = rw[MOM0], mx = rw[MOM0 + 1], my = rw[MOM0 + 2], mxx = rw[MOM0 + 3], mxy = rw[MOM0 + 4],
                     myy = rw[MOM0 + 5];
@@ -434,7 +436,7 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     // request instead of one per float.
     for (int idx = lane; idx < cnt * NM; idx += 64) {
         const int e = idx / NM, v = idx - e * NM;
-        if ((touched >> e) & 1ull) {
+        {
             const size_t g = __float_as_uint(qf[e * SF + 2]);
             atomic_add_f32(grad_acc + g * GRAD_RS + v, qf[e * SF + MOM0 + v]);
         }
