@@ -247,7 +247,7 @@ scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __
     const int shard = (int)(blockIdx.x & (NSHARD - 1));
     const size_t Tp = shard_stride(T);
     // side job of the first T threads: expand the per-tile segment counts into the unit table -- everything a unit of
-    // the backward blend (or of tile_mask_kernel) has to know about its tile in ONE 16-byte load instead of a chain of
+    // the backward blend has to know about its tile in ONE 16-byte load instead of a chain of
     // three (it lives in the binning buffer, which did not exist yet when the scan kernel ran)
     if (idx < T) {
         const uint32_t u0 = seg_off[idx], u1 = seg_off[idx + 1];

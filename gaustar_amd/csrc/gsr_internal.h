@@ -101,8 +101,8 @@ inline ImageState carve_image(void* base, int W, int H)
 }
 
 // A tile's depth-sorted list is cut into SEGMENTS of SEG = 64 instances (UNITS when counted over all tiles, U of them);
-// a unit carries one 64-bit mask word per pixel of its tile (gsr_mask.hip): candidates before the forward blend, the
-// instances actually blended after it.
+// a unit carries one 64-bit candidate word per pixel of its tile (gsr_mask.h) and one snapshot of the pixel's running
+// (T, C), and is the work item of the backward blend.
 constexpr int SEG = 64;
 
 // List positions staged in LDS at a time by the forward blend (gsr_blend_fwd.hip).  A wave's trip count per chunk is

@@ -22,10 +22,10 @@
 // 27 vector instructions per block instead of 64 ballots.  ~500 instructions per unit, all 64 lanes busy.
 //
 // The forward blend calls unit_masks() on the records of a chunk while it parks them in LDS (lane = instance, one unit
-// per wave and fetch round) and consumes the words from LDS; what it writes to global memory,
-// masks[(unit * 4 + block) * 64 + lane] = uint2 {positions 0-31, positions 32-63} with block = 2*by + bx and
-// lane = 8*(y - block_y0) + (x - block_x0), are the bits it actually BLENDED (per half bit-reversed): the backward
-// blend finds its snapshots through them.
+// per wave and fetch round), consumes the words from LDS and -- when a backward pass may follow -- also writes them to
+// global memory, masks[(unit * 4 + block) * 64 + lane] = uint2 {positions 0-31, positions 32-63} with block = 2*by + bx and
+// lane = 8*(y - block_y0) + (x - block_x0): the backward blend derives from them which instances of a unit any pixel of
+// a block replays, and in which later unit a pixel's snapshot sits.
 #pragma once
 #include "gsr_internal.h"
 #include "gsr_sort.h"
