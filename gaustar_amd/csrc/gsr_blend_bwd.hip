@@ -15,17 +15,19 @@
 //    starts from (T_final, 0) like the reference; a pixel that ended before it is idle.  Units have bounded
 //    size, so the dispatcher can balance them and nothing carries a 1 600-instance serial chain;
 //  * which instances of the segment the block needs comes from the forward's per-pixel candidate words (gsr_mask.h):
-//    the OR over the block's pixels of (word AND "positions this pixel replays").  Only those are fetched (lane i
-//    takes position i) and queued in LDS -- no geometric test is repeated here;
+//    the OR over the block's pixels of (word AND "positions this pixel replays").  The unit's 64 records arrive as
+//    three contiguous rows the forward left in list order (lane i takes position 63 - i, together with every other
+//    load of the unit's head); only the needed ones are queued in LDS -- no geometric test is repeated here;
 //  * for a queued instance every lane evaluates its pixel and produces just TWO numbers,
 //    w = alpha*T and r = G*dL_dalpha.  Everything the gradients need is a sum over the block's pixels of w or r
 //    times a per-pixel constant:   sum w*dL_dpix_{r,g,b}   and   sum r*{1, x, y, x^2, xy, y^2}  (x, y = pixel
 //    coordinates relative to the block centre).  That is a contraction over the 64 pixels,
 //        [instances x pixels] . [pixels x 9],
 //    and it runs on the matrix pipe: w and r are parked in LDS one row per instance, read back transposed, and
-//    reduced by v_mfma_f32_16x16x4_f32 (exact f32 multiply-add, 16 issues cover 64 pixels) while the vector
-//    ALU already works on the next instances.  This is the one place on the path that IS a contraction; it
-//    replaces a 26-instruction cross-lane VALU reduction per instance (30 % of the kernel before);
+//    reduced by v_mfma_f32_16x16x4_f32 (exact f32 multiply-add, 16 issues cover 64 pixels).  This is the one
+//    place on the path that IS a contraction; the f32 matrix instruction occupies the SIMD's vector multipliers for its
+//    32 cycles (it does not overlap with vector work: tools/micro/mfma_valu_overlap.hip) -- what it saves is
+//    instructions: 16 per eight instances replace a 26-instruction cross-lane reduction PER instance;
 //    The moments land in the fields of the instance's LDS queue slot that are dead by then;
 //  * one lane per instance then re-centres the six spatial sums on the splat (dx = x_splat - x_pixel) --
 //    dL_dcolor, dL_dopacity, dL_dmean2D and dL_dconic are fixed per-Gaussian linear maps of the nine moments,
