@@ -437,7 +437,7 @@ int gsr_backward_mt(int P, int D, int M, int R, int num_segments, int num_channe
     if (!means3D || !viewmatrix || !projmatrix || !campos || !radii || !geom_buffer || !image_buffer || !dL_dpix ||
         !background)
         return fail_msg("gsr_backward: required pointer is null");
-    if (!grad_scratch || !dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
+    if (!grad_scratch || !dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D || (cov3D_precomp && !dL_dcov3D))
         return fail_msg("gsr_backward: required gradient pointer is null");
     if (shs && !dL_dsh) return fail_msg("gsr_backward: dL_dsh is null in SH mode");
     if (!cov3D_precomp && (!scales || !rotations || !dL_dscale || !dL_drot))

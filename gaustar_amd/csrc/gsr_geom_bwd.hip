@@ -35,8 +35,10 @@ geom_bwd_body(int idx, int P, int D, int M, int C, const float* __restrict__ mea
         for (int ch = 0; ch < C; ch++) dL_dcolor[(size_t)C * i + ch] = 0.f;
         dL_dopacity[i] = 0.f;
         dL_dmean3D[3 * i] = 0.f; dL_dmean3D[3 * i + 1] = 0.f; dL_dmean3D[3 * i + 2] = 0.f;
+        if (dL_dcov3D) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) dL_dcov3D[6 * i + k] = 0.f;
+            for (int k = 0; k < 6; k++) dL_dcov3D[6 * i + k] = 0.f;
+        }
         if (dL_dscale) { dL_dscale[3 * i] = 0.f; dL_dscale[3 * i + 1] = 0.f; dL_dscale[3 * i + 2] = 0.f; }
         if (dL_drot) reinterpret_cast<float4*>(dL_drot)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (my_sh)
@@ -102,8 +104,10 @@ geom_bwd_body(int idx, int P, int D, int M, int C, const float* __restrict__ mea
         dcov[2] = 2 * a0[0] * a0[2] * dL_da + (a0[0] * a1[2] + a0[2] * a1[0]) * dL_db + 2 * a1[0] * a1[2] * dL_dc;
         dcov[4] = 2 * a0[2] * a0[1] * dL_da + (a0[1] * a1[2] + a0[2] * a1[1]) * dL_db + 2 * a1[1] * a1[2] * dL_dc;
     }
+    if (dL_dcov3D) {   // (NULL when the covariances come from scales and rotations: nobody reads this gradient then)
 #pragma unroll
-    for (int k = 0; k < 6; k++) dL_dcov3D[6 * i + k] = dcov[k];
+        for (int k = 0; k < 6; k++) dL_dcov3D[6 * i + k] = dcov[k];
+    }
 
     float dT0[3], dT1[3];
 #pragma unroll

@@ -203,7 +203,8 @@ def rasterize_gaussians_backward_native(background, means3D, radii, colors, scal
         prezeroed = zeroed_scratch is not None and zeroed_scratch.numel() == lib.gsr_grad_scratch_bytes(P)
         grad_scratch = zeroed_scratch if prezeroed else torch.empty(lib.gsr_grad_scratch_bytes(P), dtype=torch.uint8, device=dev)
         dL_dopacity = torch.empty(P, 1, **f32)
-        dL_dcov3D = torch.empty(P, 6, **f32)
+        # (only read by autograd when the covariances were an input; the library skips the 24 B/Gaussian otherwise)
+        dL_dcov3D = torch.empty(P, 6, **f32) if has_cov else None
         dL_dsh = torch.empty(P, M, 3, **f32)
         dL_dscales = torch.zeros(P, 3, **f32) if has_cov else torch.empty(P, 3, **f32)
         dL_drotations = torch.zeros(P, 4, **f32) if has_cov else torch.empty(P, 4, **f32)

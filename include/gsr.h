@@ -136,7 +136,8 @@ int gsr_forward(gsr_alloc_fn geometry_buffer, gsr_alloc_fn binning_buffer, gsr_a
  * Output gradient arrays need NOT be zeroed by the caller (the reference requires zeroed
  * tensors, DGR/rasterize_points.cu:151-159; here the fill is part of the call):
  *   grad_scratch: gsr_grad_scratch_bytes(P) bytes of work space (contents undefined afterwards);
- *   dL_dmean2D [P,3], dL_dopacity [P], dL_dcolor [P,3], dL_dmean3D [P,3], dL_dcov3D [P,6],
+ *   dL_dmean2D [P,3], dL_dopacity [P], dL_dcolor [P,3], dL_dmean3D [P,3], dL_dcov3D [P,6] (may be NULL when
+ *   cov3D_precomp is NULL: the reference writes it regardless, rasterizer_impl.cu:401-416, and its binding then drops it),
  *   dL_dsh [P,M,3] (NULL when M == 0), dL_dscale [P,3], dL_drot [P,4] (both NULL when cov3D_precomp
  *   is given). */
 int gsr_backward(int P, int D, int M, int R, int num_segments, const float* background, int W, int H,
