@@ -77,11 +77,26 @@ __device__ __forceinline__ void lds_request(SlotRegs<VECS>& r, uint32_t addr)
     if constexpr (VECS > 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r.v[2]) : "v"(addr), "n"(OFF + 32) : "memory");
     if constexpr (VECS > 3) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r.v[3]) : "v"(addr), "n"(OFF + 48) : "memory");
 }
-template <int VECS>
+template <int OFF>
+__device__ __forceinline__ void lds_store_b32(uint32_t addr, float v)
+{
+    asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+// PENDING: LDS operations issued AFTER the request that may still be in flight when the data are used (LDS operations
+// complete in order, so "at most PENDING outstanding" implies the older request has landed).  The pair loop passes 2 --
+// the previous pair's two table stores; waiting for those as well (lgkmcnt(0)) stalled every pair for a store's latency.
+// The "memory" clobber keeps the compiler from moving those stores behind the wait.
+template <int PENDING, int VECS>
 __device__ __forceinline__ void lds_wait(SlotRegs<VECS>& r)
 {
-    if constexpr (VECS == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]));
-    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]), "+v"(r.v[3]));
+    static_assert(PENDING == 0 || PENDING == 2, "");
+    if constexpr (PENDING == 0) {
+        if constexpr (VECS == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]) : : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]), "+v"(r.v[3]) : : "memory");
+    } else {
+        if constexpr (VECS == 3) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]) : : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]), "+v"(r.v[3]) : : "memory");
+    }
 }
 
 // OR over the 64 lanes of a wave, returned as a scalar: the classic DPP ladder (three row shifts of the input, two masked
@@ -144,7 +159,6 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     static_assert(QCAP >= GRP && QCAP <= 64 && QCAP % GRP == 0, "queue capacity: whole MFMA groups, at most one batch");
     __shared__ __attribute__((aligned(16))) float qf[QCAP * SF];   // queue slots (see SlotLayout)
     __shared__ __attribute__((aligned(16))) float Rm[2 * GRP * RSTRIDE];   // rows 0..7: r, rows 8..15: w, [row][pixel lane]
-    float* const Wm = Rm + GRP * RSTRIDE;
     // one wave64 per workgroup: unit = (tile, segment), wave = 8x8 block of the tile.
     // XCD-aware placement: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the
     // naive map (unit = id / 4) would put the four blocks of a unit -- which read the SAME instance records -- on
@@ -329,6 +343,7 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     __builtin_amdgcn_wave_barrier();
 
     const uint32_t q_base = lds_byte_address(qf);
+    const uint32_t rw_addr = lds_byte_address(Rm) + 4u * (uint32_t)lane;   // this lane's column of the r|w table
     // where this lane's four accumulator registers go: rows 4 kap .. 4 kap + 3 of the D tile = instances (row & 7)
     static_assert(GRP == 8, "the write-back below assumes rows 0-7 = r, 8-15 = w");
     const int wb_row0 = 4 * (kap & 1);
@@ -348,7 +363,7 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
             // flight must not cross a control-flow merge, where the compiler may copy them -- reading them before the
             // data have landed.  Likewise the wait is on the requested registers themselves, the copy comes after it.
             // (Slot j + 1 < QCAP exists in LDS; past the end of the queue it holds stale numbers nobody uses.)
-            lds_wait(nxt);
+            lds_wait<(jj == 0 ? 0 : 2)>(nxt);   // (jj > 0: the two table stores of pair jj - 1 were issued after this request)
             const SlotRegs<L::IN_VECS> cur = nxt;
             if constexpr (jj + 1 < GRP) lds_request<L::IN_VECS, (jj + 1) * SF * 4>(nxt, q_grp);
             if (j < cnt) {
@@ -384,8 +399,10 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
                     }
                 }
             }
-            Rm[jj * RSTRIDE + lane] = r;
-            Wm[jj * RSTRIDE + lane] = w;
+            // (explicit instructions: the wait above counts on exactly these two LDS operations behind every request --
+            // the compiler must neither fuse them into one ds_write2 nor move them)
+            lds_store_b32<jj * RSTRIDE * 4>(rw_addr, r);
+            lds_store_b32<(GRP + jj) * RSTRIDE * 4>(rw_addr, w);
         });
         __builtin_amdgcn_wave_barrier();
         // ---- matrix pipe: [16 rows = r and w of GRP instances] x [64 pixels] . [64 pixels x 16 columns].
