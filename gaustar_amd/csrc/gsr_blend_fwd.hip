@@ -231,6 +231,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     // Everything but the snapshot store is branch-free: lanes need a new word in different trips, and a conditional block
     // that almost every trip enters for a few lanes costs more than selects for all.  Returns whether the pixel stopped.
     const auto walk = [&](uint32_t c0, uint32_t nz) {
+        const uint32_t mk_lane = (uint32_t)(size_t)&mk[wave][0][lane];   // LDS byte address of this lane's word 0 (+ 256 per word)
         uint32_t cur = 0, nw = 0;
         int h = 0, nh = 0;
         bool stopped = false;
@@ -248,14 +249,16 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                     store_snapshot<C>(snap + ((size_t)(unit0 + seg_new * (SNAP_SEG / 64)) * 256 + pix_in_tile) * SV, T, Cc);
                 }
             }
-            {   // refill the look-ahead slot (reads a word every trip; consumed only by lanes that needed one)
-                const int t = __builtin_ctz(nz | 0x80000000u) & (NH - 1);
-                const uint32_t wnext = mk[wave][t][lane];
-                nw = need ? (nz != 0u ? wnext : 0u) : nw;
-                nh = need ? t : nh;
-                nz = need ? (nz & (nz - 1u)) : nz;
+            // refill of the look-ahead slot: the word is REQUESTED here, by every lane and in every trip (an explicit
+            // ds_read: left to the compiler the read sits in a block only the lanes that need a word enter, followed by
+            // a wait for it -- a full LDS round trip in front of most trips), and consumed after the pair's arithmetic
+            const int t = __builtin_ctz(nz | 0x80000000u) & (NH - 1);
+            uint32_t wnext;
+            asm volatile("ds_read_b32 %0, %1" : "=v"(wnext) : "v"(mk_lane + (uint32_t)t * 256u) : "memory");
+            if (__ballot(cur != 0u) == 0ull) {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wnext) : : "memory");   // (nothing may stay in flight into a dead register)
+                break;
             }
-            if (__ballot(cur != 0u) == 0ull) break;
             // a lane without a candidate evaluates some record of its current word and drops it
             const bool act = cur != 0u;
             const int j = __builtin_ctz(cur | 0x80000000u);
@@ -279,6 +282,10 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             for (int ch = 0; ch < C; ch++) Cc[ch] += col[ch] * w;
             T = upd ? test_T : T;
             last = upd ? c0 + slot + 1u : last;
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wnext) : : "memory");   // (long landed: the gathers above were issued after it)
+            nw = need ? (nz != 0u ? wnext : 0u) : nw;
+            nh = need ? t : nh;
+            nz = need ? (nz & (nz - 1u)) : nz;
             // a pixel that terminates drops the rest of its candidates
             stopped = stopped || stop;
             cur = stop ? 0u : cur;
