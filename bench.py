@@ -265,9 +265,14 @@ def main():
                     if vi:
                         # secondary roofline: vector-ALU issue.  frac = share of the chip's VALU issue
                         # slots the kernel's own vector instructions occupy while it runs
+                        # The model prices every instruction at 4 cycles; and/sub/mov-class instructions issue in
+                        # 2.4-2.9 (tools/micro/valu_rates.hip), so a kernel full of them can exceed 1 under it: the
+                        # uncapped figure and the 2.4-cycle floor are reported next to the capped one.
                         t_s = kern[dom]["ms_per_launch"] * 1e-3
+                        f4 = vi * 4 / N_SIMD / (t_s * CLOCK_HZ)
                         valu = {"insts_per_launch": int(vi), "issue_cycles_per_simd": round(vi * 4 / N_SIMD, 1),
-                                "frac": round(vi * 4 / N_SIMD / (t_s * CLOCK_HZ), 4), "unit": "wave64 VALU instructions",
+                                "frac": round(min(1.0, f4), 4), "frac_4_cycle_model_uncapped": round(f4, 4),
+                                "frac_floor_2p4_cycles_each": round(f4 * 2.4 / 4, 4), "unit": "wave64 VALU instructions",
                                 "salu_insts_per_launch": pmc[dom].get("salu_insts")}
             except Exception:
                 traffic, valu = None, None

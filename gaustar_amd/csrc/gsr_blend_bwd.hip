@@ -24,10 +24,12 @@
 //    coordinates relative to the block centre).  That is a contraction over the 64 pixels,
 //        [instances x pixels] . [pixels x 9],
 //    and it runs on the matrix pipe: w and r are parked in LDS one row per instance, read back transposed, and
-//    reduced by v_mfma_f32_16x16x4_f32 (exact f32 multiply-add, 16 issues cover 64 pixels).  This is the one
-//    place on the path that IS a contraction; the f32 matrix instruction occupies the SIMD's vector multipliers for its
-//    32 cycles (it does not overlap with vector work: tools/micro/mfma_valu_overlap.hip) -- what it saves is
-//    instructions: 16 per eight instances replace a 26-instruction cross-lane reduction PER instance;
+//    reduced by matrix instructions.  This is the one place on the path that IS a contraction.  Four and six channels use
+//    v_mfma_f32_16x16x4_f32 (exact f32 multiply-add, 16 issues cover 64 pixels): it occupies the SIMD's vector
+//    multipliers for its 32 cycles (no overlap with vector work: tools/micro/mfma_valu_overlap.hip) -- what it saves is
+//    instructions, 16 per eight instances instead of a 26-instruction cross-lane reduction PER instance.  Three channels
+//    (the reference's case) use the bf16 pipe on exact three-way splits of the f32 values (see GSR_BWD_BF16 below): 6
+//    issues of ~17 cycles instead of 16 of 32, bought with 88 vector instructions of splitting per eight instances;
 //    The moments land in the fields of the instance's LDS queue slot that are dead by then;
 //  * one lane per instance then re-centres the six spatial sums on the splat (dx = x_splat - x_pixel) --
 //    dL_dcolor, dL_dopacity, dL_dmean2D and dL_dconic are fixed per-Gaussian linear maps of the nine moments,
@@ -47,6 +49,24 @@
 namespace gsr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef GSR_BWD_BF16
+#define GSR_BWD_BF16 1
+#endif
+// Three channels: the contraction runs on the bf16 matrix pipe WITHOUT giving up f32 accuracy.  An f32 is exactly
+// hi + mid + lo with eight significant bits each (truncate to the upper 16 bits, subtract, twice: the second remainder has
+// at most eight bits left), the monomials are exact in bf16, dL_dpix takes three columns per channel (6 + 3 C = 15 <= 16).
+// Six v_mfma_f32_16x16x32_bf16 (K = 32 pixels x {hi, mid, lo} of the A operand, products exact, f32 accumulation) replace
+// sixteen v_mfma_f32_16x16x4_f32: ~100 instead of 512 cycles of the SIMD per eight instances, paid for with 5.5 vector
+// instructions per table value for the splits (tools/micro/mfma_bf16_valu_overlap.hip).  Four and six
+// channels would need a second column tile and keep the f32 instruction.
+__device__ __forceinline__ uint32_t bf16_pair(float lo_elem, float hi_elem)   // upper halves of two floats, element order (lo, hi)
+{
+    return __builtin_amdgcn_perm(__float_as_uint(hi_elem), __float_as_uint(lo_elem), 0x07060302u);
+}
+__device__ __forceinline__ float bf16_rest(float x) { return x - __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
 
 // LDS queue slot of one fetched instance, as floats:
 //   [0] x  [1] y  [2] gaussian id (uint bits)  [3..5] conic a, b, c in the exp2 domain (conic_to_exp2)  [6] opacity
@@ -152,8 +172,10 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     static_assert(NM <= 16 && NM <= GRAD_RS, "moment columns must fit one MFMA tile and one record");
     static_assert(L::IN_VECS == 3 || L::IN_VECS == 4, "slot reads are written for three or four float4");
     const uint64_t t_start = trace ? wall_clock64() : 0;
+    // (bf16 path: 69 registers allow seven waves per SIMD, which the LDS budget only admits with 16 slots -- 5 120 bytes
+    // per wave; chunks are whole MFMA groups, so a batch of 28 is grouped 8+8 | 8+4 either way)
 #ifndef GSR_BWD_QCAP
-#define GSR_BWD_QCAP 32
+#define GSR_BWD_QCAP (GSR_BWD_BF16 && C == 3 ? 16 : 32)
 #endif
     constexpr int QCAP = GSR_BWD_QCAP;
     static_assert(QCAP >= GRP && QCAP <= 64 && QCAP % GRP == 0, "queue capacity: whole MFMA groups, at most one batch");
@@ -290,7 +312,9 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     // pixels of ITS column with four ds_read_b128: rows 0..5 the monomials of the lane's own pixel (exact small
     // half-integers), row 6 + ch = dL_dpix channel ch, one all-zero row for the unused columns.  (Forming the monomials
     // per (lane, step) in registers took 90 vector instructions per wave.)
-    static_assert((6 + C + 1) * 64 <= 2 * GRP * RSTRIDE, "B-operand staging must fit the r|w table");
+    constexpr bool BF16 = GSR_BWD_BF16 && C == 3;   // 6 + 3 C columns have to fit the tile
+    constexpr int BROWS = BF16 ? 6 + 3 * C : 6 + C;
+    static_assert((BROWS + 1) * 64 <= 2 * GRP * RSTRIDE, "B-operand staging must fit the r|w table");
     {
         const float xr = (float)(lane & 7) - 3.5f, yr = (float)(lane >> 3) - 3.5f;
         Rm[0 * 64 + lane] = 1.0f;
@@ -299,18 +323,39 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
         Rm[3 * 64 + lane] = xr * xr;
         Rm[4 * 64 + lane] = xr * yr;
         Rm[5 * 64 + lane] = yr * yr;
+        if constexpr (BF16) {
 #pragma unroll
-        for (int ch = 0; ch < C; ch++) Rm[(6 + ch) * 64 + lane] = dp[ch];
-        Rm[(6 + C) * 64 + lane] = 0.f;
+            for (int ch = 0; ch < C; ch++) {
+                const float d1 = bf16_rest(dp[ch]), d2 = bf16_rest(d1);
+                Rm[(6 + 3 * ch) * 64 + lane] = dp[ch];      // (the operand takes the upper halves: hi, mid, lo)
+                Rm[(7 + 3 * ch) * 64 + lane] = d1;
+                Rm[(8 + 3 * ch) * 64 + lane] = d2;
+            }
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) Rm[(6 + ch) * 64 + lane] = dp[ch];
+        }
+        Rm[BROWS * 64 + lane] = 0.f;
     }
     __builtin_amdgcn_wave_barrier();
-    float Bf[16];
+    float Bf[BF16 ? 1 : 16];
+    u32x4 Bp[BF16 ? 2 : 1];
     {
-        const float4* pd = reinterpret_cast<const float4*>(&Rm[(col < 6 + C ? col : 6 + C) * 64 + 16 * kap]);
+        const float4* pd = reinterpret_cast<const float4*>(&Rm[(col < BROWS ? col : BROWS) * 64 + 16 * kap]);
+        float bv[16];
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) {
             const float4 v = pd[qd];
-            Bf[4 * qd] = v.x; Bf[4 * qd + 1] = v.y; Bf[4 * qd + 2] = v.z; Bf[4 * qd + 3] = v.w;
+            bv[4 * qd] = v.x; bv[4 * qd + 1] = v.y; bv[4 * qd + 2] = v.z; bv[4 * qd + 3] = v.w;
+        }
+        if constexpr (BF16) {
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) Bp[h][q] = bf16_pair(bv[8 * h + 2 * q], bv[8 * h + 2 * q + 1]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; t++) Bf[t] = bv[t];
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -347,8 +392,9 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     // where this lane's four accumulator registers go: rows 4 kap .. 4 kap + 3 of the D tile = instances (row & 7)
     static_assert(GRP == 8, "the write-back below assumes rows 0-7 = r, 8-15 = w");
     const int wb_row0 = 4 * (kap & 1);
-    const bool wb_take = kap < 2 ? col < 6 : (col >= 6 && col < NM);
-    float* const wb_ptr = &qf[wb_row0 * SF + MOM0 + col];
+    // (bf16 path: the colour moment of channel ch is the sum of columns 6 + 3 ch .. + 2, gathered into the first of them)
+    const bool wb_take = kap < 2 ? col < 6 : BF16 ? (col >= 6 && col < 6 + 3 * C && (col % 3) == 0) : (col >= 6 && col < NM);
+    float* const wb_ptr = &qf[wb_row0 * SF + MOM0 + (BF16 && col >= 6 ? 6 + (col - 6) / 3 : col)];
     for (int g0i = 0; g0i < cnt; g0i += GRP) {
         // ---- vector ALU: w and r of GRP instances for this lane's pixel, parked row-wise in LDS.  The slot of the
         // group's first instance is requested here, every further one while its predecessor is being evaluated.
@@ -406,9 +452,10 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
         });
         __builtin_amdgcn_wave_barrier();
         // ---- matrix pipe: [16 rows = r and w of GRP instances] x [64 pixels] . [64 pixels x 16 columns].
-        // A operand: lane l carries table row (l & 15) and, for step t, pixel 16*kap + t -> its 16 steps are
-        // 16 consecutive floats of the row (four ds_read_b128).  Two interleaved accumulators (even / odd steps)
-        // halve the dependent-accumulator chain.
+        // A operand: lane l carries table row (l & 15) and the 16 pixels 16*kap .. 16*kap + 15 -> 16 consecutive floats of
+        // the row (four ds_read_b128).  f32 instruction: step t consumes pixel 16*kap + t; two interleaved accumulators
+        // (even / odd steps) halve the dependent-accumulator chain.  bf16 instruction: K = 32 = the lanes' first (h = 0)
+        // resp. second (h = 1) eight pixels; per half one issue each for the lo, mid and hi parts, smallest first.
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         float ra[16];
         {
@@ -419,10 +466,41 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
                 ra[4 * qd] = v.x; ra[4 * qd + 1] = v.y; ra[4 * qd + 2] = v.z; ra[4 * qd + 3] = v.w;
             }
         }
+        if constexpr (BF16) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                u32x4 a_hi, a_mid, a_lo;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float x0 = ra[8 * h + 2 * q], x1 = ra[8 * h + 2 * q + 1];
+                    const float y0 = bf16_rest(x0), y1 = bf16_rest(x1);
+                    const float z0 = bf16_rest(y0), z1 = bf16_rest(y1);
+                    a_hi[q] = bf16_pair(x0, x1);
+                    a_mid[q] = bf16_pair(y0, y1);
+                    a_lo[q] = bf16_pair(z0, z1);
+                }
+                const bf16x8 b = __builtin_bit_cast(bf16x8, Bp[h]);
+                f32x4& acc = h ? acc1 : acc0;
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_lo), b, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_mid), b, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_hi), b, acc, 0, 0, 0);
+            }
+            // colour rows: the three split columns of a channel sit in neighbouring lanes of the 16-lane row
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float v = acc0[i] + acc1[i];
+                const float v1 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x101, 0xf, 0xf, true));   // row_shl:1
+                const float v2 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x102, 0xf, 0xf, true));   // row_shl:2
+                acc0[i] = kap < 2 ? v : (v2 + v1) + v;
+            }
+        } else {
 #pragma unroll
         for (int t = 0; t < 16; t += 2) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[t], Bf[t], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[t + 1], Bf[t + 1], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc0[i] += acc1[i];
         }
         // D layout: lane l, register i -> operand row 4*(l >> 4) + i, column l & 15.
         // rows 0..7: r of instance row, columns 0..5 = spatial sums; rows 8..15: w of instance row-8, columns 6..6+C-1.
@@ -432,7 +510,7 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
             const int left = cnt - g0i - wb_row0;     // instances of this group at or behind the lane's first row
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                if (i < left) dst[i * SF] = acc0[i] + acc1[i];
+                if (i < left) dst[i * SF] = acc0[i];
         }
         __builtin_amdgcn_wave_barrier();
     }
