@@ -92,10 +92,12 @@ template <int VECS> struct SlotRegs { f32x4 v[VECS]; };
 template <int VECS, int OFF>   // OFF: compile-time byte offset from `addr` (one address register serves a whole group)
 __device__ __forceinline__ void lds_request(SlotRegs<VECS>& r, uint32_t addr)
 {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r.v[0]) : "v"(addr), "n"(OFF) : "memory");
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r.v[1]) : "v"(addr), "n"(OFF + 16) : "memory");
-    if constexpr (VECS > 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r.v[2]) : "v"(addr), "n"(OFF + 32) : "memory");
-    if constexpr (VECS > 3) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r.v[3]) : "v"(addr), "n"(OFF + 48) : "memory");
+    // (early-clobber outputs: the address register must survive the request, it serves the whole group -- otherwise the
+    // last read lands on it and every pair re-materialises it)
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(r.v[0]) : "v"(addr), "n"(OFF) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(r.v[1]) : "v"(addr), "n"(OFF + 16) : "memory");
+    if constexpr (VECS > 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(r.v[2]) : "v"(addr), "n"(OFF + 32) : "memory");
+    if constexpr (VECS > 3) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(r.v[3]) : "v"(addr), "n"(OFF + 48) : "memory");
 }
 template <int OFF>
 __device__ __forceinline__ void lds_store_b32(uint32_t addr, float v)
@@ -220,22 +222,45 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     // vector address arithmetic; gsr_forward_stage1 caps the image at 8k x 8k, so channel * H * W + pixel fits)
     const uint32_t pix = (uint32_t)W * (uint32_t)py + (uint32_t)px;
     const uint32_t HW = (uint32_t)H * (uint32_t)W;
-    const float T_final = inside ? final_T[pix] : 0.f;
-    const int my_last = inside ? (int)n_contrib[pix] : 0;   // 1-based position of the last contributor
+    // (explicit 32-bit BYTE offsets: `base[pix]` widens the index to 64 bits and the compiler then builds a 64-bit vector
+    // address per load; one `if` around all of them: as separate conditional expressions each load got its own branch)
+    const auto at32 = [](const auto* base, uint32_t byte_off) {
+        return *reinterpret_cast<std::remove_reference_t<decltype(*base)>*>(reinterpret_cast<const char*>(base) + byte_off);
+    };
+    float T_final = 0.f;
+    int my_last = 0;   // 1-based position of the last contributor
     float dp[C];
 #pragma unroll
-    for (int ch = 0; ch < C; ch++) dp[ch] = inside ? dL_dpix[ch * HW + pix] : 0.f;
+    for (int ch = 0; ch < C; ch++) dp[ch] = 0.f;
+    if (inside) {
+        T_final = at32(final_T, pix * 4u);
+        my_last = (int)at32(n_contrib, pix * 4u);
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) dp[ch] = at32(dL_dpix, ((uint32_t)ch * HW + pix) * 4u);
+    }
     // this pixel's candidate word over the unit's 64 positions, from the forward (gsr_mask.h); the forward's lanes are
     // the block's pixels in the same row-major order as here
     const uint2* const my_words = masks + ((size_t)unit * 4 + wave) * 64 + (uint32_t)lane;   // + 256 per unit
-    uint2 word = my_words[0];
-    const uint2 word_next = has_next ? my_words[256] : make_uint2(0u, 0u);
+    const uint2* const words_u = masks + ((size_t)unit * 4 + wave) * 64;                      // (uniform part)
+    uint2 word = at32(words_u, (uint32_t)lane * 8u);
+    const uint2 word_next = has_next ? at32(words_u + 256, (uint32_t)lane * 8u) : make_uint2(0u, 0u);
     const int pidx = 16 * (py - ty * TILE) + (px - tx * TILE);
     float Ts = 1.f, Tf = 0.f, cs[C], cf[C];
 #pragma unroll
     for (int ch = 0; ch < C; ch++) cs[ch] = cf[ch] = 0.f;
-    if (has_next) load_snapshot<C>(snap + (size_t)(unit + 1u) * 256 * SV + (uint32_t)(pidx * SV), Ts, cs);
-    if (multi) load_snapshot<C>(snap + (size_t)unit0 * 256 * SV + (uint32_t)(pidx * SV), Tf, cf);   // final (T, C) kept in the tile's first slot
+    const auto load_snap32 = [&](const float4* base_u, float& T_, float (&c_)[C]) {   // uniform base, this pixel's slot
+        float v[4 * SV];
+#pragma unroll
+        for (int q = 0; q < SV; q++) {
+            const float4 t = at32(base_u, (uint32_t)(pidx * SV + q) * 16u);
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+        T_ = v[0];
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) c_[ch] = v[ch + 1];
+    };
+    if (has_next) load_snap32(snap + (size_t)(unit + 1u) * 256 * SV, Ts, cs);
+    if (multi) load_snap32(snap + (size_t)unit0 * 256 * SV, Tf, cf);   // final (T, C) kept in the tile's first slot
     // lane l holds list position s0 + 63 - l (queue order == back-to-front order)
     const int k = s0 + 63 - lane;
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
@@ -245,10 +270,10 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     uint32_t gid = 0;
     if (k < n) {
         const uint32_t kl = (uint32_t)(63 - lane);   // (uniform base list0 + s0, lane offset)
-        ra = (rec_a + list0 + s0)[kl];
-        rb = (rec_b + list0 + s0)[kl];
-        rc = (rec_c + list0 + s0)[kl];
-        gid = (point_list + list0 + s0)[kl];
+        ra = at32(rec_a + list0 + s0, kl * 16u);
+        rb = at32(rec_b + list0 + s0, kl * 16u);
+        rc = at32(rec_c + list0 + s0, kl * (uint32_t)sizeof(RecTail<C>));
+        gid = at32(point_list + list0 + s0, kl * 4u);
     }
     float bg_dot_dpixel = 0.f;
 #pragma unroll
@@ -399,7 +424,10 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
         // ---- vector ALU: w and r of GRP instances for this lane's pixel, parked row-wise in LDS.  The slot of the
         // group's first instance is requested here, every further one while its predecessor is being evaluated.
         SlotRegs<L::IN_VECS> nxt;
-        const uint32_t q_grp = q_base + (uint32_t)(g0i * SF * 4);
+        // (the group's slot address is pinned in a vector register: as a uniform value the compiler keeps it scalar and
+        // copies it into a fresh vector register for every pair)
+        uint32_t q_grp = q_base + (uint32_t)(g0i * SF * 4);
+        asm volatile("" : "+v"(q_grp));
         lds_request<L::IN_VECS, 0>(nxt, q_grp);
         static_for<GRP>([&](auto JJ) {
             constexpr int jj = decltype(JJ)::value;
@@ -486,13 +514,25 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_hi), b, acc, 0, 0, 0);
             }
             // colour rows: the three split columns of a channel sit in neighbouring lanes of the 16-lane row
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const float v = acc0[i] + acc1[i];
-                const float v1 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x101, 0xf, 0xf, true));   // row_shl:1
-                const float v2 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x102, 0xf, 0xf, true));   // row_shl:2
-                acc0[i] = kap < 2 ? v : (v2 + v1) + v;
-            }
+            // (lane c: hi column, c + 1: mid, c + 2: lo.  s = v + v[c + 1] holds mid + lo in lane c + 1; v + s[c + 1] is
+            // hi + (mid + lo) -- two fused DPP adds per register, smallest parts first.  One block, so that the two
+            // wait states a DPP read needs behind the instruction that wrote its source are there by construction: the
+            // leading s_nop covers the compiler's adds, every t reads an s written four instructions earlier)
+            float v0 = acc0[0] + acc1[0], v1 = acc0[1] + acc1[1], v2 = acc0[2] + acc1[2], v3 = acc0[3] + acc1[3];
+            float s0_, s1_, s2_, s3_, t0_, t1_, t2_, t3_;
+            asm("s_nop 1\n\t"
+                "v_add_f32_dpp %0, %8, %8 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_add_f32_dpp %1, %9, %9 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_add_f32_dpp %2, %10, %10 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_add_f32_dpp %3, %11, %11 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_add_f32_dpp %4, %0, %8 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_add_f32_dpp %5, %1, %9 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_add_f32_dpp %6, %2, %10 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_add_f32_dpp %7, %3, %11 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                : "=&v"(s0_), "=&v"(s1_), "=&v"(s2_), "=&v"(s3_), "=&v"(t0_), "=&v"(t1_), "=&v"(t2_), "=&v"(t3_)
+                : "v"(v0), "v"(v1), "v"(v2), "v"(v3));
+            const bool spatial = kap < 2;
+            acc0[0] = spatial ? v0 : t0_; acc0[1] = spatial ? v1 : t1_; acc0[2] = spatial ? v2 : t2_; acc0[3] = spatial ? v3 : t3_;
         } else {
 #pragma unroll
         for (int t = 0; t < 16; t += 2) {
