@@ -153,7 +153,8 @@ int forward_stage1_impl(int P, int D, int M, const float* means3D, const float* 
                         const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                         const float* campos, int W, int H, float tan_fovx, float tan_fovy, int prefiltered, int* radii,
                         void* geom_buffer, void* image_buffer, int* num_rendered, int* max_tile_instances,
-                        int* num_segments, uint32_t* counters, gsr_stream_t stream)
+                        int* num_segments, uint32_t* counters, gsr_stream_t stream, void* early_bin = nullptr,
+                        size_t early_capacity = 0, int early_C = 3)
 {
     (void)prefiltered;   // the reference only uses it to trap on a culled point (auxiliary.h:156-160)
     g_err.clear();
@@ -219,6 +220,15 @@ int forward_stage1_impl(int P, int D, int M, const float* means3D, const float* 
         launch_tile_scan(im, t.T, g_pinned, seq, view_token, st);
     }
     GSR_CHECK_LAUNCH("tile_scan_kernel");
+    if (early_bin && P > 0) {
+        // The fused forward already holds a binning buffer: scatter goes out right behind the scan and resolves its
+        // pointers from the totals on the device, instead of idling the GPU for the host's round trip (~4.6 us per view).
+        {
+            Scope sc(ST_SCATTER, st);
+            launch_scatter_early(P, W, H, early_C, carve_geom(geom_buffer, P), im, early_bin, early_capacity, st);
+        }
+        GSR_CHECK_LAUNCH("scatter_kernel");
+    }
     if (spin) {
         // Normal waits are far below a millisecond and touch nothing but the pad.  The stream is only consulted (did it
         // finish or fault?) once a wait has lasted 2 ms, then every 2 ms: hipStreamQuery takes runtime locks.
@@ -266,7 +276,8 @@ int gsr_forward_stage1(int P, int D, int M, const float* means3D, const float* s
 namespace {
 int forward_stage2_impl(int P, int R, int max_tile_instances, int num_segments, int num_channels, int W, int H,
                         const float* background, const float* colors_precomp, void* geom_buffer, void* binning_buffer,
-                        void* image_buffer, float* out_color, void* grad_scratch, uint32_t* counters, gsr_stream_t stream);
+                        void* image_buffer, float* out_color, void* grad_scratch, uint32_t* counters, gsr_stream_t stream,
+                        bool scattered);
 }
 
 int gsr_forward_fused(int P, int D, int M, int num_channels, int need_backward, const float* means3D, const float* shs,
@@ -285,10 +296,13 @@ int gsr_forward_fused(int P, int D, int M, int num_channels, int need_backward, 
     const size_t cnt_words = sane ? 2 * (size_t)shard_stride(tiles_of(W, H).T) * NSHARD : 0;
     Counters* own = sane ? acquire_counters(st, cnt_words) : nullptr;
     CountersLease lease{own};
+    static const bool early_ok = !(getenv("GSR_EARLY_SCATTER") && atoi(getenv("GSR_EARLY_SCATTER")) == 0);
+    const bool early = early_ok && sane && binning_buffer != nullptr && binning_capacity > 0;
     const int rc = forward_stage1_impl(P, D, M, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
                                        cov3D_precomp, viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, prefiltered,
                                        radii, geom_buffer, image_buffer, num_rendered, max_tile_instances, num_segments,
-                                       own ? own->base : nullptr, stream);
+                                       own ? own->base : nullptr, stream, early ? binning_buffer : nullptr, binning_capacity,
+                                       num_channels);
     if (rc != 0) return rc;   // (own stays marked dirty: re-filled on its next use)
     if (gsr_binning_bytes_mt(*num_rendered, *num_segments, num_channels) > binning_capacity || (*num_rendered > 0 && !binning_buffer)) {
         // the guess was too small: the caller allocates exactly and runs stage 2 itself -- over the image buffer's own
@@ -305,7 +319,7 @@ int gsr_forward_fused(int P, int D, int M, int num_channels, int need_backward, 
     const int rc2 = forward_stage2_impl(P, *num_rendered, *max_tile_instances, need_backward ? *num_segments : -*num_segments,
                                         num_channels, W, H, background, colors_precomp, geom_buffer, binning_buffer,
                                         image_buffer, out_color, need_backward ? grad_scratch : nullptr,
-                                        own ? own->base : nullptr, stream);
+                                        own ? own->base : nullptr, stream, early);
     if (rc2 == 0) {
         *blended = 1;
         if (own) own->clean = true;   // the forward blend zeroes every tile's counters and cursors
@@ -325,7 +339,8 @@ namespace {
 // grad_scratch != nullptr: the backward's accumulation table, cleared by the forward blend on the side (gsr_forward_fused)
 int forward_stage2_impl(int P, int R, int max_tile_instances, int num_segments, int num_channels, int W, int H,
                         const float* background, const float* colors_precomp, void* geom_buffer, void* binning_buffer,
-                        void* image_buffer, float* out_color, void* grad_scratch, uint32_t* counters, gsr_stream_t stream)
+                        void* image_buffer, float* out_color, void* grad_scratch, uint32_t* counters, gsr_stream_t stream,
+                        bool scattered)
 {
     g_err.clear();
     if (W <= 0 || H <= 0) return fail_msg("gsr_forward_stage2: image size must be positive");
@@ -350,11 +365,11 @@ int forward_stage2_impl(int P, int R, int max_tile_instances, int num_segments, 
     BinState b = carve_bin(binning_buffer, R > 0 ? R : 0, num_segments, C);
     bool sort_in_blend = false;
     if (R > 0) {
-        {
+        if (!scattered) {   // (the fused forward has launched it behind the scan already)
             Scope sc(ST_SCATTER, st);
             launch_scatter(P, W, H, (uint32_t)(max_tile_instances > 0 ? max_tile_instances : 0), g, im, b, st);
+            GSR_CHECK_LAUNCH("scatter_kernel");
         }
-        GSR_CHECK_LAUNCH("scatter_kernel");
         {
             Scope sc(ST_TILE_SORT, st);
             const char* e_fuse = getenv("GSR_SORT_IN_BLEND");   // read per call (tools/ab_env.py); "0": separate sort kernel
@@ -380,7 +395,7 @@ int gsr_forward_stage2_mt(int P, int R, int max_tile_instances, int num_segments
                           void* image_buffer, float* out_color, gsr_stream_t stream)
 {
     return forward_stage2_impl(P, R, max_tile_instances, num_segments, num_channels, W, H, background, colors_precomp,
-                               geom_buffer, binning_buffer, image_buffer, out_color, nullptr, nullptr, stream);
+                               geom_buffer, binning_buffer, image_buffer, out_color, nullptr, nullptr, stream, false);
 }
 
 int gsr_forward(gsr_alloc_fn geometry_buffer, gsr_alloc_fn binning_buffer, gsr_alloc_fn image_buffer, void* alloc_ctx,

@@ -240,8 +240,19 @@ scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __
                uint4* __restrict__ unit_info, const uint32_t* __restrict__ tile_count,
                const uint2* __restrict__ ranges, const uint4* __restrict__ wg_recs, const uint2* __restrict__ wg_tab,
                const uint32_t* __restrict__ wg_nrec, uint32_t* __restrict__ totals, uint2* __restrict__ part_list,
-               uint32_t split_n)
+               uint32_t split_n, void* early_base, size_t early_capacity, int early_C)
 {
+    if (early_base != nullptr) {
+        // (uniform) launched right behind the scan, before the host has seen its totals (gsr_forward_fused): where the
+        // keys, the unit table and the part list live follows from R and U exactly as on the host (carve_bin), and a
+        // view that does not fit the buffer the caller guessed is left alone -- the host then runs stage 2 itself.
+        // (split_n carries the view-independent threshold `split_from` here.)
+        const uint32_t R = totals[0], maxc = totals[1], U = totals[3];
+        const BinState eb = carve_bin(early_base, (int)R, (int)U, early_C);
+        if (eb.bytes > early_capacity) return;
+        keys = eb.keys; unit_info = eb.unit_info; part_list = eb.part_list;
+        split_n = split_threshold_from(maxc, split_n);
+    }
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int shard = (int)(blockIdx.x & (NSHARD - 1));
@@ -327,7 +338,16 @@ void launch_scatter(int P, int W, int H, uint32_t max_count, GeomState g, ImageS
     const int n = P > t.T ? P : t.T;
     scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(P, t.gx, g.rect, g.g0, g.g1, g.depth, im.tile_cursor, b.keys, t.T,
                                                     im.seg_off, b.unit_info, im.tile_count, im.ranges, g.wg_recs, g.wg_tab,
-                                                    g.wg_nrec, im.totals, b.part_list, split_threshold(max_count));
+                                                    g.wg_nrec, im.totals, b.part_list, split_threshold(max_count), nullptr, 0, 3);
+}
+
+void launch_scatter_early(int P, int W, int H, int C, GeomState g, ImageState im, void* binning_base, size_t capacity, hipStream_t st)
+{
+    const Tiles t = tiles_of(W, H);
+    const int n = P > t.T ? P : t.T;
+    scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(P, t.gx, g.rect, g.g0, g.g1, g.depth, im.tile_cursor, nullptr, t.T,
+                                                    im.seg_off, nullptr, im.tile_count, im.ranges, g.wg_recs, g.wg_tab,
+                                                    g.wg_nrec, im.totals, nullptr, split_from(), binning_base, capacity, C);
 }
 
 // ---- per-tile bitonic sort of 64-bit keys in LDS.

@@ -160,12 +160,17 @@ __host__ __device__ inline size_t part_capacity(int R, int U) { return (size_t)U
 // its longest list would otherwise hold the kernel up -- above SPLIT_FROM entries -- and then every list above LONG_LIST
 // is split; 0xffffffff: nothing is.  (Config B's two 2 100-entry tiles are faster left alone: 0.116 vs 0.144 ms.)
 constexpr uint32_t SPLIT_FROM = 4096;
-inline uint32_t split_threshold(uint32_t max_count)
+inline uint32_t split_from()
 {
     static const uint32_t from = getenv("GSR_SPLIT_FROM") ? (uint32_t)atoi(getenv("GSR_SPLIT_FROM")) : SPLIT_FROM;   // (tests: 0)
+    return from;
+}
+__host__ __device__ inline uint32_t split_threshold_from(uint32_t max_count, uint32_t from)
+{
     return max_count > from && max_count > LONG_LIST ? LONG_LIST : 0xffffffffu;
 }
-inline BinState carve_bin(void* base, int R, int U, int C = 3)
+inline uint32_t split_threshold(uint32_t max_count) { return split_threshold_from(max_count, split_from()); }
+__host__ __device__ inline BinState carve_bin(void* base, int R, int U, int C = 3)
 {
     // (everything up to and including `masks` sits at offsets that do not depend on C: the debug exports carve with C = 3)
     BinState s; size_t o = 0; char* b = (char*)base;
@@ -233,6 +238,9 @@ void launch_preprocess(int P, int D, int M, const float* means3D, const float* s
                        hipStream_t st);
 void launch_tile_scan(ImageState im, int T, uint32_t* host_totals, uint32_t host_seq, uint32_t view_token, hipStream_t st);
 void launch_scatter(int P, int W, int H, uint32_t max_count, GeomState g, ImageState im, BinState b, hipStream_t st);
+// the same launch before the host knows R, U and max_count (gsr_forward_fused): the kernel carves `binning_base` itself from
+// the totals the scan left, and does nothing if the carve would not fit `capacity` bytes
+void launch_scatter_early(int P, int W, int H, int C, GeomState g, ImageState im, void* binning_base, size_t capacity, hipStream_t st);
 // -> true if lists of up to 2 048 entries were left for the forward blend to sort (gsr_sort.h)
 bool launch_tile_sort(int W, int H, int R, int U, uint32_t max_count, ImageState im, BinState b, bool blend_sorts_small, hipStream_t st);
 // Launch positions [0, front_of_order(R, T)) of `order` hold every tile with 2 017 or more entries: they all fall into
