@@ -210,7 +210,10 @@ def main():
 
     for s in range(args.warmup):
         step(s)
+    wait_ns, waits = ctypes.c_longlong(0), ctypes.c_longlong(0)
+    lib.gsr_debug_host_wait(None, None, 1)
     dt = timed(step, args.steps, world, device)
+    lib.gsr_debug_host_wait(ctypes.byref(wait_ns), ctypes.byref(waits), 0)
     ms_per_step = dt / args.steps * 1e3
     value = args.steps * world / dt
 
@@ -296,6 +299,10 @@ def main():
                          "instrumented_ms_per_step": round(dt_prof / args.steps * 1e3, 4), "kernels": kern},
         }
         out["config"]["host_cpus_pinned"] = len(pinned)
+        # how long the host sat in the forward's one synchronisation per step (gsr_debug_host_wait): the slack between the
+        # host's own work (Python, autograd, launches) and the GPU's -- near zero means the step is host-bound
+        out["host"] = {"wait_ms_per_step": round(wait_ns.value / 1e6 / max(args.steps, 1), 4),
+                       "waits_per_step": round(waits.value / max(args.steps, 1), 2)}
         if world > 1:
             out["config"]["allreduce_payload_MB"] = round(reducer.payload_bytes() / 1e6, 1)
             out["config"]["allreduce_buckets_issued_during_backward"] = reducer.issued_early

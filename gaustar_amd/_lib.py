@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_longlong, c_si
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSR_LIB_PATH", os.path.join(_HERE, "libgsr_hip.so"))   # override: experiment variants
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 ALLOC_FN = ctypes.CFUNCTYPE(c_void_p, c_void_p, c_size_t)
 
 # name -> (restype, argtypes); mirrors include/gsr.h one to one (tests check both directions).
@@ -78,6 +78,7 @@ SIGNATURES = {
     "gsr_stage_name": (c_char_p, [c_int]),
     "gsr_profile_enable": (c_int, [c_int]),
     "gsr_profile_read": (c_int, [POINTER(c_float), POINTER(c_int), c_int]),
+    "gsr_debug_host_wait": (c_int, [POINTER(c_longlong), POINTER(c_longlong), c_int]),
 }
 
 _lib = None

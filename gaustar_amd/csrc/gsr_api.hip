@@ -22,7 +22,8 @@ namespace gsr { uint64_t* g_trace = nullptr; }
 namespace {
 thread_local std::string g_err;
 thread_local uint32_t g_pinned_seq = 0;
-thread_local uint32_t* g_pinned = nullptr;   // pinned, device-mapped landing pad for the stage-1 totals (written by tile_scan)
+thread_local uint32_t* g_pinned = nullptr;
+std::atomic<long long> g_wait_ns{0}, g_waits{0};   // gsr_debug_host_wait   // pinned, device-mapped landing pad for the stage-1 totals (written by tile_scan)
 
 // ---- optional per-kernel timing (gsr_profile_*): HIP events on the launch stream around every stage.
 enum Stage { ST_PREPROCESS = 0, ST_TILE_SCAN, ST_SCATTER, ST_TILE_SORT, ST_BLEND_FWD, ST_ZERO_FILL, ST_BLEND_BWD,
@@ -87,7 +88,7 @@ int fail_msg(const char* msg)
 
 extern "C" {
 
-int gsr_abi_version(void) { return 9; }
+int gsr_abi_version(void) { return 10; }
 
 const char* gsr_last_error(void) { return g_err.c_str(); }
 
@@ -129,10 +130,12 @@ Counters* acquire_counters(hipStream_t st, size_t words)
     if (off || hipGetDevice(&dev) != hipSuccess) return nullptr;
     Counters* c;
     {
+        // (the lease is taken under the lock: gsr_release_stream_state tests `busy` under the same lock before it frees
+        // the block and erases the node, so a block can never be freed between the lookup and the exchange)
         std::lock_guard<std::mutex> lk(g_cnt_mu);
         c = &g_cnt[std::make_pair(dev, st)];   // std::map: the address stays valid
+        if (c->busy.exchange(true, std::memory_order_acquire)) return nullptr;   // another thread's call owns it right now
     }
-    if (c->busy.exchange(true, std::memory_order_acquire)) return nullptr;   // another thread's call owns it right now
     if (c->words < words) {
         if (c->base) { (void)hipStreamSynchronize(st); (void)hipFree(c->base); }
         c->base = nullptr; c->words = 0; c->clean = false;
@@ -229,6 +232,7 @@ int forward_stage1_impl(int P, int D, int M, const float* means3D, const float* 
         }
         GSR_CHECK_LAUNCH("scatter_kernel");
     }
+    const auto t_wait0 = std::chrono::steady_clock::now();
     if (spin) {
         // Normal waits are far below a millisecond and touch nothing but the pad.  The stream is only consulted (did it
         // finish or fault?) once a wait has lasted 2 ms, then every 2 ms: hipStreamQuery takes runtime locks.
@@ -254,12 +258,23 @@ int forward_stage1_impl(int P, int D, int M, const float* means3D, const float* 
     } else {
         GSR_CHECK(hipStreamSynchronize(st));   // the forward's single host sync (cf. rasterizer_impl.cu:281)
     }
+    g_wait_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_wait0).count(),
+                        std::memory_order_relaxed);
+    g_waits.fetch_add(1, std::memory_order_relaxed);
     *num_rendered = (int)g_pinned[0];
     *max_tile_instances = (int)g_pinned[1];
     *num_segments = (int)g_pinned[3];
     return 0;
 }
 }  // namespace
+
+int gsr_debug_host_wait(long long* wait_ns, long long* waits, int reset)
+{
+    if (wait_ns) *wait_ns = g_wait_ns.load(std::memory_order_relaxed);
+    if (waits) *waits = g_waits.load(std::memory_order_relaxed);
+    if (reset) { g_wait_ns.store(0); g_waits.store(0); }
+    return 0;
+}
 
 int gsr_forward_stage1(int P, int D, int M, const float* means3D, const float* shs, const float* colors_precomp,
                        const float* opacities, const float* scales, float scale_modifier, const float* rotations,

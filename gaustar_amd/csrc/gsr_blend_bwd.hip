@@ -55,6 +55,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #ifndef GSR_BWD_BF16
 #define GSR_BWD_BF16 1
 #endif
+#ifndef GSR_BWD_DOT2
+#define GSR_BWD_DOT2 1   // residuals of the bf16 split by v_dot2_f32_bf16 (0: v_and + v_sub)
+#endif
 // Three channels: the contraction runs on the bf16 matrix pipe WITHOUT giving up f32 accuracy.  An f32 is exactly
 // hi + mid + lo with eight significant bits each (truncate to the upper 16 bits, subtract, twice: the second remainder has
 // at most eight bits left), the monomials are exact in bf16, dL_dpix takes three columns per channel (6 + 3 C = 15 <= 16).
@@ -67,6 +70,19 @@ __device__ __forceinline__ uint32_t bf16_pair(float lo_elem, float hi_elem)   //
     return __builtin_amdgcn_perm(__float_as_uint(hi_elem), __float_as_uint(lo_elem), 0x07060302u);
 }
 __device__ __forceinline__ float bf16_rest(float x) { return x - __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+// The same residuals for BOTH elements of an already packed pair {hi(x0), hi(x1)}: x - hi(x) = dot2(pair, {-1, 0}, x0) resp.
+// dot2(pair, {0, -1}, x1) -- one v_dot2_f32_bf16 each (4.7 cycles) instead of v_and + v_sub (6.4), and bit-identical: the
+// dot unit keeps all 24 bits of the f32 addend (tools/micro/dot2_split.hip checks 16.8 M residuals of both levels).
+// The constant pairs {-1, 0} / {0, -1} must reach the instruction in VECTOR registers the compiler cannot see through
+// (`asm volatile("" : "+v"(k))` at the use site): given the literal, __builtin_amdgcn_fdot2_f32_bf16 folds {-1, 0} into the
+// inline constant -1.0, which the hardware does not read as that bf16 pair, and a scalar-register operand is not read as
+// one either (tools/micro/dot2_split.hip checks each spelling bit for bit).  The builtin rather than inline assembly: the
+// compiler has to know the opcode to keep the wait states dot instructions need next to matrix instructions.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float bf16_rest_of(uint32_t pair, float x, uint32_t minus_one_at)
+{
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pair), __builtin_bit_cast(bf16x2, minus_one_at), x, false);
+}
 
 // LDS queue slot of one fetched instance, as floats:
 //   [0] x  [1] y  [2] gaussian id (uint bits)  [3..5] conic a, b, c in the exp2 domain (conic_to_exp2)  [6] opacity
@@ -243,7 +259,10 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     const uint2* const my_words = masks + ((size_t)unit * 4 + wave) * 64 + (uint32_t)lane;   // + 256 per unit
     const uint2* const words_u = masks + ((size_t)unit * 4 + wave) * 64;                      // (uniform part)
     uint2 word = at32(words_u, (uint32_t)lane * 8u);
-    const uint2 word_next = has_next ? at32(words_u + 256, (uint32_t)lane * 8u) : make_uint2(0u, 0u);
+    // (unconditional load from a uniform, always valid address, masked once everything is in flight: as `has_next ? load : 0`
+    // the compiler waited for the load inside the branch -- before the snapshot and record loads below were even issued,
+    // two trips to memory in a row at the head of every unit)
+    uint2 word_next = at32(words_u + (has_next ? 256 : 0), (uint32_t)lane * 8u);
     const int pidx = 16 * (py - ty * TILE) + (px - tx * TILE);
     float Ts = 1.f, Tf = 0.f, cs[C], cf[C];
 #pragma unroll
@@ -275,6 +294,7 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
         rc = at32(rec_c + list0 + s0, kl * (uint32_t)sizeof(RecTail<C>));
         gid = at32(point_list + list0 + s0, kl * 4u);
     }
+    if (!has_next) word_next = make_uint2(0u, 0u);
     float bg_dot_dpixel = 0.f;
 #pragma unroll
     for (int ch = 0; ch < C; ch++) bg_dot_dpixel += bg[ch] * dp[ch];
@@ -495,16 +515,24 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
             }
         }
         if constexpr (BF16) {
+            uint32_t kMinusOneLo = 0x0000BF80u, kMinusOneHi = 0xBF800000u;   // bf16 pairs {-1, 0}, {0, -1}
+            asm volatile("" : "+v"(kMinusOneLo), "+v"(kMinusOneHi));
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 u32x4 a_hi, a_mid, a_lo;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const float x0 = ra[8 * h + 2 * q], x1 = ra[8 * h + 2 * q + 1];
-                    const float y0 = bf16_rest(x0), y1 = bf16_rest(x1);
-                    const float z0 = bf16_rest(y0), z1 = bf16_rest(y1);
                     a_hi[q] = bf16_pair(x0, x1);
+#if GSR_BWD_DOT2
+                    const float y0 = bf16_rest_of(a_hi[q], x0, kMinusOneLo), y1 = bf16_rest_of(a_hi[q], x1, kMinusOneHi);
                     a_mid[q] = bf16_pair(y0, y1);
+                    const float z0 = bf16_rest_of(a_mid[q], y0, kMinusOneLo), z1 = bf16_rest_of(a_mid[q], y1, kMinusOneHi);
+#else
+                    const float y0 = bf16_rest(x0), y1 = bf16_rest(x1);
+                    a_mid[q] = bf16_pair(y0, y1);
+                    const float z0 = bf16_rest(y0), z1 = bf16_rest(y1);
+#endif
                     a_lo[q] = bf16_pair(z0, z1);
                 }
                 const bf16x8 b = __builtin_bit_cast(bf16x8, Bp[h]);

@@ -144,7 +144,14 @@ class GradAllReducer:
 
     Parameters whose grad is None on this rank (a Gaussian set no pixel of this view touched) contribute zeros, so
     every rank issues identical collectives in identical order.  The views stay valid until the next backward;
-    callers that keep gradients across steps must clone them."""
+    callers that keep gradients across steps must clone them.
+
+    More than one backward per call (gradient accumulation, a separate regulariser backward) is supported: a bucket that
+    was flattened and issued during the first backward and whose gradients were accumulated into again afterwards is
+    detected at call time (every gradient's identity and version counter are recorded when its bucket is issued), waited
+    for, flattened again and reduced again -- the early collective was wasted, nothing is lost.  A step that is
+    abandoned after its backward (NaN loss, an evaluation backward) must call `reset()` before the next backward, or its
+    in-flight buckets would be taken for the next step's; the reducer cannot tell the two apart."""
 
     def __init__(self, params: Iterable[torch.Tensor], bucket_bytes: int = 32 << 20, average: bool = True,
                  overlap: bool = True, run_at_world_size_1: bool = False):
@@ -167,6 +174,8 @@ class GradAllReducer:
         self._ready = [0] * len(self.buckets)          # gradients accumulated since the last call, per bucket
         self._works: List = [None] * len(self.buckets)  # in-flight collectives
         self._fast = [False] * len(self.buckets)
+        self._stamp: List = [None] * len(self.buckets)  # per issued bucket: (id, version) of every gradient at issue time
+        self.reissued = 0                              # buckets reduced twice because their gradients changed after issue
         self._hooks = []
         self.issued_early = 0                          # buckets whose all-reduce started during backward (last step)
         if overlap:
@@ -224,8 +233,23 @@ class GradAllReducer:
                 else:
                     flat[off:off + k].copy_(p.grad.reshape(-1))
                 off += k
+        self._stamp[bi] = self._grad_stamp(bucket)
         # SUM + one divide kernel on every backend: gloo has no AVG, and a 12 us kernel is not worth a second code path
         self._works[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+
+    @staticmethod
+    def _grad_stamp(bucket):
+        return tuple((None if p.grad is None else (id(p.grad), p.grad._version)) for p in bucket)
+
+    def reset(self) -> None:
+        """Forget a backward whose step will not be taken: wait for the collectives already in flight (every rank issued
+        them, so they complete) and drop them, so that the next backward starts from scratch."""
+        for bi, w in enumerate(self._works):
+            if w is not None:
+                w.wait()
+        self._ready = [0] * len(self.buckets)
+        self._works = [None] * len(self.buckets)
+        self._stamp = [None] * len(self.buckets)
 
     @torch.no_grad()
     def __call__(self) -> None:
@@ -234,6 +258,15 @@ class GradAllReducer:
         if ws == 1 and not self.solo:
             return
         early = sum(1 for w in self._works if w is not None)
+        # a gradient that changed after its bucket was issued (second backward before this call): the early reduction
+        # holds a stale value -- wait for it (collectives complete in issue order on every rank) and reduce the bucket again.
+        # Every rank ran the same sequence of backwards, so every rank takes the same decision for every bucket.
+        for bi in range(len(self.buckets)):
+            if self._works[bi] is not None and self._stamp[bi] != self._grad_stamp(self.buckets[bi]):
+                self._works[bi].wait()
+                self._works[bi] = None
+                self.reissued += 1
+                early -= 1
         for bi in range(len(self.buckets)):
             if self._works[bi] is None:
                 self._issue(bi)
@@ -254,6 +287,7 @@ class GradAllReducer:
         self.issued_early = early
         self._ready = [0] * len(self.buckets)
         self._works = [None] * len(self.buckets)
+        self._stamp = [None] * len(self.buckets)
 
 
 def allreduce_grads(params: Sequence[torch.Tensor], average: bool = True) -> None:

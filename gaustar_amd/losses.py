@@ -15,11 +15,11 @@ from typing import Optional, Sequence
 
 import torch
 
-from . import _lib
+from . import _host, _lib
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _host.raw_stream(torch._C._cuda_getDevice())
 
 
 def _chw_view(t: torch.Tensor, what: str) -> torch.Tensor:
@@ -57,7 +57,7 @@ class _L1DSSIM(torch.autograd.Function):
             raise RuntimeError("the margin leaves an empty image")
         dev = p.device
         need_grad = ctx.needs_input_grad[0]
-        with torch.cuda.device(dev):
+        with _host.on_device(dev):
             ws = torch.empty(lib.gsr_l1_ssim_workspace_bytes(C, H, W), dtype=torch.uint8, device=dev)
             out = torch.empty(3, dtype=torch.float32, device=dev)
             grad_full = gv = None
@@ -120,7 +120,7 @@ class _DepthL1(torch.autograd.Function):
         H, W = (int(v) for v in p.shape)
         dev = p.device
         need_grad = ctx.needs_input_grad[0]
-        with torch.cuda.device(dev):
+        with _host.on_device(dev):
             ws = torch.empty(lib.gsr_depth_l1_workspace_bytes(), dtype=torch.uint8, device=dev)
             out = torch.empty(4, dtype=torch.float32, device=dev)
             grad = torch.empty(H, W, dtype=torch.float32, device=dev) if need_grad else None
@@ -175,7 +175,7 @@ class _RGBDepthLoss(torch.autograd.Function):
         Hd, Wd = (int(v) for v in d.shape)
         dev = x.device
         need_grad = ctx.needs_input_grad[0]
-        with torch.cuda.device(dev):
+        with _host.on_device(dev):
             ws = torch.empty(lib.gsr_l1_ssim_workspace_bytes(C, H, W), dtype=torch.uint8, device=dev)
             wd = torch.empty(lib.gsr_depth_l1_workspace_bytes(), dtype=torch.uint8, device=dev)
             out = torch.empty(7, dtype=torch.float32, device=dev)      # {loss, l1, ssim | depth term, mask term, #fg, #bg}

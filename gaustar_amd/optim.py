@@ -13,7 +13,7 @@ import ctypes
 
 import torch
 
-from . import _lib
+from . import _host, _lib
 
 
 def _bump_version(p: torch.Tensor) -> None:
@@ -59,11 +59,10 @@ class Adam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
                 g = p.grad if (p.grad.dtype == torch.float32 and p.grad.is_contiguous()) else p.grad.float().contiguous()
-                with torch.cuda.device(p.device):
+                with _host.on_device(p.device):
                     _lib.check(lib.gsr_adam_step(
-                        p.numel(), ctypes.c_void_p(p.data_ptr()), ctypes.c_void_p(g.data_ptr()),
-                        ctypes.c_void_p(st["exp_avg"].data_ptr()), ctypes.c_void_p(st["exp_avg_sq"].data_ptr()), lr, float(b1),
-                        float(b2), eps, int(st["step"].item()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                        p.numel(), p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), lr,
+                        float(b1), float(b2), eps, int(st["step"].item()), _host.raw_stream(p.device.index)),
                         "gsr_adam_step")
                 _bump_version(p)
         return loss

@@ -10,11 +10,11 @@ import ctypes
 
 import torch
 
-from . import _lib
+from . import _host, _lib
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _host.raw_stream(torch._C._cuda_getDevice())
 
 
 def _p(t):
@@ -51,7 +51,7 @@ class _PointsRGB(torch.autograd.Function):
         if view is not None and depth_channels not in (1, 3):
             raise RuntimeError("depth_channels must be 1 (colours [P,4]) or 3 (colours [P,6])")
         rgb = torch.empty(P, 3 if view is None else 3 + int(depth_channels), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _host.on_device(dev):
             if view is None:
                 _lib.check(lib.gsr_sh_to_rgb(P, D, M, _p(pos), _p(cam), _p(sh), _p(rgb), _stream()), "gsr_sh_to_rgb")
             else:
@@ -70,7 +70,7 @@ class _PointsRGB(torch.autograd.Function):
         g = dL_drgb.to(torch.float32).contiguous()
         dsh = torch.empty_like(sh)
         dpos = torch.empty_like(pos)
-        with torch.cuda.device(pos.device):
+        with _host.on_device(pos.device):
             if view is None:
                 _lib.check(lib.gsr_sh_to_rgb_backward(P, ctx.D, M, _p(pos), _p(cam), _p(sh), _p(g), _p(dsh), _p(dpos),
                                                       _stream()), "gsr_sh_to_rgb_backward")
@@ -124,7 +124,7 @@ class _MeshGaussians(torch.autograd.Function):
         scaling = torch.empty(N, 3, dtype=torch.float32, device=dev)
         quats = torch.empty(N, 4, dtype=torch.float32, device=dev)
         op = lambda t: None if t is None else _p(t)
-        with torch.cuda.device(dev):
+        with _host.on_device(dev):
             _lib.check(lib.gsr_mesh_gaussians(F, G, _p(v), _p(fc), _p(bc), _p(rs), _p(rc), float(thickness), lo, hi, op(dt),
                                               op(dr), _p(points), _p(scaling), _p(quats), _stream()), "gsr_mesh_gaussians")
         ctx.save_for_backward(v, fc, bc, rs, rc, dr)
@@ -144,7 +144,7 @@ class _MeshGaussians(torch.autograd.Function):
         d_dt = torch.empty(F * G, 3, dtype=torch.float32, device=dev) if has_dt else None
         d_dr = torch.empty_like(dr) if dr is not None else None
         op = lambda t: None if t is None else _p(t)
-        with torch.cuda.device(dev):
+        with _host.on_device(dev):
             _lib.check(lib.gsr_mesh_gaussians_backward(
                 F, G, V, _p(v), _p(fc), _p(bc), _p(rs), _p(rc), lo, hi, op(dr), op(g_points), op(g_scaling), op(g_quats),
                 _p(d_verts), _p(d_rs), _p(d_rc), op(d_dt), op(d_dr), _stream()), "gsr_mesh_gaussians_backward")
@@ -164,21 +164,22 @@ def mesh_bound_gaussians(verts: torch.Tensor, faces: torch.Tensor, bary_coords: 
                                 max_scale, delta_t, delta_r)
 
 
-_FACES_CHECKED: dict = {}   # (data_ptr, numel, version) -> number of vertices the indices were checked against
+_FACES_ATTR = "_gsr_checked_faces"   # set on the tensor OBJECT: (version, number of vertices the indices were checked against)
 
 
 def _check_faces(faces: torch.Tensor, n_verts: int) -> None:
     """A face index outside [0, V) would read out of bounds in the forward kernel and ADD out of bounds in the backward
     (silent corruption; the reference's `self._points[self._surface_mesh_faces]` raises).  Checked once per faces tensor
-    (one device reduction), then remembered until the tensor is modified."""
+    OBJECT (one device reduction) and remembered on the object itself until it is modified in place -- not keyed on the
+    data pointer, which the caching allocator hands to the next tensor of the same size."""
     if faces.numel() == 0:
         return
-    key = (faces.data_ptr(), faces.numel(), faces._version)
-    if _FACES_CHECKED.get(key) == n_verts:
+    if getattr(faces, _FACES_ATTR, None) == (faces._version, n_verts):
         return
     lo, hi = int(faces.min()), int(faces.max())
     if lo < 0 or hi >= n_verts:
         raise IndexError(f"faces hold vertex indices in [{lo}, {hi}] but there are {n_verts} vertices")
-    if len(_FACES_CHECKED) > 64:
-        _FACES_CHECKED.clear()
-    _FACES_CHECKED[key] = n_verts
+    try:
+        setattr(faces, _FACES_ATTR, (faces._version, n_verts))
+    except AttributeError:   # (a tensor subclass with __slots__: checked every call)
+        pass

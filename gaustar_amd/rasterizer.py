@@ -22,7 +22,7 @@ from typing import NamedTuple
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _host, _lib
 
 
 def cpu_deep_copy_tuple(input_tuple):
@@ -47,10 +47,14 @@ class GaussianRasterizationSettings(NamedTuple):
 
 def _ptr(t):
     """Device pointer of an optional tensor; 0-element tensors are 'absent' (NULL), as in the
-    reference where data_ptr() of an empty tensor is nullptr (rasterize_points.cu:94-111)."""
+    reference where data_ptr() of an empty tensor is nullptr (rasterize_points.cu:94-111).
+    (A plain int: the ctypes table declares the parameter types, so no c_void_p object is needed per argument.)"""
     if t is None or t.numel() == 0:
         return None
-    return ctypes.c_void_p(t.data_ptr())
+    return t.data_ptr()
+
+
+_F32 = torch.float32
 
 
 def _dev_f32(t, device):
@@ -58,6 +62,8 @@ def _dev_f32(t, device):
     viewmatrix in particular arrives as a transposed view, sugar_model.py:1149-1150)."""
     if t is None:
         return None
+    if t.dtype is _F32 and t.device == device and t.is_contiguous():   # the steady state: one test, no dispatch
+        return t
     if t.numel() == 0:
         return t
     if t.device != device:
@@ -67,8 +73,8 @@ def _dev_f32(t, device):
     return t.contiguous()
 
 
-def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+_stream = _host.raw_stream
+_on_device = _host.on_device
 
 
 def _num_channels(colors, background) -> int:
@@ -114,7 +120,7 @@ def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rot
     _require_gpu(means3D, "means3D")
     dev = means3D.device
     P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         byte_opts = dict(dtype=torch.uint8, device=dev)
         if P == 0:
             # rasterize_points.cu:68-81: zero-filled image, no rasterization at all
@@ -132,7 +138,7 @@ def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rot
         geom = torch.empty(lib.gsr_geom_bytes(P), **byte_opts)
         img = torch.empty(lib.gsr_image_bytes(W, H), **byte_opts)
         R, maxc, nseg, blended = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
-        st = _stream()
+        st = _stream(dev.index)
         # The binning scratch is sized BEFORE num_rendered is known, from what earlier views on this device needed
         # (x1.25): the library then goes from the stage-1 read-back straight into the stage-2 launches, and the GPU does
         # not idle while Python allocates and re-enters.  First view, or a guess that turns out too small: blended = 0,
@@ -176,17 +182,21 @@ def rasterize_gaussians_backward_native(background, means3D, radii, colors, scal
                                         sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug,
                                         num_segments=0, zeroed_scratch=None):
     """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
-    dL_drotations), like RasterizeGaussiansBackwardCUDA (DGR/rasterize_points.cu:117-196)."""
+    dL_drotations), like RasterizeGaussiansBackwardCUDA (DGR/rasterize_points.cu:117-196).  One deviation, for every P
+    including 0: dL_dcov3D is None unless `cov3D_precomp` was an input (the reference always returns a [P,6] tensor that
+    autograd then drops; here the 24 B per Gaussian are neither allocated nor written)."""
     lib = _lib.load()
     dev = means3D.device
     P = int(means3D.size(0))
     H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
     M = int(sh.size(1)) if sh is not None and sh.numel() != 0 else 0
     f32 = dict(dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         if P == 0:
             z = lambda *s: torch.zeros(*s, **f32)
-            return z(0, 3), z(0, int(dL_dout_color.size(0))), z(0, 1), z(0, 3), z(0, 6), z(0, M, 3), z(0, 3), z(0, 4)
+            no_cov = cov3D_precomp is None or cov3D_precomp.numel() == 0
+            return (z(0, 3), z(0, int(dL_dout_color.size(0))), z(0, 1), z(0, 3), None if no_cov else z(0, 6), z(0, M, 3), z(0, 3),
+                    z(0, 4))
         means3D = _dev_f32(means3D, dev)
         background, viewmatrix, projmatrix, campos = (_dev_f32(x, dev) for x in (background, viewmatrix, projmatrix, campos))
         colors, scales, rotations, cov3D_precomp, sh = (_dev_f32(x, dev) for x in (colors, scales, rotations, cov3D_precomp, sh))
@@ -215,7 +225,7 @@ def rasterize_gaussians_backward_native(background, means3D, radii, colors, scal
                 _ptr(imageBuffer), _ptr(dL_dout_color), _ptr(grad_scratch), _ptr(dL_dmeans2D), _ptr(dL_dopacity),
                 _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales),
                 _ptr(dL_drotations))
-        _lib.check(lib.gsr_backward_mt(*head, C, *tail, int(prezeroed), _stream()), "gsr_backward_mt")
+        _lib.check(lib.gsr_backward_mt(*head, C, *tail, int(prezeroed), _stream(dev.index)), "gsr_backward_mt")
         if debug:
             torch.cuda.synchronize(dev)
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
@@ -229,10 +239,10 @@ def mark_visible_native(means3D, viewmatrix, projmatrix):
     P = int(means3D.size(0))
     present = torch.zeros(P, dtype=torch.bool, device=dev)
     if P:
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             means3D, viewmatrix, projmatrix = (_dev_f32(x, dev) for x in (means3D, viewmatrix, projmatrix))
             _lib.check(lib.gsr_mark_visible(P, _ptr(means3D), _ptr(viewmatrix), _ptr(projmatrix),
-                                            ctypes.c_void_p(present.data_ptr()), _stream()), "gsr_mark_visible")
+                                            present.data_ptr(), _stream(dev.index)), "gsr_mark_visible")
     return present
 
 
@@ -315,6 +325,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                 present(rotations, grad_rotations), present(cov3Ds_precomp, grad_cov3Ds_precomp), None)
 
 
+_EMPTY = torch.Tensor([])
+
+
 class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings):
         super().__init__()
@@ -338,16 +351,17 @@ class GaussianRasterizer(nn.Module):
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
 
+        # (one shared 0-element placeholder instead of the reference's five `torch.Tensor([])` per call: it is never written)
         if shs is None:
-            shs = torch.Tensor([])
+            shs = _EMPTY
         if colors_precomp is None:
-            colors_precomp = torch.Tensor([])
+            colors_precomp = _EMPTY
         if scales is None:
-            scales = torch.Tensor([])
+            scales = _EMPTY
         if rotations is None:
-            rotations = torch.Tensor([])
+            rotations = _EMPTY
         if cov3D_precomp is None:
-            cov3D_precomp = torch.Tensor([])
+            cov3D_precomp = _EMPTY
 
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                    cov3D_precomp, raster_settings)

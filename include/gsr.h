@@ -80,8 +80,9 @@ int gsr_forward_stage1(int P, int D, int M, const float* means3D, const float* s
  * identifyTileRanges, FORWARD::render = forward.cu:261-374).
  *   out_color [3,H,W] planar; binning scratch sized by gsr_binning_bytes(R, num_segments).
  *   FORWARD-ONLY renders (no gsr_backward will follow): pass -num_segments here (binning scratch still sized with
- *   +num_segments): the per-segment snapshots the backward resumes from are not written.  num_segments = 0 also
- *   renders forward-only, with a binning buffer sized by gsr_binning_bytes(R, 0). */
+ *   +num_segments): the per-segment snapshots the backward resumes from are not written.  With R > 0 the stage-1
+ *   value of num_segments (or its negation) is REQUIRED -- it fixes the layout of the binning buffer -- and 0 is an
+ *   error (ABI 9; earlier versions accepted 0 as "forward-only"). */
 int gsr_forward_stage2(int P, int R, int max_tile_instances, int num_segments, int W, int H, const float* background,
                        const float* colors_precomp, void* geom_buffer, void* binning_buffer, void* image_buffer,
                        float* out_color, gsr_stream_t stream);
@@ -269,6 +270,12 @@ int gsr_num_stages(void);
 const char* gsr_stage_name(int stage);
 int gsr_profile_enable(int on);
 int gsr_profile_read(float* ms, int* counts, int reset);
+
+/* Host-side slack (benchmarks): nanoseconds this PROCESS has spent, summed over all threads, waiting for the stage-1
+ * totals to arrive (the forward's one host synchronisation, rasterizer_impl.cu:281) since the last reset, and the number
+ * of waits.  A step whose wait is near zero is bound by the host (Python, launches), not by the GPU.
+ * wait_ns, waits: [host] out, may be NULL. */
+int gsr_debug_host_wait(long long* wait_ns, long long* waits, int reset);
 
 /* ---- Optimiser step.  gsr_adam_step replaces one parameter tensor's share of torch.optim.Adam.step() as GauSTAR
  * configures it (gaustar_scene/sugar_optimizer.py:87, :99-101; torch/optim/adam.py::_single_tensor_adam without weight

@@ -30,6 +30,20 @@ def main():
     nc = tr["nc"]
     kept_total = trips_total = pairs_total = groups_total = 0
     hist = np.zeros(9, np.int64)
+    CH = (8, 16, 24, 32, 64)
+    trips_ch = {c: 0 for c in CH}
+    chunks_ch = {c: 0 for c in CH}
+    kept_hist = np.zeros(65, np.int64)
+    maxlane_hist = np.zeros(65, np.int64)
+    unit_blocks = 0
+    lanes = np.arange(64)
+    PARTS = {"halves 8x4 (top/bottom)": [lanes < 32, lanes >= 32],
+             "halves 4x8 (left/right)": [(lanes & 7) < 4, (lanes & 7) >= 4],
+             "quadrants 4x4": [((lanes & 7) < 4) & (lanes < 32), ((lanes & 7) >= 4) & (lanes < 32),
+                               ((lanes & 7) < 4) & (lanes >= 32), ((lanes & 7) >= 4) & (lanes >= 32)],
+             "row pairs 8x2": [(lanes >> 4) == q for q in range(4)]}
+    part_trips = {k: 0 for k in PARTS}
+    part_sum = {k: 0 for k in PARTS}
     for t in np.nonzero(n_per_tile > 0)[0]:
         ty, tx = divmod(int(t), gx)
         tile_nc = np.zeros((16, 16), np.int64)
@@ -46,6 +60,17 @@ def main():
                 if len(kept) == 0:
                     continue
                 kept_total += len(kept)
+                unit_blocks += 1
+                for name, sel in PARTS.items():
+                    ks = [int(w[m_].any(axis=0).sum()) for m_ in sel]
+                    part_trips[name] += max(ks)
+                    part_sum[name] += sum(ks)
+                kept_hist[len(kept)] += 1
+                maxlane_hist[int(w.sum(axis=1).max())] += 1
+                for c in CH:
+                    for g in range(0, len(kept), c):
+                        trips_ch[c] += int(w[:, kept[g:g + c]].sum(axis=1).max())
+                        chunks_ch[c] += 1
                 pairs_total += int(w.sum())
                 for g in range(0, len(kept), 8):
                     per_lane = w[:, kept[g:g + 8]].sum(axis=1)
@@ -57,6 +82,16 @@ def main():
     print(f"groups of 8: {groups_total}  trips if lanes walk their own bits {trips_total} "
           f"({trips_total / kept_total:.3f} per kept instance, {trips_total / groups_total:.2f} per group)")
     print("trips per group histogram (0..8):", hist.tolist())
+    print(f"(unit, block) pairs with work: {unit_blocks}; kept per unit-block mean {kept_total / unit_blocks:.2f}")
+    for c in CH:
+        print(f"chunks of {c:2d} kept instances: chunks {chunks_ch[c]} ({chunks_ch[c] / unit_blocks:.2f} per unit-block)  "
+              f"trips {trips_ch[c]} ({trips_ch[c] / unit_blocks:.2f} per unit-block; uniform loop {kept_total / unit_blocks:.2f})  "
+              f"lane utilisation {pairs_total / (64.0 * trips_ch[c]):.3f}")
+    for name in PARTS:
+        print(f"lock-step queues per {name}: trips {part_trips[name]} ({part_trips[name] / unit_blocks:.2f} per unit-block), "
+              f"queued records {part_sum[name]} ({part_sum[name] / unit_blocks:.2f} per unit-block)")
+    print("kept-instances histogram (0..64):", kept_hist.tolist())
+    print("busiest-lane candidate count histogram (0..64):", maxlane_hist.tolist())
 
 
 if __name__ == "__main__":
