@@ -34,10 +34,11 @@ def render(gs, cam, bg, need_backward):
     dev = torch.device("cuda:0")
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
     e = torch.Tensor([])
-    out = R.rasterize_gaussians_native(t(bg), t(gs.means3D), t(gs.colors_precomp), t(gs.opacities), t(gs.scales),
+    sh_mode = getattr(gs, "shs", None) is not None
+    out = R.rasterize_gaussians_native(t(bg), t(gs.means3D), e if sh_mode else t(gs.colors_precomp), t(gs.opacities), t(gs.scales),
                                        t(gs.rotations), 1.0, e, t(cam.viewmatrix), t(cam.projmatrix), cam.tanfovx,
-                                       cam.tanfovy, cam.H, cam.W, e, 0, t(cam.campos), False, False,
-                                       need_backward=need_backward)
+                                       cam.tanfovy, cam.H, cam.W, t(gs.shs) if sh_mode else e, int(gs.sh_degree) if sh_mode else 0,
+                                       t(cam.campos), False, False, need_backward=need_backward)
     Rn, color, radii, geom, binning, img, maxc, _ = out
     lib = _lib.load()
     P, W, H = len(gs.means3D), cam.W, cam.H
@@ -70,11 +71,9 @@ def unpack(words, reversed_bits):
     return bits.reshape(*words.shape[:-1], 64)
 
 
-def main():
-    which = sys.argv[1] if len(sys.argv) > 1 else "smoke"
-    view = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    gs, cam, bg = build(which, view)
-    tr = render(gs, cam, bg, need_backward=True)
+def verify(tr, tiles=None):
+    """-> (pairs passing the reference's alpha test, candidate bits, passing pairs WITHOUT a candidate bit) over `tiles`
+    (default: every non-empty tile), restricted to the list positions the forward certainly reached."""
     W, H = tr["W"], tr["H"]
     gx = (W + 15) // 16
     ranges, lst, m2, co = tr["ranges"], tr["list"], tr["m2"], tr["co"]
@@ -82,9 +81,8 @@ def main():
     yy, xx = np.arange(256) // 16, np.arange(256) % 16
     blk = (yy // 8) * 2 + xx // 8
     lane = (yy % 8) * 8 + xx % 8
-    tiles = np.nonzero(ranges[:, 1] > ranges[:, 0])[0]
-    if len(tiles) > 400:
-        tiles = np.random.default_rng(1).choice(tiles, 400, replace=False)
+    if tiles is None:
+        tiles = np.nonzero(ranges[:, 1] > ranges[:, 0])[0]
     unit0 = np.concatenate([[0], np.cumsum((ranges[:, 1] - ranges[:, 0] + 63) // 64)])
     n_ok = n_cand = n_missing = 0
     for t in tiles:
@@ -93,15 +91,28 @@ def main():
         ty, tx = divmod(int(t), gx)
         px = (tx * 16 + xx).astype(np.float32); py = (ty * 16 + yy).astype(np.float32)
         inside = (px < W) & (py < H)
+        nu = (n + 63) // 64
+        ncv = tr["nc"][ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16]
+        reached = min(n, (int(ncv.max()) + 63) // 64 * 64)   # the forward certainly parked the units up to its deepest contributor
+        ids = ids[:reached]
         dx = m2[ids, 0:1] - px[None]; dy = m2[ids, 1:2] - py[None]
         power = -0.5 * (co[ids, 0:1] * dx * dx + co[ids, 2:3] * dy * dy) - co[ids, 1:2] * dx * dy
         alpha = np.minimum(0.99, co[ids, 3:4] * np.exp(power))
         ok = (power <= 0) & (alpha >= 1 / 255) & inside[None]
-        nu = (n + 63) // 64
-        ncv = tr["nc"][ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16]
-        reached = min(n, (int(ncv.max()) + 63) // 64 * 64)   # the forward certainly parked the units up to its deepest contributor
         cm = cand[unit0[t]:unit0[t] + nu][:, blk, lane, :].transpose(0, 2, 1).reshape(nu * 64, 256)[:reached]
-        n_ok += int(ok[:reached].sum()); n_cand += int((cm & inside[None]).sum()); n_missing += int((ok[:reached] & ~cm).sum())
+        n_ok += int(ok.sum()); n_cand += int((cm & inside[None]).sum()); n_missing += int((ok & ~cm).sum())
+    return n_ok, n_cand, n_missing
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "smoke"
+    view = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    gs, cam, bg = build(which, view)
+    tr = render(gs, cam, bg, need_backward=True)
+    tiles = np.nonzero(tr["ranges"][:, 1] > tr["ranges"][:, 0])[0]
+    if len(tiles) > 400:
+        tiles = np.random.default_rng(1).choice(tiles, 400, replace=False)
+    n_ok, n_cand, n_missing = verify(tr, tiles)
     print(f"{which}: tiles {len(tiles)}  pairs passing the alpha test {n_ok}  candidate bits {n_cand} "
           f"({n_cand / max(n_ok, 1):.3f} per passing pair)  passing pairs WITHOUT a candidate bit: {n_missing}")
     assert n_missing == 0

@@ -76,13 +76,23 @@ def _one_iteration(level, W, H, cam_index, full_size):
     rcam, view, proj, campos = ncam.on_device(dev)
     bg_rgb = torch.tensor([0.0, 1.0, 0.0], device=dev)
 
-    def fused_image(m):
+    RASTER_INPUTS = ["means3D", "colors_rgb", "colors_depth", "opacities", "scales", "rotations"]
+
+    def fused_image(m, taps=None):
         bg4 = torch.cat([bg_rgb, torch.full((1,), MAX_DEPTH, device=dev)])
         settings, view_, campos_ = m._settings(ncam, bg4, 0)
         pts = m.points
         colors4 = producers.points_rgb_depth(pts, campos_, m.sh_coordinates, m.sh_levels, view_, depth_channels=1)
-        img, _ = GaussianRasterizer(settings)(means3D=pts, means2D=torch.zeros_like(pts), opacities=m.strengths,
-                                              colors_precomp=colors4, scales=m.scaling, rotations=m.quaternions)
+        ins = dict(means3D=pts, colors=colors4, opacities=m.strengths, scales=m.scaling, rotations=m.quaternions)
+        if taps is not None:
+            # the rasterizer's OWN input gradients: identity copies whose .grad receives nothing but the render's backward
+            # (the producers' backward adds to the originals, not to these)
+            ins = {k: v_ * 1.0 for k, v_ in ins.items()}
+            for k, v_ in ins.items():
+                v_.retain_grad()
+            taps.update(ins)
+        img, _ = GaussianRasterizer(settings)(means3D=ins["means3D"], means2D=torch.zeros_like(pts), opacities=ins["opacities"],
+                                              colors_precomp=ins["colors"], scales=ins["scales"], rotations=ins["rotations"])
         return img
 
     # ground truth: a render of a perturbed copy (SURVEY.md 8d config E's synthetic-GT recipe)
@@ -97,10 +107,15 @@ def _one_iteration(level, W, H, cam_index, full_size):
         gt_depth[gt_depth >= MAX_DEPTH - 1e-3] = 2 * MAX_DEPTH     # real captures carry "far" values behind the subject
 
     # (i) fused
-    img = fused_image(model)
+    taps_f = {}
+    img = fused_image(model, taps_f)
     loss_f = losses.rgb_depth_loss(img, gt_rgb, gt_depth, MAX_DEPTH, 0.2, 1.0, 0.5)
     loss_f.backward()
     grads_f = {k: getattr(model, k).grad.detach().cpu().numpy() for k in PARAMS}
+    cg = taps_f["colors"].grad
+    rin_f = dict(means3D=taps_f["means3D"].grad, colors_rgb=cg[:, :3], colors_depth=cg[:, 3:4], opacities=taps_f["opacities"].grad,
+                 scales=taps_f["scales"].grad, rotations=taps_f["rotations"].grad)
+    rin_f = {k: v_.detach().cpu().numpy() for k, v_ in rin_f.items()}
 
     # (ii) reference-shaped, refine.py:552-660
     render = _ref_render_fn()
@@ -114,25 +129,86 @@ def _one_iteration(level, W, H, cam_index, full_size):
         sh = torch.cat([P["_sh_coordinates_dc"], P["_sh_coordinates_rest"]], 1)
         rgb = po.points_rgb(pts, campos[None], sh, 3)
         opac = torch.sigmoid(P["all_densities"])
-        pred_rgb = render(pts, rgb, opac, scl, quat, rcam, bg_rgb)                                       # refine.py:552
-        depth_col = (pts @ view[:3, 2:3] + view[3, 2]).expand(-1, 3)                                     # :603-605
-        pred_depth = render(pts, depth_col, opac, scl, quat, rcam, torch.full((3,), MAX_DEPTH, device=dev))[0]   # :607, :616
+        depth1 = pts @ view[:3, 2:3] + view[3, 2]                                                        # :603-605
+        depth_col = depth1.expand(-1, 3)
+        # identity copies per render: their .grad is what that render's backward alone returns for its inputs
+        tap = lambda *ts: [t_ * 1.0 for t_ in ts]
+        a = tap(pts, rgb, opac, scl, quat)
+        b = tap(pts, depth1, opac, scl, quat)
+        for t_ in a + b:
+            t_.retain_grad()
+        pred_rgb = render(a[0], a[1], a[2], a[3], a[4], rcam, bg_rgb)                                    # refine.py:552
+        pred_depth = render(b[0], b[1].expand(-1, 3), b[2], b[3], b[4], rcam, torch.full((3,), MAX_DEPTH, device=dev))[0]   # :607, :616
         loss = lo.l1_dssim(pred_rgb[None], gt_rgb[None], 0.2)[0] + sum(lo.depth_mask_l1(pred_depth, gt_depth, MAX_DEPTH, 1.0, 0.5))
         loss.backward()
-        return float(loss), {k: P[k].grad.detach().cpu().numpy() for k in PARAMS}
+        # what autograd accumulates for inputs both renders share = the sum of the two backward passes
+        rin = dict(means3D=a[0].grad + b[0].grad, colors_rgb=a[1].grad, colors_depth=b[1].grad, opacities=a[2].grad + b[2].grad,
+                   scales=a[3].grad + b[3].grad, rotations=a[4].grad + b[4].grad)
+        return float(loss), {k: P[k].grad.detach().cpu().numpy() for k in PARAMS}, {k: v_.detach().cpu().numpy() for k, v_ in rin.items()}
 
-    loss_r, grads_r = reference_shaped(0.0)
+    loss_r, grads_r, rin_r = reference_shaped(0.0)
+
+    # (iii) THIS library's rasterizer on the reference-shaped chain's own inputs (torch producers, torch losses): identical
+    # Gaussians and camera on both sides, so the rasterizer-input gradients are held to the rasterizer's tolerances -- no
+    # noise-floor allowance
+    def hip_on_reference_inputs():
+        P = {k: getattr(model, k).detach().clone() for k in PARAMS}
+        with torch.no_grad():
+            pts, scl, quat = po.mesh_bound_gaussians(P["_points"], faces, model.surface_triangle_bary_coords[..., 0], P["_scales"],
+                                                     P["_quaternions"], float(model.surface_mesh_thickness), None, None, P["_delta_t"],
+                                                     P["_delta_r"])
+            rgb = po.points_rgb(pts, campos[None], torch.cat([P["_sh_coordinates_dc"], P["_sh_coordinates_rest"]], 1), 3)
+            depth1 = pts @ view[:3, 2:3] + view[3, 2]
+            opac = torch.sigmoid(P["all_densities"])
+        ins = dict(means3D=pts, colors=torch.cat([rgb, depth1], 1), opacities=opac, scales=scl, rotations=quat)
+        ins = {k: v_.clone().requires_grad_(True) for k, v_ in ins.items()}
+        bg4 = torch.cat([bg_rgb, torch.full((1,), MAX_DEPTH, device=dev)])
+        settings, _, _ = model._settings(ncam, bg4, 0)
+        img4, _ = GaussianRasterizer(settings)(means3D=ins["means3D"], means2D=torch.zeros_like(pts), opacities=ins["opacities"],
+                                               colors_precomp=ins["colors"], scales=ins["scales"], rotations=ins["rotations"])
+        loss = lo.l1_dssim(img4[:3][None], gt_rgb[None], 0.2)[0] + sum(lo.depth_mask_l1(img4[3], gt_depth, MAX_DEPTH, 1.0, 0.5))
+        loss.backward()
+        cg_ = ins["colors"].grad
+        out = dict(means3D=ins["means3D"].grad, colors_rgb=cg_[:, :3], colors_depth=cg_[:, 3:4], opacities=ins["opacities"].grad,
+                   scales=ins["scales"].grad, rotations=ins["rotations"].grad)
+        return float(loss), {k: v_.detach().cpu().numpy() for k, v_ in out.items()}
+
+    loss_h, rin_h = hip_on_reference_inputs()
+    assert abs(loss_h - loss_r) <= 2e-5 * max(1.0, abs(loss_r)), (loss_h, loss_r)
     # Noise floor of the comparison: the reference-shaped iteration against ITSELF with the vertices moved by one ulp.  The
     # losses are means over 2 M pixels (dL_dpix ~ 5e-7, smooth), so a Gaussian's gradient is a few pixel terms that nearly
     # cancel, and ONE (pixel, Gaussian) pair changing sides of the alpha >= 1/255 cut moves it by a sizeable fraction of the
     # tensor's maximum.  Rounding-level input differences flip such pairs in the reference itself; the fused path feeds the
     # blend inputs that differ from the torch chain's by rounding and is held to a small multiple of that floor.
-    _, grads_n = reference_shaped(2.0 ** -23)
+    _, grads_n, rin_n = reference_shaped(2.0 ** -23)
     lf, lr = float(loss_f), loss_r
     print(f"[iteration] N={N} {W}x{H}: loss fused {lf:.7f} reference-shaped {lr:.7f}")
     assert abs(lf - lr) <= 2e-5 * max(1.0, abs(lr)), (lf, lr)
     if os.environ.get("GSR_DUMP_ITER"):
         np.savez(os.environ["GSR_DUMP_ITER"], **{"f_" + k: grads_f[k] for k in PARAMS}, **{"r_" + k: grads_r[k] for k in PARAMS})
+    # The FUSED path's rasterizer-input gradients (before any producer's backward).  Its rasterizer inputs come out of the
+    # fused producers and differ from the torch chain's by rounding; at config-C size that alone flips (pixel, Gaussian) pairs
+    # across the alpha >= 1/255 cut (the floor below: the reference against itself one ulp away shows MORE flipped entries
+    # than the fused path against the reference), so here the bound is ONE times the floor's count -- the factor 3 further
+    # down is only for what the producers' chain rule makes of those entries -- and strict at the small size.
+    for k in RASTER_INPUTS:
+        ref = float(np.abs(rin_r[k]).max())
+        fe = np.abs(rin_n[k].astype(np.float64) - rin_r[k])
+        n_floor = int((fe > parity.GRAD_TOL * (ref + np.abs(rin_r[k]))).sum())
+        worst_floor = float(fe.max() / max(ref, 1e-30))
+        print(f"[iteration] rasterizer input {k}: reference vs itself + 1 ulp: {n_floor} of {fe.size} entries beyond tolerance, "
+              f"worst {worst_floor:.2e} of max")
+        parity.check_grad(rin_f[k], rin_r[k], f"iteration rasterizer-input {k} (fused producers)", small_tol=None,
+                          max_outlier_frac=(n_floor + 16) / fe.size if full_size else 0.0, outlier_cap=max(0.05, 2 * worst_floor))
+        # identical rasterizer inputs on both sides: strict at the small size.  At config-C size the few pairs per view
+        # whose alpha lands on the other side of 1/255 (exp2f(x log2 e) against the reference's expf(x), one ulp apart --
+        # the flips tests/parity.py allows 5e-5 of the entries for under a RANDOM image gradient) weigh more under this
+        # loss's gradient (dL_dpix ~ 5e-7 and smooth: a Gaussian's gradient is a near-cancelling sum, the tensor's
+        # maximum is small): measured 195 of 1 474 560 entries for means3D where the reference against itself one ulp
+        # away shows 2 192.  Allowed: that tolerance or a QUARTER of the floor's count, whichever is larger.
+        parity.check_grad(rin_h[k], rin_r[k], f"iteration rasterizer-input {k} (identical inputs)", small_tol=None,
+                          max_outlier_frac=max(parity.FULL_GRAD_OUTLIERS, 0.25 * n_floor / fe.size) if full_size else 0.0,
+                          outlier_cap=max(0.05, 1.25 * worst_floor))
     for k in PARAMS:
         ref = float(np.abs(grads_r[k]).max())
         tol = lambda x: parity.GRAD_TOL * (ref + np.abs(x))
