@@ -172,12 +172,99 @@ def cpu_baseline(gs, cams, bg, budget_s=20.0):
                       f"C restatement of the reference algorithm with OpenMP over {ncores} threads, {t_total:.1f} s"}
 
 
+def issue_statistics(lib, rs, params, device):
+    """Live (pixel, Gaussian) pairs of one view and the backward blend's pair trips, from the candidate words and
+    n_contrib the forward leaves behind (gsr_debug_export / gsr_debug_export_masks): a pixel's live pairs are the set bits
+    of its words below its last contributor (the words are tight: 1.006 bits per pair that passes the reference's test,
+    tests/test_gpu_masks.py); a (unit, 8x8 block) pair makes one trip per list position ANY of its pixels replays."""
+    from gaustar_amd import rasterizer as rz
+    e = torch.Tensor([])
+    P = int(params["means3D"].shape[0])
+    W, H = rs.image_width, rs.image_height
+    out = rz.rasterize_gaussians_native(rs.bg, params["means3D"].detach(), params["colors"].detach(), params["opacities"].detach(),
+                                        params["scales"].detach(), params["rotations"].detach(), 1.0, e, rs.viewmatrix, rs.projmatrix,
+                                        rs.tanfovx, rs.tanfovy, H, W, e, 0, rs.campos, False, False, need_backward=True)
+    Rn, _color, _radii, geom, binning, img, _maxc, U = out
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    T = gx * gy
+    m2 = torch.zeros(P, 2, device=device); co = torch.zeros(P, 4, device=device)
+    rng_ = torch.zeros(T, 2, dtype=torch.int32, device=device); pl = torch.zeros(max(Rn, 1), dtype=torch.int32, device=device)
+    fT = torch.zeros(H, W, device=device); nc = torch.zeros(H, W, dtype=torch.int32, device=device)
+    masks = torch.zeros(max(U, 1), 4, 64, dtype=torch.int64, device=device)
+    torch.cuda.synchronize(device)
+    p_ = lambda x: x.data_ptr()
+    _lib.check(lib.gsr_debug_export(P, Rn, U, W, H, p_(geom), p_(binning), p_(img), p_(m2), p_(co), None, None, p_(rng_), p_(pl),
+                                    p_(fT), p_(nc), None), "gsr_debug_export")
+    _lib.check(lib.gsr_debug_export_masks(Rn, U, p_(binning), p_(masks), None), "gsr_debug_export_masks")
+    torch.cuda.synchronize(device)
+    ranges = rng_.cpu().numpy().astype(np.int64)
+    n = ranges[:, 1] - ranges[:, 0]
+    units = (n + 63) // 64
+    unit0 = np.concatenate([[0], np.cumsum(units)])
+    assert int(unit0[-1]) == U, (int(unit0[-1]), U)
+    words = masks.cpu().numpy().view(np.uint64)                                  # [U, 4, 64]
+    ncp = np.zeros((gy * 16, gx * 16), np.int64)
+    ncp[:H, :W] = nc.cpu().numpy()
+    nct = ncp.reshape(gy, 2, 8, gx, 2, 8).transpose(0, 3, 1, 4, 2, 5).reshape(T, 4, 64)   # [tile, block 2*by+bx, lane 8*y+x]
+    tile_of = np.repeat(np.arange(T), units)
+    s0 = 64 * (np.arange(U) - unit0[tile_of])
+    lim = np.clip(nct[tile_of] - s0[:, None, None], 0, 64).astype(np.uint64)
+    below = np.where(lim >= 64, np.uint64(0xffffffffffffffff), (np.uint64(1) << (lim & np.uint64(63))) - np.uint64(1))
+    live_words = words & below
+    live = int(np.bitwise_count(live_words).sum())
+    kept = np.bitwise_or.reduce(live_words, axis=2)                              # [U, 4]: positions any pixel of the block replays
+    trips = int(np.bitwise_count(kept).sum())
+    return {"live_pairs_per_view": live, "bwd_pair_trips_per_view": trips, "bwd_unit_blocks_with_work": int((kept != 0).sum()),
+            "bwd_live_lanes_per_pair_trip": round(live / max(trips, 1), 2), "num_rendered": int(Rn), "units": int(U)}
+
+
+def window_benchmark():
+    """BASELINE.json configs[4]'s shape at config-C size on this GPU (tools/bench_window.py: 2 frames x 50 iterations,
+    491 520 Gaussians, 1080p, 160 cameras; producers -> one 4-channel render -> losses -> backward -> Adam)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_window
+    r = bench_window.run(argparse.Namespace(frames=2, iters=50, level=6, width=1920, height=1080, cameras=160))
+    return {"iterations_per_s": r["iterations_per_s"], "ms_per_iteration": r["ms_per_iteration"], "frames": 2, "iterations_per_frame": 50,
+            "gaussians": r["gaussians"], "cameras": r["cameras"], "image": r["image"],
+            "what": "tools/bench_window.py: refinement loop of config E's shape at config-C size, one GPU, outside the timed region"}
+
+
+def ref_gpu_baseline(gs, cams, bg, device, views=4):
+    """The REFERENCE's own kernels built for gfx950 (oracle/_ref/libgsr_ref.so, oracle/build_ref.sh: hipify-perl of the
+    sources under /root/reference + hipCUB), forward + backward on the first `views` config-C views, inputs resident."""
+    from oracle import ref
+    if not ref.available():
+        return None
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(device)
+    a = dict(means3D=t(gs.means3D), opacities=t(gs.opacities), colors_precomp=t(gs.colors_precomp), scales=t(gs.scales),
+             rotations=t(gs.rotations))
+    dpix = torch.randn(3, cams[0].H, cams[0].W, device=device)
+    bg_t = t(bg)
+    camt = [(t(c.viewmatrix), t(c.projmatrix), t(c.campos), c) for c in cams[:views]]
+
+    def one(i):
+        v, p, cp, c = camt[i]
+        rr = ref.RefRasterizer(str(device))
+        rr.forward(a["means3D"], a["opacities"], v, p, cp, c.W, c.H, c.tanfovx, c.tanfovy, bg_t, colors_precomp=a["colors_precomp"],
+                   scales=a["scales"], rotations=a["rotations"])
+        rr.backward(dpix)
+    one(0)
+    torch.cuda.synchronize(device); t0 = time.perf_counter()
+    for i in range(views):
+        one(i)
+    torch.cuda.synchronize(device); dt = time.perf_counter() - t0
+    return {"value": round(views / dt, 1), "unit": "views/s", "ms_per_view": round(dt / views * 1e3, 3), "views": views,
+            "what": "the reference's kernels (diff-gaussian-rasterization) compiled for gfx950 by oracle/build_ref.sh, fwd+bwd, "
+                    "same workload, one GPU, outside the timed region; includes the wrapper's per-call allocations and syncs"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=160)   # one pass over the 160-camera rig
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the window / reference-GPU / issue-statistics legs (N = 1 only)")
     args = ap.parse_args()
 
     # GSR_BENCH_BACKEND=gloo lets the multi-rank path be exercised on a box with fewer GPUs than ranks
@@ -258,10 +345,13 @@ def main():
         # profiles/pmc_latest.json), which carries a hash of gaustar_amd/csrc: counters of other kernels than the ones
         # timed here are dropped (null), never reported stale.
         traffic, valu = None, None
+        pmc_ok = {}
         pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_file):
             try:
                 pmc = json.load(open(pmc_file))
+                if pmc.get("_csrc_sha256") == csrc_sha256():
+                    pmc_ok = pmc
                 if pmc.get("_csrc_sha256") == csrc_sha256() and dom in pmc:
                     traffic = pmc[dom].get("hbm_bytes_per_launch")
                     vi = pmc[dom].get("valu_insts")
@@ -299,6 +389,25 @@ def main():
                          "instrumented_ms_per_step": round(dt_prof / args.steps * 1e3, 4), "kernels": kern},
         }
         out["config"]["host_cpus_pinned"] = len(pinned)
+        # sum of the per-kernel means of the instrumented pass (stages that launched nothing carry no bracket)
+        out["roofline"]["kernels_sum_ms_per_step"] = round(sum(k["ms_per_launch"] * k["launches_per_step"] for k in kern.values()), 4)
+        # the HIP-event brackets themselves add 1 - 4 us per stage (an empty bracket reads ~5 us), so the sum above exceeds the
+        # un-instrumented step; rocprofv3's own mean durations of the same kernels (profiles/, same csrc hash) do not
+        rp = [pmc_ok[k]["rocprof_avg_ns"] * kern[k]["launches_per_step"] for k in kern if isinstance(pmc_ok.get(k), dict) and
+              pmc_ok[k].get("rocprof_avg_ns")]
+        out["roofline"]["kernels_sum_rocprof_ms_per_step"] = round(sum(rp) * 1e-6, 4) if len(rp) == len(kern) and rp else None
+        if world == 1 and not args.no_extras:
+            try:
+                iss = issue_statistics(lib, rasters[0].raster_settings, params, device)
+                for kn in ("blend_fwd_kernel", "blend_bwd_kernel"):
+                    vi = (pmc_ok.get(kn) or {}).get("valu_insts")
+                    iss[kn + "_valu_insts_per_live_pair"] = round(vi / iss["live_pairs_per_view"], 3) if vi else None
+                    iss[kn + "_lane_slots_per_live_pair"] = round(64.0 * vi / iss["live_pairs_per_view"], 1) if vi else None
+                iss["what"] = ("view 0 of the rig: live pairs = set candidate bits below each pixel's last contributor; wave64 vector "
+                               "instructions of profiles/pmc_latest.json (null when csrc changed since the counters were taken)")
+                out["roofline"]["issue"] = iss
+            except Exception as ex:   # statistics only
+                out["roofline"]["issue"] = {"error": repr(ex)[:200]}
         # how long the host sat in the forward's one synchronisation per step (gsr_debug_host_wait): the slack between the
         # host's own work (Python, autograd, launches) and the GPU's -- near zero means the step is host-bound
         out["host"] = {"wait_ms_per_step": round(wait_ns.value / 1e6 / max(args.steps, 1), 4),
@@ -313,6 +422,12 @@ def main():
             except OSError:
                 pass
             out["cpu_baseline"] = cpu_baseline(gs, cams, bg)
+        if world == 1 and not args.no_extras:
+            for key, fn in (("ref_gpu_baseline", lambda: ref_gpu_baseline(gs, cams, bg, device)), ("window", window_benchmark)):
+                try:
+                    out[key] = fn()
+                except Exception as ex:
+                    out[key] = {"error": repr(ex)[:200]}
         print(json.dumps(out), flush=True)
     if world > 1:
         tdist.barrier()

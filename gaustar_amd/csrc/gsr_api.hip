@@ -50,9 +50,9 @@ struct Profiler {
 Profiler g_prof;
 struct Scope {
     int stage; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
-    Scope(int stage_, hipStream_t st_) : stage(stage_), st(st_)
+    Scope(int stage_, hipStream_t st_) : stage(stage_), st(st_)   // stage < 0: no bracket
     {
-        if (g_prof.on.load(std::memory_order_relaxed)) { a = g_prof.get(); b = g_prof.get(); (void)hipEventRecord(a, st); }
+        if (stage >= 0 && g_prof.on.load(std::memory_order_relaxed)) { a = g_prof.get(); b = g_prof.get(); (void)hipEventRecord(a, st); }
     }
     ~Scope()
     {
@@ -386,9 +386,12 @@ int forward_stage2_impl(int P, int R, int max_tile_instances, int num_segments, 
             GSR_CHECK_LAUNCH("scatter_kernel");
         }
         {
-            Scope sc(ST_TILE_SORT, st);
             const char* e_fuse = getenv("GSR_SORT_IN_BLEND");   // read per call (tools/ab_env.py); "0": separate sort kernel
             const bool fuse = !(e_fuse && e_fuse[0] == '0');
+            // (no event bracket around a stage that launches nothing -- every list of a typical view is sorted inside the
+            // forward blend; two back-to-back event records read as ~5 us of "kernel")
+            const bool launches = tile_sort_launches(R, (uint32_t)(max_tile_instances > 0 ? max_tile_instances : 0), fuse);
+            Scope sc(launches ? ST_TILE_SORT : -1, st);
             sort_in_blend = launch_tile_sort(W, H, R, num_segments, (uint32_t)(max_tile_instances > 0 ? max_tile_instances : 0), im, b, fuse, st);
         }
         GSR_CHECK_LAUNCH("tile_sort_kernel");

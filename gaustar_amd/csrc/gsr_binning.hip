@@ -524,6 +524,13 @@ long_sort_merge_kernel(const uint2* __restrict__ part_list, const uint32_t* __re
     }
 }
 
+bool tile_sort_launches(int R, uint32_t max_count, bool blend_sorts_small)
+{
+    if (R <= 0) return false;
+    if (getenv("GSR_DEBUG_SORT_CAP") || getenv("GSR_SORT_LDS") || !blend_sorts_small) return true;
+    return max_count > 2048u;
+}
+
 bool launch_tile_sort(int W, int H, int R, int U, uint32_t max_count, ImageState im, BinState b, bool blend_sorts_small, hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);

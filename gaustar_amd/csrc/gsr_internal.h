@@ -243,6 +243,8 @@ void launch_scatter(int P, int W, int H, uint32_t max_count, GeomState g, ImageS
 void launch_scatter_early(int P, int W, int H, int C, GeomState g, ImageState im, void* binning_base, size_t capacity, hipStream_t st);
 // -> true if lists of up to 2 048 entries were left for the forward blend to sort (gsr_sort.h)
 bool launch_tile_sort(int W, int H, int R, int U, uint32_t max_count, ImageState im, BinState b, bool blend_sorts_small, hipStream_t st);
+// whether launch_tile_sort will launch any kernel for such a view (the profiling bracket is skipped otherwise)
+bool tile_sort_launches(int R, uint32_t max_count, bool blend_sorts_small);
 // Launch positions [0, front_of_order(R, T)) of `order` hold every tile with 2 017 or more entries: they all fall into
 // length class 0, which sits at the front, there are at most R / 2017 of them, and the snake only permutes within
 // bands of 256.  Kernels that only concern such tiles are launched over this prefix instead of all T tiles.

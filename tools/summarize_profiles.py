@@ -47,6 +47,13 @@ for k, c in kern.items():
                   "valu_insts": c.get("SQ_INSTS_VALU"), "salu_insts": c.get("SQ_INSTS_SALU"), "lds_insts": c.get("SQ_INSTS_LDS"),
                   "lds_bank_conflict_cycles": c.get("SQ_LDS_BANK_CONFLICT"), "lds_active_cycles": c.get("SQ_ACTIVE_INST_LDS"),
                   "atomic_requests": c.get("TCC_EA0_ATOMIC_sum")}
+# rocprofv3's own per-kernel mean durations (kernel trace of the un-instrumented bench run): bench.py's HIP-event brackets add
+# 1 - 4 us per stage, so the sum of ITS means exceeds the step; the sum of these does not
+for l in out:
+    m = re.match(r'"gsr::(\w+?)(?:<[^"]*)?",(\d+),(\d+),([\d.]+),', l)
+    if m and m.group(1) in res:
+        res[m.group(1)]["rocprof_avg_ns"] = float(m.group(4))
+        res[m.group(1)]["rocprof_calls"] = int(m.group(2))
 res["_source"] = f"profiles/{name}_pmc.txt (2*FETCH_SIZE + WRITE_SIZE, KiB; see tools/summarize_profiles.py)"
 # the counters describe THESE kernels: bench.py drops them (traffic = null) once gaustar_amd/csrc has changed
 h = hashlib.sha256()
