@@ -7,8 +7,10 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the hot path over one view per rank: GaussianRasterizer forward + backward
-through the public API (all inputs already resident in HBM), and for N > 1 the SUM all-reduce of the
-rasterizer-input gradients over RCCL that precedes the optimiser step.  Rank r renders camera
+through the public API (all inputs already resident in HBM).  For N > 1 that same forward + backward
+sits inside one refinement step per rank on the reference loop's own parameters (producers, then the
+gradient reduce-scatter / rank-sharded Adam / parameter all-gather over RCCL that stands where
+sugar_optimizer.py:99-101 steps Adam) -- see build_refinement_workload.  Rank r renders camera
 (step * N + r) mod 160 of the rig -- views shard, nothing else is exchanged.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
@@ -101,34 +103,59 @@ def build_workload(device, rank):
     return gs, cams, bg, params, means2D, rasters, dpix
 
 
-# Gradient payload of one optimiser step in the reference loop (the param groups of sugar_optimizer.py:67-87 at
-# config C): `_points` 3 floats per mesh vertex + 39 floats per Gaussian (SH dc 3 + rest 24, density 1, scales 2,
-# quaternions 2, delta_t 3, delta_r 4) = 77 MB.  This step produces the 14 floats per Gaussian of the rasterizer's inputs;
-# the rest stands for what the producers' backward turns them into.  Its gradient only becomes final AFTER the
-# rasterizer's backward (it is downstream of it), so its buckets are issued behind the real ones: no overlap is claimed.
-MESH_VERTICES = 40962          # icosphere level 6
-FLOATS_PER_GAUSSIAN = 39
-RASTER_INPUT_FLOATS = 14
+# N > 1: what N view-parallel GPUs really exchange.  The step is one refinement step per rank on the reference loop's own
+# parameters (harness.SurfaceGaussians: `_points` 3 floats per mesh vertex + 39 floats per Gaussian -- SH dc 3 + rest 24,
+# density 1, scales 2, quaternions 2, delta_t 3, delta_r 4 -- = 77 MB at config C, SURVEY.md 8e / sugar_optimizer.py:67-87):
+# mesh + SH producers -> the SAME rasterizer forward + backward as at N = 1 (same Gaussians, cameras, image gradient) ->
+# producers' backward -> gradients reduce-scattered from autograd hooks as they become final -> Adam on this rank's
+# 1/N of the parameters -> all-gather of the updated parameters (gaustar_amd.dist.ShardedAdam).  Learning rates are 0 (the
+# reference constructs its Adam with lr = 0.0 and the trainer sets the rates, sugar_optimizer.py:87): the scene stays put,
+# so every step and every rank renders the workload the N = 1 line is quoted on, while the optimiser moves all its bytes.
+SH0 = 0.28209479177387814
 
 
-def optimiser_payload_standin(P, device):
-    n = 3 * MESH_VERTICES + (FLOATS_PER_GAUSSIAN - RASTER_INPUT_FLOATS) * P
-    t = torch.zeros(n, dtype=torch.float32, device=device)
-    return t, torch.zeros_like(t)
+def build_refinement_workload(device, rank, gs, cams, bg, overlap=True, solo=False):
+    from gaustar_amd import harness
+    v, f = scene.icosphere(6, scene.SUBJECT_RADIUS, scene.SUBJECT_CENTER)
+    verts, faces = torch.from_numpy(v).float().to(device), torch.from_numpy(f).long().to(device)
+    model = harness.SurfaceGaussians(verts, faces, 6, sh_levels=3, surface_mesh_thickness=scene._extent_thickness(),
+                                     loose_bind=True).to(device)
+    assert model.n_points == gs.P
+    with torch.no_grad():   # config C's opacities and colours, expressed in the harness's parameters
+        op = torch.from_numpy(gs.opacities).to(device).clamp(1e-4, 1 - 1e-4)
+        model.all_densities.copy_(torch.log(op / (1 - op)).view(-1, 1))
+        model._sh_coordinates_dc.copy_(((torch.from_numpy(gs.colors_precomp).to(device) - 0.5) / SH0).view(-1, 1, 3))
+    ncams = [harness.nerf_camera_from_scene(c) for c in cams]
+    groups = [{"params": [model._points], "lr": 0.0},
+              {"params": [model._sh_coordinates_dc, model._sh_coordinates_rest], "lr": 0.0},
+              {"params": [model._scales, model._quaternions, model.all_densities, model._delta_t, model._delta_r], "lr": 0.0}]
+    opt = gdist.ShardedAdam(groups, ready_order=model.grad_ready_order(), eps=1e-15, overlap=overlap, run_at_world_size_1=solo)
+    bg_t = torch.from_numpy(np.ascontiguousarray(bg, dtype=np.float32)).to(device)
+    dpix = torch.randn(3, cams[0].H, cams[0].W, device=device, generator=torch.Generator(device=device).manual_seed(1234 + rank))
+    return model, ncams, opt, bg_t, dpix
 
 
-def one_step(step, rank, world, params, means2D, rasters, dpix, reducer, standin=None):
+def refinement_step(step, rank, world, model, ncams, opt, bg_t, dpix):
+    ncam = ncams[(step * world + rank) % len(ncams)]
+    opt.zero_grad(set_to_none=True)
+    settings, _view, campos = model._settings(ncam, bg_t, 0)
+    pts = model.points
+    rgb = model.get_points_rgb(positions=pts, camera_centers=campos, sh_levels=model.sh_levels)
+    color, _radii = GaussianRasterizer(settings)(means3D=pts, means2D=torch.zeros_like(pts), opacities=model.strengths,
+                                                 colors_precomp=rgb, scales=model.scaling, rotations=model.quaternions)
+    color.backward(dpix)
+    opt.step()
+    return color
+
+
+def one_step(step, rank, world, params, means2D, rasters, dpix):
     r = rasters[(step * world + rank) % len(rasters)]
     for p in params.values():
         p.grad = None
     means2D.grad = None
-    if standin is not None:
-        standin[0].grad = standin[1]   # a fresh (here: constant) gradient every step, as autograd would leave it
     color, radii = r(means3D=params["means3D"], means2D=means2D, opacities=params["opacities"],
                      colors_precomp=params["colors"], scales=params["scales"], rotations=params["rotations"])
     color.backward(dpix)
-    if reducer is not None:
-        reducer()
     return color
 
 
@@ -291,9 +318,12 @@ def main():
     lib = _lib.load()
 
     gs, cams, bg, params, means2D, rasters, dpix = build_workload(device, rank)
-    standin = optimiser_payload_standin(gs.P, device) if world > 1 else None
-    reducer = gdist.GradAllReducer(list(params.values()) + [standin[0]]) if world > 1 else None
-    step = lambda s: one_step(s, rank, world, params, means2D, rasters, dpix, reducer, standin)
+    refine = None
+    if world > 1:
+        refine = build_refinement_workload(device, rank, gs, cams, bg)
+        step = lambda s: refinement_step(s, rank, world, *refine)
+    else:
+        step = lambda s: one_step(s, rank, world, params, means2D, rasters, dpix)
 
     for s in range(args.warmup):
         step(s)
@@ -377,9 +407,10 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "config C: 491520 mesh-bound surface Gaussians (icosphere level 6, 6/face), "
                                    "160-camera rig @1920x1080, colours precomputed (M=0), one view per GPU per step, "
-                                   "fwd+bwd" + ((", + all-reduce of the reference loop's %.0f MB optimiser-gradient payload (27.5 MB of it this "
-                                                 "step's input gradients, overlapped with the end of the backward; the rest a "
-                                                 "stand-in issued after it)" % (reducer.payload_bytes() / 1e6)) if world > 1 else ""),
+                                   "fwd+bwd" + ((", inside one refinement step per rank on the reference loop's parameters: mesh + SH "
+                                                 "producers fwd/bwd, reduce-scatter of the %.0f MB of gradients from autograd hooks, Adam on "
+                                                 "this rank's 1/N of the parameters, all-gather of the parameters (dist.ShardedAdam)"
+                                                 % (refine[2].payload_bytes() / 1e6)) if world > 1 else ""),
                        "gaussians": gs.P, "width": W, "height": H, "views_per_step": world,
                        "num_rendered_mean": R_mean, "parallelism": f"view-parallel x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -413,8 +444,10 @@ def main():
         out["host"] = {"wait_ms_per_step": round(wait_ns.value / 1e6 / max(args.steps, 1), 4),
                        "waits_per_step": round(waits.value / max(args.steps, 1), 2)}
         if world > 1:
-            out["config"]["allreduce_payload_MB"] = round(reducer.payload_bytes() / 1e6, 1)
-            out["config"]["allreduce_buckets_issued_during_backward"] = reducer.issued_early
+            out["config"]["exchange"] = "reduce-scatter + rank-sharded Adam + all-gather"
+            out["config"]["exchange_payload_MB"] = round(refine[2].payload_bytes() / 1e6, 1)
+            out["config"]["optimizer_state_MB_per_rank"] = round(refine[2].state_bytes_per_rank() / 1e6, 1)
+            out["config"]["buckets_issued_during_backward"] = refine[2].issued_early
         if world == 1 and not args.no_cpu_baseline:
             try:   # the CPU baseline gets every core the process started with
                 for tid in os.listdir("/proc/self/task"):
@@ -423,6 +456,20 @@ def main():
                 pass
             out["cpu_baseline"] = cpu_baseline(gs, cams, bg)
         if world == 1 and not args.no_extras:
+            try:   # the N > 1 step (refinement step: producers + render + Adam) on ONE GPU: the denominator of its scaling
+                rw = build_refinement_workload(device, 0, gs, cams, bg)
+                rstep = lambda s_: refinement_step(s_, 0, 1, *rw)
+                for s_ in range(5):
+                    rstep(s_)
+                n_r = min(args.steps, 80)
+                dt_r = timed(rstep, n_r, 1, device)
+                out["refinement_step_single_gpu"] = {"ms_per_step": round(dt_r / n_r * 1e3, 4), "steps": n_r,
+                                                     "what": "the step bench.py times at --gpus N > 1 (producers + rasterizer fwd/bwd + "
+                                                             "Adam on the reference loop's 77 MB of parameters), here on one GPU "
+                                                             "without any exchange: N x (1000 / this) views/s is perfect scaling"}
+                rw[2].close(); del rw
+            except Exception as ex:
+                out["refinement_step_single_gpu"] = {"error": repr(ex)[:200]}
             for key, fn in (("ref_gpu_baseline", lambda: ref_gpu_baseline(gs, cams, bg, device)), ("window", window_benchmark)):
                 try:
                     out[key] = fn()

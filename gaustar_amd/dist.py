@@ -146,12 +146,17 @@ class GradAllReducer:
     every rank issues identical collectives in identical order.  The views stay valid until the next backward;
     callers that keep gradients across steps must clone them.
 
-    More than one backward per call (gradient accumulation, a separate regulariser backward) is supported: a bucket that
-    was flattened and issued during the first backward and whose gradients were accumulated into again afterwards is
-    detected at call time (every gradient's identity and version counter are recorded when its bucket is issued), waited
-    for, flattened again and reduced again -- the early collective was wasted, nothing is lost.  A step that is
-    abandoned after its backward (NaN loss, an evaluation backward) must call `reset()` before the next backward, or its
-    in-flight buckets would be taken for the next step's; the reducer cannot tell the two apart."""
+    More than one backward per call (gradient accumulation, a separate regulariser backward) is supported: a parameter
+    whose hook fires a second time before the call marks its bucket DIRTY, and the call reduces every dirty bucket once
+    more, after every bucket has had its first reduction -- on every rank in the same order, whichever buckets a rank
+    happened to issue early (that differs between ranks when a parameter has no gradient on one of them, so the rule must
+    not depend on it: a rank that had not issued a dirty bucket early reduces it twice at call time, the first time
+    redundantly).  Assumption: all ranks run the same sequence of backwards over the same parameters.  Gradients edited
+    in place between the backward and the call (clipping) are invisible to the hooks: call `mark_dirty()` first -- an
+    early-issued bucket whose gradients changed without either raises instead of silently losing the change (identity and
+    version counter of every gradient are recorded at issue time).  A step that is abandoned after its backward (NaN
+    loss, an evaluation backward) must call `reset()` before the next backward, or its in-flight buckets would be taken for
+    the next step's; the reducer cannot tell the two apart."""
 
     def __init__(self, params: Iterable[torch.Tensor], bucket_bytes: int = 32 << 20, average: bool = True,
                  overlap: bool = True, run_at_world_size_1: bool = False):
@@ -175,7 +180,9 @@ class GradAllReducer:
         self._works: List = [None] * len(self.buckets)  # in-flight collectives
         self._fast = [False] * len(self.buckets)
         self._stamp: List = [None] * len(self.buckets)  # per issued bucket: (id, version) of every gradient at issue time
-        self.reissued = 0                              # buckets reduced twice because their gradients changed after issue
+        self._fired: dict = {}                         # id(param) -> hook firings since the last call
+        self._dirty = [False] * len(self.buckets)      # a second backward (or mark_dirty) touched the bucket
+        self.reissued = 0                              # buckets reduced a second time in a call
         self._hooks = []
         self.issued_early = 0                          # buckets whose all-reduce started during backward (last step)
         if overlap:
@@ -196,6 +203,11 @@ class GradAllReducer:
         if world_size() == 1 and not self.solo:
             return
         bi = self._bucket_of[id(p)]
+        n = self._fired.get(id(p), 0) + 1
+        self._fired[id(p)] = n
+        if n > 1:   # a second backward before the call: the bucket is reduced again at call time (rank-independent rule)
+            self._dirty[bi] = True
+            return
         self._ready[bi] += 1
         # issue in bucket order only (every rank must enqueue the same sequence of collectives): a later bucket that
         # completes first waits for its predecessors
@@ -241,15 +253,30 @@ class GradAllReducer:
     def _grad_stamp(bucket):
         return tuple((None if p.grad is None else (id(p.grad), p.grad._version)) for p in bucket)
 
+    def mark_dirty(self) -> None:
+        """Gradients were edited in place after the backward (clipping, scaling): every bucket is reduced (again) at call time.
+        Must be called on every rank."""
+        self._dirty = [True] * len(self.buckets)
+
     def reset(self) -> None:
-        """Forget a backward whose step will not be taken: wait for the collectives already in flight (every rank issued
-        them, so they complete) and drop them, so that the next backward starts from scratch."""
+        """Forget a backward whose step will not be taken: issue what other ranks may have issued early (so that every
+        rank's sequence of collectives stays the same), wait for everything in flight and drop it, so that the next
+        backward starts from scratch."""
+        if world_size() > 1 or self.solo:
+            for bi in range(len(self.buckets)):
+                if self._works[bi] is None:
+                    self._issue(bi)
         for bi, w in enumerate(self._works):
             if w is not None:
                 w.wait()
+        self._clear()
+
+    def _clear(self) -> None:
         self._ready = [0] * len(self.buckets)
         self._works = [None] * len(self.buckets)
         self._stamp = [None] * len(self.buckets)
+        self._dirty = [False] * len(self.buckets)
+        self._fired = {}
 
     @torch.no_grad()
     def __call__(self) -> None:
@@ -258,18 +285,20 @@ class GradAllReducer:
         if ws == 1 and not self.solo:
             return
         early = sum(1 for w in self._works if w is not None)
-        # a gradient that changed after its bucket was issued (second backward before this call): the early reduction
-        # holds a stale value -- wait for it (collectives complete in issue order on every rank) and reduce the bucket again.
-        # Every rank ran the same sequence of backwards, so every rank takes the same decision for every bucket.
-        for bi in range(len(self.buckets)):
-            if self._works[bi] is not None and self._stamp[bi] != self._grad_stamp(self.buckets[bi]):
-                self._works[bi].wait()
-                self._works[bi] = None
-                self.reissued += 1
-                early -= 1
+        # first round: every bucket that has not left yet, in bucket order
         for bi in range(len(self.buckets)):
             if self._works[bi] is None:
                 self._issue(bi)
+        # second round: dirty buckets once more, in bucket order (see the class docstring for why this may be redundant on
+        # a rank and still has to happen)
+        for bi in range(len(self.buckets)):
+            if self._dirty[bi]:
+                self._works[bi].wait()
+                self._issue(bi)
+                self.reissued += 1
+            elif self._stamp[bi] != self._grad_stamp(self.buckets[bi]):
+                raise RuntimeError("GradAllReducer: gradients of a bucket changed after its all-reduce was issued, outside a "
+                                   "backward pass; call mark_dirty() (on every rank) before the reducer")
         for bi, bucket in enumerate(self.buckets):
             self._works[bi].wait()
             flat = self._flat[bi]
@@ -285,11 +314,269 @@ class GradAllReducer:
                     p.grad.copy_(g)
                 off += k
         self.issued_early = early
-        self._ready = [0] * len(self.buckets)
-        self._works = [None] * len(self.buckets)
-        self._stamp = [None] * len(self.buckets)
+        self._clear()
 
 
 def allreduce_grads(params: Sequence[torch.Tensor], average: bool = True) -> None:
     """One-shot convenience wrapper (builds the buckets every call; no overlap)."""
     GradAllReducer(params, average=average, overlap=False)()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Reduce-scatter + rank-sharded Adam + all-gather: the optimiser step of N view-parallel ranks without N copies of Adam.
+# ------------------------------------------------------------------------------------------------------------------
+def _hip_adam_segment(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
+    """One contiguous segment through gaustar_amd's fused kernel (gsr_adam_step; the arithmetic of torch's
+    _single_tensor_adam).  HIP tensors only -- there is no CPU path."""
+    from . import _host, _lib
+    if not param.is_cuda:
+        raise RuntimeError("gaustar_amd.dist.ShardedAdam: parameters must live on a HIP (cuda) device -- there is no CPU path")
+    lib = _lib.load()
+    with _host.on_device(param.device):
+        _lib.check(lib.gsr_adam_step(param.numel(), param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                     float(lr), float(beta1), float(beta2), float(eps), int(step),
+                                     _host.raw_stream(param.device.index)), "gsr_adam_step")
+
+
+class ShardedAdam:
+    """`GradAllReducer` + `optim.Adam` for N view-parallel ranks as ONE object: reduce-scatter of the gradients, Adam on
+    this rank's 1/N of every bucket, all-gather of the updated parameters (the place of sugar_optimizer.py:99-101:
+    `optimizer.step()` right after the backward of refine.py:794).
+
+    Why.  An all-reduce followed by the same Adam step on every rank moves 2 (N-1)/N S bytes per GPU and then runs N
+    identical 28-byte-per-parameter updates (110 us for config C's 24.7 M parameters -- a third of a rendered view).
+    Reduce-scatter + all-gather moves the SAME bytes, but between the two halves each rank only updates its own 1/N of the
+    parameters (14 us at N = 8), the optimiser state shrinks to 1/N per rank, and the all-gather of an early bucket
+    overlaps the Adam kernels of the later ones (it runs on RCCL's stream).
+
+    How.  Parameters are taken in the order their gradients become final during backward (`ready_order`, e.g.
+    harness.SurfaceGaussians.grad_ready_order()) and laid out back to back -- every parameter 16-byte aligned -- in flat
+    buckets of at most `bucket_bytes`, each padded to N equal 16-byte-aligned shards.  The parameters are RE-POINTED at
+    their slices of the flat buffers (`p.data` becomes a view; values are preserved), so the all-gather lands directly in
+    the storage the next forward reads.  A post-accumulate-grad hook per parameter copies nothing: when the last gradient
+    of a bucket has arrived the bucket's gradients are packed into its flat gradient buffer and the SUM reduce-scatter
+    is issued asynchronously, in bucket order on every rank, while autograd goes on.  `step()` issues what is left and then,
+    bucket by bucket: waits for the bucket's reduce-scatter (a stream wait, not a host wait, on RCCL), divides the shard by
+    N, runs the Adam kernel on every (parameter, shard) intersection with that parameter's group's CURRENT `lr` (the
+    trainer rewrites the learning rates every iteration, sugar_optimizer.py:104-118) and issues the bucket's all-gather;
+    finally it waits for the all-gathers and bumps the parameters' version counters.
+
+    Same hyper-parameters and update rule as `torch.optim.Adam(groups, eps=...)` without weight decay / amsgrad, one step
+    counter per parameter; a parameter whose gradient is None on this rank contributes zeros (the step is still taken for
+    it: some other rank may have seen it).  After `step()` every `p.grad` still holds this rank's LOCAL gradient --
+    nothing reads it; call `zero_grad()` (set to None) before the next backward as the reference's loop does.
+    `gather_state()` reassembles torch.optim.Adam-shaped state (`step`, `exp_avg`, `exp_avg_sq` per parameter) on every
+    rank for checkpoints.  gloo (CPU tests) has no reduce-scatter: there the gradient half is an all-reduce of which the rank
+    keeps its shard -- same values, more bytes.
+
+    `segment_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step)`: the in-place update of one contiguous
+    segment; default = the HIP kernel.  Tests inject a torch implementation to run the bookkeeping on CPU."""
+
+    def __init__(self, param_groups, ready_order: Sequence[torch.Tensor] | None = None, betas=(0.9, 0.999), eps: float = 1e-8,
+                 bucket_bytes: int = 32 << 20, average: bool = True, overlap: bool = True, run_at_world_size_1: bool = False,
+                 segment_step=None):
+        self.param_groups = [dict(g) for g in param_groups]
+        for g in self.param_groups:
+            g["params"] = list(g["params"])
+            g.setdefault("lr", 1e-3)
+            g.setdefault("betas", tuple(betas))
+            g.setdefault("eps", float(eps))
+        group_of = {id(p): g for g in self.param_groups for p in g["params"]}
+        order = list(ready_order) if ready_order is not None else [p for g in self.param_groups for p in g["params"]]
+        if {id(p) for p in order} != set(group_of) or len(order) != len(group_of):
+            raise ValueError("ShardedAdam: ready_order must list every parameter of the groups exactly once")
+        self.world = world_size()
+        self.rank = rank()
+        self.solo = bool(run_at_world_size_1)
+        self.average = average
+        self._comm = self.world > 1 or self.solo
+        self._segment_step = segment_step or _hip_adam_segment
+        W = max(self.world, 1)
+        # ---- layout: (bucket, offset) per parameter
+        self.buckets: List[dict] = []
+        cur, off = [], 0
+        for p in order:
+            if p.dtype != torch.float32:
+                raise ValueError("ShardedAdam: float32 parameters only")
+            k = (p.numel() + 3) // 4 * 4
+            if cur and (off + k) * 4 > bucket_bytes:
+                self.buckets.append(dict(entries=cur, used=off))
+                cur, off = [], 0
+            cur.append((p, off))
+            off += k
+        if cur:
+            self.buckets.append(dict(entries=cur, used=off))
+        self._bucket_of = {}
+        for bi, b in enumerate(self.buckets):
+            dev = b["entries"][0][0].device
+            n = (b["used"] + 4 * W - 1) // (4 * W) * (4 * W)           # N equal shards of whole float4s
+            S = n // W
+            flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
+            with torch.no_grad():
+                for p, o in b["entries"]:
+                    flat_p[o:o + p.numel()].copy_(p.detach().reshape(-1))
+                    p.data = flat_p[o:o + p.numel()].view(p.shape)
+                    self._bucket_of[id(p)] = bi
+            b.update(n=n, S=S, flat_p=flat_p, flat_g=torch.zeros(n, dtype=torch.float32, device=dev),
+                     exp_avg=torch.zeros(S, dtype=torch.float32, device=dev), exp_avg_sq=torch.zeros(S, dtype=torch.float32, device=dev),
+                     need=sum(1 for p, _ in b["entries"] if p.requires_grad), ready=0, rs=None, stamp=None, dirty=False)
+            lo, hi = self.rank * S, (self.rank + 1) * S
+            b["shard_g"] = b["flat_g"][lo:hi]
+            # (parameter, shard) intersections: (param, group, start in the shard, start in the flat buffer, length)
+            b["segments"] = []
+            for p, o in b["entries"]:
+                a, e = max(o, lo), min(o + p.numel(), hi)
+                if e > a:
+                    b["segments"].append((p, group_of[id(p)], a - lo, a, e - a))
+        self._steps = {id(p): 0 for p in order}
+        self._fired: dict = {}
+        self._order = order
+        self.issued_early = 0
+        self.reissued = 0
+        self._hooks = []
+        if overlap and self._comm:
+            for p in order:
+                if p.requires_grad and hasattr(p, "register_post_accumulate_grad_hook"):
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    # ------------------------------------------------------------------ bookkeeping
+    def payload_bytes(self) -> int:
+        return sum(p.numel() for p in self._order) * 4
+
+    def state_bytes_per_rank(self) -> int:
+        return sum(2 * b["S"] * 4 for b in self.buckets)
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        for p in self._order:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    def close(self) -> None:
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    def mark_dirty(self) -> None:
+        """Gradients were edited in place after the backward: every bucket is reduced (again) by step() (see GradAllReducer)."""
+        for b in self.buckets:
+            b["dirty"] = True
+
+    def reset(self) -> None:
+        """Forget a backward whose step will not be taken (see GradAllReducer.reset)."""
+        for bi, b in enumerate(self.buckets):
+            if b["rs"] is None and self._comm:
+                self._issue_grads(bi)
+        for b in self.buckets:
+            if b["rs"] is not None:
+                b["rs"].wait()
+            b.update(rs=None, stamp=None, ready=0, dirty=False)
+        self._fired = {}
+
+    @staticmethod
+    def _stamp(b):
+        return tuple((None if p.grad is None else (id(p.grad), p.grad._version)) for p, _ in b["entries"])
+
+    def _on_grad(self, p: torch.Tensor) -> None:
+        bi = self._bucket_of[id(p)]
+        n = self._fired.get(id(p), 0) + 1
+        self._fired[id(p)] = n
+        if n > 1:   # second backward before the step: reduce the bucket again in step() (rank-independent rule)
+            self.buckets[bi]["dirty"] = True
+            return
+        self.buckets[bi]["ready"] += 1
+        while True:   # bucket order only: every rank must enqueue the same sequence of collectives
+            nxt = next((i for i, b in enumerate(self.buckets) if b["rs"] is None), None)
+            if nxt is None or self.buckets[nxt]["ready"] < self.buckets[nxt]["need"]:
+                break
+            self._issue_grads(nxt)
+            self.issued_early += 1
+
+    @torch.no_grad()
+    def _pack(self, b) -> None:
+        for p, o in b["entries"]:
+            dst = b["flat_g"][o:o + p.numel()]
+            if p.grad is None:
+                dst.zero_()
+            else:
+                dst.copy_(p.grad.reshape(-1))
+
+    @torch.no_grad()
+    def _issue_grads(self, bi: int) -> None:
+        b = self.buckets[bi]
+        self._pack(b)
+        b["stamp"] = self._stamp(b)
+        if not self._comm:
+            b["rs"] = _Done()
+            return
+        backend = dist.get_backend() if dist.is_initialized() else "none"
+        if backend == "gloo":   # no reduce-scatter in gloo: all-reduce, keep the shard (tests)
+            b["rs"] = dist.all_reduce(b["flat_g"], op=dist.ReduceOp.SUM, async_op=True)
+        else:
+            b["rs"] = dist.reduce_scatter_tensor(b["shard_g"], b["flat_g"], op=dist.ReduceOp.SUM, async_op=True)
+
+    # ------------------------------------------------------------------ the step
+    @torch.no_grad()
+    def step(self) -> None:
+        early = sum(1 for b in self.buckets if b["rs"] is not None)
+        for bi, b in enumerate(self.buckets):   # first round: what has not left yet, in bucket order
+            if b["rs"] is None:
+                self._issue_grads(bi)
+        for bi, b in enumerate(self.buckets):   # second round: dirty buckets once more (GradAllReducer's rule)
+            if b["dirty"]:
+                b["rs"].wait()
+                self._issue_grads(bi)
+                self.reissued += 1
+            elif b["stamp"] != self._stamp(b):
+                raise RuntimeError("ShardedAdam: gradients of a bucket changed after its reduction was issued, outside a backward "
+                                   "pass; call mark_dirty() (on every rank) before step()")
+        self.issued_early = early
+        self._fired = {}
+        for p in self._order:
+            self._steps[id(p)] += 1
+        gathers = []
+        for b in self.buckets:
+            b["rs"].wait()
+            if self.average and self._comm and self.world > 1:
+                b["shard_g"].div_(self.world)
+            lo = self.rank * b["S"]
+            for p, g, s_off, f_off, n in b["segments"]:
+                b1, b2 = g["betas"]
+                self._segment_step(b["flat_p"][f_off:f_off + n], b["shard_g"][s_off:s_off + n], b["exp_avg"][s_off:s_off + n],
+                                   b["exp_avg_sq"][s_off:s_off + n], float(g["lr"]), float(b1), float(b2), float(g["eps"]),
+                                   self._steps[id(p)])
+            if self._comm:
+                gathers.append(dist.all_gather_into_tensor(b["flat_p"], b["flat_p"][lo:lo + b["S"]], async_op=True))
+            b.update(rs=None, stamp=None, ready=0, dirty=False)
+        for w in gathers:
+            w.wait()
+        from .optim import _bump_version
+        for p in self._order:
+            _bump_version(p)
+
+    # ------------------------------------------------------------------ checkpoints
+    @torch.no_grad()
+    def gather_state(self) -> dict:
+        """{parameter: {"step", "exp_avg", "exp_avg_sq"}} with full-size tensors on every rank (a collective call): the
+        state torch.optim.Adam would hold after the same steps."""
+        out = {}
+        for b in self.buckets:
+            full = {}
+            for key in ("exp_avg", "exp_avg_sq"):
+                if self._comm and self.world > 1:
+                    t = torch.empty(b["n"], dtype=torch.float32, device=b[key].device)
+                    dist.all_gather_into_tensor(t, b[key].contiguous())
+                else:
+                    t = b[key]
+                full[key] = t
+            for p, o in b["entries"]:
+                out[p] = {"step": torch.tensor(float(self._steps[id(p)])),
+                          "exp_avg": full["exp_avg"][o:o + p.numel()].view(p.shape).clone(),
+                          "exp_avg_sq": full["exp_avg_sq"][o:o + p.numel()].view(p.shape).clone()}
+        return out
+
+
+class _Done:
+    def wait(self):
+        return True

@@ -179,3 +179,122 @@ print(json.dumps(dict(before=before, a=a, now=now, b=b)))
         pytest.skip("fewer than 8 CPUs allowed here")
     assert d["a"] and d["now"] == sorted(d["a"]) and set(d["a"]) <= set(d["before"])
     assert d["b"] and not (set(d["a"]) & set(d["b"]))
+
+
+# ------------------------------------------------------------------ reduce-scatter + rank-sharded Adam + all-gather
+def torch_adam_segment(p, g, m, v, lr, b1, b2, eps, step):
+    """torch/optim/adam.py::_single_tensor_adam on one contiguous segment (what gsr_adam_step computes on the GPU)."""
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    p.addcdiv_(m, (v.sqrt() / bc2 ** 0.5).add_(eps), value=-lr / bc1)
+
+
+def _sharded_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from gaustar_amd import dist as gd
+    gd.init_from_env("gloo")
+    torch.manual_seed(0)
+    shapes = [(1001, 3), (77,), (5000, 2), (9, 4)]
+    ps = [torch.nn.Parameter(torch.randn(*s)) for s in shapes]       # identical on both ranks (same seed)
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]        # the single-process reference
+    groups = lambda xs: [{"params": [xs[0]], "lr": 1e-2}, {"params": [xs[1], xs[2]], "lr": 3e-3}, {"params": [xs[3]], "lr": 1e-3}]
+    opt = gd.ShardedAdam(groups(ps), ready_order=[ps[2], ps[3], ps[0], ps[1]], eps=1e-15, bucket_bytes=20_000,
+                         segment_step=torch_adam_segment)
+    ref = torch.optim.Adam(groups(qs), eps=1e-15)
+    ok = len(opt.buckets) >= 2 and opt.payload_bytes() == sum(p.numel() for p in ps) * 4
+    ok = ok and opt.state_bytes_per_rank() < 1.1 * opt.payload_bytes()          # 2 states x 1/2 of the parameters (+ padding)
+    early = []
+    for it in range(6):
+        opt.zero_grad(); ref.zero_grad()
+        if it == 3:   # the trainer rewrites the learning rates (sugar_optimizer.py:104-118)
+            opt.param_groups[1]["lr"] = ref.param_groups[1]["lr"] = 7e-3
+        # this rank's loss; the reference takes the MEAN of both ranks' losses (= averaged gradients); ps[3] gets no
+        # gradient at all on rank 1
+        w = lambda r: [(i + 1.0) * (r + 1.0) for i in range(4)]
+        loss = sum(c * (p ** 2).sum() for c, p in list(zip(w(rank), ps))[:3 if rank == 1 else 4])
+        loss.backward()
+        if it == 4:   # a second backward before the step (regulariser): early buckets must be reduced again
+            (0.5 * ps[2].sum()).backward()
+        lr_ = sum(0.5 * sum(c * (p ** 2).sum() for c, p in list(zip(w(r), qs))[:3 if r == 1 else 4]) for r in range(2))
+        if it == 4:
+            lr_ = lr_ + 0.5 * qs[2].sum()
+        lr_.backward()
+        opt.step(); ref.step()
+        early.append(opt.issued_early)
+    err = max(float((p - q_).abs().max()) for p, q_ in zip(ps, qs))
+    st = opt.gather_state()
+    err_state = max(float((st[p]["exp_avg_sq"] - ref.state[q_]["exp_avg_sq"]).abs().max()) for p, q_ in zip(ps, qs))
+    steps_ok = all(float(st[p]["step"]) == 6.0 for p in ps)
+    flat = torch.cat([p.detach().reshape(-1) for p in ps])
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    torch.distributed.all_gather(both, flat)
+    same = bool(torch.equal(both[0], both[1]))                                   # the all-gather left identical parameters
+    q.put((rank, ok, err, err_state, steps_ok, same, early, opt.reissued))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_sharded_adam_gloo_world2():
+    """Two ranks with different gradients: reduce-scatter (gloo: all-reduce + shard) -> Adam on each rank's half ->
+    all-gather equals torch.optim.Adam on the averaged gradients, step after step, with rewritten learning rates, a
+    parameter without gradient on one rank and a second backward before one of the steps; both ranks end with
+    bit-identical parameters; buckets leave during backward."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, err, err_state, steps_ok, same, early, reissued in res:
+        assert ok and steps_ok and same, res
+        assert err < 2e-6 and err_state < 1e-5, res
+        assert max(early) >= 1, res              # some bucket's reduction started inside backward
+        assert reissued >= 1, res                # the second backward of step 4 invalidated an early bucket
+
+
+def _reissue_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from gaustar_amd import dist as gd
+    gd.init_from_env("gloo")
+    params = [torch.nn.Parameter(torch.zeros(3000)) for _ in range(4)]
+    red = gd.GradAllReducer(params, bucket_bytes=24_000, average=True)
+    # two backwards before one call: the bucket issued during the first holds a stale sum
+    (sum((i + 1) * (rank + 1) * p.sum() for i, p in enumerate(params))).backward()
+    (sum(10.0 * p.sum() for p in params)).backward()
+    red()
+    ok = all(torch.allclose(p.grad, torch.full_like(p, 1.5 * (i + 1) + 10.0)) for i, p in enumerate(params))
+    ok = ok and red.reissued >= 1
+    # an abandoned backward followed by reset(): the next step must not see it
+    for p in params:
+        p.grad = None
+    (sum(100.0 * p.sum() for p in params)).backward()
+    red.reset()
+    for p in params:
+        p.grad = None
+    (sum((rank + 1) * p.sum() for p in params)).backward()
+    red()
+    ok = ok and all(torch.allclose(p.grad, torch.full_like(p, 1.5)) for p in params)
+    q.put((rank, ok, red.reissued))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_allreduce_survives_a_second_backward_and_a_skipped_step_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reissue_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res

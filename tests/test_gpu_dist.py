@@ -57,6 +57,62 @@ print("RCCL_OK")
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+def test_sharded_adam_over_rccl_equals_the_fused_adam_world_size_1():
+    """dist.ShardedAdam with its collectives really issued (reduce_scatter_tensor / all_gather_into_tensor over RCCL at world
+    size 1) on the harness's parameters: after five refinement-shaped steps with the trainer's learning rates the parameters
+    are bit-identical to gaustar_amd.optim.Adam's (same kernel on the same numbers), buckets left during backward, and
+    gather_state() matches the other optimiser's state."""
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+import torch
+os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=%r, HSA_ENABLE_IPC_MODE_LEGACY="0")
+import torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1)
+from gaustar_amd import dist as gd, harness, optim, scene
+dev = torch.device("cuda:0")
+v, f = scene.icosphere(3, scene.SUBJECT_RADIUS, scene.SUBJECT_CENTER)
+verts, faces = torch.from_numpy(v).float().to(dev), torch.from_numpy(f).long().to(dev)
+def make():
+    torch.manual_seed(1)
+    m = harness.SurfaceGaussians(verts, faces, 6, 3, loose_bind=True).to(dev)
+    with torch.no_grad():
+        m._sh_coordinates_dc.copy_(torch.rand_like(m._sh_coordinates_dc) * 2 - 1)
+    return m
+groups = lambda m: [{"params": [m._points], "lr": 2e-4}, {"params": [m._sh_coordinates_dc, m._sh_coordinates_rest], "lr": 5e-3},
+                    {"params": [m._scales, m._quaternions, m.all_densities, m._delta_t, m._delta_r], "lr": 5e-3}]
+a, b = make(), make()
+oa = gd.ShardedAdam(groups(a), ready_order=a.grad_ready_order(), eps=1e-15, bucket_bytes=256 << 10, run_at_world_size_1=True)
+ob = optim.Adam(groups(b), eps=1e-15)
+cam = harness.nerf_camera_from_scene(scene.look_at_camera((0.5, 1.6, 3.0), scene.SUBJECT_CENTER, 320, 240, focal_px=260.0))
+tgt = torch.rand(240, 320, 3, device=dev)
+early = []
+for it in range(5):
+    oa.zero_grad(set_to_none=True)
+    img = a.render_image_gaussian_rasterizer(cam, bg_color=[0.0, 1.0, 0.0])
+    ((img - tgt) ** 2).mean().backward()
+    # the other optimiser steps on the SAME gradients (two renders would differ in the last bits: the backward blend sums
+    # with float atomics, and Adam with eps = 1e-15 turns a sign flip of a near-zero gradient into a full-size step)
+    for p, q in zip(a.parameters(), b.parameters()):
+        q.grad = None if p.grad is None else p.grad.clone()
+    oa.step(); ob.step()
+    early.append(oa.issued_early)
+torch.cuda.synchronize()
+for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+    assert torch.equal(p, q), n
+st = oa.gather_state()
+for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+    assert torch.equal(st[p]["exp_avg"], ob.state[q]["exp_avg"]) and torch.equal(st[p]["exp_avg_sq"], ob.state[q]["exp_avg_sq"]), n
+assert max(early) >= 1, early
+assert len(oa.buckets) >= 3
+dist.barrier(); dist.destroy_process_group()
+print("SHARDED_OK")
+''' % (ROOT, str(_free_port()))
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SHARDED_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def _torchrun(script_args, env_extra, timeout=900):
     env = dict(os.environ, GSR_BENCH_BACKEND="gloo", GSR_BENCH_NO_PIN="1", **env_extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -74,8 +130,12 @@ def test_bench_two_ranks_over_gloo():
     d = _torchrun(["bench.py", "--gpus", "2", "--steps", "8", "--warmup", "2", "--no-cpu-baseline"], {})
     assert d["n_gpus"] == 2 and d["steps"] == 8 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["views_per_step"] == 2 and "roofline" in d
-    # the exchange is the reference loop's optimiser payload (3 floats per mesh vertex + 39 per Gaussian)
-    assert abs(d["config"]["allreduce_payload_MB"] - (3 * 40962 + 39 * 491520) * 4 / 1e6) < 0.1
+    # the exchange is the reference loop's REAL optimiser payload, produced by the harness's producers' backward (SURVEY.md
+    # 8e: 3 floats per mesh vertex + 39 per Gaussian), reduce-scattered, stepped on each rank's half, all-gathered
+    assert abs(d["config"]["exchange_payload_MB"] - (3 * 40962 + 39 * 491520) * 4 / 1e6) < 0.1
+    assert d["config"]["exchange"].startswith("reduce-scatter")
+    assert d["config"]["optimizer_state_MB_per_rank"] < 0.55 * 2 * d["config"]["exchange_payload_MB"]
+    assert d["config"]["buckets_issued_during_backward"] >= 1
 
 
 def test_refinement_window_two_ranks_over_gloo():
@@ -84,5 +144,6 @@ def test_refinement_window_two_ranks_over_gloo():
     d = _torchrun([os.path.join("tools", "bench_window.py"), "--frames", "2", "--iters", "40", "--level", "3", "--width", "320",
                    "--height", "240", "--cameras", "16"], {})
     assert d["world"] == 2 and d["views_per_iteration"] == 2 and d["buckets_issued_during_backward"] >= 1
+    assert d["exchange"] == "sharded"      # reduce-scatter (gloo: all-reduce + shard) -> Adam on each rank's half -> all-gather
     for fr in d["frames"]:
         assert fr["loss_last"] < 0.95 * fr["loss_first"], d

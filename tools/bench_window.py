@@ -61,10 +61,16 @@ def run(a):
                 d = img[3].clone()
                 d[d >= MAX_DEPTH - 1e-3] = 2 * MAX_DEPTH
                 gts.append((img[:3].clone(), d))
-        reducer = gdist.GradAllReducer(model.grad_ready_order()) if world > 1 else None
-        opt = optim.Adam([{"params": [model._points], "lr": 2e-4},
-                          {"params": [model._sh_coordinates_dc, model._sh_coordinates_rest], "lr": 5e-3},
-                          {"params": [model._scales, model._quaternions, model.all_densities], "lr": 5e-3}], eps=1e-15)
+        groups = [{"params": [model._points], "lr": 2e-4},
+                  {"params": [model._sh_coordinates_dc, model._sh_coordinates_rest], "lr": 5e-3},
+                  {"params": [model._scales, model._quaternions, model.all_densities], "lr": 5e-3}]
+        sharded = world > 1 and getattr(a, "exchange", "sharded") == "sharded"
+        if sharded:   # reduce-scatter -> Adam on this rank's 1/N -> all-gather (dist.ShardedAdam), the default for N > 1
+            reducer = None
+            opt = gdist.ShardedAdam(groups, ready_order=model.grad_ready_order(), eps=1e-15)
+        else:         # all-reduce + the same Adam step on every rank
+            reducer = gdist.GradAllReducer(model.grad_ready_order()) if world > 1 else None
+            opt = optim.Adam(groups, eps=1e-15)
         hist = []
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for it in range(a.iters):
@@ -80,6 +86,9 @@ def run(a):
         if reducer is not None:
             early, payload = reducer.issued_early, reducer.payload_bytes()
             reducer.close()
+        if sharded:
+            early, payload = opt.issued_early, opt.payload_bytes()
+            opt.close()
         torch.cuda.synchronize(); t_total += time.perf_counter() - t0
         n_it += a.iters
         k = max(1, min(5, a.iters // 4))
@@ -87,7 +96,7 @@ def run(a):
     moved = float((model.points.detach() - pts_start).abs().max())
     if world > 1:
         torch.distributed.barrier()
-    extra = {} if world == 1 else {"world": world, "allreduce_payload_MB": round(payload / 1e6, 1), "buckets_issued_during_backward": early,
+    extra = {} if world == 1 else {"world": world, "exchange": getattr(a, "exchange", "sharded"), "allreduce_payload_MB": round(payload / 1e6, 1), "buckets_issued_during_backward": early,
                                   "views_per_iteration": world}
     return {**extra, "gaussians": N, "image": [a.width, a.height], "cameras": len(ncams), "frames": frames, "iterations": n_it,
             "iterations_per_s": round(n_it / t_total, 1), "ms_per_iteration": round(t_total / n_it * 1e3, 3),
@@ -99,6 +108,7 @@ def main():
     ap.add_argument("--frames", type=int, default=3); ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--level", type=int, default=6); ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080); ap.add_argument("--cameras", type=int, default=160)
+    ap.add_argument("--exchange", choices=["sharded", "allreduce"], default="sharded")
     r = run(ap.parse_args())
     if gdist.rank() == 0:
         print(json.dumps(r))
