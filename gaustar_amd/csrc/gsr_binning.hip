@@ -276,6 +276,15 @@ scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __
         if ((size_t)blockIdx.x * 256 >= (size_t)P) return;
         __shared__ uint32_t slot_base[WG_TAB_SLOTS];
         static_assert(WG_TAB_SLOTS == 256, "one thread per table slot");
+        // (the record count of this wave's quarter and its first batch of records are requested HERE, together with the
+        // table row: behind the barrier they were the third and fourth dependent trip to memory of a workgroup that makes
+        // four -- table -> tile start and shard counts -> count -> records.  A wave's quarter always exists, so the
+        // speculative read of records [0, 64) is in bounds whatever the count turns out to be)
+        constexpr uint32_t WAVE_CAP_ = WG_REC_CAP / 4;
+        const uint32_t wv_ = threadIdx.x >> 6;
+        const uint4* const recs_ = wg_recs + (size_t)blockIdx.x * WG_REC_CAP + (size_t)wv_ * WAVE_CAP_;
+        const uint32_t nr_ = wg_nrec[blockIdx.x * 4 + wv_];
+        const uint4 r0_ = recs_[lane];
         const uint2 e = wg_tab[(size_t)blockIdx.x * WG_TAB_SLOTS + threadIdx.x];
         if (e.x != 0xffffffffu) {
             // all seven lower-shard counts are requested together (a loop with `if (s < shard)` compiles to dependent trips)
@@ -290,12 +299,10 @@ scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __
         }
         __syncthreads();
         // every wave takes the records of the preprocess wave at its position (its quarter of the array)
-        constexpr uint32_t WAVE_CAP = WG_REC_CAP / 4;
-        const uint32_t wv = threadIdx.x >> 6;
-        const uint32_t nr = wg_nrec[blockIdx.x * 4 + wv];
-        const uint4* const recs = wg_recs + (size_t)blockIdx.x * WG_REC_CAP + (size_t)wv * WAVE_CAP;
-        for (uint32_t i = lane; i < nr; i += 64u) {
-            const uint4 r = recs[i];
+        const uint32_t nr = min(nr_, WAVE_CAP_);   // (a wave that produced more flagged the view: this path is not taken then)
+        if ((uint32_t)lane < nr) keys[slot_base[r0_.z] + r0_.w] = ((uint64_t)r0_.y << 32) | r0_.x;
+        for (uint32_t i = lane + 64u; i < nr; i += 64u) {
+            const uint4 r = recs_[i];
             keys[slot_base[r.z] + r.w] = ((uint64_t)r.y << 32) | r.x;
         }
         return;

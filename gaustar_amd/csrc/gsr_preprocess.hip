@@ -53,6 +53,9 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
 
     if (valid) {
         const Vec3 p = load3(means3D, idx);
+        // (requested with the other inputs: read where it is used -- behind the near-plane, determinant and rect tests -- it
+        // was a second dependent trip to memory in the middle of the kernel's one occupancy wave)
+        const float op_in = opacities[idx];
         const float view_z = view_depth(p, view);
         // Near-plane cull only (auxiliary.h:154; the NDC side test is dead code there).
         if (view_z > NEAR_Z) {
@@ -89,7 +92,7 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
                 int ry1 = min(gy, max(0, (int)((py + r + TILE - 1) / TILE)));
                 if ((rx1 - rx0) * (ry1 - ry0) != 0) {
                     out_radius = r;
-                    const float op = opacities[idx];
+                    const float op = op_in;
                     // alpha = min(0.99, op*exp(power)) >= 1/255  <=>  -power <= ln(255*op).  tau carries an
                     // absolute safety margin far above any rounding in exp or in the quadratic form.
                     if (op * 255.0f * 1.0001f >= 1.0f) {
