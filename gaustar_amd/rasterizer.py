@@ -160,11 +160,19 @@ def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rot
         if scratch is not None and blended.value:
             scratch_box.append(scratch)   # cleared by the forward blend: good for exactly one backward
         need = int(lib.gsr_binning_bytes_mt(R.value, nseg.value, C))
-        with _HINT_LOCK:
-            if need * 5 // 4 > hint:
-                _BINNING_HINT[dev.index] = max(_BINNING_HINT.get(dev.index, 0), (need * 5 // 4 + (1 << 20) - 1) >> 20 << 20)
-            elif need * 2 < hint:   # far too generous (one close-up view long ago): come down 10 % per call
-                _BINNING_HINT[dev.index] = max(need * 5 // 4, hint * 9 // 10 + (1 << 20) - 1) >> 20 << 20
+        # The hint only moves in steps of 32 MB and only comes down when a view needs less than a QUARTER of it (then it
+        # halves): every change of the size is a new block for the caching allocator -- a hipMalloc of a few hundred MB costs
+        # tens of milliseconds -- and a hint that shrank by 10 % whenever a view needed less than half of it made a rig of
+        # near and far cameras oscillate between shrinking and the exact-size fallback (82 ms iterations in the windowed
+        # refinement loop).  288 GB of HBM make a generous buffer the cheap side of this trade.
+        if need > hint or need * 4 < hint:
+            with _HINT_LOCK:
+                cur = _BINNING_HINT.get(dev.index, 0)
+                step = 32 << 20
+                if need > cur:
+                    _BINNING_HINT[dev.index] = (need * 5 // 4 + step - 1) // step * step
+                elif need * 4 < cur:
+                    _BINNING_HINT[dev.index] = max((need * 5 // 4 + step - 1) // step * step, (cur // 2 + step - 1) // step * step)
         if not blended.value:
             # forward-only renders hand stage 2 the NEGATED segment count: no per-segment snapshots are written (gsr.h)
             nseg2 = nseg.value if need_backward else -nseg.value

@@ -10,7 +10,7 @@ frame, train_seq.py:101-244 / gaustar_trainers/refine.py:529-841) assembled from
 
 Not included (out of scope): mesh regularisers (pytorch3d), topology update (Open3D),
 flow warp.  Prints iterations/s over all frames and the loss at the start / end of every frame."""
-import argparse, json, os, sys, time
+import argparse, gc, json, os, sys, time
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -48,7 +48,7 @@ def run(a):
     bg4 = torch.tensor([0.0, 1.0, 0.0, MAX_DEPTH], device=dev)
     target = harness.SurfaceGaussians(verts, faces, 6, 3).to(dev)
     target.load_state_dict(model.state_dict())
-    frames, n_it = [], 0
+    frames, n_it, per_it = [], 0, []
     pts_start = model.points.detach().clone()
     t_total = 0.0
     for fi in range(a.frames):
@@ -72,8 +72,14 @@ def run(a):
             reducer = gdist.GradAllReducer(model.grad_ready_order()) if world > 1 else None
             opt = optim.Adam(groups, eps=1e-15)
         hist = []
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.iters + 1)]   # GPU time of every iteration, no host sync
+        # Python's cyclic collector is run HERE, between frames, and held off inside the frame: a generation-2 pass over the
+        # few thousand tensor / autograd objects of a frame stops the host for 50 - 80 ms -- one "iteration" of 73 ms in a
+        # loop whose iterations take 0.85 (measured: tools/window_diag.py; gone with the collector off)
+        gc.collect(); gc.disable()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for it in range(a.iters):
+            marks[it].record()
             ci = gdist.shard_views(len(ncams), fi * a.iters + it, rank, world)
             opt.zero_grad(set_to_none=True)
             img = render4(model, ncams[ci], bg4)
@@ -89,10 +95,15 @@ def run(a):
         if sharded:
             early, payload = opt.issued_early, opt.payload_bytes()
             opt.close()
+        marks[a.iters].record()
         torch.cuda.synchronize(); t_total += time.perf_counter() - t0
+        gc.enable()
+        frame_s = time.perf_counter() - t0
+        per_it.extend(marks[i].elapsed_time(marks[i + 1]) for i in range(a.iters))
         n_it += a.iters
         k = max(1, min(5, a.iters // 4))
-        frames.append({"loss_first": round(float(torch.stack(hist[:k]).mean()), 5), "loss_last": round(float(torch.stack(hist[-k:]).mean()), 5)})
+        frames.append({"loss_first": round(float(torch.stack(hist[:k]).mean()), 5), "loss_last": round(float(torch.stack(hist[-k:]).mean()), 5),
+                       "ms_per_iteration": round(frame_s / a.iters * 1e3, 3)})
     moved = float((model.points.detach() - pts_start).abs().max())
     if world > 1:
         torch.distributed.barrier()
@@ -100,6 +111,10 @@ def run(a):
                                   "views_per_iteration": world}
     return {**extra, "gaussians": N, "image": [a.width, a.height], "cameras": len(ncams), "frames": frames, "iterations": n_it,
             "iterations_per_s": round(n_it / t_total, 1), "ms_per_iteration": round(t_total / n_it * 1e3, 3),
+            # the steady state: median over all iterations of the time between their start marks on the stream (the wall
+            # figure above also carries every frame's one-off costs: optimiser state allocation, first-use allocations)
+            "median_ms_per_iteration": round(float(np.median(per_it)), 3), "p90_ms_per_iteration": round(float(np.percentile(per_it, 90)), 3),
+            "slowest_iterations": [[int(i), round(float(per_it[i]), 2)] for i in np.argsort(per_it)[::-1][:4]],
             "geometry_moved": moved}
 
 
