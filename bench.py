@@ -114,7 +114,7 @@ def build_workload(device, rank):
 SH0 = 0.28209479177387814
 
 
-def build_refinement_workload(device, rank, gs, cams, bg, overlap=True, solo=False):
+def build_refinement_workload(device, rank, gs, cams, bg, overlap=True, solo=False, communicate=True):
     from gaustar_amd import harness
     v, f = scene.icosphere(6, scene.SUBJECT_RADIUS, scene.SUBJECT_CENTER)
     verts, faces = torch.from_numpy(v).float().to(device), torch.from_numpy(f).long().to(device)
@@ -129,7 +129,8 @@ def build_refinement_workload(device, rank, gs, cams, bg, overlap=True, solo=Fal
     groups = [{"params": [model._points], "lr": 0.0},
               {"params": [model._sh_coordinates_dc, model._sh_coordinates_rest], "lr": 0.0},
               {"params": [model._scales, model._quaternions, model.all_densities, model._delta_t, model._delta_r], "lr": 0.0}]
-    opt = gdist.ShardedAdam(groups, ready_order=model.grad_ready_order(), eps=1e-15, overlap=overlap, run_at_world_size_1=solo)
+    opt = gdist.ShardedAdam(groups, ready_order=model.grad_ready_order(), eps=1e-15, overlap=overlap, run_at_world_size_1=solo,
+                            communicate=communicate)
     bg_t = torch.from_numpy(np.ascontiguousarray(bg, dtype=np.float32)).to(device)
     dpix = torch.randn(3, cams[0].H, cams[0].W, device=device, generator=torch.Generator(device=device).manual_seed(1234 + rank))
     return model, ncams, opt, bg_t, dpix
@@ -160,6 +161,8 @@ def one_step(step, rank, world, params, means2D, rasters, dpix):
 
 
 def timed(fn, steps, world, device):
+    import gc
+    gc.collect(); gc.disable()   # (a generation-2 pass of Python's collector stops the host for tens of milliseconds; between timed regions, not inside)
     if world > 1:
         tdist.barrier()
     torch.cuda.synchronize(device)
@@ -167,6 +170,7 @@ def timed(fn, steps, world, device):
     for s in range(steps):
         fn(s)
     torch.cuda.synchronize(device)
+    gc.enable()
     if world > 1:
         tdist.barrier()
     dt = time.perf_counter() - t0
@@ -322,8 +326,17 @@ def main():
     lib = _lib.load()
 
     gs, cams, bg, params, means2D, rasters, dpix = build_workload(device, rank)
-    refine = None
+    refine, same_step_1gpu_ms = None, None
     if world > 1:
+        # the SAME step without any exchange, every rank on its own GPU at once: the single-GPU denominator of this step's
+        # scaling (the N = 1 line of this script times the rasterizer alone, which is what the metric is quoted on)
+        solo_w = build_refinement_workload(device, rank, gs, cams, bg, communicate=False)
+        solo_step = lambda s: refinement_step(s, rank, world, *solo_w)
+        for s in range(5):
+            solo_step(s)
+        n_solo = max(10, min(args.steps, 40))
+        same_step_1gpu_ms = timed(solo_step, n_solo, world, device) / n_solo * 1e3
+        solo_w[2].close(); del solo_w, solo_step
         refine = build_refinement_workload(device, rank, gs, cams, bg)
         step = lambda s: refinement_step(s, rank, world, *refine)
     else:
@@ -452,6 +465,10 @@ def main():
             out["config"]["exchange_payload_MB"] = round(refine[2].payload_bytes() / 1e6, 1)
             out["config"]["optimizer_state_MB_per_rank"] = round(refine[2].state_bytes_per_rank() / 1e6, 1)
             out["config"]["buckets_issued_during_backward"] = refine[2].issued_early
+            # `value` / N x this = speed-up of THIS step over one GPU running it without any exchange (max over ranks, measured
+            # in this very job); the N = 1 line's value is the rasterizer alone and is not the denominator of this step
+            out["same_step_on_one_gpu"] = {"ms_per_step": round(same_step_1gpu_ms, 4),
+                                           "speedup_of_this_step": round(world * same_step_1gpu_ms / ms_per_step, 3)}
         if world == 1 and not args.no_cpu_baseline:
             try:   # the CPU baseline gets every core the process started with
                 for tid in os.listdir("/proc/self/task"):

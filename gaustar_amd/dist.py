@@ -381,7 +381,7 @@ class ShardedAdam:
 
     def __init__(self, param_groups, ready_order: Sequence[torch.Tensor] | None = None, betas=(0.9, 0.999), eps: float = 1e-8,
                  bucket_bytes: int = 32 << 20, average: bool = True, overlap: bool = True, run_at_world_size_1: bool = False,
-                 segment_step=None):
+                 segment_step=None, communicate: bool = True):
         self.param_groups = [dict(g) for g in param_groups]
         for g in self.param_groups:
             g["params"] = list(g["params"])
@@ -392,9 +392,11 @@ class ShardedAdam:
         order = list(ready_order) if ready_order is not None else [p for g in self.param_groups for p in g["params"]]
         if {id(p) for p in order} != set(group_of) or len(order) != len(group_of):
             raise ValueError("ShardedAdam: ready_order must list every parameter of the groups exactly once")
-        self.world = world_size()
-        self.rank = rank()
-        self.solo = bool(run_at_world_size_1)
+        # communicate = False: this process steps ALL parameters on its own, whatever the process group (the single-GPU
+        # reference of a scaling measurement taken inside a multi-rank job)
+        self.world = world_size() if communicate else 1
+        self.rank = rank() if communicate else 0
+        self.solo = bool(run_at_world_size_1) and communicate
         self.average = average
         self._comm = self.world > 1 or self.solo
         self._segment_step = segment_step or _hip_adam_segment
