@@ -519,7 +519,7 @@ int gsr_sh_to_rgb(int P, int D, int M, const float* positions, const float* camp
     g_err.clear();
     if (P <= 0) return 0;
     if (!positions || !campos || !shs || !rgb) return fail_msg("gsr_sh_to_rgb: required pointer is null");
-    if (D < 0 || D > 3 || (D + 1) * (D + 1) > M) return fail_msg("gsr_sh_to_rgb: sh degree must be 0..3 and fit in M coefficients");
+    if (D < 0 || D > 4 || (D + 1) * (D + 1) > M) return fail_msg("gsr_sh_to_rgb: sh degree must be 0..4 and fit in M coefficients");
     hipStream_t st = (hipStream_t)stream;
     {
         Scope sc(ST_PRODUCERS, st);
@@ -536,8 +536,8 @@ int gsr_sh_to_rgb_backward(int P, int D, int M, const float* positions, const fl
     if (P <= 0) return 0;
     if (!positions || !campos || !shs || !dL_drgb || !dL_dsh || !dL_dpos)
         return fail_msg("gsr_sh_to_rgb_backward: required pointer is null");
-    if (D < 0 || D > 3 || (D + 1) * (D + 1) > M)
-        return fail_msg("gsr_sh_to_rgb_backward: sh degree must be 0..3 and fit in M coefficients");
+    if (D < 0 || D > 4 || (D + 1) * (D + 1) > M)
+        return fail_msg("gsr_sh_to_rgb_backward: sh degree must be 0..4 and fit in M coefficients");
     hipStream_t st = (hipStream_t)stream;
     {
         Scope sc(ST_PRODUCERS, st);
@@ -554,7 +554,7 @@ int gsr_sh_to_rgbd(int P, int D, int M, const float* positions, const float* cam
     if (depth_channels != 1 && depth_channels != 3) return fail_msg("gsr_sh_to_rgbd: depth_channels must be 1 or 3");
     if (P <= 0) return 0;
     if (!positions || !campos || !shs || !viewmatrix || !colors6) return fail_msg("gsr_sh_to_rgbd: required pointer is null");
-    if (D < 0 || D > 3 || (D + 1) * (D + 1) > M) return fail_msg("gsr_sh_to_rgbd: sh degree must be 0..3 and fit in M coefficients");
+    if (D < 0 || D > 4 || (D + 1) * (D + 1) > M) return fail_msg("gsr_sh_to_rgbd: sh degree must be 0..4 and fit in M coefficients");
     hipStream_t st = (hipStream_t)stream;
     {
         Scope sc(ST_PRODUCERS, st);
@@ -573,8 +573,8 @@ int gsr_sh_to_rgbd_backward(int P, int D, int M, const float* positions, const f
     if (P <= 0) return 0;
     if (!positions || !campos || !shs || !viewmatrix || !dL_dcolors6 || !dL_dsh || !dL_dpos)
         return fail_msg("gsr_sh_to_rgbd_backward: required pointer is null");
-    if (D < 0 || D > 3 || (D + 1) * (D + 1) > M)
-        return fail_msg("gsr_sh_to_rgbd_backward: sh degree must be 0..3 and fit in M coefficients");
+    if (D < 0 || D > 4 || (D + 1) * (D + 1) > M)
+        return fail_msg("gsr_sh_to_rgbd_backward: sh degree must be 0..4 and fit in M coefficients");
     hipStream_t st = (hipStream_t)stream;
     {
         Scope sc(ST_PRODUCERS, st);

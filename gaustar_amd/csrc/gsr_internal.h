@@ -276,6 +276,12 @@ __device__ constexpr float kSH2[5] = {1.0925484305920792f, -1.0925484305920792f,
 __device__ constexpr float kSH3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
                                       0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
                                       -0.5900435899266435f};
+// degree 4: only the Python-side producer reaches it (gaustar_utils/spherical_harmonics.py:23-33, :162-171); the
+// rasterizer's in-kernel SH stops at degree 3 like the reference's (auxiliary.h:22-39)
+__device__ constexpr float kSH4[9] = {2.5033429417967046f, -1.7701307697799304f, 0.9461746957575601f,
+                                      -0.6690465435572892f, 0.10578554691520431f, -0.6690465435572892f,
+                                      0.47308734787878004f, -1.7701307697799304f, 0.6258357354491761f};
+constexpr int SH_MAX_BASIS = 25;
 
 struct Vec3 { float x, y, z; };
 
@@ -375,8 +381,8 @@ __device__ __forceinline__ void cov2d_from(const Ewa& e, const float c[6], float
     cc = e.a1[0] * v1[0] + e.a1[1] * v1[1] + e.a1[2] * v1[2] + 0.3f;
 }
 
-// Real-SH basis values for direction d (deg <= 3): b[0..(deg+1)^2).
-__device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float b[16])
+// Real-SH basis values for direction d (deg <= 4): b[0..(deg+1)^2); b must hold SH_MAX_BASIS entries when deg can be 4.
+__device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float* b)
 {
     b[0] = kSH0;
     if (deg > 0) {
@@ -390,6 +396,17 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
                 b[11] = kSH3[2] * y * (4.0f * zz - xx - yy); b[12] = kSH3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
                 b[13] = kSH3[4] * x * (4.0f * zz - xx - yy); b[14] = kSH3[5] * z * (xx - yy);
                 b[15] = kSH3[6] * x * (xx - 3.0f * yy);
+                if (deg > 3) {   // spherical_harmonics.py:162-171, term for term
+                    b[16] = kSH4[0] * xy * (xx - yy);
+                    b[17] = kSH4[1] * yz * (3.0f * xx - yy);
+                    b[18] = kSH4[2] * xy * (7.0f * zz - 1.0f);
+                    b[19] = kSH4[3] * yz * (7.0f * zz - 3.0f);
+                    b[20] = kSH4[4] * (zz * (35.0f * zz - 30.0f) + 3.0f);
+                    b[21] = kSH4[5] * xz * (7.0f * zz - 3.0f);
+                    b[22] = kSH4[6] * (xx - yy) * (7.0f * zz - 1.0f);
+                    b[23] = kSH4[7] * xz * (xx - 3.0f * yy);
+                    b[24] = kSH4[8] * (xx * (xx - 3.0f * yy) - yy * (3.0f * xx - yy));
+                }
             }
         }
     }
@@ -405,7 +422,7 @@ __device__ __forceinline__ void sh_colour_backward(int D, int M, Vec3 mean, cons
     const float ox = mean.x - campos[0], oy = mean.y - campos[1], oz = mean.z - campos[2];
     const float inv = 1.0f / sqrtf(ox * ox + oy * oy + oz * oz);
     const float x = ox * inv, y = oy * inv, z = oz * inv;
-    float basis[16];
+    float basis[SH_MAX_BASIS];
     sh_basis(D, x, y, z, basis);
     const int nb = (D + 1) * (D + 1);
     // recompute the clamp decision of the forward (forward.cu:63-70)
@@ -436,6 +453,20 @@ __device__ __forceinline__ void sh_colour_backward(int D, int M, Vec3 mean, cons
                        kSH3[6] * s15 * -3.f * 2.f * xy;
                 ddz += kSH3[1] * s10 * xy + kSH3[2] * s11 * 4.f * 2.f * yz + kSH3[3] * s12 * 3.f * (2.f * zz - xx - yy) +
                        kSH3[4] * s13 * 4.f * 2.f * xz + kSH3[5] * s14 * (xx - yy);
+                if (D > 3) {   // partial derivatives of the nine degree-4 polynomials as the reference writes them (:162-171)
+                    const float s16 = SHD(16), s17 = SHD(17), s18 = SHD(18), s19 = SHD(19), s20 = SHD(20), s21 = SHD(21),
+                                s22 = SHD(22), s23 = SHD(23), s24 = SHD(24);
+                    const float z7m1 = 7.f * zz - 1.f, z7m3 = 7.f * zz - 3.f, z21m3 = 21.f * zz - 3.f;
+                    ddx += kSH4[0] * s16 * y * (3.f * xx - yy) + kSH4[1] * s17 * 6.f * xy * z + kSH4[2] * s18 * y * z7m1 +
+                           kSH4[5] * s21 * z * z7m3 + kSH4[6] * s22 * 2.f * x * z7m1 + kSH4[7] * s23 * 3.f * z * (xx - yy) +
+                           kSH4[8] * s24 * 4.f * x * (xx - 3.f * yy);
+                    ddy += kSH4[0] * s16 * x * (xx - 3.f * yy) + kSH4[1] * s17 * 3.f * z * (xx - yy) + kSH4[2] * s18 * x * z7m1 +
+                           kSH4[3] * s19 * z * z7m3 - kSH4[6] * s22 * 2.f * y * z7m1 - kSH4[7] * s23 * 6.f * xy * z +
+                           kSH4[8] * s24 * 4.f * y * (yy - 3.f * xx);
+                    ddz += kSH4[1] * s17 * y * (3.f * xx - yy) + kSH4[2] * s18 * 14.f * xy * z + kSH4[3] * s19 * y * z21m3 +
+                           kSH4[4] * s20 * z * (140.f * zz - 60.f) + kSH4[5] * s21 * x * z21m3 + kSH4[6] * s22 * 14.f * z * (xx - yy) +
+                           kSH4[7] * s23 * x * (xx - 3.f * yy);
+                }
             }
         }
     }

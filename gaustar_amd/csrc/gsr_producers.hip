@@ -28,7 +28,7 @@ sh_to_rgb_kernel(int P, int D, int M, const float* __restrict__ positions, const
     const Vec3 p = load3(positions, i);
     const float dx = p.x - campos[0], dy = p.y - campos[1], dz = p.z - campos[2];
     const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-    float basis[16];
+    float basis[SH_MAX_BASIS];
     sh_basis(D, dx * inv, dy * inv, dz * inv, basis);
     const int nb = (D + 1) * (D + 1);
     const float* sh = wave_rows + lane * sh_row_stride(M);
@@ -494,9 +494,16 @@ void launch_mesh_gaussians_bwd(int F, int G, const float* verts, const long long
 }
 
 // view == nullptr: rgb [P,3]; otherwise rgb + depth-as-colour [P, 3 + depth_channels] (gsr_sh_to_rgbd)
+// rows of 25 coefficients (degree 4) stage 77 KB per workgroup: above the 64 KB a kernel may take without asking
+static void sh_lds_limit(const void* fn, size_t bytes)
+{
+    if (bytes > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 void launch_sh_to_rgb(int P, int D, int M, const float* positions, const float* campos, const float* shs, const float* view,
                       int depth_channels, float* out, hipStream_t st)
 {
+    sh_lds_limit(reinterpret_cast<const void*>(&sh_to_rgb_kernel), sh_stage_bytes(M, 4));
     sh_to_rgb_kernel<<<(P + 255) / 256, 256, sh_stage_bytes(M, 4), st>>>(P, D, M, positions, campos, shs, view, out,
                                                                           view ? 3 + depth_channels : 3);
 }
@@ -504,6 +511,7 @@ void launch_sh_to_rgb(int P, int D, int M, const float* positions, const float* 
 void launch_sh_to_rgb_bwd(int P, int D, int M, const float* positions, const float* campos, const float* shs, const float* view,
                           int depth_channels, const float* dL_dout, float* dL_dsh, float* dL_dpos, hipStream_t st)
 {
+    sh_lds_limit(reinterpret_cast<const void*>(&sh_to_rgb_bwd_kernel), sh_stage_bytes(M, 4));
     sh_to_rgb_bwd_kernel<<<(P + 255) / 256, 256, sh_stage_bytes(M, 4), st>>>(P, D, M, positions, campos, shs, view, dL_dout,
                                                                               view ? 3 + depth_channels : 3, dL_dsh, dL_dpos);
 }

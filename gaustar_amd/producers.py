@@ -35,8 +35,8 @@ class _PointsRGB(torch.autograd.Function):
             raise RuntimeError("sh_coordinates must have dimensions (num_points, n_coeffs, 3)")
         D = int(sh_levels) - 1
         M = int(sh_coordinates.size(1))
-        if D < 0 or D > 3 or (D + 1) ** 2 > M:
-            raise RuntimeError(f"sh_levels must be 1..4 and sh_levels**2 <= n_coeffs ({M})")
+        if D < 0 or D > 4 or (D + 1) ** 2 > M:   # eval_sh asserts deg <= 4 (spherical_harmonics.py:130)
+            raise RuntimeError(f"sh_levels must be 1..5 and sh_levels**2 <= n_coeffs ({M})")
         dev = positions.device
         pos = positions.detach().to(torch.float32).contiguous()
         cam = camera_center.detach().to(dev, torch.float32).reshape(-1)[:3].contiguous()

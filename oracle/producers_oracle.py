@@ -13,7 +13,11 @@ C3 = [-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.37317633259
       1.445305721320277, -0.5900435899266435]
 
 
-def eval_sh(deg, sh, dirs):                                          # spherical_harmonics.py:117-158 (deg <= 3)
+C4 = [2.5033429417967046, -1.7701307697799304, 0.9461746957575601, -0.6690465435572892, 0.10578554691520431,
+      -0.6690465435572892, 0.47308734787878004, -1.7701307697799304, 0.6258357354491761]
+
+
+def eval_sh(deg, sh, dirs):                                          # spherical_harmonics.py:117-172 (deg <= 4)
     result = C0 * sh[..., 0]
     if deg > 0:
         x, y, z = dirs[..., 0:1], dirs[..., 1:2], dirs[..., 2:3]
@@ -28,6 +32,12 @@ def eval_sh(deg, sh, dirs):                                          # spherical
                           C3[2] * y * (4 * zz - xx - yy) * sh[..., 11] + C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * sh[..., 12] +
                           C3[4] * x * (4 * zz - xx - yy) * sh[..., 13] + C3[5] * z * (xx - yy) * sh[..., 14] +
                           C3[6] * x * (xx - 3 * yy) * sh[..., 15])
+                if deg > 3:                                          # :162-171
+                    result = (result + C4[0] * xy * (xx - yy) * sh[..., 16] + C4[1] * yz * (3 * xx - yy) * sh[..., 17] +
+                              C4[2] * xy * (7 * zz - 1) * sh[..., 18] + C4[3] * yz * (7 * zz - 3) * sh[..., 19] +
+                              C4[4] * (zz * (35 * zz - 30) + 3) * sh[..., 20] + C4[5] * xz * (7 * zz - 3) * sh[..., 21] +
+                              C4[6] * (xx - yy) * (7 * zz - 1) * sh[..., 22] + C4[7] * xz * (xx - 3 * yy) * sh[..., 23] +
+                              C4[8] * (xx * (xx - 3 * yy) - yy * (3 * xx - yy)) * sh[..., 24])
     return result
 
 

@@ -11,7 +11,7 @@ from gaustar_utils.spherical_harmonics import eval_sh   # noqa: E402
 
 out = {}
 g = torch.Generator().manual_seed(0)
-for sh_levels, M in ((1, 1), (2, 4), (3, 16), (4, 16)):
+for sh_levels, M in ((1, 1), (2, 4), (3, 16), (4, 16), (5, 25)):   # (5, 25): degree 4, the highest eval_sh accepts
     P = 700
     pos = (torch.rand(P, 3, generator=g) * 2 - 1).requires_grad_(True)
     cam = torch.tensor([[0.3, 1.4, -3.0]])

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 KAT = os.path.join(ROOT, "tests", "golden", "producers_kat.npz")
 
 
-@pytest.mark.parametrize("lv", [1, 2, 3, 4])
+@pytest.mark.parametrize("lv", [1, 2, 3, 4, 5])   # 5 = degree 4, the highest eval_sh accepts
 def test_points_rgb_matches_reference_vectors(lv, hip_lib):
     from gaustar_amd import producers
     z = np.load(KAT)

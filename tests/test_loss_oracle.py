@@ -54,7 +54,7 @@ def test_points_rgb_oracle_matches_reference_vectors():
     """oracle/producers_oracle.py against vectors made with the reference's own eval_sh (producers_kat.npz)."""
     from oracle import producers_oracle
     z = np.load(os.path.join(ROOT, "tests", "golden", "producers_kat.npz"))
-    for lv in (1, 2, 3, 4):
+    for lv in (1, 2, 3, 4, 5):
         k = f"l{lv}"
         pos = torch.from_numpy(z[f"{k}_pos"]).requires_grad_(True)
         sh = torch.from_numpy(z[f"{k}_sh"]).requires_grad_(True)
