@@ -10,18 +10,54 @@
 #include "gsr_internal.h"
 #include "gsr_sort.h"
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 namespace gsr {
 
-// ---- wave64 inclusive scan via DPP-free shuffles (log-step); T is tiny, this kernel is latency-bound.
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
+// ---- wave64 inclusive scan (sum) on the DPP network: three row shifts of the input, two masked row shifts, two row
+// broadcasts -- seven fused adds.  (As a ladder of six __shfl_up steps it was six dependent ds_bpermute round trips per
+// scan; the kernel is ONE workgroup, so its time is the sum of such chains: tile_scan's "two wave scans + barrier" phase
+// took 2.8 us of the kernel's 11.4, phase stamps of a GSR_SCAN_TRACE build.)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x, int /*lane*/)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t n = __shfl_up(v, d, 64);
-        if (lane >= d) v += n;
-    }
+    const auto dpp = [](uint32_t v, auto ctrl, auto row_mask, auto bank_mask) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, decltype(row_mask)::value,
+                                                     decltype(bank_mask)::value, true);   // lanes without a source add 0
+    };
+    using std::integral_constant;
+    uint32_t v = x + dpp(x, integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{});   // row_shr:1
+    v += dpp(x, integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{});               // row_shr:2
+    v += dpp(x, integral_constant<int, 0x113>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{});               // row_shr:3
+    v += dpp(v, integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xe>{});               // row_shr:4
+    v += dpp(v, integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xc>{});               // row_shr:8
+    v += dpp(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{}, integral_constant<int, 0xf>{});               // row_bcast:15
+    v += dpp(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{}, integral_constant<int, 0xf>{});               // row_bcast:31
     return v;
+}
+// max over the wave, complete in lane 63 (same ladder; counts are unsigned, so a missing source contributes 0)
+__device__ __forceinline__ uint32_t wave_max_to_lane63(uint32_t x)
+{
+    const auto dpp = [](uint32_t v, auto ctrl, auto row_mask, auto bank_mask) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, decltype(row_mask)::value,
+                                                     decltype(bank_mask)::value, true);
+    };
+    using std::integral_constant;
+    uint32_t v = max(x, dpp(x, integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{}));
+    v = max(v, dpp(x, integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{}));
+    v = max(v, dpp(x, integral_constant<int, 0x113>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{}));
+    v = max(v, dpp(v, integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xe>{}));
+    v = max(v, dpp(v, integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xc>{}));
+    v = max(v, dpp(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{}, integral_constant<int, 0xf>{}));
+    v = max(v, dpp(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{}, integral_constant<int, 0xf>{}));
+    return v;
+}
+// Barrier of the scan kernel: LDS traffic only.  __syncthreads() also waits for the global stores in flight (ranges,
+// segment offsets, totals, the pinned host pad) -- a store's full latency, 2 - 3 us, at each of the kernel's barriers, although
+// nothing in the kernel ever reads those back.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // One workgroup scans all T tile counts: ranges[t] = {start, start+count}, cursor[t] = start,
@@ -55,6 +91,13 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
     __shared__ uint32_t hist[NHIST];   // [bucket][copy]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int copy = lane & (NCOPY - 1);
+#ifdef GSR_SCAN_TRACE
+    uint64_t stamp[8]; int ns = 0;
+#define SCAN_STAMP() do { if (tid == 0) stamp[ns++] = wall_clock64(); } while (0)
+#else
+#define SCAN_STAMP() do { } while (0)
+#endif
+    SCAN_STAMP();
     for (int i = tid; i < NHIST; i += 1024) hist[i] = 0;
     // PER > 0: this thread's PER tiles live in registers.  PER == 0 (images above 8 192 tiles): the thread owns
     // ceil(T / 1024) consecutive tiles and re-reads their counters (L2-resident) in each of the three passes.
@@ -93,6 +136,10 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
         if constexpr (IN_REGS) return c[k]; else return count_of(t0 + k);
     };
     uint32_t sum = 0, vmax = 0, segs = 0;
+#ifdef GSR_SCAN_TRACE
+    if constexpr (IN_REGS) { if (c[0] == 0xfffffff0u) hist[0] = 1; }   // (keeps the loads ahead of the stamp; never true)
+#endif
+    SCAN_STAMP();   // counts loaded
 #pragma unroll
     for (int k = 0; k < per; k++) {
         const uint32_t ck = cnt(k);
@@ -102,11 +149,10 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
     }
     const uint32_t incl = wave_incl_scan(sum, lane);
     const uint32_t incl_seg = wave_incl_scan(segs, lane);
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, d, 64));
-    if (lane == 63) { wave_sum[wave] = incl; wave_seg[wave] = incl_seg; }
-    if (lane == 0) wave_max[wave] = vmax;
-    __syncthreads();
+    vmax = wave_max_to_lane63(vmax);
+    if (lane == 63) { wave_sum[wave] = incl; wave_seg[wave] = incl_seg; wave_max[wave] = vmax; }
+    lds_barrier();
+    SCAN_STAMP();   // wave scans + first barrier
     uint32_t woff = 0, total = 0, gmax = 0, woff_seg = 0, total_seg = 0;
 #pragma unroll
     for (int w = 0; w < 16; w++) {
@@ -163,24 +209,19 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
     }
     }
     if (n_empty) atomicAdd(&hist[(NBUCKET - 1) * NCOPY + copy], n_empty);
-    __syncthreads();
+    lds_barrier();
+    SCAN_STAMP();   // ranges / seg_off stored, histogram counted
+    uint32_t nonempty = 0;   // (thread 0)
     if (tid == 0) {
         uint32_t empty = 0;
         for (int i = 0; i < NCOPY; i++) empty += hist[(NBUCKET - 1) * NCOPY + i];
+        nonempty = (uint32_t)T - empty;
         totals[0] = total;
         totals[1] = gmax;
-        totals[2] = (uint32_t)T - empty;
+        totals[2] = nonempty;
         totals[3] = total_seg;
         totals[6] = 0u;           // scatter counts the parts of long lists here
         totals[5] = view_token;   // scatter compares it with totals[4] (set by a preprocess workgroup that ran out of room)
-        // The host's copy goes straight into its pinned, device-mapped landing pad -- no separate device-to-host copy
-        // (a 5 us blit kernel plus its dispatch) -- followed by the call's sequence number with system-scope release:
-        // the host polls that word (gsr_forward_stage1) and starts launching stage 2 while this kernel still builds
-        // `order`; stage 2 is stream-ordered behind this kernel either way.
-        if (host_totals) {
-            *reinterpret_cast<uint4*>(host_totals) = make_uint4(total, gmax, (uint32_t)T - empty, total_seg);
-            __hip_atomic_store(&host_totals[4], host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
         seg_off[T] = total_seg;
     }
     // exclusive prefix over the flattened [bucket][copy] histogram (in place): two entries per thread
@@ -189,7 +230,8 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
     const uint32_t hs = e0 + e1;
     const uint32_t hincl = wave_incl_scan(hs, lane);
     if (lane == 63) wave_hist[wave] = hincl;
-    __syncthreads();   // also orders thread 0's reads of the empty bucket before the overwrite below
+    lds_barrier();   // also orders thread 0's reads of the empty bucket before the overwrite below
+    SCAN_STAMP();   // totals out, histogram prefix (wave level)
     uint32_t hoff = 0;
 #pragma unroll
     for (int w = 0; w < 16; w++) hoff += w < wave ? wave_hist[w] : 0u;
@@ -198,23 +240,45 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
         hist[2 * tid] = excl;
         hist[2 * tid + 1] = excl + e0;
     }
-    __syncthreads();
+    lds_barrier();
+    SCAN_STAMP();   // histogram prefix done
     // Launch positions follow a SNAKE over bands of 256 (one workgroup per CU per band under the observed
     // round-robin dispatch): CU k gets ranks k, 511-k, 512+k, ... so per-CU sums of list lengths even out
     // instead of CU 0 collecting the longest tile of every band.  Pure scheduling heuristic.
     auto snake = [](uint32_t pos) { return (pos & 256u) ? (pos ^ 255u) : pos; };
     uint32_t empty_at = n_empty ? atomicAdd(&hist[(NBUCKET - 1) * NCOPY + copy], n_empty) : 0u;
+    const auto place = [&](uint32_t pos, int t) {
+        const uint32_t sp = snake(pos);
+        if (sp < (uint32_t)T && (pos | 255u) < (uint32_t)T) pos = sp;   // only inside complete bands
+        order[pos] = (uint32_t)t;
+    };
+    // (one LDS atomic per RUN of equal length classes among a thread's eight tiles instead of one per tile was tried: the
+    // grouping code costs more than the atomics it saves, 11.1 -> 13.9 us)
 #pragma unroll
     for (int k = 0; k < per; k++) {
         const int t = t0 + k;
         if (t < T) {
             const uint32_t ck = cnt(k);
-            uint32_t pos = (ck == 0) ? empty_at++ : atomicAdd(&hist[length_bucket(ck) * NCOPY + copy], 1u);
-            const uint32_t sp = snake(pos);
-            if (sp < (uint32_t)T && (pos | 255u) < (uint32_t)T) pos = sp;   // only inside complete bands
-            order[pos] = (uint32_t)t;
+            const uint32_t pos = (ck == 0) ? empty_at++ : atomicAdd(&hist[length_bucket(ck) * NCOPY + copy], 1u);
+            place(pos, t);
         }
     }
+    // The host's copy of the totals goes straight into its pinned, device-mapped landing pad -- no separate device-to-host
+    // copy (a 5 us blit kernel plus its dispatch) -- followed by the call's sequence number with system-scope release; the
+    // host polls that word (gsr_forward_stage1).  LAST thing thread 0 does: the release waits for the stores to the pad to
+    // cross the bus (~1 us), and in the middle of the kernel the other fifteen waves stood at the next barrier for it.  The
+    // host does not need the totals sooner: what it launches with them is stream-ordered behind scatter anyway.
+    if (tid == 0 && host_totals) {
+        *reinterpret_cast<uint4*>(host_totals) = make_uint4(total, gmax, nonempty, total_seg);
+        __hip_atomic_store(&host_totals[4], host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+#ifdef GSR_SCAN_TRACE
+    lds_barrier();
+    SCAN_STAMP();   // order stored
+    if (tid == 0 && (host_seq & 63u) == 0u)
+        printf("scan phases (10 ns ticks): load %llu, scan+barrier %llu, ranges+hist %llu, totals+prefix1 %llu, prefix2 %llu, order %llu\n",
+               stamp[1] - stamp[0], stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[4] - stamp[3], stamp[5] - stamp[4], stamp[6] - stamp[5]);
+#endif
 }
 
 void launch_tile_scan(ImageState im, int T, uint32_t* host_totals, uint32_t host_seq, uint32_t view_token, hipStream_t st)

@@ -359,34 +359,36 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     // per (lane, step) in registers took 90 vector instructions per wave.)
     constexpr bool BF16 = GSR_BWD_BF16 && C == 3;   // 6 + 3 C columns have to fit the tile
     constexpr int BROWS = BF16 ? 6 + 3 * C : 6 + C;
-    static_assert((BROWS + 1) * 64 <= 2 * GRP * RSTRIDE, "B-operand staging must fit the r|w table");
+    constexpr int BS = RSTRIDE;   // row stride of the staging rows: with 64 the sixteen columns a 16-lane group reads sit in the same
+                              // four banks (a 16-way conflict on each of the four reads below); 68 spreads them over all 64
+    static_assert((BROWS + 1) * BS <= 2 * GRP * RSTRIDE, "B-operand staging must fit the r|w table");
     {
         const float xr = (float)(lane & 7) - 3.5f, yr = (float)(lane >> 3) - 3.5f;
-        Rm[0 * 64 + lane] = 1.0f;
-        Rm[1 * 64 + lane] = xr;
-        Rm[2 * 64 + lane] = yr;
-        Rm[3 * 64 + lane] = xr * xr;
-        Rm[4 * 64 + lane] = xr * yr;
-        Rm[5 * 64 + lane] = yr * yr;
+        Rm[0 * BS + lane] = 1.0f;
+        Rm[1 * BS + lane] = xr;
+        Rm[2 * BS + lane] = yr;
+        Rm[3 * BS + lane] = xr * xr;
+        Rm[4 * BS + lane] = xr * yr;
+        Rm[5 * BS + lane] = yr * yr;
         if constexpr (BF16) {
 #pragma unroll
             for (int ch = 0; ch < C; ch++) {
                 const float d1 = bf16_rest(dp[ch]), d2 = bf16_rest(d1);
-                Rm[(6 + 3 * ch) * 64 + lane] = dp[ch];      // (the operand takes the upper halves: hi, mid, lo)
-                Rm[(7 + 3 * ch) * 64 + lane] = d1;
-                Rm[(8 + 3 * ch) * 64 + lane] = d2;
+                Rm[(6 + 3 * ch) * BS + lane] = dp[ch];      // (the operand takes the upper halves: hi, mid, lo)
+                Rm[(7 + 3 * ch) * BS + lane] = d1;
+                Rm[(8 + 3 * ch) * BS + lane] = d2;
             }
         } else {
 #pragma unroll
-            for (int ch = 0; ch < C; ch++) Rm[(6 + ch) * 64 + lane] = dp[ch];
+            for (int ch = 0; ch < C; ch++) Rm[(6 + ch) * BS + lane] = dp[ch];
         }
-        Rm[BROWS * 64 + lane] = 0.f;
+        Rm[BROWS * BS + lane] = 0.f;
     }
     __builtin_amdgcn_wave_barrier();
     float Bf[BF16 ? 1 : 16];
     u32x4 Bp[BF16 ? 2 : 1];
     {
-        const float4* pd = reinterpret_cast<const float4*>(&Rm[(col < BROWS ? col : BROWS) * 64 + 16 * kap]);
+        const float4* pd = reinterpret_cast<const float4*>(&Rm[(col < BROWS ? col : BROWS) * BS + 16 * kap]);
         float bv[16];
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) {
