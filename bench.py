@@ -167,10 +167,12 @@ def timed(fn, steps, world, device):
         tdist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    for s in range(steps):
-        fn(s)
-    torch.cuda.synchronize(device)
-    gc.enable()
+    try:
+        for s in range(steps):
+            fn(s)
+        torch.cuda.synchronize(device)
+    finally:
+        gc.enable()
     if world > 1:
         tdist.barrier()
     dt = time.perf_counter() - t0

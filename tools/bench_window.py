@@ -78,17 +78,21 @@ def run(a):
         # loop whose iterations take 0.85 (measured: tools/window_diag.py; gone with the collector off)
         gc.collect(); gc.disable()
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        for it in range(a.iters):
-            marks[it].record()
-            ci = gdist.shard_views(len(ncams), fi * a.iters + it, rank, world)
-            opt.zero_grad(set_to_none=True)
-            img = render4(model, ncams[ci], bg4)
-            loss = losses.rgb_depth_loss(img, gts[ci][0], gts[ci][1], MAX_DEPTH, 0.2, 1.0, 0.5)
-            loss.backward()
-            if reducer is not None:
-                reducer()                      # the hook in front of sugar_optimizer.py:99-101
-            opt.step()
-            hist.append(loss.detach())
+        try:
+            for it in range(a.iters):
+                marks[it].record()
+                ci = gdist.shard_views(len(ncams), fi * a.iters + it, rank, world)
+                opt.zero_grad(set_to_none=True)
+                img = render4(model, ncams[ci], bg4)
+                loss = losses.rgb_depth_loss(img, gts[ci][0], gts[ci][1], MAX_DEPTH, 0.2, 1.0, 0.5)
+                loss.backward()
+                if reducer is not None:
+                    reducer()                      # the hook in front of sugar_optimizer.py:99-101
+                opt.step()
+                hist.append(loss.detach())
+        except BaseException:
+            gc.enable()
+            raise
         if reducer is not None:
             early, payload = reducer.issued_early, reducer.payload_bytes()
             reducer.close()
