@@ -102,11 +102,27 @@ class ForwardSweep:
                                        rotations=self.rotations)
         return img[0]
 
-    def sweep(self, cameras: Sequence, per_view: Callable, rank: Optional[int] = None, world: Optional[int] = None) -> torch.Tensor:
+    def sweep(self, cameras: Sequence, per_view: Callable, rank: Optional[int] = None, world: Optional[int] = None,
+              views_in_flight: int = 2) -> torch.Tensor:
         """Renders this rank's shard of `cameras`, reduces each view to a row with per_view(index, cam, rgb, depth) ->
-        1-D tensor, and returns the [len(cameras), K] table on every rank."""
+        1-D tensor, and returns the [len(cameras), K] table on every rank.  The views of a sweep are independent (nothing
+        is written but the rows), so `views_in_flight` of them are rendered at a time on as many streams
+        (gaustar_amd.pipelines: the small kernels of one view run under the blend of another); per_view runs on the
+        worker's stream."""
         mine = camera_shard(len(cameras), rank, world)
-        rows = [per_view(i, cameras[i], *self.render_rgb_depth(cameras[i])) for i in mine]
         dev = self.means3D.device
+        if views_in_flight > 1 and len(mine) > 1 and dev.type == "cuda":
+            from . import pipelines
+            for cam in (cameras[i] for i in mine):
+                self._cam(cam)                      # upload the matrices before the workers start (the cache is not locked)
+            slots = [None] * len(mine)
+
+            def work(_t, j):
+                i = mine[j]
+                slots[j] = per_view(i, cameras[i], *self.render_rgb_depth(cameras[i]))
+            pipelines.ViewPipelines(min(int(views_in_flight), len(mine)), dev).run(work, list(range(len(mine))))
+            rows = slots
+        else:
+            rows = [per_view(i, cameras[i], *self.render_rgb_depth(cameras[i])) for i in mine]
         local = torch.stack(rows) if rows else torch.zeros(0, 1, device=dev)
         return gather_rows(local, len(cameras), rank, world)
