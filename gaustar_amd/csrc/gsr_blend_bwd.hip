@@ -137,24 +137,21 @@ __device__ __forceinline__ void lds_wait(SlotRegs<VECS>& r)
     }
 }
 
-// OR over the 64 lanes of a wave, returned as a scalar: the classic DPP ladder (three row shifts of the input, two masked
-// row shifts, two row broadcasts -- seven fused v_or_b32_dpp) and one v_readlane of lane 63, instead of six
-// ds_bpermute round trips.
-__device__ __forceinline__ uint32_t wave_or_u32(uint32_t x)
+// OR over the 64 lanes of a wave of a 64-bit value, through LDS: every lane clears the scratch word (same value, one
+// instruction), ORs its own in (ds_or_b64, lanes serialise inside the one instruction) and reads the result back; LDS
+// operations of one wave execute in order, so no barrier is needed.  -> wave-uniform.
+__device__ __forceinline__ unsigned long long wave_or_u64_lds(uint32_t scratch_addr, uint32_t lo, uint32_t hi)
 {
-    const auto dpp = [](uint32_t v, auto ctrl, auto row_mask, auto bank_mask) {
-        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, decltype(row_mask)::value,
-                                                     decltype(bank_mask)::value, true);
-    };
-    using std::integral_constant;
-    uint32_t v = x | dpp(x, integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{});   // row_shr:1
-    v |= dpp(x, integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{});               // row_shr:2
-    v |= dpp(x, integral_constant<int, 0x113>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{});               // row_shr:3
-    v |= dpp(v, integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xe>{});               // row_shr:4
-    v |= dpp(v, integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xc>{});               // row_shr:8
-    v |= dpp(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{}, integral_constant<int, 0xf>{});               // row_bcast:15
-    v |= dpp(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{}, integral_constant<int, 0xf>{});               // row_bcast:31
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
+    const u32x2_ zero = {0u, 0u}, mine = {lo, hi};
+    u32x2_ all;
+    asm volatile("ds_write_b64 %1, %2\n\t"
+                 "ds_or_b64 %1, %3\n\t"
+                 "ds_read_b64 %0, %1\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(all) : "v"(scratch_addr), "v"(zero), "v"(mine) : "memory");
+    return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)all[1]) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)all[0]);
 }
 
 __device__ __forceinline__ void atomic_add_f32(float* p, float v)
@@ -264,9 +261,7 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     // two trips to memory in a row at the head of every unit)
     uint2 word_next = at32(words_u + (has_next ? 256 : 0), (uint32_t)lane * 8u);
     const int pidx = 16 * (py - ty * TILE) + (px - tx * TILE);
-    float Ts = 1.f, Tf = 0.f, cs[C], cf[C];
-#pragma unroll
-    for (int ch = 0; ch < C; ch++) cs[ch] = cf[ch] = 0.f;
+    float Ts, Tf, cs[C], cf[C];
     const auto load_snap32 = [&](const float4* base_u, float& T_, float (&c_)[C]) {   // uniform base, this pixel's slot
         float v[4 * SV];
 #pragma unroll
@@ -278,22 +273,19 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
 #pragma unroll
         for (int ch = 0; ch < C; ch++) c_[ch] = v[ch + 1];
     };
-    if (has_next) load_snap32(snap + (size_t)(unit + 1u) * 256 * SV, Ts, cs);
-    if (multi) load_snap32(snap + (size_t)unit0 * 256 * SV, Tf, cf);   // final (T, C) kept in the tile's first slot
+    // (both are only USED by a pixel whose last contributor lies beyond this unit -- then the tile has a next unit and more
+    // than one of them -- so they are loaded unconditionally, from a slot that always exists: no defaults to set, no branches)
+    load_snap32(snap + (size_t)(unit + (has_next ? 1u : 0u)) * 256 * SV, Ts, cs);
+    load_snap32(snap + (size_t)unit0 * 256 * SV, Tf, cf);   // final (T, C) kept in the tile's first slot
     // lane l holds list position s0 + 63 - l (queue order == back-to-front order)
     const int k = s0 + 63 - lane;
-    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
-    RecTail<C> rc;
-#pragma unroll
-    for (int ch = 2; ch < C; ch++) rc.c[ch - 2] = 0.f;
-    uint32_t gid = 0;
-    if (k < n) {
-        const uint32_t kl = (uint32_t)(63 - lane);   // (uniform base list0 + s0, lane offset)
-        ra = at32(rec_a + list0 + s0, kl * 16u);
-        rb = at32(rec_b + list0 + s0, kl * 16u);
-        rc = at32(rec_c + list0 + s0, kl * (uint32_t)sizeof(RecTail<C>));
-        gid = at32(point_list + list0 + s0, kl * 4u);
-    }
+    // (a lane whose position lies past the end of the list reads the list's last record instead of carrying zeros: no
+    // candidate bit can name such a position, so the lane is never kept, and nothing has to be initialised or branched over)
+    const uint32_t kl = (uint32_t)(min(k, n - 1) - s0);   // (uniform base list0 + s0, lane offset)
+    const float4 ra = at32(rec_a + list0 + s0, kl * 16u);
+    const float4 rb = at32(rec_b + list0 + s0, kl * 16u);
+    const RecTail<C> rc = at32(rec_c + list0 + s0, kl * (uint32_t)sizeof(RecTail<C>));
+    const uint32_t gid = at32(point_list + list0 + s0, kl * 4u);
     if (!has_next) word_next = make_uint2(0u, 0u);
     float bg_dot_dpixel = 0.f;
 #pragma unroll
@@ -337,7 +329,9 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
         word.x &= lim >= 32 ? 0xffffffffu : lim > 0 ? (1u << lim) - 1u : 0u;
         word.y &= lim >= 64 ? 0xffffffffu : lim > 32 ? (1u << (lim - 32)) - 1u : 0u;
     }
-    const unsigned long long kany = ((unsigned long long)wave_or_u32(word.y) << 32) | wave_or_u32(word.x);
+    // (one same-address LDS atomic for the whole wave instead of two seven-step DPP ladders: three LDS instructions and
+    // five vector ones where there were eighteen; the r|w table is not in use yet and lends its first eight bytes)
+    const unsigned long long kany = wave_or_u64_lds(lds_byte_address(Rm), word.x, word.y);
 #ifdef GSR_TRACE_DETAIL
     const uint64_t t_head = wall_clock64();
     if (trace && lane == 0 && kany == 0ull) {
@@ -415,7 +409,9 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     // resident, and a typical batch keeps ~22): a batch that keeps more is worked off in chunks, back-to-front order intact.
     for (int q0 = 0; q0 < cnt_all; q0 += QCAP) {
     const int cnt = min(cnt_all - q0, QCAP);
-    const int slot = __popcll(m & ((1ull << lane) - 1ull)) - q0;
+    // (v_mbcnt_lo / v_mbcnt_hi: set bits of m below this lane in two instructions; `m & ((1ull << lane) - 1)` is a 64-bit
+    // shift, a 64-bit subtract, two ands and two bit counts)
+    const int slot = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) - q0;
     if (keep && slot >= 0 && slot < QCAP) {
         float4* qs = reinterpret_cast<float4*>(&qf[slot * SF]);
         float col[C];

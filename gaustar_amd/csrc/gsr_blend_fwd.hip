@@ -265,7 +265,11 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             const uint32_t slot = (uint32_t)(h * 32 + j);
             cur &= cur - 1u;
             const float4 A = ga[slot], B = gb[slot];
-            const RecTail<C> K = gc[slot];
+            // (the colour tail's index goes through an opaque copy: from `slot` itself the compiler derives slot * 4 as
+            // slot * 16 - slot * 12 with a 64-bit multiply-add, a quarter-rate instruction in every trip)
+            uint32_t slot_c = slot;
+            asm("" : "+v"(slot_c));
+            const RecTail<C> K = gc[slot_c];
             float col[C];
             col[0] = B.z; col[1] = B.w;
 #pragma unroll

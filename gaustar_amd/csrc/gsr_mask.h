@@ -104,9 +104,14 @@ __device__ __forceinline__ void unit_masks(float4 a, float4 b, int tile_x0, int 
         const float half = __builtin_fmaf(sD, inva, eps);
         const float mid = __builtin_fmaf(-boa, Y, cxl);
         const float lo_f = fminf(fmaxf(mid - half, 0.0f), 16.0f), hi_f = fminf(fmaxf(mid + half, -1.0f), 15.0f);
-        const int li = (int)ceilf(lo_f), hi_i = (int)floorf(hi_f);
-        const int wd = max(hi_i - li + 1, 0);
-        uint32_t rm = ((1u << wd) - 1u) << li;                    // v_bfm_b32
+        // floor + convert in one instruction each (ceil(x) = -floor(-x)), and the row mask in one v_bfm_b32: the compiler
+        // spells `((1 << wd) - 1) << li` as shift, not, shift and floor / ceil / two conversions as four (-3 per row)
+        int nli, hi_i;
+        asm("v_cvt_flr_i32_f32_e64 %0, -%1" : "=v"(nli) : "v"(lo_f));   // = -ceil(lo_f)
+        asm("v_cvt_flr_i32_f32_e32 %0, %1" : "=v"(hi_i) : "v"(hi_f));
+        const int wd = max(hi_i + nli + 1, 0);                            // hi - li + 1 in [-16, 16]
+        uint32_t rm;
+        asm("v_bfm_b32 %0, %1, %2" : "=v"(rm) : "v"(wd), "v"(-nli));     // ((1 << wd) - 1) << li
         rm = (visible && !tame) ? 0xffffu : rm;
         if (r & 1) pk[r >> 1] |= rm << 16; else pk[r >> 1] = rm;
     }
