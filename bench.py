@@ -362,7 +362,6 @@ def main():
         def pipe_step(t, s):
             ps = leaves[t]
             one_step(s, 0, 1, {k: v for k, v in ps.items() if k != "means2D"}, ps["means2D"], rasters, dpix)
-        pipes.run(pipe_step, list(range(max(args.warmup, 2 * V))))
         dt_single = timed(step, args.steps, world, device)
         single = {"value": round(args.steps / dt_single, 2), "ms_per_step": round(dt_single / args.steps * 1e3, 4),
                   "what": "the same K steps one view at a time on one stream (how rounds 1 and 2 quoted the metric)"}
@@ -370,13 +369,18 @@ def main():
         clock = {}
         gc.collect(); gc.disable()
         try:
+            pipes.run(pipe_step, list(range(max(args.warmup, 2 * V))))   # untimed: every pipeline warms its stream and allocator
             lib.gsr_debug_host_wait(None, None, 1)
             pipes.run(pipe_step, list(range(args.steps)), before=lambda: clock.__setitem__("t0", time.perf_counter()),
                       after=lambda: clock.__setitem__("t1", time.perf_counter()))
             lib.gsr_debug_host_wait(ctypes.byref(wait_ns), ctypes.byref(waits), 0)
+            dt = clock["t1"] - clock["t0"]
+        except Exception as ex:   # a box on which the threaded run fails still reports the one-at-a-time figure, and says so
+            print(f"bench.py: {V} pipelines failed ({ex!r}); reporting one view at a time", file=sys.stderr)
+            V, dt = 1, dt_single
+            wait_ns.value, waits.value = 0, 0
         finally:
             gc.enable()
-        dt = clock["t1"] - clock["t0"]
     else:
         lib.gsr_debug_host_wait(None, None, 1)
         dt = timed(step, args.steps, world, device)
