@@ -20,3 +20,12 @@ for rnd in range(3):
     torch.cuda.synchronize(); out.append((time.perf_counter() - t0) / 160 * 1e3)
 ms = sorted(out)[1]
 print(json.dumps({"forward_only_ms_per_view": round(ms, 4), "views_per_s": round(1e3 / ms, 1)}))
+# the same with two views in flight (gaustar_amd.pipelines: what ForwardSweep.sweep does by default)
+from gaustar_amd import pipelines
+pipes = pipelines.ViewPipelines(2, dev)
+pipes.run(lambda t, s: step(s), list(range(20)))
+clock = {}
+pipes.run(lambda t, s: step(s), list(range(480)), before=lambda: clock.__setitem__("a", time.perf_counter()),
+          after=lambda: clock.__setitem__("b", time.perf_counter()))
+ms2 = (clock["b"] - clock["a"]) / 480 * 1e3
+print(json.dumps({"forward_only_two_in_flight_ms_per_view": round(ms2, 4), "views_per_s": round(1e3 / ms2, 1)}))
