@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_longlong, c_si
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSR_LIB_PATH", os.path.join(_HERE, "libgsr_hip.so"))   # override: experiment variants
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 ALLOC_FN = ctypes.CFUNCTYPE(c_void_p, c_void_p, c_size_t)
 
 # name -> (restype, argtypes); mirrors include/gsr.h one to one (tests check both directions).
@@ -59,6 +59,10 @@ SIGNATURES = {
     "gsr_sh_to_rgbd": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "gsr_sh_to_rgbd_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                         c_void_p, c_void_p]),
+    "gsr_sh_colors_split": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                    c_void_p, c_void_p]),
+    "gsr_sh_colors_split_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "gsr_mesh_gaussians": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                    c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsr_mesh_gaussians_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -73,6 +77,8 @@ SIGNATURES = {
                              c_float, c_float, c_void_p, c_void_p, c_void_p, c_longlong, c_longlong, c_void_p]),
     "gsr_adam_step": (c_int, [c_longlong, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_double, c_int,
                               c_void_p]),
+    "gsr_adam_step_multi": (c_int, [c_int, POINTER(c_longlong), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                    POINTER(c_void_p), POINTER(c_double), c_double, c_double, c_double, c_int, c_void_p]),
     "gsr_debug_set_trace": (c_int, [c_void_p]),
     "gsr_num_stages": (c_int, []),
     "gsr_stage_name": (c_char_p, [c_int]),

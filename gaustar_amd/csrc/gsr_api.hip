@@ -88,7 +88,7 @@ int fail_msg(const char* msg)
 
 extern "C" {
 
-int gsr_abi_version(void) { return 10; }
+int gsr_abi_version(void) { return 11; }
 
 const char* gsr_last_error(void) { return g_err.c_str(); }
 
@@ -523,7 +523,7 @@ int gsr_sh_to_rgb(int P, int D, int M, const float* positions, const float* camp
     hipStream_t st = (hipStream_t)stream;
     {
         Scope sc(ST_PRODUCERS, st);
-        launch_sh_to_rgb(P, D, M, positions, campos, shs, nullptr, 0, rgb, st);
+        launch_sh_to_rgb(P, D, M, positions, campos, shs, nullptr, nullptr, 0, rgb, nullptr, nullptr, st);
     }
     GSR_CHECK_LAUNCH("sh_to_rgb_kernel");
     return 0;
@@ -541,7 +541,7 @@ int gsr_sh_to_rgb_backward(int P, int D, int M, const float* positions, const fl
     hipStream_t st = (hipStream_t)stream;
     {
         Scope sc(ST_PRODUCERS, st);
-        launch_sh_to_rgb_bwd(P, D, M, positions, campos, shs, nullptr, 0, dL_drgb, dL_dsh, dL_dpos, st);
+        launch_sh_to_rgb_bwd(P, D, M, positions, campos, shs, nullptr, nullptr, 0, dL_drgb, dL_dsh, nullptr, dL_dpos, 0, nullptr, nullptr, nullptr, st);
     }
     GSR_CHECK_LAUNCH("sh_to_rgb_bwd_kernel");
     return 0;
@@ -558,7 +558,7 @@ int gsr_sh_to_rgbd(int P, int D, int M, const float* positions, const float* cam
     hipStream_t st = (hipStream_t)stream;
     {
         Scope sc(ST_PRODUCERS, st);
-        launch_sh_to_rgb(P, D, M, positions, campos, shs, viewmatrix, depth_channels, colors6, st);
+        launch_sh_to_rgb(P, D, M, positions, campos, shs, nullptr, viewmatrix, depth_channels, colors6, nullptr, nullptr, st);
     }
     GSR_CHECK_LAUNCH("sh_to_rgb_kernel");
     return 0;
@@ -578,9 +578,98 @@ int gsr_sh_to_rgbd_backward(int P, int D, int M, const float* positions, const f
     hipStream_t st = (hipStream_t)stream;
     {
         Scope sc(ST_PRODUCERS, st);
-        launch_sh_to_rgb_bwd(P, D, M, positions, campos, shs, viewmatrix, depth_channels, dL_dcolors6, dL_dsh, dL_dpos, st);
+        launch_sh_to_rgb_bwd(P, D, M, positions, campos, shs, nullptr, viewmatrix, depth_channels, dL_dcolors6, dL_dsh, nullptr, dL_dpos, 0, nullptr, nullptr, nullptr, st);
     }
     GSR_CHECK_LAUNCH("sh_to_rgb_bwd_kernel");
+    return 0;
+}
+
+int gsr_sh_colors_split(int P, int D, int M, const float* positions, const float* campos, const float* sh_dc,
+                        const float* sh_rest, const float* viewmatrix, int depth_channels, const float* densities,
+                        float* colors, float* opacity, gsr_stream_t stream)
+{
+    g_err.clear();
+    if (viewmatrix ? (depth_channels != 1 && depth_channels != 3) : depth_channels != 0)
+        return fail_msg("gsr_sh_colors_split: depth_channels must be 1 or 3 with a view matrix, 0 without");
+    if (P <= 0) return 0;
+    if (!positions || !campos || !sh_dc || !colors || (M > 1 && !sh_rest)) return fail_msg("gsr_sh_colors_split: required pointer is null");
+    if ((densities == nullptr) != (opacity == nullptr)) return fail_msg("gsr_sh_colors_split: densities and opacity go together");
+    if (D < 0 || D > 4 || (D + 1) * (D + 1) > M) return fail_msg("gsr_sh_colors_split: sh degree must be 0..4 and fit in M coefficients");
+    hipStream_t st = (hipStream_t)stream;
+    {
+        Scope sc(ST_PRODUCERS, st);
+        // (M == 1: the one-array layout IS the dc array)
+        launch_sh_to_rgb(P, D, M, positions, campos, sh_dc, M > 1 ? sh_rest : nullptr, viewmatrix, depth_channels, colors, densities,
+                         opacity, st);
+    }
+    GSR_CHECK_LAUNCH("sh_to_rgb_kernel");
+    return 0;
+}
+
+int gsr_sh_colors_split_backward(int P, int D, int M, const float* positions, const float* campos, const float* sh_dc,
+                                 const float* sh_rest, const float* viewmatrix, int depth_channels, const float* dL_dcolors,
+                                 const float* opacity, const float* dL_dopacity, float* dL_dsh_dc, float* dL_dsh_rest,
+                                 float* dL_dpos, int accumulate_pos, float* dL_ddensities, gsr_stream_t stream)
+{
+    g_err.clear();
+    if (viewmatrix ? (depth_channels != 1 && depth_channels != 3) : depth_channels != 0)
+        return fail_msg("gsr_sh_colors_split_backward: depth_channels must be 1 or 3 with a view matrix, 0 without");
+    if (P <= 0) return 0;
+    if (!positions || !campos || !sh_dc || !dL_dcolors || !dL_dsh_dc || !dL_dpos || (M > 1 && (!sh_rest || !dL_dsh_rest)))
+        return fail_msg("gsr_sh_colors_split_backward: required pointer is null");
+    if ((opacity == nullptr) != (dL_dopacity == nullptr) || (opacity == nullptr) != (dL_ddensities == nullptr))
+        return fail_msg("gsr_sh_colors_split_backward: opacity, dL_dopacity and dL_ddensities go together");
+    if (D < 0 || D > 4 || (D + 1) * (D + 1) > M)
+        return fail_msg("gsr_sh_colors_split_backward: sh degree must be 0..4 and fit in M coefficients");
+    hipStream_t st = (hipStream_t)stream;
+    {
+        Scope sc(ST_PRODUCERS, st);
+        launch_sh_to_rgb_bwd(P, D, M, positions, campos, sh_dc, M > 1 ? sh_rest : nullptr, viewmatrix, depth_channels, dL_dcolors,
+                             dL_dsh_dc, M > 1 ? dL_dsh_rest : nullptr, dL_dpos, accumulate_pos ? 1 : 0, opacity, dL_dopacity,
+                             dL_ddensities, st);
+    }
+    GSR_CHECK_LAUNCH("sh_to_rgb_bwd_kernel");
+    return 0;
+}
+
+int gsr_adam_step_multi(int count, const long long* numel, float* const* params, const float* const* grads,
+                        float* const* exp_avgs, float* const* exp_avg_sqs, const double* lrs, double beta1, double beta2,
+                        double eps, int step, gsr_stream_t stream)
+{
+    g_err.clear();
+    if (count <= 0) return 0;
+    if (!numel || !params || !grads || !exp_avgs || !exp_avg_sqs || !lrs) return fail_msg("gsr_adam_step_multi: required pointer is null");
+    if (step < 1) return fail_msg("gsr_adam_step_multi: step counts from 1");
+    for (int i = 0; i < count; i++) {
+        if (numel[i] <= 0) continue;
+        if (!params[i] || !grads[i] || !exp_avgs[i] || !exp_avg_sqs[i]) return fail_msg("gsr_adam_step_multi: a tensor pointer is null");
+        if (((uintptr_t)params[i] | (uintptr_t)grads[i] | (uintptr_t)exp_avgs[i] | (uintptr_t)exp_avg_sqs[i]) & 15u)
+            return fail_msg("gsr_adam_step_multi: arrays must be 16-byte aligned");
+    }
+    const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
+    hipStream_t st = (hipStream_t)stream;
+    {
+        Scope sc(ST_OPTIM, st);
+        AdamBatch b;
+        b.count = 0; b.blocks = 0;
+        const auto flush = [&]() {
+            if (b.count) launch_adam_multi(b, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)std::sqrt(bc2), st);
+            b.count = 0; b.blocks = 0;
+        };
+        for (int i = 0; i < count; i++) {
+            if (numel[i] <= 0) continue;
+            // one 16-byte element per thread, 256 threads per workgroup (as gsr_adam_step); a launch takes up to 16 tensors
+            const long long want = ((numel[i] >> 2) + 255) / 256;
+            const unsigned nb = (unsigned)(want < 1 ? 1 : (want > 256 * 1024 ? 256 * 1024 : want));
+            if (b.count == ADAM_BATCH || (unsigned long long)b.blocks + nb > 0x7fffffffull) flush();
+            AdamTensor& t = b.t[b.count++];
+            t.param = params[i]; t.grad = grads[i]; t.exp_avg = exp_avgs[i]; t.exp_avg_sq = exp_avg_sqs[i];
+            t.n = numel[i]; t.step_size = (float)(lrs[i] / bc1); t.block0 = b.blocks;
+            b.blocks += nb;
+        }
+        flush();
+    }
+    GSR_CHECK_LAUNCH("adam_multi_kernel");
     return 0;
 }
 

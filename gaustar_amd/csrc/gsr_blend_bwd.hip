@@ -24,7 +24,7 @@
 //    coordinates relative to the block centre).  That is a contraction over the 64 pixels,
 //        [instances x pixels] . [pixels x 9],
 //    and it runs on the matrix pipe: w and r are parked in LDS one row per instance, read back transposed, and
-//    reduced by matrix instructions.  This is the one place on the path that IS a contraction.  Four and six channels use
+//    reduced by matrix instructions.  This is the one place on the path that IS a contraction.  Six channels use
 //    v_mfma_f32_16x16x4_f32 (exact f32 multiply-add, 16 issues cover 64 pixels): it occupies the SIMD's vector
 //    multipliers for its 32 cycles (no overlap with vector work: tools/micro/mfma_valu_overlap.hip) -- what it saves is
 //    instructions, 16 per eight instances instead of a 26-instruction cross-lane reduction PER instance.  Three channels
@@ -56,6 +56,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define GSR_BWD_BF16 1
 #endif
 #ifndef GSR_BWD_DOT2
+#ifndef GSR_BWD_BF16_TILES2
+#define GSR_BWD_BF16_TILES2 1   // four channels: the same contraction with a SECOND B tile for channel 3 (0: f32 MFMA)
+#endif
 #define GSR_BWD_DOT2 1   // residuals of the bf16 split by v_dot2_f32_bf16 (0: v_and + v_sub)
 #endif
 // Three channels: the contraction runs on the bf16 matrix pipe WITHOUT giving up f32 accuracy.  An f32 is exactly
@@ -63,8 +66,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // at most eight bits left), the monomials are exact in bf16, dL_dpix takes three columns per channel (6 + 3 C = 15 <= 16).
 // Six v_mfma_f32_16x16x32_bf16 (K = 32 pixels x {hi, mid, lo} of the A operand, products exact, f32 accumulation) replace
 // sixteen v_mfma_f32_16x16x4_f32: ~100 instead of 512 cycles of the SIMD per eight instances, paid for with 5.5 vector
-// instructions per table value for the splits (tools/micro/mfma_bf16_valu_overlap.hip).  Four and six
-// channels would need a second column tile and keep the f32 instruction.
+// instructions per table value for the splits (tools/micro/mfma_bf16_valu_overlap.hip).  Four channels
+// take a second column tile for channel 3 (six more matrix issues on the same split A operand, 0.140 -> 0.134 ms); six
+// channels gain nothing from it and keep the f32 instruction.
 __device__ __forceinline__ uint32_t bf16_pair(float lo_elem, float hi_elem)   // upper halves of two floats, element order (lo, hi)
 {
     return __builtin_amdgcn_perm(__float_as_uint(hi_elem), __float_as_uint(lo_elem), 0x07060302u);
@@ -229,7 +233,6 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     const float bx0 = (float)sx, by0 = (float)sy;
     const int s1 = min(s0 + BSEG, n);
     const bool has_next = s1 < n;                       // (uniform) the tile has a unit behind this one
-    const bool multi = n > BSEG;                        // (uniform) the tile's first snapshot slot holds the final (T, C)
 
     // (32-bit element indices on uniform base pointers: the loads take an SGPR base + a VGPR offset instead of 64-bit
     // vector address arithmetic; gsr_forward_stage1 caps the image at 8k x 8k, so channel * H * W + pixel fits)
@@ -351,8 +354,13 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     // pixels of ITS column with four ds_read_b128: rows 0..5 the monomials of the lane's own pixel (exact small
     // half-integers), row 6 + ch = dL_dpix channel ch, one all-zero row for the unused columns.  (Forming the monomials
     // per (lane, step) in registers took 90 vector instructions per wave.)
-    constexpr bool BF16 = GSR_BWD_BF16 && C == 3;   // 6 + 3 C columns have to fit the tile
-    constexpr int BROWS = BF16 ? 6 + 3 * C : 6 + C;
+    // bf16 path: tile 1 = the six monomials + three split columns for each of the first three channels (15 of 16 columns);
+    // channels 3 .. C-1 take a second B tile (their split columns 0 .. 3 (C - 3) - 1) fed with the SAME split A operand:
+    // six more matrix issues per eight instances, no further splitting.
+    // (measured, config C: four channels 0.140 -> 0.134 ms; six channels gain nothing -- 0.158 either way -- and stay on f32)
+    constexpr bool BF16 = GSR_BWD_BF16 && (C == 3 || (GSR_BWD_BF16_TILES2 && C == 4));
+    constexpr int C1 = BF16 ? (C < 3 ? C : 3) : C, C2 = BF16 ? C - C1 : 0;
+    constexpr int BROWS = BF16 ? 6 + 3 * C1 : 6 + C;
     constexpr int BS = RSTRIDE;   // row stride of the staging rows: with 64 the sixteen columns a 16-lane group reads sit in the same
                               // four banks (a 16-way conflict on each of the four reads below); 68 spreads them over all 64
     static_assert((BROWS + 1) * BS <= 2 * GRP * RSTRIDE, "B-operand staging must fit the r|w table");
@@ -366,7 +374,7 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
         Rm[5 * BS + lane] = yr * yr;
         if constexpr (BF16) {
 #pragma unroll
-            for (int ch = 0; ch < C; ch++) {
+            for (int ch = 0; ch < C1; ch++) {
                 const float d1 = bf16_rest(dp[ch]), d2 = bf16_rest(d1);
                 Rm[(6 + 3 * ch) * BS + lane] = dp[ch];      // (the operand takes the upper halves: hi, mid, lo)
                 Rm[(7 + 3 * ch) * BS + lane] = d1;
@@ -381,6 +389,7 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     __builtin_amdgcn_wave_barrier();
     float Bf[BF16 ? 1 : 16];
     u32x4 Bp[BF16 ? 2 : 1];
+    u32x4 Bp2[C2 > 0 ? 2 : 1];
     {
         const float4* pd = reinterpret_cast<const float4*>(&Rm[(col < BROWS ? col : BROWS) * BS + 16 * kap]);
         float bv[16];
@@ -400,6 +409,29 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
         }
     }
     __builtin_amdgcn_wave_barrier();
+    if constexpr (C2 > 0) {   // second tile: the same staging once more, rows 0 .. 3 C2 - 1 = (hi, mid, lo) of channels 3 ..
+#pragma unroll
+        for (int ch = 0; ch < C2; ch++) {
+            const float d0 = dp[C1 + ch], d1 = bf16_rest(d0), d2 = bf16_rest(d1);
+            Rm[(3 * ch) * BS + lane] = d0;
+            Rm[(3 * ch + 1) * BS + lane] = d1;
+            Rm[(3 * ch + 2) * BS + lane] = d2;
+        }
+        Rm[3 * C2 * BS + lane] = 0.f;
+        __builtin_amdgcn_wave_barrier();
+        const float4* pd = reinterpret_cast<const float4*>(&Rm[(col < 3 * C2 ? col : 3 * C2) * BS + 16 * kap]);
+        float bv[16];
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++) {
+            const float4 v = pd[qd];
+            bv[4 * qd] = v.x; bv[4 * qd + 1] = v.y; bv[4 * qd + 2] = v.z; bv[4 * qd + 3] = v.w;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) Bp2[h][q] = bf16_pair(bv[8 * h + 2 * q], bv[8 * h + 2 * q + 1]);
+        __builtin_amdgcn_wave_barrier();
+    }
 
     {
     const bool keep = ((kany >> (63 - lane)) & 1ull) != 0ull;
@@ -436,8 +468,11 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     static_assert(GRP == 8, "the write-back below assumes rows 0-7 = r, 8-15 = w");
     const int wb_row0 = 4 * (kap & 1);
     // (bf16 path: the colour moment of channel ch is the sum of columns 6 + 3 ch .. + 2, gathered into the first of them)
-    const bool wb_take = kap < 2 ? col < 6 : BF16 ? (col >= 6 && col < 6 + 3 * C && (col % 3) == 0) : (col >= 6 && col < NM);
+    const bool wb_take = kap < 2 ? col < 6 : BF16 ? (col >= 6 && col < 6 + 3 * C1 && (col % 3) == 0) : (col >= 6 && col < NM);
     float* const wb_ptr = &qf[wb_row0 * SF + MOM0 + (BF16 && col >= 6 ? 6 + (col - 6) / 3 : col)];
+    // (second tile: its w rows hold channel 3 + col / 3 in columns 0, 3, ..)
+    const bool wb_take2 = C2 > 0 && kap >= 2 && col < 3 * C2 && (col % 3) == 0;
+    float* const wb_ptr2 = &qf[wb_row0 * SF + MOM0 + 6 + C1 + (col < 3 * C2 ? col / 3 : 0)];
     for (int g0i = 0; g0i < cnt; g0i += GRP) {
         // ---- vector ALU: w and r of GRP instances for this lane's pixel, parked row-wise in LDS.  The slot of the
         // group's first instance is requested here, every further one while its predecessor is being evaluated.
@@ -503,6 +538,7 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
         // (even / odd steps) halve the dependent-accumulator chain.  bf16 instruction: K = 32 = the lanes' first (h = 0)
         // resp. second (h = 1) eight pixels; per half one issue each for the lo, mid and hi parts, smallest first.
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};   // second tile (C2 > 0)
         float ra[16];
         {
             const float4* pr = reinterpret_cast<const float4*>(&Rm[(col < 2 * GRP ? col : 0) * RSTRIDE + 16 * kap]);
@@ -538,25 +574,41 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_lo), b, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_mid), b, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_hi), b, acc, 0, 0, 0);
+                if constexpr (C2 > 0) {
+                    const bf16x8 b2 = __builtin_bit_cast(bf16x8, Bp2[h]);
+                    f32x4& bcc = acc2;   // (one chain for both halves: four registers less, and the matrix pipe is far from busy)
+                    bcc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_lo), b2, bcc, 0, 0, 0);
+                    bcc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_mid), b2, bcc, 0, 0, 0);
+                    bcc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_hi), b2, bcc, 0, 0, 0);
+                }
             }
             // colour rows: the three split columns of a channel sit in neighbouring lanes of the 16-lane row
             // (lane c: hi column, c + 1: mid, c + 2: lo.  s = v + v[c + 1] holds mid + lo in lane c + 1; v + s[c + 1] is
             // hi + (mid + lo) -- two fused DPP adds per register, smallest parts first.  One block, so that the two
             // wait states a DPP read needs behind the instruction that wrote its source are there by construction: the
             // leading s_nop covers the compiler's adds, every t reads an s written four instructions earlier)
-            float v0 = acc0[0] + acc1[0], v1 = acc0[1] + acc1[1], v2 = acc0[2] + acc1[2], v3 = acc0[3] + acc1[3];
-            float s0_, s1_, s2_, s3_, t0_, t1_, t2_, t3_;
-            asm("s_nop 1\n\t"
-                "v_add_f32_dpp %0, %8, %8 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                "v_add_f32_dpp %1, %9, %9 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                "v_add_f32_dpp %2, %10, %10 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                "v_add_f32_dpp %3, %11, %11 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                "v_add_f32_dpp %4, %0, %8 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                "v_add_f32_dpp %5, %1, %9 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                "v_add_f32_dpp %6, %2, %10 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                "v_add_f32_dpp %7, %3, %11 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-                : "=&v"(s0_), "=&v"(s1_), "=&v"(s2_), "=&v"(s3_), "=&v"(t0_), "=&v"(t1_), "=&v"(t2_), "=&v"(t3_)
-                : "v"(v0), "v"(v1), "v"(v2), "v"(v3));
+            const auto split_sum = [](float v0, float v1, float v2, float v3, float& t0_, float& t1_, float& t2_, float& t3_) {
+                float s0_, s1_, s2_, s3_;
+                asm("s_nop 1\n\t"
+                    "v_add_f32_dpp %0, %8, %8 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %1, %9, %9 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %2, %10, %10 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %3, %11, %11 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %4, %0, %8 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %5, %1, %9 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %6, %2, %10 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %7, %3, %11 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                    : "=&v"(s0_), "=&v"(s1_), "=&v"(s2_), "=&v"(s3_), "=&v"(t0_), "=&v"(t1_), "=&v"(t2_), "=&v"(t3_)
+                    : "v"(v0), "v"(v1), "v"(v2), "v"(v3));
+            };
+            const float v0 = acc0[0] + acc1[0], v1 = acc0[1] + acc1[1], v2 = acc0[2] + acc1[2], v3 = acc0[3] + acc1[3];
+            float t0_, t1_, t2_, t3_;
+            split_sum(v0, v1, v2, v3, t0_, t1_, t2_, t3_);
+            if constexpr (C2 > 0) {
+                float u0, u1, u2, u3;
+                split_sum(acc2[0], acc2[1], acc2[2], acc2[3], u0, u1, u2, u3);
+                acc2[0] = u0; acc2[1] = u1; acc2[2] = u2; acc2[3] = u3;
+            }
             const bool spatial = kap < 2;
             acc0[0] = spatial ? v0 : t0_; acc0[1] = spatial ? v1 : t1_; acc0[2] = spatial ? v2 : t2_; acc0[3] = spatial ? v3 : t3_;
         } else {
@@ -577,6 +629,15 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
 #pragma unroll
             for (int i = 0; i < 4; i++)
                 if (i < left) dst[i * SF] = acc0[i];
+        }
+        if constexpr (C2 > 0) {
+            if (wb_take2) {
+                float* const dst = wb_ptr2 + g0i * SF;
+                const int left = cnt - g0i - wb_row0;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (i < left) dst[i * SF] = acc2[i];
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -649,7 +710,11 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
                            dL_dpix, grad_acc, trace);                                                                         \
     }
 GSR_BWD_SPECIALISE(3, 6)
-GSR_BWD_SPECIALISE(4, 6)   // 92 registers left alone; held at 80 it spills four and still wins (iteration 0.780 -> 0.757 ms)
+#ifndef GSR_BWD_WAVES4
+#define GSR_BWD_WAVES4 5
+#endif
+// Four channels (two B tiles): 85 registers left alone = five waves; held at 80 for six it spills ten and loses (0.146 vs 0.134 ms)
+GSR_BWD_SPECIALISE(4, GSR_BWD_WAVES4)
 
 void launch_blend_bwd(int C, int W, int H, int U, const float* bg, const float* feats, GeomState g, ImageState im,
                       BinState b, const float* dL_dpix, float* grad_acc, hipStream_t st)

@@ -193,10 +193,16 @@ __host__ __device__ inline BinState carve_bin(void* base, int R, int U, int C = 
 // producers of rasterizer inputs (gsr_producers.hip)
 void launch_adam(long long n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float step_size,
                  float one_minus_b1, float b2, float one_minus_b2, float eps, float bc2s, hipStream_t st);
-void launch_sh_to_rgb(int P, int D, int M, const float* positions, const float* campos, const float* shs, const float* view,
-                      int depth_channels, float* out, hipStream_t st);
-void launch_sh_to_rgb_bwd(int P, int D, int M, const float* positions, const float* campos, const float* shs, const float* view,
-                          int depth_channels, const float* dL_dout, float* dL_dsh, float* dL_dpos, hipStream_t st);
+void launch_sh_to_rgb(int P, int D, int M, const float* positions, const float* campos, const float* shs, const float* shs_rest,
+                      const float* view, int depth_channels, float* out, const float* densities, float* opacity, hipStream_t st);
+void launch_sh_to_rgb_bwd(int P, int D, int M, const float* positions, const float* campos, const float* shs,
+                          const float* shs_rest, const float* view, int depth_channels, const float* dL_dout, float* dL_dsh,
+                          float* dL_dsh_rest, float* dL_dpos, int accumulate_pos, const float* opacity, const float* dL_dopacity,
+                          float* dL_ddensity, hipStream_t st);
+struct AdamTensor { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; long long n; float step_size; unsigned block0; };
+constexpr int ADAM_BATCH = 16;
+struct AdamBatch { AdamTensor t[ADAM_BATCH]; int count; unsigned blocks; };
+void launch_adam_multi(const AdamBatch& b, float one_minus_b1, float b2, float one_minus_b2, float eps, float bc2s, hipStream_t st);
 
 void launch_mesh_gaussians(int F, int G, const float* verts, const long long* faces, const float* bary,
                            const float* raw_scales, const float* raw_complex, float thickness, float min_scale,
@@ -491,10 +497,13 @@ __device__ __forceinline__ void sh_colour_backward(int D, int M, Vec3 mean, cons
 __host__ __device__ inline int sh_row_stride(int M) { return (3 * M) | 1; }
 __host__ __device__ inline size_t sh_stage_bytes(int M, int waves) { return (size_t)waves * 64 * sh_row_stride(M) * sizeof(float); }
 // global [g_base + g][3M] -> lds[g * stride + k], g = 0..63 (rows beyond P are left untouched)
-__device__ __forceinline__ void sh_stage_load(float* __restrict__ lds, const float* __restrict__ src, size_t g_base, int P, int M,
-                                              int lane)
+// (general form: rows of W3 floats in global memory land at column col0 of LDS rows RS floats apart -- the coefficients
+// of a Gaussian may live in two arrays, SuGaR's `_sh_coordinates_dc` [P,1,3] and `_sh_coordinates_rest` [P,M-1,3])
+__device__ __forceinline__ void sh_stage_load_cols(float* __restrict__ lds, const float* __restrict__ src, size_t g_base, int P,
+                                                   int W3, int RS, int col0, int lane)
 {
-    const int W3 = 3 * M, RS = sh_row_stride(M);
+    if (W3 <= 0) return;
+    lds += col0;
     const long long rows = (long long)P - (long long)g_base;
     const int n_rows = (int)(rows >= 64 ? 64 : (rows > 0 ? rows : 0));
     const float* s = src + g_base * (size_t)W3;
@@ -552,10 +561,16 @@ __device__ __forceinline__ void sh_stage_load(float* __restrict__ lds, const flo
         while (k >= W3) { k -= W3; g++; }
     }
 }
-__device__ __forceinline__ void sh_stage_store(const float* __restrict__ lds, float* __restrict__ dst, size_t g_base, int P, int M,
-                                               int lane)
+__device__ __forceinline__ void sh_stage_load(float* __restrict__ lds, const float* __restrict__ src, size_t g_base, int P, int M,
+                                              int lane)
 {
-    const int W3 = 3 * M, RS = sh_row_stride(M);
+    sh_stage_load_cols(lds, src, g_base, P, 3 * M, sh_row_stride(M), 0, lane);
+}
+__device__ __forceinline__ void sh_stage_store_cols(const float* __restrict__ lds, float* __restrict__ dst, size_t g_base, int P,
+                                                    int W3, int RS, int col0, int lane)
+{
+    if (W3 <= 0) return;
+    lds += col0;
     const long long rows = (long long)P - (long long)g_base;
     const int n_rows = (int)(rows >= 64 ? 64 : (rows > 0 ? rows : 0));
     float* d = dst + g_base * (size_t)W3;
@@ -579,6 +594,11 @@ __device__ __forceinline__ void sh_stage_store(const float* __restrict__ lds, fl
         k += 64;
         while (k >= W3) { k -= W3; g++; }
     }
+}
+__device__ __forceinline__ void sh_stage_store(const float* __restrict__ lds, float* __restrict__ dst, size_t g_base, int P, int M,
+                                               int lane)
+{
+    sh_stage_store_cols(lds, dst, g_base, P, 3 * M, sh_row_stride(M), 0, lane);
 }
 
 // Gaussian exponent of one (pixel, splat) pair: power = -0.5*(a dx^2 + c dy^2) - b dx dy (forward.cu:334), evaluated in

@@ -15,16 +15,27 @@ namespace gsr {
 
 __global__ void __launch_bounds__(256)
 sh_to_rgb_kernel(int P, int D, int M, const float* __restrict__ positions, const float* __restrict__ campos,
-                 const float* __restrict__ shs, const float* __restrict__ view, float* __restrict__ rgb, int stride)
+                 const float* __restrict__ shs, const float* __restrict__ shs_rest, const float* __restrict__ view,
+                 float* __restrict__ rgb, int stride, const float* __restrict__ densities, float* __restrict__ opacity)
 {
+    // shs_rest == nullptr: shs is [P, M, 3]; otherwise shs is SuGaR's `_sh_coordinates_dc` [P, 1, 3] and shs_rest its
+    // `_sh_coordinates_rest` [P, M - 1, 3] (sugar_model.py:449-450 concatenates them on every access: 53 MB written and
+    // read again per render at config C) -- both land in the same LDS rows.  densities != nullptr: opacity =
+    // sigmoid(density) rides along (SuGaR.strengths, sugar_model.py:442-447).
     extern __shared__ float sh_lds[];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     float* wave_rows = sh_lds + (size_t)(threadIdx.x >> 6) * 64 * sh_row_stride(M);
-    sh_stage_load(wave_rows, shs, (size_t)(idx - lane), P, M, lane);   // coalesced, see gsr_internal.h
+    if (shs_rest == nullptr) {
+        sh_stage_load(wave_rows, shs, (size_t)(idx - lane), P, M, lane);   // coalesced, see gsr_internal.h
+    } else {
+        sh_stage_load_cols(wave_rows, shs, (size_t)(idx - lane), P, 3, sh_row_stride(M), 0, lane);
+        sh_stage_load_cols(wave_rows, shs_rest, (size_t)(idx - lane), P, 3 * (M - 1), sh_row_stride(M), 3, lane);
+    }
     __builtin_amdgcn_wave_barrier();
     if (idx >= P) return;
     const size_t i = (size_t)idx;
+    if (densities != nullptr) opacity[i] = 1.0f / (1.0f + expf(-densities[i]));   // torch.sigmoid
     const Vec3 p = load3(positions, i);
     const float dx = p.x - campos[0], dy = p.y - campos[1], dz = p.z - campos[2];
     const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
@@ -46,14 +57,24 @@ sh_to_rgb_kernel(int P, int D, int M, const float* __restrict__ positions, const
 
 __global__ void __launch_bounds__(256)
 sh_to_rgb_bwd_kernel(int P, int D, int M, const float* __restrict__ positions, const float* __restrict__ campos,
-                     const float* __restrict__ shs, const float* __restrict__ view, const float* __restrict__ dL_drgb,
-                     int stride, float* __restrict__ dL_dsh, float* __restrict__ dL_dpos)
+                     const float* __restrict__ shs, const float* __restrict__ shs_rest, const float* __restrict__ view,
+                     const float* __restrict__ dL_drgb, int stride, float* __restrict__ dL_dsh, float* __restrict__ dL_dsh_rest,
+                     float* __restrict__ dL_dpos, int accumulate_pos, const float* __restrict__ opacity,
+                     const float* __restrict__ dL_dopacity, float* __restrict__ dL_ddensity)
 {
+    // (shs_rest / dL_dsh_rest: the two-array layout of the forward kernel.  accumulate_pos: dL_dpos already holds the
+    // rasterizer's gradient w.r.t. the positions and takes this one on top -- the add autograd would launch.  opacity !=
+    // nullptr: dL_ddensity = dL_dopacity (1 - o) o, torch's sigmoid_backward.)
     extern __shared__ float sh_lds[];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     float* wave_rows = sh_lds + (size_t)(threadIdx.x >> 6) * 64 * sh_row_stride(M);
-    sh_stage_load(wave_rows, shs, (size_t)(idx - lane), P, M, lane);
+    if (shs_rest == nullptr) {
+        sh_stage_load(wave_rows, shs, (size_t)(idx - lane), P, M, lane);
+    } else {
+        sh_stage_load_cols(wave_rows, shs, (size_t)(idx - lane), P, 3, sh_row_stride(M), 0, lane);
+        sh_stage_load_cols(wave_rows, shs_rest, (size_t)(idx - lane), P, 3 * (M - 1), sh_row_stride(M), 3, lane);
+    }
     __builtin_amdgcn_wave_barrier();
     if (idx < P) {
         const size_t i = (size_t)idx;
@@ -68,10 +89,21 @@ sh_to_rgb_bwd_kernel(int P, int D, int M, const float* __restrict__ positions, c
             for (int c = 4; c < stride; c++) gzv += gi[c];
             gx += gzv * view[2]; gy += gzv * view[6]; gz += gzv * view[10];
         }
+        if (accumulate_pos) { gx += dL_dpos[3 * i]; gy += dL_dpos[3 * i + 1]; gz += dL_dpos[3 * i + 2]; }
         dL_dpos[3 * i] = gx; dL_dpos[3 * i + 1] = gy; dL_dpos[3 * i + 2] = gz;
+        if (opacity != nullptr) {
+#pragma clang fp contract(off)
+            const float o = opacity[i];
+            dL_ddensity[i] = (dL_dopacity[i] * (1.0f - o)) * o;
+        }
     }
     __builtin_amdgcn_wave_barrier();
-    sh_stage_store(wave_rows, dL_dsh, (size_t)(idx - lane), P, M, lane);
+    if (dL_dsh_rest == nullptr) {
+        sh_stage_store(wave_rows, dL_dsh, (size_t)(idx - lane), P, M, lane);
+    } else {
+        sh_stage_store_cols(wave_rows, dL_dsh, (size_t)(idx - lane), P, 3, sh_row_stride(M), 0, lane);
+        sh_stage_store_cols(wave_rows, dL_dsh_rest, (size_t)(idx - lane), P, 3 * (M - 1), sh_row_stride(M), 3, lane);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -500,20 +532,23 @@ static void sh_lds_limit(const void* fn, size_t bytes)
     if (bytes > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-void launch_sh_to_rgb(int P, int D, int M, const float* positions, const float* campos, const float* shs, const float* view,
-                      int depth_channels, float* out, hipStream_t st)
+void launch_sh_to_rgb(int P, int D, int M, const float* positions, const float* campos, const float* shs, const float* shs_rest,
+                      const float* view, int depth_channels, float* out, const float* densities, float* opacity, hipStream_t st)
 {
     sh_lds_limit(reinterpret_cast<const void*>(&sh_to_rgb_kernel), sh_stage_bytes(M, 4));
-    sh_to_rgb_kernel<<<(P + 255) / 256, 256, sh_stage_bytes(M, 4), st>>>(P, D, M, positions, campos, shs, view, out,
-                                                                          view ? 3 + depth_channels : 3);
+    sh_to_rgb_kernel<<<(P + 255) / 256, 256, sh_stage_bytes(M, 4), st>>>(P, D, M, positions, campos, shs, shs_rest, view, out,
+                                                                          view ? 3 + depth_channels : 3, densities, opacity);
 }
 
-void launch_sh_to_rgb_bwd(int P, int D, int M, const float* positions, const float* campos, const float* shs, const float* view,
-                          int depth_channels, const float* dL_dout, float* dL_dsh, float* dL_dpos, hipStream_t st)
+void launch_sh_to_rgb_bwd(int P, int D, int M, const float* positions, const float* campos, const float* shs,
+                          const float* shs_rest, const float* view, int depth_channels, const float* dL_dout, float* dL_dsh,
+                          float* dL_dsh_rest, float* dL_dpos, int accumulate_pos, const float* opacity, const float* dL_dopacity,
+                          float* dL_ddensity, hipStream_t st)
 {
     sh_lds_limit(reinterpret_cast<const void*>(&sh_to_rgb_bwd_kernel), sh_stage_bytes(M, 4));
-    sh_to_rgb_bwd_kernel<<<(P + 255) / 256, 256, sh_stage_bytes(M, 4), st>>>(P, D, M, positions, campos, shs, view, dL_dout,
-                                                                              view ? 3 + depth_channels : 3, dL_dsh, dL_dpos);
+    sh_to_rgb_bwd_kernel<<<(P + 255) / 256, 256, sh_stage_bytes(M, 4), st>>>(
+        P, D, M, positions, campos, shs, shs_rest, view, dL_dout, view ? 3 + depth_channels : 3, dL_dsh, dL_dsh_rest, dL_dpos,
+        accumulate_pos, opacity, dL_dopacity, dL_ddensity);
 }
 
 }  // namespace gsr

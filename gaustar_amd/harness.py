@@ -22,7 +22,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import producers, scene
+from . import producers, rasterizer as _rasterizer, scene
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 BARY_COORDS = {  # sugar_model.py:186-226
@@ -85,6 +85,62 @@ def nerf_camera_from_scene(cam: scene.Camera, znear: float = 1e-4, zfar: float =
     fx = cam.W / (2.0 * cam.tanfovx)
     fy = cam.H / (2.0 * cam.tanfovy)
     return NerfCamera(c2w=c2w[:3, :], fx=fx, fy=fy, width=cam.W, height=cam.H, znear=znear, zfar=zfar)
+
+
+class _RenderMeshBound(torch.autograd.Function):
+    """A render of mesh-bound Gaussians as ONE autograd node: the model's parameters in, the image out.  Forward = mesh
+    producer -> colour producer (coefficients read from `_sh_coordinates_dc` / `_sh_coordinates_rest` where they live,
+    sigmoid of the densities from the same kernel) -> rasterizer; backward = the three backward calls in reverse, the
+    colour producer's gradient w.r.t. the positions added in place to the rasterizer's.  The same kernels on the same
+    numbers as the composition of autograd nodes in render_image_gaussian_rasterizer -- what goes away is what autograd puts
+    between them per iteration at config-C size: torch.cat of the coefficients and the two copies that split its gradient
+    (53 MB each way), sigmoid and its backward, the add of the two position gradients, the zero fill of the screen-space
+    gradient carrier, and five graph nodes' worth of host work (tools/window_phases.py)."""
+
+    @staticmethod
+    def forward(ctx, verts, raw_scales, raw_complex, densities, sh_dc, sh_rest, delta_t, delta_r, cfg):
+        dev = verts.device
+        f32 = lambda t: None if t is None else _rasterizer._dev_f32(t.detach(), dev)
+        v, rs, rc, dens, dc, rest, dt, dr = (f32(t) for t in (verts, raw_scales, raw_complex, densities, sh_dc, sh_rest, delta_t, delta_r))
+        st = cfg["settings"]
+        D, M = cfg["sh_levels"] - 1, 1 + int(rest.size(1))
+        view = st.viewmatrix if cfg["depth_channels"] else None
+        points, scaling, quats = producers._mesh_forward_raw(v, cfg["faces"], cfg["bary"], rs, rc, cfg["thickness"], cfg["lo"],
+                                                             cfg["hi"], dt, dr)
+        colors, opac = producers._sh_forward_raw(points, st.campos, dc, rest, D, M, view, cfg["depth_channels"], dens)
+        need_bwd = any(ctx.needs_input_grad)
+        box = []
+        out = _rasterizer.rasterize_gaussians_native(
+            st.bg, points, colors, opac, scaling, quats, st.scale_modifier, None, st.viewmatrix, st.projmatrix, st.tanfovx,
+            st.tanfovy, st.image_height, st.image_width, None, 0, st.campos, st.prefiltered, st.debug, need_backward=need_bwd,
+            scratch_box=box)
+        num_rendered, color, radii, geom, binning, img, _max_tile, num_segments = out
+        ctx.save_for_backward(v, rs, rc, dr, dc, rest, points, scaling, quats, colors, opac, radii, geom, binning, img)
+        ctx.cfg, ctx.counts = cfg, (num_rendered, num_segments, D, M, dt is not None, tuple(densities.shape))
+        ctx.zeroed_scratch = box[0] if box else None
+        ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_color, _):
+        if grad_color is None:
+            return (None,) * 9
+        v, rs, rc, dr, dc, rest, points, scaling, quats, colors, opac, radii, geom, binning, img = ctx.saved_tensors
+        cfg, (num_rendered, num_segments, D, M, has_dt, dens_shape) = ctx.cfg, ctx.counts
+        st = cfg["settings"]
+        zeroed, ctx.zeroed_scratch = ctx.zeroed_scratch, None
+        _dm2d, d_colors, d_opac, d_points, _dcov, _dsh, d_scaling, d_quats = _rasterizer.rasterize_gaussians_backward_native(
+            st.bg, points, radii, colors, scaling, quats, st.scale_modifier, None, st.viewmatrix, st.projmatrix, st.tanfovx,
+            st.tanfovy, grad_color, None, 0, st.campos, geom, num_rendered, binning, img, st.debug, num_segments=num_segments,
+            zeroed_scratch=zeroed)
+        view = st.viewmatrix if cfg["depth_channels"] else None
+        d_dc, d_rest, _, d_dens = producers._sh_backward_raw(points, _rasterizer._dev_f32(st.campos, points.device), dc, rest, D, M,
+                                                             _rasterizer._dev_f32(view, points.device), cfg["depth_channels"], d_colors, opac, d_opac,
+                                                             dpos_inout=d_points)
+        d_verts, d_rs, d_rc, d_dt, d_dr = producers._mesh_backward_raw(v, cfg["faces"], cfg["bary"], rs, rc, dr, cfg["lo"], cfg["hi"],
+                                                                       has_dt, d_points, d_scaling, d_quats)
+        return d_verts, d_rs, d_rc, d_dens.view(dens_shape), d_dc, d_rest, d_dt, d_dr, None
 
 
 class SurfaceGaussians(nn.Module):
@@ -161,6 +217,17 @@ class SurfaceGaussians(nn.Module):
     def n_points(self) -> int:
         return int(self._scales.shape[0])
 
+    def _thickness(self) -> float:
+        """surface_mesh_thickness as a Python float, read back from the device ONCE per value: `float(buffer)` is a
+        device-to-host copy that waits for everything queued before it -- as a per-render call it drained the GPU once per
+        iteration (the host could never run ahead of the previous iteration's optimiser step)."""
+        t = self.surface_mesh_thickness
+        c = getattr(self, "_thickness_cache", None)
+        if c is None or c[0] is not t or c[1] != t._version:
+            c = (t, t._version, float(t))
+            self._thickness_cache = c
+        return c[2]
+
     def _geometry(self):
         """(points, scaling, quaternions) from one fused call, shared by the three properties while no parameter
         changes (the reference recomputes each property from scratch on every access)."""
@@ -169,7 +236,7 @@ class SurfaceGaussians(nn.Module):
         if self._geom_cache is None or self._geom_cache[0] != key:
             out = producers.mesh_bound_gaussians(
                 self._points, self._surface_mesh_faces, self.surface_triangle_bary_coords[..., 0], self._scales,
-                self._quaternions, float(self.surface_mesh_thickness), self.min_gaussian_scale, self.max_gaussian_scale,
+                self._quaternions, self._thickness(), self.min_gaussian_scale, self.max_gaussian_scale,
                 self._delta_t if self._loose_bind else None, self._delta_r if self._loose_bind else None)
             self._geom_cache = (key, out)
         return self._geom_cache[1]
@@ -270,17 +337,40 @@ class SurfaceGaussians(nn.Module):
         positions = self.points if positions is None else positions
         return (positions @ view[:3, 2:3] + view[3, 2]).expand(-1, 3)
 
+    def render_channels(self, camera: NerfCamera, bg: torch.Tensor, sh_deg: Optional[int] = None, depth_channels: int = 1):
+        """-> (image [3 + depth_channels, H, W], radii): SH colours (+ view-space depth as `depth_channels` = 0, 1 or 3 more
+        colour channels; bg has one entry per channel) rendered through ONE autograd node (_RenderMeshBound) -- the
+        refinement loop's render.  Values and gradients are those of render_image_gaussian_rasterizer / the composition of
+        producers.points_rgb_depth, torch.sigmoid and GaussianRasterizer (tests/test_gpu_harness.py)."""
+        if depth_channels not in (0, 1, 3):
+            raise ValueError("depth_channels must be 0, 1 or 3")
+        sh_deg = self.sh_levels - 1 if sh_deg is None else int(sh_deg)
+        settings, _view, _campos = self._settings(camera, bg, 0)
+        producers._check_faces(self._surface_mesh_faces, int(self._points.shape[0]))
+        dev = self.device
+        cfg = {"settings": settings, "faces": self._surface_mesh_faces, "bary": self._bary_rows(), "depth_channels": int(depth_channels),
+               "thickness": self._thickness(),
+               "lo": float("-inf") if self.min_gaussian_scale is None else float(self.min_gaussian_scale),
+               "hi": float("inf") if self.max_gaussian_scale is None else float(self.max_gaussian_scale), "sh_levels": sh_deg + 1}
+        if settings.campos.device != dev or settings.campos.dtype != torch.float32:
+            raise RuntimeError("camera matrices must be float32 tensors on the model's device")
+        return _RenderMeshBound.apply(self._points, self._scales, self._quaternions, self.all_densities, self._sh_coordinates_dc,
+                                      self._sh_coordinates_rest, self._delta_t if self._loose_bind else None,
+                                      self._delta_r if self._loose_bind else None, cfg)
+
+    def _bary_rows(self):
+        b = getattr(self, "_bary_rows_cache", None)
+        if b is None or b.device != self.device:
+            b = self.surface_triangle_bary_coords[..., 0].detach().to(torch.float32).contiguous()
+            self._bary_rows_cache = b
+        return b
+
     def render_rgb_depth(self, camera: NerfCamera, bg_color=None, max_depth: float = 10.0, sh_deg: Optional[int] = None):
         """The two renders of a refinement iteration (refine.py:552 RGB, :607 depth-as-colour with bg = max_depth) as ONE
-        4-channel pass (RGB + one depth channel): -> (rgb [H,W,3], depth [H,W])."""
+        4-channel pass (RGB + one depth channel) through one autograd node (render_channels):
+        -> (rgb [H,W,3], depth [H,W])."""
         dev = self.device
         bg_rgb = torch.zeros(3, device=dev) if bg_color is None else torch.as_tensor(bg_color, dtype=torch.float32, device=dev)
-        bg6 = torch.cat([bg_rgb, torch.full((1,), float(max_depth), device=dev)])   # RGB + one depth channel
-        sh_deg = self.sh_levels - 1 if sh_deg is None else int(sh_deg)
-        settings, view, campos = self._settings(camera, bg6, 0)
-        positions = self.points
-        # SH colours and view-space depth of every Gaussian from one fused producer (no cat, no skinny matmul)
-        colors6 = producers.points_rgb_depth(positions, campos, self.sh_coordinates, sh_deg + 1, view, depth_channels=1)
-        img, _ = GaussianRasterizer(settings)(means3D=positions, means2D=torch.zeros_like(positions), opacities=self.strengths,
-                                              colors_precomp=colors6, scales=self.scaling, rotations=self.quaternions)
+        bg4 = torch.cat([bg_rgb, torch.full((1,), float(max_depth), device=dev)])   # RGB + one depth channel
+        img, _ = self.render_channels(camera, bg4, sh_deg=sh_deg, depth_channels=1)
         return img[:3].permute(1, 2, 0), img[3]

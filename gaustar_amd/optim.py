@@ -5,8 +5,8 @@ with per-group learning rates that the trainer rewrites every iteration (:104-11
 torch/optim/adam.py::_single_tensor_adam (no weight decay, no amsgrad, not maximising).  `Adam` below is a
 `torch.optim.Optimizer`: same constructor arguments, same `param_groups`, same state keys (`step`, `exp_avg`,
 `exp_avg_sq`), so SuGaROptimizer-style wrappers and `state_dict()` round trips with torch.optim.Adam work unchanged;
-only `step()` differs: 28 bytes per parameter through one kernel (`gsr_adam_step`) instead of PyTorch's multi-tensor
-kernels.  There is no CPU path: parameters must be float32 HIP tensors."""
+only `step()` differs: 28 bytes per parameter through one kernel for all tensors of a step (`gsr_adam_step_multi`) instead
+of PyTorch's multi-tensor kernels.  There is no CPU path: parameters must be float32 HIP tensors."""
 from __future__ import annotations
 
 import ctypes
@@ -35,6 +35,8 @@ class Adam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0.0, amsgrad=False))
 
+    multi_tensor = True   # one launch per 16 tensors (gsr_adam_step_multi); False: one launch per tensor (gsr_adam_step)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -42,6 +44,8 @@ class Adam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load()
+        # tensors that share everything but the learning rate go out together: (device, betas, eps, step count) -> entries
+        batches = {}
         for group in self.param_groups:
             lr, (b1, b2), eps = float(group["lr"]), group["betas"], float(group["eps"])
             for p in group["params"]:
@@ -59,10 +63,21 @@ class Adam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
                 g = p.grad if (p.grad.dtype == torch.float32 and p.grad.is_contiguous()) else p.grad.float().contiguous()
-                with _host.on_device(p.device):
-                    _lib.check(lib.gsr_adam_step(
-                        p.numel(), p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), lr,
-                        float(b1), float(b2), eps, int(st["step"].item()), _host.raw_stream(p.device.index)),
-                        "gsr_adam_step")
-                _bump_version(p)
+                key = (p.device.index, float(b1), float(b2), eps, int(st["step"].item()))
+                batches.setdefault(key, []).append((p, g, st["exp_avg"], st["exp_avg_sq"], lr))
+        for (dev_index, b1, b2, eps, step), entries in batches.items():
+            with _host.on_device(entries[0][0].device):
+                stream = _host.raw_stream(dev_index)
+                if self.multi_tensor and len(entries) > 1:
+                    n = len(entries)
+                    ptrs = lambda k: (ctypes.c_void_p * n)(*[e[k].data_ptr() for e in entries])
+                    _lib.check(lib.gsr_adam_step_multi(
+                        n, (ctypes.c_longlong * n)(*[e[0].numel() for e in entries]), ptrs(0), ptrs(1), ptrs(2), ptrs(3),
+                        (ctypes.c_double * n)(*[e[4] for e in entries]), b1, b2, eps, step, stream), "gsr_adam_step_multi")
+                else:
+                    for p, g, m, v, lr in entries:
+                        _lib.check(lib.gsr_adam_step(p.numel(), p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), lr, b1, b2,
+                                                     eps, step, stream), "gsr_adam_step")
+            for e in entries:
+                _bump_version(e[0])
         return loss

@@ -21,6 +21,62 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def _op(t):
+    return None if t is None else _p(t)
+
+
+def _sh_forward_raw(pos, cam, sh, sh_rest, D, M, view, depth_channels, densities=None):
+    """The colour producer on prepared tensors (float32, contiguous, detached, one device): sh [P,M,3] with sh_rest None,
+    or sh = `_sh_coordinates_dc` [P,1,3] and sh_rest = `_sh_coordinates_rest` [P,M-1,3].  -> (colors, opacity or None)."""
+    lib = _lib.load()
+    P = int(pos.size(0))
+    dev = pos.device
+    colors = torch.empty(P, 3 + (int(depth_channels) if view is not None else 0), dtype=torch.float32, device=dev)
+    opacity = torch.empty(P, 1, dtype=torch.float32, device=dev) if densities is not None else None
+    with _host.on_device(dev):
+        if sh_rest is None and densities is None:
+            if view is None:
+                _lib.check(lib.gsr_sh_to_rgb(P, D, M, _p(pos), _p(cam), _p(sh), _p(colors), _stream()), "gsr_sh_to_rgb")
+            else:
+                _lib.check(lib.gsr_sh_to_rgbd(P, D, M, _p(pos), _p(cam), _p(sh), _p(view), int(depth_channels), _p(colors), _stream()),
+                           "gsr_sh_to_rgbd")
+        else:
+            if sh_rest is None and M != 1:
+                raise RuntimeError("opacities ride along only with the two-array coefficient layout")
+            _lib.check(lib.gsr_sh_colors_split(P, D, M, _p(pos), _p(cam), _p(sh), _op(sh_rest if M > 1 else None), _op(view),
+                                               int(depth_channels) if view is not None else 0, _op(densities), _p(colors),
+                                               _op(opacity), _stream()), "gsr_sh_colors_split")
+    return colors, opacity
+
+
+def _sh_backward_raw(pos, cam, sh, sh_rest, D, M, view, depth_channels, g, opacity=None, dL_dopacity=None, dpos_inout=None):
+    """-> (dL_dsh, dL_dsh_rest or None, dL_dpos, dL_ddensities or None).  dpos_inout: a [P,3] gradient w.r.t. the positions
+    that takes this producer's on top (in place) instead of a fresh array."""
+    lib = _lib.load()
+    P = int(pos.size(0))
+    dsh = torch.empty_like(sh)
+    drest = torch.empty_like(sh_rest) if sh_rest is not None else None
+    dpos = dpos_inout if dpos_inout is not None else torch.empty_like(pos)
+    ddens = torch.empty_like(opacity) if opacity is not None else None
+    with _host.on_device(pos.device):
+        if sh_rest is None and opacity is None and dpos_inout is None:
+            if view is None:
+                _lib.check(lib.gsr_sh_to_rgb_backward(P, D, M, _p(pos), _p(cam), _p(sh), _p(g), _p(dsh), _p(dpos), _stream()),
+                           "gsr_sh_to_rgb_backward")
+            else:
+                _lib.check(lib.gsr_sh_to_rgbd_backward(P, D, M, _p(pos), _p(cam), _p(sh), _p(view), int(depth_channels), _p(g),
+                                                       _p(dsh), _p(dpos), _stream()), "gsr_sh_to_rgbd_backward")
+        else:
+            if sh_rest is None and M != 1:
+                raise RuntimeError("the fused backward takes the two-array coefficient layout")
+            _lib.check(lib.gsr_sh_colors_split_backward(
+                P, D, M, _p(pos), _p(cam), _p(sh), _op(sh_rest if M > 1 else None), _op(view),
+                int(depth_channels) if view is not None else 0, _p(g), _op(opacity), _op(dL_dopacity), _p(dsh),
+                _op(drest if M > 1 else None), _p(dpos), int(dpos_inout is not None), _op(ddens), _stream()),
+                "gsr_sh_colors_split_backward")
+    return dsh, drest, dpos, ddens
+
+
 class _PointsRGB(torch.autograd.Function):
     """view is None: rgb [P,3]; otherwise rgb + view-space depth as a second colour target [P,6] (points_rgb_depth)."""
 
@@ -50,13 +106,7 @@ class _PointsRGB(torch.autograd.Function):
             view = view.detach().to(dev, torch.float32).contiguous()
         if view is not None and depth_channels not in (1, 3):
             raise RuntimeError("depth_channels must be 1 (colours [P,4]) or 3 (colours [P,6])")
-        rgb = torch.empty(P, 3 if view is None else 3 + int(depth_channels), dtype=torch.float32, device=dev)
-        with _host.on_device(dev):
-            if view is None:
-                _lib.check(lib.gsr_sh_to_rgb(P, D, M, _p(pos), _p(cam), _p(sh), _p(rgb), _stream()), "gsr_sh_to_rgb")
-            else:
-                _lib.check(lib.gsr_sh_to_rgbd(P, D, M, _p(pos), _p(cam), _p(sh), _p(view), int(depth_channels), _p(rgb), _stream()),
-                           "gsr_sh_to_rgbd")
+        rgb, _ = _sh_forward_raw(pos, cam, sh, None, D, M, view, depth_channels)
         ctx.save_for_backward(pos, cam, sh, view)
         ctx.D = D
         ctx.depth_channels = int(depth_channels)
@@ -64,19 +114,10 @@ class _PointsRGB(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dL_drgb):
-        lib = _lib.load()
         pos, cam, sh, view = ctx.saved_tensors
-        P, M = int(pos.size(0)), int(sh.size(1))
+        M = int(sh.size(1))
         g = dL_drgb.to(torch.float32).contiguous()
-        dsh = torch.empty_like(sh)
-        dpos = torch.empty_like(pos)
-        with _host.on_device(pos.device):
-            if view is None:
-                _lib.check(lib.gsr_sh_to_rgb_backward(P, ctx.D, M, _p(pos), _p(cam), _p(sh), _p(g), _p(dsh), _p(dpos),
-                                                      _stream()), "gsr_sh_to_rgb_backward")
-            else:
-                _lib.check(lib.gsr_sh_to_rgbd_backward(P, ctx.D, M, _p(pos), _p(cam), _p(sh), _p(view), ctx.depth_channels, _p(g),
-                                                       _p(dsh), _p(dpos), _stream()), "gsr_sh_to_rgbd_backward")
+        dsh, _, dpos, _ = _sh_backward_raw(pos, cam, sh, None, ctx.D, M, view, ctx.depth_channels, g)
         return dpos, None, dsh, None, None, None
 
 
@@ -99,10 +140,95 @@ def points_rgb_depth(positions: torch.Tensor, camera_centers: torch.Tensor, sh_c
     return _PointsRGB.apply(positions, camera_centers, sh_coordinates, int(sh_levels), viewmatrix, int(depth_channels))
 
 
+class _PointsColorsSplit(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, positions, camera_center, sh_dc, sh_rest, sh_levels, view, depth_channels, densities):
+        if not positions.is_cuda:
+            raise RuntimeError("gaustar_amd.producers: positions must live on a HIP (cuda) device -- there is no CPU path")
+        P = int(positions.size(0)) if positions.dim() == 2 else -1
+        if positions.dim() != 2 or positions.size(1) != 3:
+            raise RuntimeError("positions must have dimensions (num_points, 3)")
+        if tuple(sh_dc.shape) != (P, 1, 3) or sh_rest.dim() != 3 or sh_rest.size(0) != P or sh_rest.size(2) != 3:
+            raise RuntimeError("sh_dc must be (num_points, 1, 3) and sh_rest (num_points, n_coeffs - 1, 3)")
+        D, M = int(sh_levels) - 1, 1 + int(sh_rest.size(1))
+        if D < 0 or D > 4 or (D + 1) ** 2 > M:
+            raise RuntimeError(f"sh_levels must be 1..5 and sh_levels**2 <= n_coeffs ({M})")
+        if camera_center.numel() != 3:
+            raise RuntimeError("camera_center must hold one 3-vector (shape (3,) or (1, 3))")
+        if view is not None and (tuple(view.shape) != (4, 4) or depth_channels not in (1, 3)):
+            raise RuntimeError("viewmatrix must be (4, 4) and depth_channels 1 or 3")
+        if densities is not None and densities.numel() != P:
+            raise RuntimeError("densities must hold one value per point")
+        dev = positions.device
+        f32 = lambda t: None if t is None else t.detach().to(dev, torch.float32).contiguous()
+        pos, dc, rest, view, dens = f32(positions), f32(sh_dc), f32(sh_rest), f32(view), f32(densities)
+        cam = camera_center.detach().to(dev, torch.float32).reshape(-1).contiguous()
+        colors, opacity = _sh_forward_raw(pos, cam, dc, rest, D, M, view, depth_channels if view is not None else 0, dens)
+        ctx.save_for_backward(pos, cam, dc, rest, view, opacity)
+        ctx.cfg = (D, M, int(depth_channels) if view is not None else 0)
+        ctx.dens_shape = None if densities is None else tuple(densities.shape)
+        if opacity is None:
+            return colors
+        return colors, opacity
+
+    @staticmethod
+    def backward(ctx, dL_dcolors, dL_dopacity=None):
+        pos, cam, dc, rest, view, opacity = ctx.saved_tensors
+        D, M, dch = ctx.cfg
+        g = dL_dcolors.to(torch.float32).contiguous()
+        if opacity is not None:
+            dL_dopacity = torch.zeros_like(opacity) if dL_dopacity is None else dL_dopacity.to(torch.float32).contiguous()
+        ddc, drest, dpos, ddens = _sh_backward_raw(pos, cam, dc, rest, D, M, view, dch, g, opacity, dL_dopacity)
+        if ddens is not None:
+            ddens = ddens.view(ctx.dens_shape)
+        return dpos, None, ddc, drest, None, None, None, ddens
+
+
+def points_colors_split(positions: torch.Tensor, camera_centers: torch.Tensor, sh_dc: torch.Tensor, sh_rest: torch.Tensor,
+                        sh_levels: int, viewmatrix: torch.Tensor = None, depth_channels: int = 1, densities: torch.Tensor = None):
+    """points_rgb / points_rgb_depth reading SuGaR's coefficients where they live -- `_sh_coordinates_dc` [P,1,3] and
+    `_sh_coordinates_rest` [P,n-1,3] (sugar_model.py:449-450 concatenates them on every access) -- and, with `densities`
+    ([P,1] `all_densities`), returning SuGaR.strengths (sigmoid, sugar_model.py:442-447) from the same kernel:
+    -> colors [P,3] (viewmatrix None) or [P, 3 + depth_channels]; with densities: (colors, opacities [P,1]).
+    Bit-identical to points_rgb_depth(torch.cat([sh_dc, sh_rest], 1)) and torch.sigmoid, forward and backward."""
+    return _PointsColorsSplit.apply(positions, camera_centers, sh_dc, sh_rest, int(sh_levels), viewmatrix, int(depth_channels),
+                                    densities)
+
+
+def _mesh_forward_raw(v, fc, bc, rs, rc, thickness, lo, hi, dt, dr):
+    """The mesh producer on prepared tensors (float32 / int64, contiguous, detached, one device) -> (points, scaling, quats)."""
+    lib = _lib.load()
+    dev = v.device
+    F, G = int(fc.size(0)), int(bc.size(0))
+    N = F * G
+    points = torch.empty(N, 3, dtype=torch.float32, device=dev)
+    scaling = torch.empty(N, 3, dtype=torch.float32, device=dev)
+    quats = torch.empty(N, 4, dtype=torch.float32, device=dev)
+    with _host.on_device(dev):
+        _lib.check(lib.gsr_mesh_gaussians(F, G, _p(v), _p(fc), _p(bc), _p(rs), _p(rc), float(thickness), lo, hi, _op(dt),
+                                          _op(dr), _p(points), _p(scaling), _p(quats), _stream()), "gsr_mesh_gaussians")
+    return points, scaling, quats
+
+
+def _mesh_backward_raw(v, fc, bc, rs, rc, dr, lo, hi, has_dt, g_points, g_scaling, g_quats):
+    """-> (d_verts, d_raw_scales, d_raw_complex, d_delta_t or None, d_delta_r or None); absent output gradients are None."""
+    lib = _lib.load()
+    dev = v.device
+    F, G, V = int(fc.size(0)), int(bc.size(0)), int(v.size(0))
+    d_verts = torch.empty_like(v)
+    d_rs, d_rc = torch.empty_like(rs), torch.empty_like(rc)
+    d_dt = torch.empty(F * G, 3, dtype=torch.float32, device=dev) if has_dt else None
+    d_dr = torch.empty_like(dr) if dr is not None else None
+    with _host.on_device(dev):
+        _lib.check(lib.gsr_mesh_gaussians_backward(
+            F, G, V, _p(v), _p(fc), _p(bc), _p(rs), _p(rc), lo, hi, _op(dr), _op(g_points), _op(g_scaling), _op(g_quats),
+            _p(d_verts), _p(d_rs), _p(d_rc), _op(d_dt), _op(d_dr), _stream()), "gsr_mesh_gaussians_backward")
+    return d_verts, d_rs, d_rc, d_dt, d_dr
+
+
 class _MeshGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, verts, faces, bary, raw_scales, raw_complex, thickness, min_scale, max_scale, delta_t, delta_r):
-        lib = _lib.load()
         if not verts.is_cuda:
             raise RuntimeError("gaustar_amd.producers: verts must live on a HIP (cuda) device -- there is no CPU path")
         dev = verts.device
@@ -110,7 +236,7 @@ class _MeshGaussians(torch.autograd.Function):
         v, rs, rc, dt, dr = f32(verts), f32(raw_scales), f32(raw_complex), f32(delta_t), f32(delta_r)
         fc = faces.detach().to(dev, torch.int64).contiguous()
         bc = f32(bary).reshape(-1, 3)
-        F, G, V = int(fc.size(0)), int(bc.size(0)), int(v.size(0))
+        F, G = int(fc.size(0)), int(bc.size(0))
         N = F * G
         if v.dim() != 2 or v.size(1) != 3 or fc.dim() != 2 or fc.size(1) != 3:
             raise RuntimeError("verts must be (V, 3) and faces (F, 3)")
@@ -120,34 +246,18 @@ class _MeshGaussians(torch.autograd.Function):
             raise RuntimeError(f"delta_t must be ({N}, 3) and delta_r ({N}, 4)")
         lo = float("-inf") if min_scale is None else float(min_scale)
         hi = float("inf") if max_scale is None else float(max_scale)
-        points = torch.empty(N, 3, dtype=torch.float32, device=dev)
-        scaling = torch.empty(N, 3, dtype=torch.float32, device=dev)
-        quats = torch.empty(N, 4, dtype=torch.float32, device=dev)
-        op = lambda t: None if t is None else _p(t)
-        with _host.on_device(dev):
-            _lib.check(lib.gsr_mesh_gaussians(F, G, _p(v), _p(fc), _p(bc), _p(rs), _p(rc), float(thickness), lo, hi, op(dt),
-                                              op(dr), _p(points), _p(scaling), _p(quats), _stream()), "gsr_mesh_gaussians")
+        points, scaling, quats = _mesh_forward_raw(v, fc, bc, rs, rc, thickness, lo, hi, dt, dr)
         ctx.save_for_backward(v, fc, bc, rs, rc, dr)
-        ctx.dims = (F, G, V, lo, hi, dt is not None)
+        ctx.dims = (lo, hi, dt is not None)
         return points, scaling, quats
 
     @staticmethod
     def backward(ctx, g_points, g_scaling, g_quats):
-        lib = _lib.load()
         v, fc, bc, rs, rc, dr = ctx.saved_tensors
-        F, G, V, lo, hi, has_dt = ctx.dims
-        dev = v.device
+        lo, hi, has_dt = ctx.dims
         c = lambda t: None if t is None else t.to(torch.float32).contiguous()
-        g_points, g_scaling, g_quats = c(g_points), c(g_scaling), c(g_quats)
-        d_verts = torch.empty_like(v)
-        d_rs, d_rc = torch.empty_like(rs), torch.empty_like(rc)
-        d_dt = torch.empty(F * G, 3, dtype=torch.float32, device=dev) if has_dt else None
-        d_dr = torch.empty_like(dr) if dr is not None else None
-        op = lambda t: None if t is None else _p(t)
-        with _host.on_device(dev):
-            _lib.check(lib.gsr_mesh_gaussians_backward(
-                F, G, V, _p(v), _p(fc), _p(bc), _p(rs), _p(rc), lo, hi, op(dr), op(g_points), op(g_scaling), op(g_quats),
-                _p(d_verts), _p(d_rs), _p(d_rc), op(d_dt), op(d_dr), _stream()), "gsr_mesh_gaussians_backward")
+        d_verts, d_rs, d_rc, d_dt, d_dr = _mesh_backward_raw(v, fc, bc, rs, rc, dr, lo, hi, has_dt, c(g_points), c(g_scaling),
+                                                             c(g_quats))
         return d_verts, None, None, d_rs, d_rc, None, None, None, d_dt, d_dr
 
 

@@ -210,6 +210,25 @@ int gsr_sh_to_rgbd_backward(int P, int D, int M, const float* positions, const f
                             const float* viewmatrix, int depth_channels, const float* dL_dcolors6, float* dL_dsh,
                             float* dL_dpos, gsr_stream_t stream);
 
+/* The same producer reading SuGaR's coefficients where they live: `_sh_coordinates_dc` [P,1,3] and `_sh_coordinates_rest`
+ * [P,M-1,3] (gaustar_scene/sugar_model.py:449-450 concatenates the two on EVERY access of `sh_coordinates`, and autograd
+ * splits the gradient again: 53 MB written and read back each way per render at 491 520 Gaussians, sh_levels 3), and
+ * taking SuGaR.strengths (sugar_model.py:442-447: sigmoid of `all_densities`) along.
+ *   M = 1 + number of rest coefficients (sh_rest may be NULL when M == 1); viewmatrix NULL: colors [P,3], depth_channels
+ *   must be 0; otherwise colors [P, 3 + depth_channels] as gsr_sh_to_rgbd.  densities / opacity [P]: both NULL or both
+ *   given, opacity = 1 / (1 + exp(-density)).
+ * Backward: dL_dsh_dc [P,1,3] and dL_dsh_rest [P,M-1,3] written outright; dL_dpos [P,3] written, or -- accumulate_pos != 0
+ * -- ADDED to what the array holds (the rasterizer's gradient w.r.t. the same positions: the sum autograd would form with
+ * one more kernel); opacity / dL_dopacity / dL_ddensities [P]: all NULL or all given, dL_ddensities = dL_dopacity (1 - o) o.
+ * Results are bit-identical to gsr_sh_to_rgbd on the concatenated array + torch.sigmoid. */
+int gsr_sh_colors_split(int P, int D, int M, const float* positions, const float* campos, const float* sh_dc,
+                        const float* sh_rest, const float* viewmatrix, int depth_channels, const float* densities,
+                        float* colors, float* opacity, gsr_stream_t stream);
+int gsr_sh_colors_split_backward(int P, int D, int M, const float* positions, const float* campos, const float* sh_dc,
+                                 const float* sh_rest, const float* viewmatrix, int depth_channels, const float* dL_dcolors,
+                                 const float* opacity, const float* dL_dopacity, float* dL_dsh_dc, float* dL_dsh_rest,
+                                 float* dL_dpos, int accumulate_pos, float* dL_ddensities, gsr_stream_t stream);
+
 /* gsr_mesh_gaussians replaces the properties SuGaR.points / .scaling / .quaternions for Gaussians bound to a
  * triangle mesh (gaustar_scene/sugar_model.py:417-435, :457-476, :478-508; pytorch3d 0.7.4 face normals,
  * quaternion_to_matrix, matrix_to_quaternion): Gaussian n = f*G + g of face f gets
@@ -284,6 +303,13 @@ int gsr_debug_host_wait(long long* wait_ns, long long* waits, int reset);
  * reference holds them in Python floats: 1 - beta2 formed from a float32 beta2 would already be off by 1e-5. */
 int gsr_adam_step(long long n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, double lr, double beta1,
                   double beta2, double eps, int step, gsr_stream_t stream);
+/* The same update for `count` tensors in one launch per 16 tensors (the optimiser of sugar_optimizer.py:67-87 holds eight
+ * tensors, five of them a few MB: a launch each is mostly overhead).  numel, params, grads, exp_avgs, exp_avg_sqs, lrs:
+ * [host] arrays of `count` entries (device pointers / element counts / per-tensor learning rates -- the groups differ in
+ * nothing else); tensors with numel <= 0 are skipped.  Element for element the result of gsr_adam_step. */
+int gsr_adam_step_multi(int count, const long long* numel, float* const* params, const float* const* grads,
+                        float* const* exp_avgs, float* const* exp_avg_sqs, const double* lrs, double beta1, double beta2,
+                        double eps, int step, gsr_stream_t stream);
 
 #ifdef __cplusplus
 }

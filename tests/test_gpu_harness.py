@@ -112,3 +112,59 @@ def test_checkpoint_round_trip_through_the_model(tmp_path, hip_lib):
     m3 = harness.SurfaceGaussians(sd["_points"], sd["_surface_mesh_faces"], loose_bind=True, surface_mesh_thickness=1.0)
     m3.load_state_dict(sd)
     assert torch.equal(m3.scaling, m.scaling)
+
+
+@pytest.mark.parametrize("loose,depth_channels", [(False, 1), (True, 1), (True, 0), (False, 3)])
+def test_one_node_render_equals_the_composition_of_nodes(loose, depth_channels, hip_lib):
+    """SurfaceGaussians.render_channels (ONE autograd node: parameters in, image out) against the same render composed of
+    autograd nodes the way the reference's harness composes it (properties -> SH colours -> sigmoid -> rasterizer): the
+    image is bit-identical (same kernels on the same numbers), every parameter's gradient agrees to the run-to-run noise
+    of the float atomics in the two blends' and the mesh producer's backward."""
+    from gaustar_amd import GaussianRasterizer, harness, producers, scene
+    m = _model(3, loose, seed=9)
+    ncam = harness.nerf_camera_from_scene(scene.look_at_camera((0.7, 1.7, 2.6), (0.0, 1.2, 0.0), 320, 240, focal_px=260.0))
+    C = 3 + depth_channels
+    bg = torch.tensor([0.0, 1.0, 0.0] + [10.0] * depth_channels, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    d_img = torch.randn(C, 240, 320, device="cuda", generator=g)
+
+    def grads():
+        out = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        m.zero_grad(set_to_none=True)
+        return out
+
+    img, radii = m.render_channels(ncam, bg, sh_deg=3, depth_channels=depth_channels)
+    (img * d_img).sum().backward()
+    got = grads()
+
+    settings, view, campos = m._settings(ncam, bg, 0)
+    pts = m.points
+    if depth_channels:
+        col = producers.points_rgb_depth(pts, campos, m.sh_coordinates, 4, view, depth_channels=depth_channels)
+    else:
+        col = producers.points_rgb(pts, campos, m.sh_coordinates, 4)
+    img_ref, radii_ref = GaussianRasterizer(settings)(means3D=pts, means2D=torch.zeros_like(pts), opacities=m.strengths,
+                                                      colors_precomp=col, scales=m.scaling, rotations=m.quaternions)
+    (img_ref * d_img).sum().backward()
+    want = grads()
+    assert torch.equal(img, img_ref) and torch.equal(radii, radii_ref)
+    assert set(got) == set(want) and len(got) == (8 if loose else 6)
+    for n in want:
+        scale = float(want[n].abs().max())
+        assert scale > 0, n
+        assert float((got[n] - want[n]).abs().max()) <= 2e-5 * scale, (n, float((got[n] - want[n]).abs().max()), scale)
+    # forward only: no graph, same image
+    with torch.no_grad():
+        img2, _ = m.render_channels(ncam, bg, sh_deg=3, depth_channels=depth_channels)
+    assert torch.equal(img2, img_ref)
+
+
+def test_thickness_is_read_back_once(hip_lib):
+    """surface_mesh_thickness lives in a device buffer (state-dict compatibility); the render path must not read it back
+    per call (a device-to-host copy drains the queue: one pipeline bubble per iteration)."""
+    m = _model(2, False, seed=1)
+    a = m._thickness()
+    assert a == pytest.approx(3e-6) and m._thickness() is m._thickness_cache[2]
+    with torch.no_grad():
+        m.surface_mesh_thickness.fill_(5e-6)          # in-place change: version bump -> re-read
+    assert m._thickness() == pytest.approx(5e-6)

@@ -80,3 +80,31 @@ def test_validation(hip_lib):
     p.grad = torch.ones(3)
     with pytest.raises(RuntimeError, match="no CPU path"):
         o.step()
+
+
+def test_one_launch_for_all_tensors_equals_one_launch_per_tensor(hip_lib):
+    """gsr_adam_step_multi (the default: every tensor of a step in one launch, per-tensor learning rates in the kernel
+    arguments) against gsr_adam_step per tensor: bit-identical parameters and moments, including tensors that skip a step
+    (their bias correction then differs from the others': a launch of their own) and more than 16 tensors (two launches)."""
+    from gaustar_amd import optim
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(21)
+    shapes = [(4099, 3), (2051, 1, 3), (2051, 15, 3), (2051, 1), (7,), (1,), (260_000, 4)] + [(33 + i, 5) for i in range(14)]
+    mk = lambda: [torch.randn(*s, generator=torch.Generator().manual_seed(100 + i)).to(dev).requires_grad_(True) for i, s in enumerate(shapes)]
+    pa, pb = mk(), mk()
+    grp = lambda ps: [{"params": [p], "lr": 1e-3 * (1 + i)} for i, p in enumerate(ps)]
+    a, b = optim.Adam(grp(pa), eps=1e-15), optim.Adam(grp(pb), eps=1e-15)
+    b.multi_tensor = False
+    gen = torch.Generator(device=dev).manual_seed(4)
+    for it in range(7):
+        for i, (x, y) in enumerate(zip(pa, pb)):
+            if it == 2 and i in (1, 4):
+                x.grad = y.grad = None            # skipped once: their step count lags behind from here on
+                continue
+            gr = torch.randn(x.shape, device=dev, generator=gen)
+            x.grad, y.grad = gr.clone(), gr.clone()
+        a.step(); b.step()
+    for x, y in zip(pa, pb):
+        assert torch.equal(x, y)
+        assert torch.equal(a.state[x]["exp_avg"], b.state[y]["exp_avg"]) and torch.equal(a.state[x]["exp_avg_sq"], b.state[y]["exp_avg_sq"])
+        assert float(a.state[x]["step"]) == float(b.state[y]["step"])

@@ -261,3 +261,57 @@ def test_hip_mesh_producer_against_scipy_float64(hip_lib):
         q = quat.cpu().numpy().astype(np.float64)
         np.testing.assert_allclose(np.linalg.norm(q, axis=1), 1.0, atol=1e-6)
         np.testing.assert_allclose(crosscheck.quat_wxyz_to_matrix(q), R64, atol=5e-6)
+
+
+@pytest.mark.parametrize("lv,n_rest,view_on,dens_on", [(1, 0, False, False), (3, 8, True, True), (4, 15, True, False), (2, 15, False, True),
+                                                       (5, 24, True, True)])
+def test_points_colors_split_is_bit_identical_to_the_one_array_path(lv, n_rest, view_on, dens_on, hip_lib):
+    """producers.points_colors_split reads `_sh_coordinates_dc` / `_sh_coordinates_rest` where SuGaR keeps them and takes
+    sigmoid(all_densities) along: same bits as points_rgb / points_rgb_depth on torch.cat of the two + torch.sigmoid,
+    forward and backward (ragged P: the last wave's rows end inside a 64-row block)."""
+    from gaustar_amd import producers
+    g = torch.Generator(device="cuda").manual_seed(11 * lv + n_rest)
+    P = 64 * 37 + 29
+    pos = (torch.randn(P, 3, device="cuda", generator=g) * 0.5 + torch.tensor([0.0, 1.2, 0.0], device="cuda")).requires_grad_(True)
+    dc = (torch.rand(P, 1, 3, device="cuda", generator=g) * 2 - 1).requires_grad_(True)
+    rest = (0.3 * torch.randn(P, n_rest, 3, device="cuda", generator=g)).requires_grad_(True)
+    dens = (2.0 * torch.randn(P, 1, device="cuda", generator=g)).requires_grad_(True)
+    campos = torch.tensor([0.4, 1.5, 3.0], device="cuda")
+    view = torch.eye(4, device="cuda"); view[:3, :3] = torch.linalg.qr(torch.randn(3, 3, device="cuda", generator=g))[0]; view[3, :3] = torch.tensor([0.1, -1.0, 3.0])
+    C = 3 + (1 if view_on else 0)
+    d_col = torch.randn(P, C, device="cuda", generator=g)
+    d_op = torch.randn(P, 1, device="cuda", generator=g)
+
+    out = producers.points_colors_split(pos, campos, dc, rest, lv, view if view_on else None, 1, dens if dens_on else None)
+    col, op = out if dens_on else (out, None)
+    loss = (col * d_col).sum() + ((op * d_op).sum() if dens_on else 0.0)
+    loss.backward()
+    got = [t.grad.clone() for t in (pos, dc, rest)] + ([dens.grad.clone()] if dens_on else [])
+    for t in (pos, dc, rest, dens):
+        t.grad = None
+
+    sh = torch.cat([dc, rest], 1)
+    col_ref = producers.points_rgb_depth(pos, campos, sh, lv, view, depth_channels=1) if view_on else producers.points_rgb(pos, campos, sh, lv)
+    op_ref = torch.sigmoid(dens) if dens_on else None
+    loss = (col_ref * d_col).sum() + ((op_ref * d_op).sum() if dens_on else 0.0)
+    loss.backward()
+    want = [t.grad for t in (pos, dc, rest)] + ([dens.grad] if dens_on else [])
+    assert torch.equal(col, col_ref)
+    if dens_on:
+        assert torch.equal(op, op_ref)
+    for a, b, n in zip(got, want, ("positions", "sh_dc", "sh_rest", "densities")):
+        assert torch.equal(a, b), n
+
+
+def test_points_colors_split_validation(hip_lib):
+    from gaustar_amd import producers
+    pos = torch.zeros(8, 3, device="cuda"); dc = torch.zeros(8, 1, 3, device="cuda"); rest = torch.zeros(8, 3, 3, device="cuda")
+    cam = torch.zeros(3, device="cuda")
+    with pytest.raises(RuntimeError, match="sh_levels"):
+        producers.points_colors_split(pos, cam, dc, rest, 3)                       # 9 coefficients needed, 4 given
+    with pytest.raises(RuntimeError, match="sh_dc must be"):
+        producers.points_colors_split(pos, cam, dc[:, 0], rest, 2)
+    with pytest.raises(RuntimeError, match="densities"):
+        producers.points_colors_split(pos, cam, dc, rest, 2, None, 1, torch.zeros(7, 1, device="cuda"))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        producers.points_colors_split(pos.cpu(), cam, dc, rest, 2)

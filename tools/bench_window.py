@@ -10,16 +10,22 @@ frame, train_seq.py:101-244 / gaustar_trainers/refine.py:529-841) assembled from
 
 Not included (out of scope): mesh regularisers (pytorch3d), topology update (Open3D),
 flow warp.  Prints iterations/s over all frames and the loss at the start / end of every frame."""
-import argparse, gc, json, os, sys, time
+import argparse, ctypes, gc, json, os, sys, time
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from gaustar_amd import GaussianRasterizer, dist as gdist, harness, losses, optim, producers, scene
+from gaustar_amd import GaussianRasterizer, _lib, dist as gdist, harness, losses, optim, producers, scene
 
 MAX_DEPTH = 10.0
 
 
 def render4(model, ncam, bg4):
+    # RGB + depth-as-colour in one 4-channel pass through ONE autograd node (harness.SurfaceGaussians.render_channels)
+    return model.render_channels(ncam, bg4, depth_channels=1)[0]
+
+
+def render4_composed(model, ncam, bg4):
+    """The same render composed of autograd nodes (properties -> colours -> sigmoid -> rasterizer), as rounds 1-2 ran it."""
     settings, view, campos = model._settings(ncam, bg4, 0)
     pts = model.points
     colors4 = producers.points_rgb_depth(pts, campos, model.sh_coordinates, model.sh_levels, view, depth_channels=1)
@@ -29,6 +35,7 @@ def render4(model, ncam, bg4):
 
 
 def run(a):
+    render = render4_composed if getattr(a, "composed", False) else render4
     # torchrun: one process per GPU, one camera per rank per iteration, parameter gradients averaged over the ranks right
     # before the optimiser step (gaustar_amd.dist; GSR_BENCH_BACKEND=gloo lets ranks share a GPU for tests)
     backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")
@@ -49,6 +56,7 @@ def run(a):
     target = harness.SurfaceGaussians(verts, faces, 6, 3).to(dev)
     target.load_state_dict(model.state_dict())
     frames, n_it, per_it = [], 0, []
+    host_wait_ns = 0
     pts_start = model.points.detach().clone()
     t_total = 0.0
     for fi in range(a.frames):
@@ -57,7 +65,7 @@ def run(a):
             target._sh_coordinates_dc.add_(0.2 * torch.randn(N, 1, 3, device=dev, generator=g))
             gts = []
             for nc in ncams:
-                img = render4(target, nc, bg4)
+                img = render(target, nc, bg4)
                 d = img[3].clone()
                 d[d >= MAX_DEPTH - 1e-3] = 2 * MAX_DEPTH
                 gts.append((img[:3].clone(), d))
@@ -77,13 +85,14 @@ def run(a):
         # few thousand tensor / autograd objects of a frame stops the host for 50 - 80 ms -- one "iteration" of 73 ms in a
         # loop whose iterations take 0.85 (measured: tools/window_diag.py; gone with the collector off)
         gc.collect(); gc.disable()
+        _lib.load().gsr_debug_host_wait(None, None, 1)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         try:
             for it in range(a.iters):
                 marks[it].record()
                 ci = gdist.shard_views(len(ncams), fi * a.iters + it, rank, world)
                 opt.zero_grad(set_to_none=True)
-                img = render4(model, ncams[ci], bg4)
+                img = render(model, ncams[ci], bg4)
                 loss = losses.rgb_depth_loss(img, gts[ci][0], gts[ci][1], MAX_DEPTH, 0.2, 1.0, 0.5)
                 loss.backward()
                 if reducer is not None:
@@ -102,6 +111,9 @@ def run(a):
         marks[a.iters].record()
         torch.cuda.synchronize(); t_total += time.perf_counter() - t0
         gc.enable()
+        w_ns, w_n = ctypes.c_longlong(0), ctypes.c_longlong(0)
+        _lib.load().gsr_debug_host_wait(ctypes.byref(w_ns), ctypes.byref(w_n), 1)
+        host_wait_ns += w_ns.value
         frame_s = time.perf_counter() - t0
         per_it.extend(marks[i].elapsed_time(marks[i + 1]) for i in range(a.iters))
         n_it += a.iters
@@ -119,6 +131,9 @@ def run(a):
             # figure above also carries every frame's one-off costs: optimiser state allocation, first-use allocations)
             "median_ms_per_iteration": round(float(np.median(per_it)), 3), "p90_ms_per_iteration": round(float(np.percentile(per_it, 90)), 3),
             "slowest_iterations": [[int(i), round(float(per_it[i]), 2)] for i in np.argsort(per_it)[::-1][:4]],
+            # time the host spent in the forward's one wait per iteration (for the instance count): what is left of an
+            # iteration after it is the host's own work -- close to preprocess + scan (~40 us) means the host is the bound
+            "host_wait_ms_per_iteration": round(host_wait_ns / 1e6 / max(n_it, 1), 4),
             "geometry_moved": moved}
 
 
@@ -128,6 +143,7 @@ def main():
     ap.add_argument("--level", type=int, default=6); ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080); ap.add_argument("--cameras", type=int, default=160)
     ap.add_argument("--exchange", choices=["sharded", "allreduce"], default="sharded")
+    ap.add_argument("--composed", action="store_true", help="render through the composition of autograd nodes instead of the one-node render")
     r = run(ap.parse_args())
     if gdist.rank() == 0:
         print(json.dumps(r))
