@@ -139,11 +139,8 @@ def build_refinement_workload(device, rank, gs, cams, bg, overlap=True, solo=Fal
 def refinement_step(step, rank, world, model, ncams, opt, bg_t, dpix):
     ncam = ncams[(step * world + rank) % len(ncams)]
     opt.zero_grad(set_to_none=True)
-    settings, _view, campos = model._settings(ncam, bg_t, 0)
-    pts = model.points
-    rgb = model.get_points_rgb(positions=pts, camera_centers=campos, sh_levels=model.sh_levels)
-    color, _radii = GaussianRasterizer(settings)(means3D=pts, means2D=torch.zeros_like(pts), opacities=model.strengths,
-                                                 colors_precomp=rgb, scales=model.scaling, rotations=model.quaternions)
+    # parameters in, image out: mesh producer -> SH colours + sigmoid -> rasterizer as one autograd node (harness.py)
+    color, _radii = model.render_channels(ncam, bg_t, depth_channels=0)
     color.backward(dpix)
     opt.step()
     return color
