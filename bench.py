@@ -131,6 +131,7 @@ def build_refinement_workload(device, rank, gs, cams, bg, overlap=True, solo=Fal
               {"params": [model._scales, model._quaternions, model.all_densities, model._delta_t, model._delta_r], "lr": 0.0}]
     opt = gdist.ShardedAdam(groups, ready_order=model.grad_ready_order(), eps=1e-15, overlap=overlap, run_at_world_size_1=solo,
                             communicate=communicate)
+    model.grad_sink = opt   # the render's backward writes the parameter gradients straight into the optimiser's flat buffer
     bg_t = torch.from_numpy(np.ascontiguousarray(bg, dtype=np.float32)).to(device)
     dpix = torch.randn(3, cams[0].H, cams[0].W, device=device, generator=torch.Generator(device=device).manual_seed(1234 + rank))
     return model, ncams, opt, bg_t, dpix

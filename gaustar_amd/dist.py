@@ -443,6 +443,10 @@ class ShardedAdam:
         self.issued_early = 0
         self.reissued = 0
         self._hooks = []
+        # gradient sink (grad_views / written): parameters whose gradient a backward wrote straight into the flat buffer
+        self._sunk: set = set()
+        self._expect_hook: set = set()
+        self._views = None
         if overlap and self._comm:
             for p in order:
                 if p.requires_grad and hasattr(p, "register_post_accumulate_grad_hook"):
@@ -467,6 +471,35 @@ class ShardedAdam:
             h.remove()
         self._hooks = []
 
+    # ------------------------------------------------------------------ gradient sink
+    def grad_views(self) -> dict:
+        """{id(parameter): view of the flat gradient buffer, shaped like the parameter}.  A backward that controls where its
+        gradients are written (harness.SurfaceGaussians with `grad_sink = this optimiser`) writes them HERE and returns the
+        views to autograd: `p.grad` then aliases the buffer the reduce-scatter reads, the packing copy of the hook path (the
+        whole payload read and written once more per step, one kernel per parameter) disappears, and `written()` lets a
+        bucket leave while the rest of that backward is still being computed.  Only for parameters whose `.grad` is None
+        when the backward runs (an accumulating second backward must go through autograd's own addition)."""
+        if self._views is None:
+            self._views = {id(p): b["flat_g"][o:o + p.numel()].view(p.shape) for b in self.buckets for p, o in b["entries"]}
+        return self._views
+
+    def written(self, params) -> None:
+        """The gradients of `params` now sit in their grad_views() (kernels launched on the current stream): count them as
+        arrived and issue every bucket that is complete, in bucket order -- exactly what the post-accumulate hook does when
+        autograd delivers a gradient, only earlier.  The hook that fires for the same parameter later in this backward is
+        ignored once."""
+        for p in params:
+            if id(p) in self._sunk:          # a second delivery before the step: reduce the bucket again in step()
+                self.buckets[self._bucket_of[id(p)]]["dirty"] = True
+                continue
+            self._sunk.add(id(p))
+            if self._hooks:
+                self._expect_hook.add(id(p))
+            self._fired[id(p)] = self._fired.get(id(p), 0) + 1
+            self.buckets[self._bucket_of[id(p)]]["ready"] += 1
+        if self._hooks:                      # (no hooks = no overlap: step() issues everything)
+            self._issue_ready()
+
     def mark_dirty(self) -> None:
         """Gradients were edited in place after the backward: every bucket is reduced (again) by step() (see GradAllReducer)."""
         for b in self.buckets:
@@ -482,12 +515,17 @@ class ShardedAdam:
                 b["rs"].wait()
             b.update(rs=None, stamp=None, ready=0, dirty=False)
         self._fired = {}
+        self._sunk.clear(); self._expect_hook.clear()
 
-    @staticmethod
-    def _stamp(b):
-        return tuple((None if p.grad is None else (id(p.grad), p.grad._version)) for p, _ in b["entries"])
+    def _stamp(self, b):
+        # (a gradient delivered through the sink may be issued before autograd has set p.grad: its stamp is the sink's)
+        return tuple(("sunk" if id(p) in self._sunk else None if p.grad is None else (id(p.grad), p.grad._version))
+                     for p, _ in b["entries"])
 
     def _on_grad(self, p: torch.Tensor) -> None:
+        if id(p) in self._expect_hook:   # delivered through the sink earlier in this backward: already counted
+            self._expect_hook.discard(id(p))
+            return
         bi = self._bucket_of[id(p)]
         n = self._fired.get(id(p), 0) + 1
         self._fired[id(p)] = n
@@ -495,6 +533,9 @@ class ShardedAdam:
             self.buckets[bi]["dirty"] = True
             return
         self.buckets[bi]["ready"] += 1
+        self._issue_ready()
+
+    def _issue_ready(self) -> None:
         while True:   # bucket order only: every rank must enqueue the same sequence of collectives
             nxt = next((i for i, b in enumerate(self.buckets) if b["rs"] is None), None)
             if nxt is None or self.buckets[nxt]["ready"] < self.buckets[nxt]["need"]:
@@ -506,6 +547,10 @@ class ShardedAdam:
     def _pack(self, b) -> None:
         for p, o in b["entries"]:
             dst = b["flat_g"][o:o + p.numel()]
+            if p.grad is not None and p.grad.data_ptr() == dst.data_ptr():
+                continue                      # written in place through the sink and adopted by autograd as p.grad
+            if id(p) in self._sunk and (p.grad is None or not b["dirty"]):
+                continue                      # in place already; autograd has not delivered it yet, or kept a private copy
             if p.grad is None:
                 dst.zero_()
             else:
@@ -560,6 +605,7 @@ class ShardedAdam:
             b.update(rs=None, stamp=None, ready=0, dirty=False)
         for w in gathers:
             w.wait()
+        self._sunk.clear(); self._expect_hook.clear()
         from .optim import _bump_version
         for p in self._order:
             _bump_version(p)

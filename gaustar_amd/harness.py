@@ -135,12 +135,29 @@ class _RenderMeshBound(torch.autograd.Function):
             st.tanfovy, grad_color, None, 0, st.campos, geom, num_rendered, binning, img, st.debug, num_segments=num_segments,
             zeroed_scratch=zeroed)
         view = st.viewmatrix if cfg["depth_channels"] else None
+        # A gradient sink (dist.ShardedAdam: views of its flat gradient buffer) takes the parameter gradients where the
+        # reduce-scatter reads them, and hears about the colour producer's -- 70 % of the bytes -- BEFORE the mesh producer's
+        # backward is launched, so their buckets leave while that one still runs.  Only parameters without a gradient yet.
+        sink, params = cfg.get("sink"), cfg["params"]
+        views = sink.grad_views() if sink is not None else {}
+        buf = lambda p: views.get(id(p)) if (p is not None and p.grad is None) else None
+        p_verts, p_rs, p_rc, p_dens, p_dc, p_rest, p_dt, p_dr = params
+        o_dc, o_rest, o_dens = buf(p_dc), buf(p_rest), buf(p_dens)
         d_dc, d_rest, _, d_dens = producers._sh_backward_raw(points, _rasterizer._dev_f32(st.campos, points.device), dc, rest, D, M,
                                                              _rasterizer._dev_f32(view, points.device), cfg["depth_channels"], d_colors, opac, d_opac,
-                                                             dpos_inout=d_points)
+                                                             dpos_inout=d_points, out=(o_dc, o_rest if M > 1 else None, o_dens))
+        if sink is not None:
+            sink.written([p for p, o in ((p_dc, o_dc), (p_rest, o_rest if M > 1 else None), (p_dens, o_dens)) if o is not None])
+        o_mesh = (buf(p_verts), buf(p_rs), buf(p_rc), buf(p_dt), buf(p_dr))
         d_verts, d_rs, d_rc, d_dt, d_dr = producers._mesh_backward_raw(v, cfg["faces"], cfg["bary"], rs, rc, dr, cfg["lo"], cfg["hi"],
-                                                                       has_dt, d_points, d_scaling, d_quats)
-        return d_verts, d_rs, d_rc, d_dens.view(dens_shape), d_dc, d_rest, d_dt, d_dr, None
+                                                                       has_dt, d_points, d_scaling, d_quats, out=o_mesh)
+        if sink is not None:
+            sink.written([p for p, o in zip((p_verts, p_rs, p_rc, p_dt, p_dr), o_mesh) if o is not None and p is not None])
+        # (sink views go back to autograd as FRESH tensor objects: AccumulateGrad adopts an incoming gradient as p.grad only
+        # if nobody else holds that tensor object -- the optimiser's cached views would make it clone all 77 MB instead)
+        new = lambda t, o: t if (t is None or o is None) else t.view(t.shape)
+        return (new(d_verts, o_mesh[0]), new(d_rs, o_mesh[1]), new(d_rc, o_mesh[2]), d_dens.view(dens_shape), new(d_dc, o_dc),
+                new(d_rest, o_rest), new(d_dt, o_mesh[3]), new(d_dr, o_mesh[4]), None)
 
 
 class SurfaceGaussians(nn.Module):
@@ -180,6 +197,9 @@ class SurfaceGaussians(nn.Module):
             self._delta_t = nn.Parameter(torch.zeros(N, 3, device=dev))
             self._delta_r = nn.Parameter(torch.tensor([1.0, 0.0, 0.0, 0.0], device=dev).repeat(N, 1))
         self._geom_cache = None
+        # optional: an object with grad_views() / written(params) (gaustar_amd.dist.ShardedAdam) that receives the parameter
+        # gradients of render_channels' backward in place -- see _RenderMeshBound.backward
+        self.grad_sink = None
 
     # -------------------------------------------------------------------------------- construction from a checkpoint
     @classmethod
@@ -351,7 +371,11 @@ class SurfaceGaussians(nn.Module):
         cfg = {"settings": settings, "faces": self._surface_mesh_faces, "bary": self._bary_rows(), "depth_channels": int(depth_channels),
                "thickness": self._thickness(),
                "lo": float("-inf") if self.min_gaussian_scale is None else float(self.min_gaussian_scale),
-               "hi": float("inf") if self.max_gaussian_scale is None else float(self.max_gaussian_scale), "sh_levels": sh_deg + 1}
+               "hi": float("inf") if self.max_gaussian_scale is None else float(self.max_gaussian_scale), "sh_levels": sh_deg + 1,
+               "sink": getattr(self, "grad_sink", None),
+               "params": (self._points, self._scales, self._quaternions, self.all_densities, self._sh_coordinates_dc,
+                          self._sh_coordinates_rest, self._delta_t if self._loose_bind else None,
+                          self._delta_r if self._loose_bind else None)}
         if settings.campos.device != dev or settings.campos.dtype != torch.float32:
             raise RuntimeError("camera matrices must be float32 tensors on the model's device")
         return _RenderMeshBound.apply(self._points, self._scales, self._quaternions, self.all_densities, self._sh_coordinates_dc,

@@ -49,15 +49,17 @@ def _sh_forward_raw(pos, cam, sh, sh_rest, D, M, view, depth_channels, densities
     return colors, opacity
 
 
-def _sh_backward_raw(pos, cam, sh, sh_rest, D, M, view, depth_channels, g, opacity=None, dL_dopacity=None, dpos_inout=None):
+def _sh_backward_raw(pos, cam, sh, sh_rest, D, M, view, depth_channels, g, opacity=None, dL_dopacity=None, dpos_inout=None,
+                     out=(None, None, None)):
     """-> (dL_dsh, dL_dsh_rest or None, dL_dpos, dL_ddensities or None).  dpos_inout: a [P,3] gradient w.r.t. the positions
-    that takes this producer's on top (in place) instead of a fresh array."""
+    that takes this producer's on top (in place) instead of a fresh array.  out: contiguous float32 tensors to write
+    dL_dsh / dL_dsh_rest / dL_ddensities into instead of fresh ones (e.g. views of an optimiser's flat gradient buffer)."""
     lib = _lib.load()
     P = int(pos.size(0))
-    dsh = torch.empty_like(sh)
-    drest = torch.empty_like(sh_rest) if sh_rest is not None else None
+    dsh = out[0] if out[0] is not None else torch.empty_like(sh)
+    drest = (out[1] if out[1] is not None else torch.empty_like(sh_rest)) if sh_rest is not None else None
     dpos = dpos_inout if dpos_inout is not None else torch.empty_like(pos)
-    ddens = torch.empty_like(opacity) if opacity is not None else None
+    ddens = (out[2] if out[2] is not None else torch.empty_like(opacity)) if opacity is not None else None
     with _host.on_device(pos.device):
         if sh_rest is None and opacity is None and dpos_inout is None:
             if view is None:
@@ -210,15 +212,17 @@ def _mesh_forward_raw(v, fc, bc, rs, rc, thickness, lo, hi, dt, dr):
     return points, scaling, quats
 
 
-def _mesh_backward_raw(v, fc, bc, rs, rc, dr, lo, hi, has_dt, g_points, g_scaling, g_quats):
-    """-> (d_verts, d_raw_scales, d_raw_complex, d_delta_t or None, d_delta_r or None); absent output gradients are None."""
+def _mesh_backward_raw(v, fc, bc, rs, rc, dr, lo, hi, has_dt, g_points, g_scaling, g_quats, out=(None,) * 5):
+    """-> (d_verts, d_raw_scales, d_raw_complex, d_delta_t or None, d_delta_r or None); absent output gradients are None.
+    out: contiguous float32 tensors to write the five gradients into instead of fresh ones."""
     lib = _lib.load()
     dev = v.device
     F, G, V = int(fc.size(0)), int(bc.size(0)), int(v.size(0))
-    d_verts = torch.empty_like(v)
-    d_rs, d_rc = torch.empty_like(rs), torch.empty_like(rc)
-    d_dt = torch.empty(F * G, 3, dtype=torch.float32, device=dev) if has_dt else None
-    d_dr = torch.empty_like(dr) if dr is not None else None
+    pick = lambda o, make: o if o is not None else make()
+    d_verts = pick(out[0], lambda: torch.empty_like(v))
+    d_rs, d_rc = pick(out[1], lambda: torch.empty_like(rs)), pick(out[2], lambda: torch.empty_like(rc))
+    d_dt = pick(out[3], lambda: torch.empty(F * G, 3, dtype=torch.float32, device=dev)) if has_dt else None
+    d_dr = pick(out[4], lambda: torch.empty_like(dr)) if dr is not None else None
     with _host.on_device(dev):
         _lib.check(lib.gsr_mesh_gaussians_backward(
             F, G, V, _p(v), _p(fc), _p(bc), _p(rs), _p(rc), lo, hi, _op(dr), _op(g_points), _op(g_scaling), _op(g_quats),

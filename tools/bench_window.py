@@ -76,6 +76,7 @@ def run(a):
         if sharded:   # reduce-scatter -> Adam on this rank's 1/N -> all-gather (dist.ShardedAdam), the default for N > 1
             reducer = None
             opt = gdist.ShardedAdam(groups, ready_order=model.grad_ready_order(), eps=1e-15)
+            model.grad_sink = None if getattr(a, "composed", False) else opt   # gradients land in the flat buffer directly
         else:         # all-reduce + the same Adam step on every rank
             reducer = gdist.GradAllReducer(model.grad_ready_order()) if world > 1 else None
             opt = optim.Adam(groups, eps=1e-15)
@@ -108,6 +109,7 @@ def run(a):
         if sharded:
             early, payload = opt.issued_early, opt.payload_bytes()
             opt.close()
+            model.grad_sink = None
         marks[a.iters].record()
         torch.cuda.synchronize(); t_total += time.perf_counter() - t0
         gc.enable()
