@@ -168,3 +168,22 @@ def test_thickness_is_read_back_once(hip_lib):
     with torch.no_grad():
         m.surface_mesh_thickness.fill_(5e-6)          # in-place change: version bump -> re-read
     assert m._thickness() == pytest.approx(5e-6)
+
+
+def test_one_node_render_with_constant_colours_only(hip_lib):
+    """sh_levels = 1: `_sh_coordinates_rest` is an empty [N,0,3] parameter -- the one-node render reads the dc array alone and
+    returns an empty gradient for the empty parameter."""
+    from gaustar_amd import harness, scene
+    v, f = scene.icosphere(2, radius=0.9, center=(0.0, 1.2, 0.0))
+    m = harness.SurfaceGaussians(torch.from_numpy(v).float().cuda(), torch.from_numpy(f).long().cuda(), sh_levels=1)
+    with torch.no_grad():
+        m._sh_coordinates_dc.copy_(torch.rand(m.n_points, 1, 3, generator=torch.Generator().manual_seed(2)) * 2 - 1)
+    ncam = harness.nerf_camera_from_scene(scene.look_at_camera((0.7, 1.7, 2.6), (0.0, 1.2, 0.0), 160, 120, focal_px=130.0))
+    bg = torch.tensor([0.0, 1.0, 0.0, 10.0], device="cuda")
+    img, _ = m.render_channels(ncam, bg, depth_channels=1)
+    img.sum().backward()
+    assert tuple(m._sh_coordinates_rest.shape) == (m.n_points, 0, 3)
+    assert m._sh_coordinates_rest.grad is None or m._sh_coordinates_rest.grad.numel() == 0
+    assert float(m._sh_coordinates_dc.grad.abs().max()) > 0 and torch.isfinite(m._points.grad).all()
+    ref = m.render_image_gaussian_rasterizer(ncam, bg_color=[0.0, 1.0, 0.0])
+    assert torch.equal(img[:3].permute(1, 2, 0), ref)
