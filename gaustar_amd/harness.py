@@ -322,6 +322,12 @@ class SurfaceGaussians(nn.Module):
         dev = self.device
         bg = torch.zeros(3, device=dev) if bg_color is None else torch.as_tensor(bg_color, dtype=torch.float32, device=dev)
         sh_deg = self.sh_levels - 1 if sh_deg is None else int(sh_deg)
+        if (positions is None and point_colors is None and quaternions is None and not compute_color_in_rasterizer
+                and not use_solid_surface and not use_same_scale_in_all_directions
+                and not (return_2d_radii or return_opacities or return_colors)):
+            # the plain call (what the refinement loop issues, refine.py:552): the whole render as one autograd node
+            img, _ = self.render_channels(camera, bg, sh_deg=sh_deg, depth_channels=0)
+            return img.transpose(0, 1).transpose(1, 2)                        # :1298
         settings, _view, campos = self._settings(camera, bg, sh_deg)
         positions = self.points if positions is None else positions
         shs = splat_colors = None

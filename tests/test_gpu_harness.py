@@ -185,5 +185,6 @@ def test_one_node_render_with_constant_colours_only(hip_lib):
     assert tuple(m._sh_coordinates_rest.shape) == (m.n_points, 0, 3)
     assert m._sh_coordinates_rest.grad is None or m._sh_coordinates_rest.grad.numel() == 0
     assert float(m._sh_coordinates_dc.grad.abs().max()) > 0 and torch.isfinite(m._points.grad).all()
-    ref = m.render_image_gaussian_rasterizer(ncam, bg_color=[0.0, 1.0, 0.0])
+    ref = m.render_image_gaussian_rasterizer(ncam, bg_color=[0.0, 1.0, 0.0], return_opacities=True)["image"]   # (the composition of nodes)
     assert torch.equal(img[:3].permute(1, 2, 0), ref)
+    assert torch.equal(m.render_image_gaussian_rasterizer(ncam, bg_color=[0.0, 1.0, 0.0]), ref)                  # (the plain call: one node)
