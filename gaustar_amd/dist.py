@@ -430,7 +430,13 @@ class ShardedAdam:
                      exp_avg=torch.zeros(S, dtype=torch.float32, device=dev), exp_avg_sq=torch.zeros(S, dtype=torch.float32, device=dev),
                      need=sum(1 for p, _ in b["entries"] if p.requires_grad), ready=0, rs=None, stamp=None, dirty=False)
             lo, hi = self.rank * S, (self.rank + 1) * S
-            b["shard_g"] = b["flat_g"][lo:hi]
+            # The reduction lands in a buffer of its OWN (1/N of the bucket), not in place: with a gradient sink p.grad aliases
+            # flat_g, and a second backward before the step must find this rank's LOCAL gradient there to add to -- an in-place
+            # reduce-scatter had replaced this rank's shard of it by the sum over ranks, which the re-issued reduction then
+            # counted twice (found by tests/test_dist.py::test_sharded_adam_gradient_sink_gloo_world2).
+            # (Nothing is exchanged without communication: the "reduced" shard then IS the local gradient.)
+            b["shard_g"] = torch.zeros(S, dtype=torch.float32, device=dev) if self._comm else b["flat_g"][lo:hi]
+            b["shard_lo"] = lo
             # (parameter, shard) intersections: (param, group, start in the shard, start in the flat buffer, length)
             b["segments"] = []
             for p, o in b["entries"]:
@@ -561,12 +567,15 @@ class ShardedAdam:
         b = self.buckets[bi]
         self._pack(b)
         b["stamp"] = self._stamp(b)
+        lo = b["shard_lo"]
         if not self._comm:
             b["rs"] = _Done()
             return
         backend = dist.get_backend() if dist.is_initialized() else "none"
-        if backend == "gloo":   # no reduce-scatter in gloo: all-reduce, keep the shard (tests)
-            b["rs"] = dist.all_reduce(b["flat_g"], op=dist.ReduceOp.SUM, async_op=True)
+        if backend == "gloo":   # no reduce-scatter in gloo: all-reduce a copy, keep the shard (tests)
+            tmp = b["flat_g"].clone()
+            b["rs"] = _Then(dist.all_reduce(tmp, op=dist.ReduceOp.SUM, async_op=True),
+                            lambda: b["shard_g"].copy_(tmp[lo:lo + b["S"]]))
         else:
             b["rs"] = dist.reduce_scatter_tensor(b["shard_g"], b["flat_g"], op=dist.ReduceOp.SUM, async_op=True)
 
@@ -635,3 +644,17 @@ class ShardedAdam:
 class _Done:
     def wait(self):
         return True
+
+
+class _Then:
+    """An asynchronous work handle plus something to do once it has completed (first wait() only)."""
+
+    def __init__(self, work, after):
+        self.work, self.after = work, after
+
+    def wait(self):
+        r = self.work.wait()
+        if self.after is not None:
+            self.after()
+            self.after = None
+        return r

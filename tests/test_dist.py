@@ -258,6 +258,94 @@ def test_sharded_adam_gloo_world2():
         assert reissued >= 1, res                # the second backward of step 4 invalidated an early bucket
 
 
+class _SinkLoss(torch.autograd.Function):
+    """sum_i c_i (p_i ** 2).sum() whose backward writes the gradients where a gradient sink wants them (the shape of
+    harness._RenderMeshBound.backward: two stages with a `written` notification after each, fresh view objects returned)."""
+
+    @staticmethod
+    def forward(ctx, sink, coeffs, *ps):
+        ctx.sink, ctx.coeffs, ctx.params = sink, coeffs, ps
+        ctx.save_for_backward(*[p.detach() for p in ps])
+        return sum(c * (p.detach() ** 2).sum() for c, p in zip(coeffs, ps))
+
+    @staticmethod
+    def backward(ctx, g):
+        views = ctx.sink.grad_views()
+        outs, stage = [], []
+        for i, (c, p, x) in enumerate(zip(ctx.coeffs, ctx.params, ctx.saved_tensors)):
+            o = views.get(id(p)) if p.grad is None else None
+            val = 2.0 * c * x * g
+            if o is not None:
+                o.copy_(val); stage.append(p); outs.append(o.view(o.shape))
+            else:
+                outs.append(val)
+            if i == 1:                       # "the colour producer's backward is launched": its parameters may leave
+                ctx.sink.written(stage); stage = []
+        ctx.sink.written(stage)
+        return (None, None, *outs)
+
+
+def _sink_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from gaustar_amd import dist as gd
+    gd.init_from_env("gloo")
+    torch.manual_seed(0)
+    shapes = [(5000, 2), (9, 4), (1001, 3), (77,)]
+    ps = [torch.nn.Parameter(torch.randn(*s)) for s in shapes]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    groups = lambda xs: [{"params": [xs[0], xs[1]], "lr": 1e-2}, {"params": [xs[2], xs[3]], "lr": 3e-3}]
+    opt = gd.ShardedAdam(groups(ps), ready_order=ps, eps=1e-15, bucket_bytes=20_000, segment_step=torch_adam_segment)
+    ref = torch.optim.Adam(groups(qs), eps=1e-15)
+    w = lambda r: [(i + 1.0) * (r + 1.0) for i in range(4)]
+    aliased, early = [], []
+    for it in range(5):
+        opt.zero_grad(); ref.zero_grad()
+        _SinkLoss.apply(opt, w(rank), *ps).backward()
+        views = opt.grad_views()
+        aliased.append(sum(1 for p in ps if p.grad is not None and p.grad.data_ptr() == views[id(p)].data_ptr()))
+        if it == 2:      # a second backward before the step: gradients exist, so it goes through autograd's addition + the hooks
+            _SinkLoss.apply(opt, [0.5 * c for c in w(rank)], *ps).backward()
+        if it == 3:      # and a plain autograd backward on top (regulariser)
+            (0.25 * ps[0].sum()).backward()
+        lr_ = sum(0.5 * sum(c * (p ** 2).sum() for c, p in zip(w(r), qs)) for r in range(2))
+        if it == 2:
+            lr_ = lr_ + sum(0.5 * sum(0.5 * c * (p ** 2).sum() for c, p in zip(w(r), qs)) for r in range(2))
+        if it == 3:
+            lr_ = lr_ + 0.25 * qs[0].sum()
+        lr_.backward()
+        opt.step(); ref.step()
+        early.append(opt.issued_early)
+    err = max(float((p - q_).abs().max()) for p, q_ in zip(ps, qs))
+    flat = torch.cat([p.detach().reshape(-1) for p in ps])
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    torch.distributed.all_gather(both, flat)
+    q.put((rank, err, bool(torch.equal(both[0], both[1])), aliased, early, opt.reissued))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_sharded_adam_gradient_sink_gloo_world2():
+    """ShardedAdam.grad_views() / written(): a backward that writes its gradients straight into the flat exchange buffer
+    (as harness._RenderMeshBound does on the GPU) -- p.grad aliases the buffer, the first stage's buckets leave before the
+    second stage, a second sink backward and a plain autograd backward before a step are reduced again -- equals
+    torch.optim.Adam on the averaged gradients, and both ranks end bit-identical."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sink_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, same, aliased, early, reissued in res:
+        assert err < 2e-6 and same, res
+        assert aliased == [4, 4, 4, 4, 4], res      # every first backward's gradients were adopted in place
+        assert max(early) >= 1 and reissued >= 2, res
+
+
 def _reissue_worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
