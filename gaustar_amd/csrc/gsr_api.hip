@@ -724,7 +724,7 @@ int gsr_mesh_gaussians_backward(int F, int G, int V, const float* verts, const l
     if (V < 0) return fail_msg("gsr_mesh_gaussians_backward: negative V");
     if (V > 0 && !dL_dverts) return fail_msg("gsr_mesh_gaussians_backward: dL_dverts is null");
     hipStream_t st = (hipStream_t)stream;
-    if (V > 0) GSR_CHECK(hipMemsetAsync(dL_dverts, 0, sizeof(float) * 3 * (size_t)V, st));
+    if (V > 0) launch_zero_f32(dL_dverts, 3 * (size_t)V, st);
     if (F <= 0) return 0;
     if (G <= 0 || G > 64) return fail_msg("gsr_mesh_gaussians_backward: Gaussians per face must be 1..64");
     if (!verts || !faces || !bary || !raw_scales || !raw_complex || !dL_draw_scales || !dL_draw_complex)

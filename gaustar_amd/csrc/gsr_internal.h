@@ -199,6 +199,7 @@ void launch_sh_to_rgb_bwd(int P, int D, int M, const float* positions, const flo
                           const float* shs_rest, const float* view, int depth_channels, const float* dL_dout, float* dL_dsh,
                           float* dL_dsh_rest, float* dL_dpos, int accumulate_pos, const float* opacity, const float* dL_dopacity,
                           float* dL_ddensity, hipStream_t st);
+void launch_zero_f32(float* p, size_t n, hipStream_t st);
 struct AdamTensor { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; long long n; float step_size; unsigned block0; };
 constexpr int ADAM_BATCH = 16;
 struct AdamBatch { AdamTensor t[ADAM_BATCH]; int count; unsigned blocks; };

@@ -525,6 +525,26 @@ void launch_mesh_gaussians_bwd(int F, int G, const float* verts, const long long
                                                               dL_draw_scales, dL_draw_complex, dL_ddelta_t, dL_ddelta_r);
 }
 
+// Zero fill of a small array (the vertex-gradient accumulator in front of the mesh producer's backward): hipMemsetAsync of
+// 0.5 MB goes out as TWO runtime kernels (aligned body + remainder), 10 us on the stream for what one launch does in 2.
+__global__ void __launch_bounds__(256) zero_f32_kernel(float* __restrict__ p, size_t n)
+{
+    const size_t n4 = n >> 2;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) p4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t t = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < n) p[t] = 0.f;
+}
+
+void launch_zero_f32(float* p, size_t n, hipStream_t st)
+{
+    if (n == 0) return;
+    if (((uintptr_t)p & 15u) != 0) { (void)hipMemsetAsync(p, 0, n * sizeof(float), st); return; }
+    size_t blocks = ((n >> 2) + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    zero_f32_kernel<<<(unsigned)blocks, 256, 0, st>>>(p, n);
+}
+
 // view == nullptr: rgb [P,3]; otherwise rgb + depth-as-colour [P, 3 + depth_channels] (gsr_sh_to_rgbd)
 // rows of 25 coefficients (degree 4) stage 77 KB per workgroup: above the 64 KB a kernel may take without asking
 static void sh_lds_limit(const void* fn, size_t bytes)

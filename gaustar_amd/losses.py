@@ -75,6 +75,7 @@ class _L1DSSIM(torch.autograd.Function):
         ctx.grad_full = grad_full
         ctx.pred_shape = pred.shape
         ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)   # no zero-filled "gradient" of the parts vector per backward (one fill kernel)
         return out[0], out
 
     @staticmethod
@@ -132,6 +133,7 @@ class _DepthL1(torch.autograd.Function):
                 _stream()), "gsr_depth_l1")
         ctx.grad = grad
         ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)   # no zero-filled "gradient" of the parts vector per backward (one fill kernel)
         return out[0] + out[1], out
 
     @staticmethod
@@ -201,6 +203,7 @@ class _RGBDepthLoss(torch.autograd.Function):
         ctx.grad6 = grad6
         ctx.in_dtype = img6.dtype
         ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)   # no zero-filled "gradient" of the parts vector per backward (one fill kernel)
         return out[0] + out[3] + out[4], out
 
     @staticmethod
