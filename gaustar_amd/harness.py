@@ -201,6 +201,15 @@ class SurfaceGaussians(nn.Module):
         # gradients of render_channels' backward in place -- see _RenderMeshBound.backward
         self.grad_sink = None
 
+    def __getstate__(self):
+        """copy.deepcopy / pickle of the model: the gradient sink (an optimiser with process-group handles and hooks on THIS
+        model's parameters) and the per-object caches stay behind."""
+        d = self.__dict__.copy()
+        for k in ("grad_sink", "_geom_cache", "_thickness_cache", "_bary_rows_cache"):
+            if k in d:
+                d[k] = None
+        return d
+
     # -------------------------------------------------------------------------------- construction from a checkpoint
     @classmethod
     def from_checkpoint(cls, ckpt: Dict, device, **kw) -> "SurfaceGaussians":

@@ -70,3 +70,24 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "gsr_oracle" not in src and "libgsr_ref" not in src, f
+
+
+def test_model_copies_leave_the_gradient_sink_behind():
+    """harness.SurfaceGaussians on CPU tensors (construction launches nothing): deepcopy / pickle keep parameters and buffers
+    and drop the gradient sink and the per-object caches (an optimiser with hooks on the ORIGINAL's parameters must not be
+    cloned along); the thickness is read back once per value."""
+    import copy
+    import pickle
+    import torch
+    from gaustar_amd import harness, scene
+    v, f = scene.icosphere(1, 1.0, (0.0, 0.0, 0.0))
+    m = harness.SurfaceGaussians(torch.from_numpy(v).float(), torch.from_numpy(f).long(), 3, 2, surface_mesh_thickness=2e-6,
+                                 loose_bind=True)
+    assert m._thickness() == 2e-6 or abs(m._thickness() - 2e-6) < 1e-12
+    m.grad_sink = object()
+    for c in (copy.deepcopy(m), pickle.loads(pickle.dumps(m))):
+        assert c.grad_sink is None and c._geom_cache is None and c._thickness_cache is None
+        assert all(torch.equal(a, b) for a, b in zip(c.state_dict().values(), m.state_dict().values()))
+        assert c._points is not m._points
+    assert m.grad_sink is not None
+    assert [tuple(p.shape) for p in m.grad_ready_order()][-1] == tuple(m._points.shape)
