@@ -198,9 +198,24 @@ def cpu_baseline(gs, cams, bg, budget_s=20.0):
         oracle.backward(st, dpix)
         t_total += time.perf_counter() - t0
         n += 1
-    return {"value": n / t_total, "unit": "views/s", "cores": ncores, "kind": "port",
-            "sample": f"first {n} of the 160 views of the same workload (491520 Gaussians, 1920x1080, fwd+bwd), "
-                      f"C restatement of the reference algorithm with OpenMP over {ncores} threads, {t_total:.1f} s"}
+    out = {"value": n / t_total, "unit": "views/s", "cores": ncores, "kind": "port",
+           "sample": f"first {n} of the 160 views of the same workload (491520 Gaussians, 1920x1080, fwd+bwd), "
+                     f"C restatement of the reference algorithm with OpenMP over {ncores} threads, {t_total:.1f} s"}
+    try:   # SURVEY.md 8d's own form of the CPU figure: configs[0] (10k random Gaussians, 512x512), median of 7 runs
+        ga, ca, bga = scene.config_A()
+        dA = rng.normal(size=(3, ca.H, ca.W)).astype(np.float32)
+        ts = []
+        for _ in range(7):
+            t0 = time.perf_counter()
+            st = oracle.forward(ga.means3D, ga.opacities, ca.viewmatrix, ca.projmatrix, ca.campos, ca.W, ca.H, ca.tanfovx,
+                                ca.tanfovy, bga, colors_precomp=ga.colors_precomp, scales=ga.scales, rotations=ga.rotations)
+            oracle.backward(st, dA)
+            ts.append(time.perf_counter() - t0)
+        out["config_A"] = {"median_ms_per_view": round(float(np.median(ts)) * 1e3, 3), "runs": 7,
+                           "what": "BASELINE configs[0]: 10k random Gaussians, one camera at 512x512, fwd+bwd, same C port and threads"}
+    except Exception as ex:
+        out["config_A"] = {"error": repr(ex)[:200]}
+    return out
 
 
 def issue_statistics(lib, rs, params, device):
