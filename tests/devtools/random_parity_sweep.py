@@ -16,7 +16,7 @@ for case in range(N):
     W, H = int(rng.integers(1, 260)), int(rng.integers(1, 200))
     P = int(rng.choice([1, 7, 100, 1500, 6000]))
     deg = int(rng.integers(0, 4))
-    mode = rng.choice(["sh", "rgb", "rgb6"])
+    mode = rng.choice(["sh", "rgb", "rgb6", "rgb4"])
     s_lo = float(rng.choice([0.005, 0.03, 0.2]))
     gs = scene.random_gaussians(P, rng, sh_degree=deg, with_sh=(mode == "sh"), scale_range=(s_lo, s_lo * float(rng.choice([2, 10]))))
     lo = float(rng.choice([0.003, 0.3, 0.9]))
@@ -32,13 +32,20 @@ for case in range(N):
     hip = None
     try:
         st, g = parity.run_oracle(kw, dpix)
-        if mode == "rgb6":
+        if mode in ("rgb6", "rgb4"):
+            NX = 3 if mode == "rgb6" else 1      # rgb4: RGB + ONE scalar target (the oracle renders it three times over)
             extra = rng.uniform(0, 3, (P, 3)).astype(np.float32)
+            if NX == 1:
+                extra[:, 1:] = extra[:, :1]
             kw2 = dict(kw, colors_precomp=extra, bg=np.full(3, 7.0, np.float32))
             d2 = rng.normal(size=(3, H, W)).astype(np.float32)
+            if NX == 1:
+                d2[1:] = 0.0
             st2, g2 = parity.run_oracle(kw2, d2)
-            kw6 = dict(kw, colors_precomp=np.concatenate([gs.colors_precomp, extra], 1), bg=np.concatenate([kw["bg"], kw2["bg"]]))
-            hip = parity.run_hip(kw6, np.concatenate([dpix, d2]))
+            if NX == 1:                           # the three identical colour columns share one gradient: their sum
+                st2 = dict(st2, color=st2["color"][:1]); g2 = dict(g2, dL_dcolors=np.asarray(g2["dL_dcolors"]).sum(1, keepdims=True))
+            kw6 = dict(kw, colors_precomp=np.concatenate([gs.colors_precomp, extra[:, :NX]], 1), bg=np.concatenate([kw["bg"], kw2["bg"][:NX]]))
+            hip = parity.run_hip(kw6, np.concatenate([dpix, d2[:NX]]))
             nflip = int((hip["radii"] != st["radii"]).sum())
             assert nflip <= 2, f"radii differ in {nflip} entries"
             flips += nflip
@@ -55,7 +62,7 @@ for case in range(N):
         # One (pixel, Gaussian) pair sitting within an ulp of a hard threshold (alpha >= 1/255, T < 1e-4) may fall on the other
         # side of it here than in the oracle -- the two evaluate the exponent with different roundings.  It shows as ONE or
         # two pixels off by up to alpha*T*c and a gradient difference confined to that pair; anything wider is a failure.
-        img_ref = st["color"] if mode != "rgb6" else np.concatenate([st["color"], st2["color"]])
+        img_ref = st["color"] if mode not in ("rgb6", "rgb4") else np.concatenate([st["color"], st2["color"]])
         off = int((np.abs(hip["color"] - img_ref).max(0) > 1e-4).sum()) if hip is not None and hip["color"].shape == img_ref.shape else 99
         if 1 <= off <= 2:
             pair_flips += 1
