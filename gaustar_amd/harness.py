@@ -393,6 +393,8 @@ class SurfaceGaussians(nn.Module):
                           self._delta_r if self._loose_bind else None)}
         if settings.campos.device != dev or settings.campos.dtype != torch.float32:
             raise RuntimeError("camera matrices must be float32 tensors on the model's device")
+        if cfg["sink"] is not None and not (hasattr(cfg["sink"], "grad_views") and hasattr(cfg["sink"], "written")):
+            raise TypeError("grad_sink must provide grad_views() and written(params) (gaustar_amd.dist.ShardedAdam)")
         return _RenderMeshBound.apply(self._points, self._scales, self._quaternions, self.all_densities, self._sh_coordinates_dc,
                                       self._sh_coordinates_rest, self._delta_t if self._loose_bind else None,
                                       self._delta_r if self._loose_bind else None, cfg)
