@@ -264,6 +264,73 @@ def issue_statistics(lib, rs, params, device):
             "bwd_live_lanes_per_pair_trip": round(live / max(trips, 1), 2), "num_rendered": int(Rn), "units": int(U)}
 
 
+def other_config(name, device, lib, steps=20, repeats=3):
+    """BASELINE.json's other single-GPU configs through the same public API, outside the timed region: B (configs[1]: 200 400
+    mesh-bound Gaussians, precomputed colours), D (configs[3]: 1 001 232 Gaussians, SH degree 3 evaluated in the kernels;
+    refine.py:552's pass) and D_depth (the same geometry, depth as colour with bg = 10; refine.py:607's pass).  Per config:
+    median ms per view over `repeats` regions of `steps` forward + backward passes, num_rendered, the algorithmic bytes of
+    SURVEY.md 8(d) with the config's own beta_P (464 for M = 0, 494 + 48 M for in-kernel SH: 1 262 at M = 16), per-kernel
+    HIP-event means with each kernel's share of those bytes, and the fraction of the 8 TB/s roofline for the path and for
+    the kernel with the best and the largest figure."""
+    from gaustar_amd import rasterizer as rz
+    gs, cam, bg = scene.config_B() if name == "B" else scene.config_D()
+    t = lambda x, g=False: None if x is None else torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(device).requires_grad_(g)
+    shs, cols, deg = gs.shs, gs.colors_precomp, gs.sh_degree
+    if name == "D_depth":
+        shs, cols, deg, bg = None, scene.view_depth_colors(gs, cam), 0, np.array([10.0, 10.0, 10.0], np.float32)
+    M = 0 if shs is None else int(shs.shape[1])
+    m3, op, sc, ro = t(gs.means3D, True), t(gs.opacities, True), t(gs.scales, True), t(gs.rotations, True)
+    sh_t, col_t = t(shs, True), t(cols, True)
+    m2 = torch.zeros(gs.P, 3, device=device, requires_grad=True)
+    st = GaussianRasterizationSettings(cam.H, cam.W, cam.tanfovx, cam.tanfovy, t(bg), 1.0, t(cam.viewmatrix), t(cam.projmatrix), deg,
+                                       t(cam.campos), False, False)
+    r = GaussianRasterizer(st)
+    dp = torch.randn(3, cam.H, cam.W, device=device, generator=torch.Generator(device=device).manual_seed(99))
+    leaves = [x for x in (m3, op, sc, ro, sh_t, col_t, m2) if x is not None]
+
+    def step(_s):
+        for x in leaves:
+            x.grad = None
+        img, _ = r(means3D=m3, means2D=m2, opacities=op, shs=sh_t, colors_precomp=col_t, scales=sc, rotations=ro)
+        img.backward(dp)
+    for s_ in range(4):
+        step(s_)
+    dts = [timed(step, steps, 1, device) for _ in range(repeats)]
+    ms = float(np.median(dts)) / steps * 1e3
+    nst = lib.gsr_num_stages()
+    names = [lib.gsr_stage_name(i).decode() for i in range(nst)]
+    msv = (ctypes.c_float * nst)()
+    cnt = (ctypes.c_int * nst)()
+    lib.gsr_profile_enable(1)
+    timed(step, steps, 1, device)
+    _lib.check(lib.gsr_profile_read(msv, cnt, 1), "gsr_profile_read")
+    lib.gsr_profile_enable(0)
+    e = torch.Tensor([])
+    Rn = rz.rasterize_gaussians_native(st.bg, m3.detach(), e if col_t is None else col_t.detach(), op.detach(), sc.detach(), ro.detach(),
+                                       1.0, e, st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy, cam.H, cam.W,
+                                       e if sh_t is None else sh_t.detach(), deg, st.campos, False, False)[0]
+    total_b, per_kernel_b = algorithmic_bytes(gs.P, Rn, cam.W, cam.H, M)
+    kern = {}
+    for i, nme in enumerate(names):
+        if cnt[i]:
+            lps, mean_ms = cnt[i] / steps, msv[i] / cnt[i]
+            gbs = per_kernel_b.get(nme, 0) / lps / (mean_ms * 1e-3) / 1e9
+            kern[nme] = {"ms_per_launch": round(mean_ms, 5), "launches_per_step": lps, "alg_bytes_per_step": int(per_kernel_b.get(nme, 0)),
+                         "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    dom = max(kern, key=lambda k_: kern[k_]["ms_per_launch"] * kern[k_]["launches_per_step"])
+    best = max(kern, key=lambda k_: kern[k_]["frac"])
+    path_gbs = total_b / (ms * 1e-3) / 1e9
+    out = {"gaussians": gs.P, "sh_coeffs_in_kernel": M, "beta_P": 464 if M == 0 else 494 + 48 * M, "image": [cam.W, cam.H],
+           "ms_per_view": round(ms, 4), "views_per_s": round(1e3 / ms, 1),
+           "ms_per_view_min_max": [round(min(dts) / steps * 1e3, 4), round(max(dts) / steps * 1e3, 4)], "steps": steps, "repeats": repeats,
+           "num_rendered": int(Rn), "alg_bytes_per_view": int(total_b), "path_achieved_GBps": round(path_gbs, 1),
+           "path_frac": round(path_gbs / HBM_PEAK_GBS, 4), "dominant_kernel": dom, "dominant_frac": kern[dom]["frac"],
+           "best_kernel": best, "best_frac": kern[best]["frac"], "kernels": kern}
+    del m3, op, sc, ro, sh_t, col_t, m2, r, dp, leaves
+    torch.cuda.empty_cache()
+    return out
+
+
 def window_benchmark():
     """BASELINE.json configs[4]'s shape at config-C size on this GPU (tools/bench_window.py: 2 frames x 50 iterations,
     491 520 Gaussians, 1080p, 160 cameras; producers -> one 4-channel render -> losses -> backward -> Adam)."""
@@ -315,6 +382,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the window / reference-GPU / issue-statistics legs (N = 1 only)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the K-step timed region is run this many times back to back (modes interleaved); the MEDIAN is reported")
+    ap.add_argument("--scale-step", action="store_true",
+                    help="N = 1: time the refinement step that --gpus N > 1 times (producers + render + Adam) instead of the rasterizer "
+                         "alone, so that value(N) / value(1) is the scaling of ONE thing (also GSR_BENCH_SCALE_STEP=1)")
     ap.add_argument("--views-in-flight", type=int, default=2,
                     help="N = 1: independent view pipelines (host thread + HIP stream each, gaustar_amd.pipelines); 1 = one view at a time")
     args = ap.parse_args()
@@ -343,6 +415,11 @@ def main():
     lib = _lib.load()
 
     gs, cams, bg, params, means2D, rasters, dpix = build_workload(device, rank)
+    scale_step = world == 1 and (args.scale_step or os.environ.get("GSR_BENCH_SCALE_STEP", "0") == "1")
+    R = max(1, args.repeats)
+    med = lambda xs: float(np.median(xs))
+    spread = lambda dts: {"repeats": len(dts), "ms_per_step_min": round(min(dts) / args.steps * 1e3, 4),
+                          "ms_per_step_max": round(max(dts) / args.steps * 1e3, 4)}
     refine, same_step_1gpu_ms = None, None
     if world > 1:
         # the SAME step without any exchange, every rank on its own GPU at once: the single-GPU denominator of this step's
@@ -352,22 +429,28 @@ def main():
         for s in range(5):
             solo_step(s)
         n_solo = max(10, min(args.steps, 40))
-        same_step_1gpu_ms = timed(solo_step, n_solo, world, device) / n_solo * 1e3
+        same_step_1gpu_ms = med([timed(solo_step, n_solo, world, device) for _ in range(3)]) / n_solo * 1e3
         solo_w[2].close(); del solo_w, solo_step
         refine = build_refinement_workload(device, rank, gs, cams, bg)
         step = lambda s: refinement_step(s, rank, world, *refine)
+    elif scale_step:
+        refine = build_refinement_workload(device, rank, gs, cams, bg)
+        step = lambda s: refinement_step(s, 0, 1, *refine)
     else:
         step = lambda s: one_step(s, rank, world, params, means2D, rasters, dpix)
+    raster_step = lambda s: one_step(s, rank, world, params, means2D, rasters, dpix)   # (the instrumented pass below)
 
     for s in range(args.warmup):
         step(s)
     wait_ns, waits = ctypes.c_longlong(0), ctypes.c_longlong(0)
-    V = max(1, args.views_in_flight) if world == 1 else 1
-    single = None
+    V = max(1, args.views_in_flight) if (world == 1 and not scale_step) else 1
+    single, value_spread = None, None
     if V > 1:
         # V independent view pipelines (gaustar_amd/pipelines.py): every step is still ONE complete forward + backward of one
         # view through the public API; step s runs on pipeline s % V, with that pipeline's own leaf tensors, stream and host
-        # thread.  The K timed steps are K views, as before.  The one-view-at-a-time figure is measured next to it.
+        # thread.  The K timed steps are K views, as before.  The one-view-at-a-time figure is measured next to it, the two
+        # modes INTERLEAVED, R times each (single, pipelined, single, ...): the medians are what is reported -- a 20-step region
+        # is 6 ms, and one hiccup of the box moved a single measurement by 10 %.
         from gaustar_amd import pipelines
         pipes = pipelines.ViewPipelines(V, device)
         leaves = pipelines.clone_leaves(dict(params, means2D=means2D), V)
@@ -375,29 +458,46 @@ def main():
         def pipe_step(t, s):
             ps = leaves[t]
             one_step(s, 0, 1, {k: v for k, v in ps.items() if k != "means2D"}, ps["means2D"], rasters, dpix)
-        dt_single = timed(step, args.steps, world, device)
-        single = {"value": round(args.steps / dt_single, 2), "ms_per_step": round(dt_single / args.steps * 1e3, 4),
-                  "what": "the same K steps one view at a time on one stream (how rounds 1 and 2 quoted the metric)"}
         import gc
         clock = {}
+        dts_single, dts_pipe = [], []
+        pipe_error = None
         gc.collect(); gc.disable()
         try:
             pipes.run(pipe_step, list(range(max(args.warmup, 2 * V))))   # untimed: every pipeline warms its stream and allocator
-            lib.gsr_debug_host_wait(None, None, 1)
-            pipes.run(pipe_step, list(range(args.steps)), before=lambda: clock.__setitem__("t0", time.perf_counter()),
-                      after=lambda: clock.__setitem__("t1", time.perf_counter()))
-            lib.gsr_debug_host_wait(ctypes.byref(wait_ns), ctypes.byref(waits), 0)
-            dt = clock["t1"] - clock["t0"]
+            for rep in range(R):
+                dts_single.append(timed(step, args.steps, world, device))
+                gc.disable()   # (timed() switches the collector back on)
+                lib.gsr_debug_host_wait(None, None, 1)
+                pipes.run(pipe_step, list(range(args.steps)), before=lambda: clock.__setitem__("t0", time.perf_counter()),
+                          after=lambda: clock.__setitem__("t1", time.perf_counter()))
+                lib.gsr_debug_host_wait(ctypes.byref(wait_ns), ctypes.byref(waits), 0)
+                dts_pipe.append(clock["t1"] - clock["t0"])
         except Exception as ex:   # a box on which the threaded run fails still reports the one-at-a-time figure, and says so
             print(f"bench.py: {V} pipelines failed ({ex!r}); reporting one view at a time", file=sys.stderr)
-            V, dt = 1, dt_single
-            wait_ns.value, waits.value = 0, 0
+            pipe_error = repr(ex)[:200]
         finally:
             gc.enable()
+        while len(dts_single) < R:
+            dts_single.append(timed(step, args.steps, world, device))
+        dt_single = med(dts_single)
+        single = {"value": round(args.steps / dt_single, 2), "ms_per_step": round(dt_single / args.steps * 1e3, 4), **spread(dts_single),
+                  "what": "the same K steps one view at a time on one stream (how rounds 1 and 2 quoted the metric); median of the "
+                          "repeats, interleaved with the pipelined ones"}
+        if pipe_error is None and len(dts_pipe) == R:
+            dt = med(dts_pipe)
+            value_spread = spread(dts_pipe)
+        else:
+            V, dt, value_spread = 1, dt_single, spread(dts_single)
+            wait_ns.value, waits.value = 0, 0
     else:
-        lib.gsr_debug_host_wait(None, None, 1)
-        dt = timed(step, args.steps, world, device)
-        lib.gsr_debug_host_wait(ctypes.byref(wait_ns), ctypes.byref(waits), 0)
+        dts = []
+        for rep in range(R):
+            lib.gsr_debug_host_wait(None, None, 1)
+            dts.append(timed(step, args.steps, world, device))
+            lib.gsr_debug_host_wait(ctypes.byref(wait_ns), ctypes.byref(waits), 0)
+        dt = med(dts)
+        value_spread = spread(dts)
     ms_per_step = dt / args.steps * 1e3
     value = args.steps * world / dt
 
@@ -407,7 +507,7 @@ def main():
     ms = (ctypes.c_float * nst)()
     cnt = (ctypes.c_int * nst)()
     lib.gsr_profile_enable(1)
-    dt_prof = timed(step, args.steps, world, device)
+    dt_prof = timed(step, args.steps, world, device)   # (under --scale-step / N > 1 the brackets see the same six rasterizer kernels)
     _lib.check(lib.gsr_profile_read(ms, cnt, 1), "gsr_profile_read")
     lib.gsr_profile_enable(0)
 
@@ -481,6 +581,17 @@ def main():
                        "gaussians": gs.P, "width": W, "height": H, "views_per_step": world,
                        "num_rendered_mean": R_mean, "parallelism": f"view-parallel x{world}",
                        "views_in_flight": V,
+                       "value_definition": (
+                           ("MEDIAN over %d back-to-back timed regions of K = %d steps each, views per second; " % (R, args.steps)) +
+                           ("a step = one complete forward + backward of one 1080p view of config C through the public API; "
+                            if not (scale_step or world > 1) else
+                            "a step = one whole refinement step per rank (mesh + SH producers, rasterizer forward + backward, their "
+                            "backward, sharded Adam) on one view per rank; ") +
+                           (("%d independent views in flight on one GPU (host thread + HIP stream each) -- a sweep / evaluation / "
+                             "V-views-per-optimiser-step schedule; the reference's one-view-then-Adam loop (refine.py:538-548) has no "
+                             "independent views: for it read single_pipeline (same K steps, one view at a time) and window" % V)
+                            if V > 1 else "one view at a time per GPU")),
+                       "value_spread": value_spread,
                        "pipelines": (f"{V} independent view pipelines on the GPU (host thread + HIP stream + leaf tensors each, "
                                      "gaustar_amd.pipelines): step s = one complete forward + backward of view s on pipeline s % "
                                      f"{V}; the small kernels of one view run under the blends of another") if V > 1 else "one view at a time"},
@@ -518,8 +629,19 @@ def main():
                 out["roofline"]["issue"] = {"error": repr(ex)[:200]}
         # how long the host sat in the forward's one synchronisation per step (gsr_debug_host_wait): the slack between the
         # host's own work (Python, autograd, launches) and the GPU's -- near zero means the step is host-bound
-        out["host"] = {"wait_ms_per_step": round(wait_ns.value / 1e6 / max(args.steps, 1), 4),
-                       "waits_per_step": round(waits.value / max(args.steps, 1), 2)}
+        # (accumulated over the R pipelined repeats and over the V pipeline threads: per pipeline, a thread waits this long
+        # for every view IT renders -- 1 / V of the steps)
+        n_timed = max(args.steps, 1) * R
+        out["host"] = {"wait_ms_per_view_per_pipeline": round(wait_ns.value / 1e6 / n_timed, 4),
+                       "wait_ms_per_step": round(wait_ns.value / 1e6 / n_timed / max(V, 1), 4),
+                       "waits_per_step": round(waits.value / n_timed, 2), "pipelines": V,
+                       "what": "time the host threads sat in the forward's one synchronisation (gsr_debug_host_wait); "
+                               "wait_ms_per_step = total / steps / pipelines: the share of a step's wall time a pipeline's host thread "
+                               "had nothing to do but wait for its GPU work"}
+        if scale_step:
+            out["config"]["scale_step"] = True
+            out["config"]["workload"] += (", inside one refinement step (mesh + SH producers fwd/bwd, Adam on the reference loop's "
+                                          "%.0f MB of parameters): the step `--gpus N` times, here on one GPU" % (refine[2].payload_bytes() / 1e6))
         if world > 1:
             out["config"]["exchange"] = "reduce-scatter + rank-sharded Adam + all-gather"
             out["config"]["exchange_payload_MB"] = round(refine[2].payload_bytes() / 1e6, 1)
@@ -537,13 +659,26 @@ def main():
                 pass
             out["cpu_baseline"] = cpu_baseline(gs, cams, bg)
         if world == 1 and not args.no_extras:
+            oc = {}
+            for cname in ("B", "D", "D_depth"):
+                try:
+                    oc[cname] = other_config(cname, device, lib)
+                except Exception as ex:   # a report leg only
+                    oc[cname] = {"error": repr(ex)[:200]}
+            out["other_configs"] = oc
+        if world == 1 and not args.no_extras and not scale_step:
             try:   # the N > 1 step (refinement step: producers + render + Adam) on ONE GPU: the denominator of its scaling
                 rw = build_refinement_workload(device, 0, gs, cams, bg)
                 rstep = lambda s_: refinement_step(s_, 0, 1, *rw)
                 for s_ in range(5):
                     rstep(s_)
                 n_r = min(args.steps, 80)
-                dt_r = timed(rstep, n_r, 1, device)
+                dt_r = med([timed(rstep, n_r, 1, device) for _ in range(3)])
+                # the same figure under the name the scaling curve needs: value(N) of `--gpus N` divided by N x THIS is the
+                # scaling of one and the same step (`--gpus 1 --scale-step` or GSR_BENCH_SCALE_STEP=1 makes it the line's value)
+                out["scale_base"] = {"value": round(n_r / dt_r, 2), "unit": "views/s", "ms_per_step": round(dt_r / n_r * 1e3, 4),
+                                     "what": "the refinement step `--gpus N > 1` times, on ONE GPU without any exchange (median of 3 "
+                                             "regions): value(N) / (N x this) is that step's scaling efficiency"}
                 out["refinement_step_single_gpu"] = {"ms_per_step": round(dt_r / n_r * 1e3, 4), "steps": n_r,
                                                      "what": "the step bench.py times at --gpus N > 1 (producers + rasterizer fwd/bwd + "
                                                              "Adam on the reference loop's 77 MB of parameters), here on one GPU "

@@ -382,6 +382,7 @@ class ShardedAdam:
     def __init__(self, param_groups, ready_order: Sequence[torch.Tensor] | None = None, betas=(0.9, 0.999), eps: float = 1e-8,
                  bucket_bytes: int = 32 << 20, average: bool = True, overlap: bool = True, run_at_world_size_1: bool = False,
                  segment_step=None, communicate: bool = True):
+        self._defaults = {"lr": 1e-3, "betas": tuple(betas), "eps": float(eps)}
         self.param_groups = [dict(g) for g in param_groups]
         for g in self.param_groups:
             g["params"] = list(g["params"])
@@ -400,23 +401,48 @@ class ShardedAdam:
         self.average = average
         self._comm = self.world > 1 or self.solo
         self._segment_step = segment_step or _hip_adam_segment
-        W = max(self.world, 1)
-        # ---- layout: (bucket, offset) per parameter
+        self._group_of = group_of
+        self._bucket_bytes = int(bucket_bytes)
         self.buckets: List[dict] = []
+        self._bucket_of = {}
+        self._lay_out(order)
+        self._steps = {id(p): 0 for p in order}
+        self._fired: dict = {}
+        self._order = order
+        self.issued_early = 0
+        self.reissued = 0
+        self._hooks = []
+        # gradient sink (grad_views / written): parameters whose gradient a backward wrote straight into the flat buffer
+        self._sunk: set = set()
+        self._expect_hook: set = set()
+        self._views = None
+        self._hooks_on = bool(overlap and self._comm)
+        if self._hooks_on:
+            for p in order:
+                if p.requires_grad and hasattr(p, "register_post_accumulate_grad_hook"):
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def _lay_out(self, order) -> None:
+        """Append flat buckets for `order` (parameters in the order their gradients become final): (bucket, offset) per
+        parameter, every parameter 16-byte aligned, each bucket padded to N equal 16-byte-aligned shards; the parameters are
+        re-pointed at their slices (values preserved)."""
+        W = max(self.world, 1)
+        group_of = self._group_of
+        first_new = len(self.buckets)
         cur, off = [], 0
         for p in order:
             if p.dtype != torch.float32:
                 raise ValueError("ShardedAdam: float32 parameters only")
             k = (p.numel() + 3) // 4 * 4
-            if cur and (off + k) * 4 > bucket_bytes:
+            if cur and (off + k) * 4 > self._bucket_bytes:
                 self.buckets.append(dict(entries=cur, used=off))
                 cur, off = [], 0
             cur.append((p, off))
             off += k
         if cur:
             self.buckets.append(dict(entries=cur, used=off))
-        self._bucket_of = {}
-        for bi, b in enumerate(self.buckets):
+        for bi in range(first_new, len(self.buckets)):
+            b = self.buckets[bi]
             dev = b["entries"][0][0].device
             n = (b["used"] + 4 * W - 1) // (4 * W) * (4 * W)           # N equal shards of whole float4s
             S = n // W
@@ -443,18 +469,30 @@ class ShardedAdam:
                 a, e = max(o, lo), min(o + p.numel(), hi)
                 if e > a:
                     b["segments"].append((p, group_of[id(p)], a - lo, a, e - a))
-        self._steps = {id(p): 0 for p in order}
-        self._fired: dict = {}
-        self._order = order
-        self.issued_early = 0
-        self.reissued = 0
-        self._hooks = []
-        # gradient sink (grad_views / written): parameters whose gradient a backward wrote straight into the flat buffer
-        self._sunk: set = set()
-        self._expect_hook: set = set()
         self._views = None
-        if overlap and self._comm:
-            for p in order:
+
+    def add_param_group(self, param_group: dict) -> None:
+        """torch.optim.Optimizer.add_param_group (the reference wrapper forwards to it, sugar_optimizer.py:117-118): the new
+        parameters get flat buckets of their own behind the existing ones -- call it on every rank, between steps."""
+        if any(b["rs"] is not None for b in self.buckets):
+            raise RuntimeError("ShardedAdam.add_param_group: a reduction is in flight; call it between step() and the next backward")
+        g = dict(param_group)
+        ps = g["params"]
+        g["params"] = [ps] if isinstance(ps, torch.Tensor) else list(ps)
+        g.setdefault("lr", self._defaults["lr"])
+        g.setdefault("betas", self._defaults["betas"])
+        g.setdefault("eps", self._defaults["eps"])
+        for p in g["params"]:
+            if id(p) in self._group_of:
+                raise ValueError("some parameters appear in more than one parameter group")
+        self.param_groups.append(g)
+        for p in g["params"]:
+            self._group_of[id(p)] = g
+            self._steps[id(p)] = 0
+        self._order.extend(g["params"])
+        self._lay_out(g["params"])
+        if self._hooks_on:
+            for p in g["params"]:
                 if p.requires_grad and hasattr(p, "register_post_accumulate_grad_hook"):
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
@@ -488,6 +526,13 @@ class ShardedAdam:
         if self._views is None:
             self._views = {id(p): b["flat_g"][o:o + p.numel()].view(p.shape) for b in self.buckets for p, o in b["entries"]}
         return self._views
+
+    def accepts(self, p) -> bool:
+        """Whether a backward may write the gradient of `p` straight into its grad_views() slot: only the FIRST delivery of a
+        step, and only while `p.grad` is None.  A second render in the same backward (two sink nodes under one loss) must hand
+        its gradient to autograd as an ordinary tensor -- autograd then sums the two out of place, `p.grad` stops aliasing the
+        flat buffer, and the bucket is packed and reduced again in step() (see _on_grad / _pack)."""
+        return p is not None and p.grad is None and id(p) not in self._sunk and p.requires_grad
 
     def written(self, params) -> None:
         """The gradients of `params` now sit in their grad_views() (kernels launched on the current stream): count them as
@@ -524,13 +569,22 @@ class ShardedAdam:
         self._sunk.clear(); self._expect_hook.clear()
 
     def _stamp(self, b):
-        # (a gradient delivered through the sink may be issued before autograd has set p.grad: its stamp is the sink's)
-        return tuple(("sunk" if id(p) in self._sunk else None if p.grad is None else (id(p.grad), p.grad._version))
+        # A gradient delivered through the sink may be issued before autograd has set p.grad, and p.grad then ALIASES the flat
+        # buffer: its stamp is the version counter of that buffer (shared by all of its views), which an in-place edit of
+        # p.grad after the backward (gradient clipping) bumps -- so the documented guard also holds with a sink.  (The
+        # kernels that fill the buffer write through raw pointers and bump nothing; _pack's own copies run before the stamp.)
+        fv = b["flat_g"]._version
+        return tuple((("sunk", fv) if id(p) in self._sunk else None if p.grad is None else (id(p.grad), p.grad._version))
                      for p, _ in b["entries"])
 
     def _on_grad(self, p: torch.Tensor) -> None:
         if id(p) in self._expect_hook:   # delivered through the sink earlier in this backward: already counted
             self._expect_hook.discard(id(p))
+            # ... unless autograd did NOT adopt the sink's view as p.grad: another contribution to the same parameter in this
+            # backward (a regulariser, a second render) makes it sum view + other OUT OF PLACE, and the flat buffer -- possibly
+            # already on its way -- holds only the sink's share.  The bucket is packed from p.grad and reduced again in step().
+            if p.grad is not None and p.grad.data_ptr() != self.grad_views()[id(p)].data_ptr():
+                self.buckets[self._bucket_of[id(p)]]["dirty"] = True
             return
         bi = self._bucket_of[id(p)]
         n = self._fired.get(id(p), 0) + 1
@@ -555,8 +609,8 @@ class ShardedAdam:
             dst = b["flat_g"][o:o + p.numel()]
             if p.grad is not None and p.grad.data_ptr() == dst.data_ptr():
                 continue                      # written in place through the sink and adopted by autograd as p.grad
-            if id(p) in self._sunk and (p.grad is None or not b["dirty"]):
-                continue                      # in place already; autograd has not delivered it yet, or kept a private copy
+            if id(p) in self._sunk and p.grad is None:
+                continue                      # in place already; autograd has not delivered it yet
             if p.grad is None:
                 dst.zero_()
             else:
@@ -586,6 +640,11 @@ class ShardedAdam:
         for bi, b in enumerate(self.buckets):   # first round: what has not left yet, in bucket order
             if b["rs"] is None:
                 self._issue_grads(bi)
+        for b in self.buckets:                  # (without hooks nobody has looked at how autograd delivered a sunk gradient)
+            if b["rs"] is not None and not b["dirty"]:
+                for p, o in b["entries"]:
+                    if id(p) in self._sunk and p.grad is not None and p.grad.data_ptr() != b["flat_g"][o:o + 1].data_ptr():
+                        b["dirty"] = True
         for bi, b in enumerate(self.buckets):   # second round: dirty buckets once more (GradAllReducer's rule)
             if b["dirty"]:
                 b["rs"].wait()
@@ -639,6 +698,63 @@ class ShardedAdam:
                           "exp_avg": full["exp_avg"][o:o + p.numel()].view(p.shape).clone(),
                           "exp_avg_sq": full["exp_avg_sq"][o:o + p.numel()].view(p.shape).clone()}
         return out
+
+
+    def _indexed_params(self):
+        return [p for g in self.param_groups for p in g["params"]]
+
+    @torch.no_grad()
+    def state_dict(self) -> dict:
+        """torch.optim.Adam-shaped state dict ({"state": {index: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...]},
+        parameters numbered over the groups in order) -- what the reference wrapper saves as `optimizer_state_dict`
+        (sugar_optimizer.py:120-121).  A collective call: the moments are gathered from all ranks."""
+        st = self.gather_state()
+        params = self._indexed_params()
+        index = {id(p): i for i, p in enumerate(params)}
+        state = {index[id(p)]: {"step": v["step"], "exp_avg": v["exp_avg"], "exp_avg_sq": v["exp_avg_sq"]}
+                 for p, v in st.items() if self._steps[id(p)] > 0}
+        groups = []
+        for g in self.param_groups:
+            d = {k: v for k, v in g.items() if k != "params"}
+            d.setdefault("weight_decay", 0); d.setdefault("amsgrad", False); d.setdefault("maximize", False)
+            d["params"] = [index[id(p)] for p in g["params"]]
+            groups.append(d)
+        return {"state": state, "param_groups": groups}
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict: dict) -> None:
+        """Inverse of state_dict(); also takes a torch.optim.Adam state dict over the same parameter groups (a single-GPU
+        checkpoint resumed on N ranks): every rank keeps its shard of the moments, the step counters and the groups'
+        hyper-parameters (sugar_optimizer.py:123-124)."""
+        groups = state_dict["param_groups"]
+        if len(groups) != len(self.param_groups) or any(len(a["params"]) != len(b["params"]) for a, b in zip(groups, self.param_groups)):
+            raise ValueError("loaded state dict has a different number of parameter groups / parameters per group")
+        for g, src in zip(self.param_groups, groups):
+            if src.get("weight_decay", 0) or src.get("amsgrad", False) or src.get("maximize", False):
+                raise ValueError("ShardedAdam implements plain Adam: weight_decay / amsgrad / maximize are not supported")
+            for k, v in src.items():
+                if k not in ("params", "weight_decay", "amsgrad", "maximize"):
+                    g[k] = tuple(v) if k == "betas" else v
+        params = self._indexed_params()
+        ids = [i for src in groups for i in src["params"]]
+        state = state_dict.get("state", {})
+        for p, i in zip(params, ids):
+            e = state.get(i, state.get(str(i)))
+            b = self.buckets[self._bucket_of[id(p)]]
+            o = next(o_ for q, o_ in b["entries"] if q is p)
+            lo, hi = b["shard_lo"], b["shard_lo"] + b["S"]
+            a, z = max(o, lo), min(o + p.numel(), hi)
+            if e is None:
+                self._steps[id(p)] = 0
+                if z > a:
+                    b["exp_avg"][a - lo:z - lo].zero_(); b["exp_avg_sq"][a - lo:z - lo].zero_()
+                continue
+            if tuple(e["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError("loaded state has a moment tensor of the wrong shape")
+            self._steps[id(p)] = int(float(e["step"]))
+            if z > a:
+                for key in ("exp_avg", "exp_avg_sq"):
+                    b[key][a - lo:z - lo].copy_(e[key].reshape(-1)[a - o:z - o].to(b[key].device, torch.float32))
 
 
 class _Done:

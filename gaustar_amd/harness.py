@@ -140,7 +140,8 @@ class _RenderMeshBound(torch.autograd.Function):
         # backward is launched, so their buckets leave while that one still runs.  Only parameters without a gradient yet.
         sink, params = cfg.get("sink"), cfg["params"]
         views = sink.grad_views() if sink is not None else {}
-        buf = lambda p: views.get(id(p)) if (p is not None and p.grad is None) else None
+        # (accepts(): first delivery of this step only -- a second render under the same loss goes through autograd's own addition)
+        buf = lambda p: views.get(id(p)) if (p is not None and sink is not None and sink.accepts(p)) else None
         p_verts, p_rs, p_rc, p_dens, p_dc, p_rest, p_dt, p_dr = params
         o_dc, o_rest, o_dens = buf(p_dc), buf(p_rest), buf(p_dens)
         d_dc, d_rest, _, d_dens = producers._sh_backward_raw(points, _rasterizer._dev_f32(st.campos, points.device), dc, rest, D, M,
@@ -179,7 +180,7 @@ class SurfaceGaussians(nn.Module):
         self.min_gaussian_scale, self.max_gaussian_scale = min_gaussian_scale, max_gaussian_scale
         self.return_one_densities = False
         self._points = nn.Parameter(verts.detach().clone().float())
-        self.register_buffer("_surface_mesh_faces", faces.detach().clone().long())
+        self.register_buffer("_surface_mesh_faces", faces.detach().long().contiguous().clone())   # (clone() keeps strides: the kernels read it as a dense [F, 3] int64 array)
         self.register_buffer("surface_triangle_bary_coords", torch.tensor(BARY_COORDS[G], dtype=torch.float32, device=dev)[..., None])
         self.register_buffer("surface_mesh_thickness", torch.tensor(float(surface_mesh_thickness), device=dev))
         # initial in-plane scale: the inscribed-circle radius of the face (sugar_model.py:216, :357)
@@ -382,6 +383,10 @@ class SurfaceGaussians(nn.Module):
         sh_deg = self.sh_levels - 1 if sh_deg is None else int(sh_deg)
         settings, _view, _campos = self._settings(camera, bg, 0)
         producers._check_faces(self._surface_mesh_faces, int(self._points.shape[0]))
+        if self._surface_mesh_faces.dtype != torch.int64 or not self._surface_mesh_faces.is_contiguous():
+            # (the one-node render hands the buffer to the kernels as a raw pointer: a strided or int32 replacement of the
+            # registered buffer would be read with the wrong layout)
+            self._surface_mesh_faces = self._surface_mesh_faces.long().contiguous()
         dev = self.device
         cfg = {"settings": settings, "faces": self._surface_mesh_faces, "bary": self._bary_rows(), "depth_channels": int(depth_channels),
                "thickness": self._thickness(),
@@ -393,8 +398,8 @@ class SurfaceGaussians(nn.Module):
                           self._delta_r if self._loose_bind else None)}
         if settings.campos.device != dev or settings.campos.dtype != torch.float32:
             raise RuntimeError("camera matrices must be float32 tensors on the model's device")
-        if cfg["sink"] is not None and not (hasattr(cfg["sink"], "grad_views") and hasattr(cfg["sink"], "written")):
-            raise TypeError("grad_sink must provide grad_views() and written(params) (gaustar_amd.dist.ShardedAdam)")
+        if cfg["sink"] is not None and not (hasattr(cfg["sink"], "grad_views") and hasattr(cfg["sink"], "written") and hasattr(cfg["sink"], "accepts")):
+            raise TypeError("grad_sink must provide grad_views(), accepts(p) and written(params) (gaustar_amd.dist.ShardedAdam)")
         return _RenderMeshBound.apply(self._points, self._scales, self._quaternions, self.all_densities, self._sh_coordinates_dc,
                                       self._sh_coordinates_rest, self._delta_t if self._loose_bind else None,
                                       self._delta_r if self._loose_bind else None, cfg)

@@ -58,32 +58,48 @@ class ViewPipelines:
         errors: List[BaseException] = []
 
         def worker(t: int) -> None:
+            # ANY failure of a worker -- before its first wait included (set_device, the stream context) -- is recorded and
+            # breaks the barrier, so neither the caller nor the other workers can be left waiting for it
             try:
                 torch.cuda.set_device(self.device)
                 with torch.cuda.stream(self.streams[t]):
                     gate.wait()      # ready
                     gate.wait()      # go
-                    try:
-                        for i in range(t, len(items), self.n):
-                            fn(t, items[i])
-                        self.streams[t].synchronize()
-                    except BaseException as ex:   # noqa: BLE001 -- handed to the caller
-                        errors.append(ex)
+                    for i in range(t, len(items), self.n):
+                        fn(t, items[i])
+                    self.streams[t].synchronize()
                     gate.wait()      # done
             except threading.BrokenBarrierError:
-                pass
+                pass                 # somebody else failed (or the caller's before() did): leave
+            except BaseException as ex:   # noqa: BLE001 -- handed to the caller
+                errors.append(ex)
+                gate.abort()
 
         threads = [threading.Thread(target=worker, args=(t,), daemon=True) for t in range(self.n)]
         for th in threads:
             th.start()
-        gate.wait()          # every worker stands at the start line
-        if before:
-            before()         # (a timer started here also counts the release of the barrier: it errs on the long side)
-        gate.wait()          # go
-        gate.wait()          # every worker has drained its stream
-        if after:
-            after()
+        caller_error = None
+        try:
+            gate.wait()          # every worker stands at the start line
+            if before:
+                before()         # (a timer started here also counts the release of the barrier: it errs on the long side)
+            gate.wait()          # go
+            gate.wait()          # every worker has drained its stream
+            if after:
+                after()
+        except threading.BrokenBarrierError:
+            pass                 # a worker failed: its exception is in `errors`
+        except BaseException as ex:   # noqa: BLE001 -- before() / after() raised: release the parked workers, then re-raise
+            caller_error = ex
+            gate.abort()
         for th in threads:
             th.join()
+        try:   # whatever the surviving workers had already launched is done before the caller sees the failure
+            for st in self.streams:
+                st.synchronize()
+        except Exception:   # noqa: BLE001
+            pass
+        if caller_error is not None:
+            raise caller_error
         if errors:
             raise errors[0]

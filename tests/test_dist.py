@@ -273,7 +273,7 @@ class _SinkLoss(torch.autograd.Function):
         views = ctx.sink.grad_views()
         outs, stage = [], []
         for i, (c, p, x) in enumerate(zip(ctx.coeffs, ctx.params, ctx.saved_tensors)):
-            o = views.get(id(p)) if p.grad is None else None
+            o = views.get(id(p)) if ctx.sink.accepts(p) else None
             val = 2.0 * c * x * g
             if o is not None:
                 o.copy_(val); stage.append(p); outs.append(o.view(o.shape))
@@ -299,9 +299,14 @@ def _sink_worker(rank, world, port, q):
     ref = torch.optim.Adam(groups(qs), eps=1e-15)
     w = lambda r: [(i + 1.0) * (r + 1.0) for i in range(4)]
     aliased, early = [], []
-    for it in range(5):
+    for it in range(7):
         opt.zero_grad(); ref.zero_grad()
-        _SinkLoss.apply(opt, w(rank), *ps).backward()
+        loss = _SinkLoss.apply(opt, w(rank), *ps)
+        if it == 5:      # a regulariser on the same parameters in the SAME backward (refine.py's loop has several): autograd sums
+            loss = loss + 0.25 * (ps[0] ** 3).sum() + 0.1 * (ps[2] ** 3).sum()   # view + other out of place, p.grad stops aliasing
+        if it == 6:      # two renders under one loss (RGB + depth-as-colour, refine.py:552 and :607): two sink nodes, one backward
+            loss = loss + _SinkLoss.apply(opt, [0.5 * c for c in w(rank)], *ps)
+        loss.backward()
         views = opt.grad_views()
         aliased.append(sum(1 for p in ps if p.grad is not None and p.grad.data_ptr() == views[id(p)].data_ptr()))
         if it == 2:      # a second backward before the step: gradients exist, so it goes through autograd's addition + the hooks
@@ -309,10 +314,12 @@ def _sink_worker(rank, world, port, q):
         if it == 3:      # and a plain autograd backward on top (regulariser)
             (0.25 * ps[0].sum()).backward()
         lr_ = sum(0.5 * sum(c * (p ** 2).sum() for c, p in zip(w(r), qs)) for r in range(2))
-        if it == 2:
+        if it in (2, 6):
             lr_ = lr_ + sum(0.5 * sum(0.5 * c * (p ** 2).sum() for c, p in zip(w(r), qs)) for r in range(2))
         if it == 3:
             lr_ = lr_ + 0.25 * qs[0].sum()
+        if it == 5:
+            lr_ = lr_ + 0.25 * (qs[0] ** 3).sum() + 0.1 * (qs[2] ** 3).sum()
         lr_.backward()
         opt.step(); ref.step()
         early.append(opt.issued_early)
@@ -342,8 +349,10 @@ def test_sharded_adam_gradient_sink_gloo_world2():
         assert p.exitcode == 0
     for rank, err, same, aliased, early, reissued in res:
         assert err < 2e-6 and same, res
-        assert aliased == [4, 4, 4, 4, 4], res      # every first backward's gradients were adopted in place
-        assert max(early) >= 1 and reissued >= 2, res
+        # every plain first backward's gradients were adopted in place; with a regulariser two of the four are sums held by
+        # autograd, with two renders under one loss all four are
+        assert aliased == [4, 4, 4, 4, 4, 2, 0], res
+        assert max(early) >= 1 and reissued >= 4, res
 
 
 def _reissue_worker(rank, world, port, q):
@@ -386,3 +395,118 @@ def test_allreduce_survives_a_second_backward_and_a_skipped_step_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# ShardedAdam as a stand-in for torch.optim.Adam inside the reference's wrapper (sugar_optimizer.py:99-124): checkpoints,
+# add_param_group, and the in-place-edit guard with a gradient sink.  Single process (run_at_world_size_1 exercises the
+# whole bookkeeping -- buckets, stamps, shards of size 1/1 -- over a one-rank gloo group).
+# ------------------------------------------------------------------------------------------------------------------
+def _solo_group():
+    import torch.distributed as tdist
+    if not tdist.is_initialized():
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        tdist.init_process_group("gloo", rank=0, world_size=1)
+
+
+def _mk(shapes, seed=0):
+    torch.manual_seed(seed)
+    ps = [torch.nn.Parameter(torch.randn(*s)) for s in shapes]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    return ps, qs
+
+
+def test_sharded_adam_state_dict_round_trip_against_torch_adam():
+    from gaustar_amd import dist as gd
+    _solo_group()
+    shapes = [(300, 2), (9, 4), (101, 3), (7,)]
+    groups = lambda xs: [{"params": [xs[0], xs[1]], "lr": 1e-2, "name": "a"}, {"params": [xs[2], xs[3]], "lr": 3e-3, "name": "b"}]
+    ps, qs = _mk(shapes)
+    opt = gd.ShardedAdam(groups(ps), eps=1e-15, bucket_bytes=2_000, segment_step=torch_adam_segment, run_at_world_size_1=True)
+    ref = torch.optim.Adam(groups(qs), lr=0.0, eps=1e-15)
+    loss = lambda xs, k: sum((i + 1.0) * ((x - 0.1 * k) ** 2).sum() for i, x in enumerate(xs))
+    for k in range(3):
+        opt.zero_grad(); ref.zero_grad()
+        loss(ps, k).backward(); loss(qs, k).backward()
+        opt.step(); ref.step()
+    sd, sd_ref = opt.state_dict(), ref.state_dict()
+    # same shape as torch.optim.Adam's: indices over the groups in order, step / exp_avg / exp_avg_sq per parameter, the groups'
+    # own keys (the reference's "name" included)
+    assert sorted(sd["state"]) == sorted(sd_ref["state"]) == [0, 1, 2, 3]
+    assert [g["params"] for g in sd["param_groups"]] == [g["params"] for g in sd_ref["param_groups"]]
+    assert [g["name"] for g in sd["param_groups"]] == ["a", "b"]
+    for i in range(4):
+        assert float(sd["state"][i]["step"]) == float(sd_ref["state"][i]["step"]) == 3.0
+        for key in ("exp_avg", "exp_avg_sq"):
+            assert torch.allclose(sd["state"][i][key], sd_ref["state"][i][key], rtol=1e-5, atol=1e-7), (i, key)   # (torch lerps exp_avg)
+    # resume: a FRESH ShardedAdam loads the ShardedAdam checkpoint, another one loads torch.optim.Adam's; all three then
+    # take the same further steps as the uninterrupted reference
+    ps2 = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    ps3 = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt2 = gd.ShardedAdam(groups(ps2), eps=1e-15, bucket_bytes=2_000, segment_step=torch_adam_segment, run_at_world_size_1=True)
+    opt3 = gd.ShardedAdam(groups(ps3), eps=1e-15, bucket_bytes=3_000, segment_step=torch_adam_segment, run_at_world_size_1=True)
+    opt2.load_state_dict(sd)
+    opt3.load_state_dict(sd_ref)
+    for k in range(3, 5):
+        for o, xs in ((opt, ps), (opt2, ps2), (opt3, ps3), (ref, qs)):
+            o.zero_grad()
+            loss(xs, k).backward()
+            o.step()
+    for a, b, c, d in zip(ps, ps2, ps3, qs):
+        assert torch.allclose(a, d, rtol=1e-6, atol=1e-7) and torch.equal(a, b) and torch.allclose(c, d, rtol=1e-6, atol=1e-7)
+    for o in (opt, opt2, opt3):
+        o.close()
+
+
+def test_sharded_adam_add_param_group():
+    from gaustar_amd import dist as gd
+    _solo_group()
+    ps, qs = _mk([(50, 3), (11,), (40, 2)], seed=1)
+    opt = gd.ShardedAdam([{"params": ps[:2], "lr": 1e-2}], eps=1e-15, bucket_bytes=400, segment_step=torch_adam_segment,
+                         run_at_world_size_1=True)
+    ref = torch.optim.Adam([{"params": qs[:2], "lr": 1e-2}], eps=1e-15)
+    loss = lambda xs: sum((i + 1.0) * (x ** 2).sum() for i, x in enumerate(xs))
+    for o, xs in ((opt, ps), (ref, qs)):
+        o.zero_grad(); loss(xs[:2]).backward(); o.step()
+    before = ps[2].detach().clone()
+    opt.add_param_group({"params": [ps[2]], "lr": 5e-3, "name": "late"})
+    ref.add_param_group({"params": [qs[2]], "lr": 5e-3, "name": "late"})
+    assert torch.equal(ps[2].detach(), before)            # re-pointed at its flat bucket, value kept
+    with pytest.raises(ValueError):
+        opt.add_param_group({"params": [ps[0]]})
+    for _ in range(2):
+        for o, xs in ((opt, ps), (ref, qs)):
+            o.zero_grad(); loss(xs).backward(); o.step()
+    for a, d in zip(ps, qs):
+        assert torch.allclose(a, d, rtol=1e-6, atol=1e-7)
+    assert opt.state_dict()["param_groups"][1]["name"] == "late" and sorted(opt.state_dict()["state"]) == [0, 1, 2]
+    opt.close()
+
+
+def test_in_place_edit_of_a_sunk_gradient_is_noticed():
+    """Gradient clipping after the backward edits p.grad in place; with a sink p.grad IS the flat exchange buffer, whose
+    reduction may already have left.  The documented contract -- mark_dirty() first, otherwise step() raises -- must hold for
+    sunk parameters too (their stamp is the flat buffer's version counter)."""
+    from gaustar_amd import dist as gd
+    _solo_group()
+    ps, qs = _mk([(64, 2), (33,)], seed=2)
+    opt = gd.ShardedAdam([{"params": ps, "lr": 1e-2}], ready_order=ps, eps=1e-15, segment_step=torch_adam_segment,
+                         run_at_world_size_1=True)
+    ref = torch.optim.Adam([{"params": qs, "lr": 1e-2}], eps=1e-15)
+    opt.zero_grad()
+    _SinkLoss.apply(opt, [1.0, 2.0], *ps).backward()
+    assert opt.issued_early >= 1 and all(p.grad.data_ptr() == opt.grad_views()[id(p)].data_ptr() for p in ps)
+    torch.nn.utils.clip_grad_norm_(ps, 0.5)
+    with pytest.raises(RuntimeError, match="mark_dirty"):
+        opt.step()
+    opt.reset()
+    # the same with mark_dirty(): the clipped gradients are what Adam sees
+    opt.zero_grad(); ref.zero_grad()
+    _SinkLoss.apply(opt, [1.0, 2.0], *ps).backward()
+    sum(c * (q ** 2).sum() for c, q in zip([1.0, 2.0], qs)).backward()
+    torch.nn.utils.clip_grad_norm_(ps, 0.5); torch.nn.utils.clip_grad_norm_(qs, 0.5)
+    opt.mark_dirty()
+    opt.step(); ref.step()
+    for a, d in zip(ps, qs):
+        assert torch.allclose(a, d, rtol=1e-6, atol=1e-7)
+    opt.close()

@@ -18,7 +18,7 @@ i=0
 for P in "${PASSES[@]}"; do
   cd /tmp
   rocprofv3 --kernel-trace --pmc $P --output-format csv -d "$R/gpurun_out/pmc_${TAG}/p$i" -o "p$i" -- \
-      python "$R/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-extras --views-in-flight 1 > "$R/gpurun_out/pmc_${TAG}_p$i.log" 2>&1 || echo "pass $i failed"
+      python "$R/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-extras --views-in-flight 1 --repeats 1 > "$R/gpurun_out/pmc_${TAG}_p$i.log" 2>&1 || echo "pass $i failed"
   cd "$R"
   i=$((i+1))
 done

@@ -7,7 +7,7 @@ TAG=$(basename "${GSR_LIB_PATH:-default}" .so)
 i=0
 for P in "FETCH_SIZE" "WRITE_SIZE"; do
   cd /tmp
-  rocprofv3 --kernel-trace --pmc $P --output-format csv -d "$R/gpurun_out/pmcf_$TAG/p$i" -o "p$i" -- python "$R/bench.py" --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1 || echo "pass $i failed"
+  rocprofv3 --kernel-trace --pmc $P --output-format csv -d "$R/gpurun_out/pmcf_$TAG/p$i" -o "p$i" -- python "$R/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-extras --views-in-flight 1 --repeats 1 > /dev/null 2>&1 || echo "pass $i failed"
   cd "$R"; i=$((i+1))
 done
 python - "$TAG" <<'PY'

@@ -4,7 +4,7 @@
 export TMPDIR=/tmp; R=$PWD; K=$1; shift
 for P in "$@"; do
   cd /tmp; rm -rf /tmp/pmcq
-  rocprofv3 --kernel-trace --pmc $P --output-format csv -d /tmp/pmcq -o q -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $P --output-format csv -d /tmp/pmcq -o q -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras --views-in-flight 1 --repeats 1 > /dev/null 2>&1
   cd $R
   python - "$K" <<'PY'
 import csv, glob, sys, collections

@@ -6,7 +6,7 @@ R="$PWD"; export TMPDIR=/tmp
 [ $# -ge 1 ] && export GSR_LIB_PATH="$(realpath "$1")"
 rm -rf "$R/gpurun_out/valu_tmp"; cd /tmp
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d "$R/gpurun_out/valu_tmp" -o v -- \
-    python "$R/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-extras --views-in-flight 1 > /dev/null 2>&1
+    python "$R/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-extras --views-in-flight 1 --repeats 1 > /dev/null 2>&1
 cd "$R"
 python - <<'PY'
 import csv, glob, collections
