@@ -130,7 +130,7 @@ def build_refinement_workload(device, rank, gs, cams, bg, overlap=True, solo=Fal
               {"params": [model._sh_coordinates_dc, model._sh_coordinates_rest], "lr": 0.0},
               {"params": [model._scales, model._quaternions, model.all_densities, model._delta_t, model._delta_r], "lr": 0.0}]
     opt = gdist.ShardedAdam(groups, ready_order=model.grad_ready_order(), eps=1e-15, overlap=overlap, run_at_world_size_1=solo,
-                            communicate=communicate)
+                            communicate=communicate, gather_first=model.mesh_parameters())
     model.grad_sink = opt   # the render's backward writes the parameter gradients straight into the optimiser's flat buffer
     bg_t = torch.from_numpy(np.ascontiguousarray(bg, dtype=np.float32)).to(device)
     dpix = torch.randn(3, cams[0].H, cams[0].W, device=device, generator=torch.Generator(device=device).manual_seed(1234 + rank))
@@ -158,9 +158,13 @@ def one_step(step, rank, world, params, means2D, rasters, dpix):
     return color
 
 
-def timed(fn, steps, world, device):
+def timed(fn, steps, world, device, prewarm=2):
     import gc
     gc.collect(); gc.disable()   # (a generation-2 pass of Python's collector stops the host for tens of milliseconds; between timed regions, not inside)
+    # (untimed: the collector pass above and whatever ran before this region -- another mode, the other config's workload --
+    # leave the GPU idle for milliseconds; a 20-step region is 6 ms, so the first steps after an idle gap would be a third of it)
+    for s in range(prewarm):
+        fn(s)
     if world > 1:
         tdist.barrier()
     torch.cuda.synchronize(device)
@@ -461,17 +465,24 @@ def main():
         import gc
         clock = {}
         dts_single, dts_pipe = [], []
+        single_wait_ns, single_waits = 0, 0
         pipe_error = None
         gc.collect(); gc.disable()
         try:
             pipes.run(pipe_step, list(range(max(args.warmup, 2 * V))))   # untimed: every pipeline warms its stream and allocator
+            w_ns, w_n = ctypes.c_longlong(0), ctypes.c_longlong(0)
             for rep in range(R):
+                lib.gsr_debug_host_wait(None, None, 1)
                 dts_single.append(timed(step, args.steps, world, device))
+                lib.gsr_debug_host_wait(ctypes.byref(w_ns), ctypes.byref(w_n), 0)
+                single_wait_ns += w_ns.value; single_waits += w_n.value
                 gc.disable()   # (timed() switches the collector back on)
+                pipes.run(pipe_step, list(range(2 * V)))   # untimed, like timed()'s own first steps
                 lib.gsr_debug_host_wait(None, None, 1)
                 pipes.run(pipe_step, list(range(args.steps)), before=lambda: clock.__setitem__("t0", time.perf_counter()),
                           after=lambda: clock.__setitem__("t1", time.perf_counter()))
-                lib.gsr_debug_host_wait(ctypes.byref(wait_ns), ctypes.byref(waits), 0)
+                lib.gsr_debug_host_wait(ctypes.byref(w_ns), ctypes.byref(w_n), 0)
+                wait_ns.value += w_ns.value; waits.value += w_n.value
                 dts_pipe.append(clock["t1"] - clock["t0"])
         except Exception as ex:   # a box on which the threaded run fails still reports the one-at-a-time figure, and says so
             print(f"bench.py: {V} pipelines failed ({ex!r}); reporting one view at a time", file=sys.stderr)
@@ -484,6 +495,8 @@ def main():
         single = {"value": round(args.steps / dt_single, 2), "ms_per_step": round(dt_single / args.steps * 1e3, 4), **spread(dts_single),
                   "what": "the same K steps one view at a time on one stream (how rounds 1 and 2 quoted the metric); median of the "
                           "repeats, interleaved with the pipelined ones"}
+        if single_waits:   # (timed()'s untimed first steps are in both numerator and denominator)
+            single["host_wait_ms_per_step"] = round(single_wait_ns / 1e6 / single_waits, 4)
         if pipe_error is None and len(dts_pipe) == R:
             dt = med(dts_pipe)
             value_spread = spread(dts_pipe)
@@ -492,10 +505,12 @@ def main():
             wait_ns.value, waits.value = 0, 0
     else:
         dts = []
+        w_ns, w_n = ctypes.c_longlong(0), ctypes.c_longlong(0)
         for rep in range(R):
             lib.gsr_debug_host_wait(None, None, 1)
             dts.append(timed(step, args.steps, world, device))
-            lib.gsr_debug_host_wait(ctypes.byref(wait_ns), ctypes.byref(waits), 0)
+            lib.gsr_debug_host_wait(ctypes.byref(w_ns), ctypes.byref(w_n), 0)
+            wait_ns.value += w_ns.value; waits.value += w_n.value
         dt = med(dts)
         value_spread = spread(dts)
     ms_per_step = dt / args.steps * 1e3
@@ -631,10 +646,10 @@ def main():
         # host's own work (Python, autograd, launches) and the GPU's -- near zero means the step is host-bound
         # (accumulated over the R pipelined repeats and over the V pipeline threads: per pipeline, a thread waits this long
         # for every view IT renders -- 1 / V of the steps)
-        n_timed = max(args.steps, 1) * R
+        n_timed = max(int(waits.value), 1)   # forward calls that went through the synchronisation = views rendered
         out["host"] = {"wait_ms_per_view_per_pipeline": round(wait_ns.value / 1e6 / n_timed, 4),
                        "wait_ms_per_step": round(wait_ns.value / 1e6 / n_timed / max(V, 1), 4),
-                       "waits_per_step": round(waits.value / n_timed, 2), "pipelines": V,
+                       "views_counted": int(waits.value), "pipelines": V,
                        "what": "time the host threads sat in the forward's one synchronisation (gsr_debug_host_wait); "
                                "wait_ms_per_step = total / steps / pipelines: the share of a step's wall time a pipeline's host thread "
                                "had nothing to do but wait for its GPU work"}

@@ -201,6 +201,7 @@ class GradAllReducer:
         return sum(p.numel() for p in self.params) * 4
 
     def close(self) -> None:
+        self.wait_params()
         for h in self._hooks:
             h.remove()
         self._hooks = []
@@ -381,7 +382,7 @@ class ShardedAdam:
 
     def __init__(self, param_groups, ready_order: Sequence[torch.Tensor] | None = None, betas=(0.9, 0.999), eps: float = 1e-8,
                  bucket_bytes: int = 32 << 20, average: bool = True, overlap: bool = True, run_at_world_size_1: bool = False,
-                 segment_step=None, communicate: bool = True):
+                 segment_step=None, communicate: bool = True, gather_first: Sequence[torch.Tensor] | None = None):
         self._defaults = {"lr": 1e-3, "betas": tuple(betas), "eps": float(eps)}
         self.param_groups = [dict(g) for g in param_groups]
         for g in self.param_groups:
@@ -416,6 +417,11 @@ class ShardedAdam:
         self._sunk: set = set()
         self._expect_hook: set = set()
         self._views = None
+        # gather_first (lazy all-gather): the parameters the NEXT forward reads first (harness.SurfaceGaussians: the mesh
+        # producer's).  step() then issues the all-gathers of THEIR buckets first and waits only for those; the other buckets'
+        # gathers (the SH coefficients: 70 % of the payload) are issued behind them and left in flight -- wait_params() is the
+        # fence their consumers call (harness._RenderMeshBound does, right before each producer).  None: step() waits for all.
+        self._gather_first = None if gather_first is None else {id(p) for p in gather_first}
         self._hooks_on = bool(overlap and self._comm)
         if self._hooks_on:
             for p in order:
@@ -454,7 +460,7 @@ class ShardedAdam:
                     self._bucket_of[id(p)] = bi
             b.update(n=n, S=S, flat_p=flat_p, flat_g=torch.zeros(n, dtype=torch.float32, device=dev),
                      exp_avg=torch.zeros(S, dtype=torch.float32, device=dev), exp_avg_sq=torch.zeros(S, dtype=torch.float32, device=dev),
-                     need=sum(1 for p, _ in b["entries"] if p.requires_grad), ready=0, rs=None, stamp=None, dirty=False)
+                     need=sum(1 for p, _ in b["entries"] if p.requires_grad), ready=0, rs=None, stamp=None, dirty=False, ag=None)
             lo, hi = self.rank * S, (self.rank + 1) * S
             # The reduction lands in a buffer of its OWN (1/N of the bucket), not in place: with a gradient sink p.grad aliases
             # flat_g, and a second backward before the step must find this rank's LOCAL gradient there to add to -- an in-place
@@ -533,6 +539,27 @@ class ShardedAdam:
         its gradient to autograd as an ordinary tensor -- autograd then sums the two out of place, `p.grad` stops aliasing the
         flat buffer, and the bucket is packed and reduced again in step() (see _on_grad / _pack)."""
         return p is not None and p.grad is None and id(p) not in self._sunk and p.requires_grad
+
+    # ------------------------------------------------------------------ lazy all-gather
+    def pending_gathers(self) -> int:
+        return sum(1 for b in self.buckets if b["ag"] is not None)
+
+    def wait_params(self, params=None) -> None:
+        """Fence for readers of parameters whose all-gather step() left in flight (`gather_first`): after it, the flat
+        buffers of the buckets holding `params` (None: all) are complete on this rank.  On RCCL `wait()` makes the CURRENT
+        stream wait for the collective (no host block), so a kernel launched next is ordered behind it; on gloo it blocks.
+        Costs a dictionary look-up per parameter when nothing is pending."""
+        if not any(b["ag"] is not None for b in self.buckets):
+            return
+        which = range(len(self.buckets)) if params is None else sorted({self._bucket_of[id(p)] for p in params if p is not None})
+        from .optim import _bump_version
+        for bi in which:
+            b = self.buckets[bi]
+            if b["ag"] is not None:
+                b["ag"].wait()
+                b["ag"] = None
+                for p, _ in b["entries"]:
+                    _bump_version(p)
 
     def written(self, params) -> None:
         """The gradients of `params` now sit in their grad_views() (kernels launched on the current stream): count them as
@@ -657,8 +684,11 @@ class ShardedAdam:
         self._fired = {}
         for p in self._order:
             self._steps[id(p)] += 1
-        gathers = []
-        for b in self.buckets:
+        self.wait_params()                      # (a previous step's lazy gathers: nobody may update a half-gathered buffer)
+        lazy = self._gather_first is not None and self._comm
+        first = [any(id(p) in self._gather_first for p, _ in b["entries"]) for b in self.buckets] if lazy else None
+        gathers, later = [], []
+        for bi, b in enumerate(self.buckets):
             b["rs"].wait()
             if self.average and self._comm and self.world > 1:
                 b["shard_g"].div_(self.world)
@@ -669,20 +699,29 @@ class ShardedAdam:
                                    b["exp_avg_sq"][s_off:s_off + n], float(g["lr"]), float(b1), float(b2), float(g["eps"]),
                                    self._steps[id(p)])
             if self._comm:
-                gathers.append(dist.all_gather_into_tensor(b["flat_p"], b["flat_p"][lo:lo + b["S"]], async_op=True))
+                if lazy and not first[bi]:
+                    later.append(bi)         # issued behind the buckets the next forward needs first (same order on every rank)
+                else:
+                    gathers.append(dist.all_gather_into_tensor(b["flat_p"], b["flat_p"][lo:lo + b["S"]], async_op=True))
             b.update(rs=None, stamp=None, ready=0, dirty=False)
+        for bi in later:
+            b = self.buckets[bi]
+            lo = self.rank * b["S"]
+            b["ag"] = dist.all_gather_into_tensor(b["flat_p"], b["flat_p"][lo:lo + b["S"]], async_op=True)
         for w in gathers:
             w.wait()
         self._sunk.clear(); self._expect_hook.clear()
         from .optim import _bump_version
         for p in self._order:
-            _bump_version(p)
+            if self.buckets[self._bucket_of[id(p)]]["ag"] is None:   # (lazily gathered parameters are bumped by wait_params)
+                _bump_version(p)
 
     # ------------------------------------------------------------------ checkpoints
     @torch.no_grad()
     def gather_state(self) -> dict:
         """{parameter: {"step", "exp_avg", "exp_avg_sq"}} with full-size tensors on every rank (a collective call): the
         state torch.optim.Adam would hold after the same steps."""
+        self.wait_params()
         out = {}
         for b in self.buckets:
             full = {}
@@ -726,6 +765,7 @@ class ShardedAdam:
         """Inverse of state_dict(); also takes a torch.optim.Adam state dict over the same parameter groups (a single-GPU
         checkpoint resumed on N ranks): every rank keeps its shard of the moments, the step counters and the groups'
         hyper-parameters (sugar_optimizer.py:123-124)."""
+        self.wait_params()
         groups = state_dict["param_groups"]
         if len(groups) != len(self.param_groups) or any(len(a["params"]) != len(b["params"]) for a, b in zip(groups, self.param_groups)):
             raise ValueError("loaded state dict has a different number of parameter groups / parameters per group")

@@ -105,8 +105,16 @@ class _RenderMeshBound(torch.autograd.Function):
         st = cfg["settings"]
         D, M = cfg["sh_levels"] - 1, 1 + int(rest.size(1))
         view = st.viewmatrix if cfg["depth_channels"] else None
+        # A sharded optimiser may have left the all-gather of some parameters in flight (dist.ShardedAdam(gather_first=...)):
+        # each producer's inputs are fenced right before it is launched, so the mesh producer runs under the SH buckets' gather
+        fence = getattr(cfg.get("sink"), "wait_params", None)
+        p_verts, p_rs, p_rc, p_dens, p_dc, p_rest, p_dt, p_dr = cfg["params"]
+        if fence is not None:
+            fence((p_verts, p_rs, p_rc, p_dt, p_dr))
         points, scaling, quats = producers._mesh_forward_raw(v, cfg["faces"], cfg["bary"], rs, rc, cfg["thickness"], cfg["lo"],
                                                              cfg["hi"], dt, dr)
+        if fence is not None:
+            fence((p_dc, p_rest, p_dens))
         colors, opac = producers._sh_forward_raw(points, st.campos, dc, rest, D, M, view, cfg["depth_channels"], dens)
         need_bwd = any(ctx.needs_input_grad)
         box = []
@@ -237,6 +245,14 @@ class SurfaceGaussians(nn.Module):
         if self._loose_bind:
             ps += [self._delta_t, self._delta_r]
         return ps + [self._points]
+
+    def mesh_parameters(self):
+        """The parameters the mesh producer reads -- the FIRST thing a render needs (dist.ShardedAdam(gather_first=...): their
+        all-gather is waited for in step(), the SH coefficients' runs under the next render's mesh producer)."""
+        ps = [self._points, self._scales, self._quaternions]
+        if self._loose_bind:
+            ps += [self._delta_t, self._delta_r]
+        return ps
 
     # -------------------------------------------------------------------------------- the reference's properties
     @property

@@ -510,3 +510,100 @@ def test_in_place_edit_of_a_sunk_gradient_is_noticed():
     for a, d in zip(ps, qs):
         assert torch.allclose(a, d, rtol=1e-6, atol=1e-7)
     opt.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Lazy all-gather (ShardedAdam(gather_first=...)): step() returns with the gathers of the buckets the next forward does not
+# need first still in flight; wait_params() is the readers' fence.  The collective is made SLOW on purpose here -- it only
+# happens when somebody waits for it -- so a reader that forgot the fence would provably see a half-gathered buffer.
+# ------------------------------------------------------------------------------------------------------------------
+class _FencedRead(torch.autograd.Function):
+    """sum_i c_i (p_i ** 2).sum() whose forward reads its parameters the way harness._RenderMeshBound does: group by group,
+    each behind the optimiser's fence."""
+
+    @staticmethod
+    def forward(ctx, sink, coeffs, n_first, *ps):
+        sink.wait_params(ps[:n_first])
+        vals = [p.detach().clone() for p in ps[:n_first]]
+        sink.wait_params(ps[n_first:])
+        vals += [p.detach().clone() for p in ps[n_first:]]
+        ctx.coeffs = coeffs
+        ctx.save_for_backward(*vals)
+        return sum(c * (v ** 2).sum() for c, v in zip(coeffs, vals))
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, None, None, *[2.0 * c * v * g for c, v in zip(ctx.coeffs, ctx.saved_tensors)])
+
+
+def _lazy_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from gaustar_amd import dist as gd
+    import torch.distributed as tdist
+    gd.init_from_env("gloo")
+    real_gather = tdist.all_gather_into_tensor
+
+    class _OnWait:           # the gather happens when it is waited for, not before
+        def __init__(self, out, inp):
+            self.out, self.inp, self.done = out, inp, False
+
+        def wait(self):
+            if not self.done:
+                real_gather(self.out, self.inp.clone())
+                self.done = True
+            return True
+    tdist.all_gather_into_tensor = lambda out, inp, async_op=False: _OnWait(out, inp) if async_op else real_gather(out, inp)
+    torch.manual_seed(0)
+    shapes = [(4000, 3), (50, 2), (33,), (700, 4)]       # [0] alone fills a bucket ("SH rest"); [1..3] share the second one
+    ps = [torch.nn.Parameter(torch.randn(*s)) for s in shapes]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    groups = lambda xs: [{"params": [xs[0], xs[1]], "lr": 1e-2}, {"params": [xs[2], xs[3]], "lr": 3e-3}]
+    opt = gd.ShardedAdam(groups(ps), ready_order=ps, eps=1e-15, bucket_bytes=40_000, segment_step=torch_adam_segment,
+                         gather_first=[ps[2], ps[3]])
+    ref = torch.optim.Adam(groups(qs), eps=1e-15)
+    assert len(opt.buckets) == 2
+    w = lambda r: [(i + 1.0) * (r + 1.0) for i in range(4)]
+    stale_seen, pending = [], []
+    order = [2, 3, 0, 1]                                   # the "forward" reads the gather_first parameters first
+    for it in range(4):
+        opt.zero_grad(); ref.zero_grad()
+        _FencedRead.apply(opt, [w(rank)[i] for i in order], 2, *[ps[i] for i in order]).backward()
+        lr_ = sum(0.5 * sum(c * (p ** 2).sum() for c, p in zip(w(r), qs)) for r in range(2))
+        lr_.backward()
+        opt.step(); ref.step()
+        pending.append(opt.pending_gathers())
+        # what a reader WITHOUT the fence would see: the other rank's shard of the lazily gathered bucket is still the old one
+        stale_seen.append(not torch.allclose(ps[0].detach(), qs[0].detach(), rtol=1e-6, atol=1e-7))
+        # ... while the parameters step() did wait for are complete
+        assert torch.allclose(ps[3].detach(), qs[3].detach(), rtol=1e-6, atol=1e-7) and torch.allclose(ps[2].detach(), qs[2].detach(), rtol=1e-6, atol=1e-7)
+    sd = opt.state_dict()                                  # (a collective that fences by itself)
+    assert opt.pending_gathers() == 0
+    err = max(float((p - q_).abs().max()) for p, q_ in zip(ps, qs))
+    flat = torch.cat([p.detach().reshape(-1) for p in ps])
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    tdist.all_gather_into_tensor = real_gather
+    torch.distributed.all_gather(both, flat)
+    q.put((rank, err, bool(torch.equal(both[0], both[1])), stale_seen, pending, sorted(sd["state"])))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_lazy_all_gather_is_fenced_gloo_world2():
+    """ShardedAdam(gather_first=[...]): step() leaves the other bucket's all-gather in flight (here: not even started until
+    waited for), an unfenced reader would see the stale shard, the fenced forward (harness._RenderMeshBound's pattern) never
+    does -- four steps equal torch.optim.Adam on the averaged gradients and both ranks end bit-identical."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_lazy_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, same, stale_seen, pending, idx in res:
+        assert err < 2e-6 and same, res
+        assert pending == [1, 1, 1, 1] and all(stale_seen), res
+        assert idx == [0, 1, 2, 3]

@@ -241,3 +241,26 @@ def test_gradient_sink_two_ranks_over_gloo_equals_one_process_averaging(tmp_path
            "--master-port", str(_free_port()), str(script)]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "SINK2_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_rccl_check_script_two_ranks_over_gloo():
+    """tools/rccl_check.py (what tools/rccl_smoke.sh runs over RCCL on a multi-GPU node), here with two ranks sharing this
+    box's GPU over gloo: ShardedAdam with the HIP Adam kernel, lazy all-gather and the render's gradient sink against
+    torch.optim.Adam on the rank-averaged gradients; ranks end bit-identical."""
+    env = dict(os.environ, GSR_BENCH_BACKEND="gloo", GSR_BENCH_NO_PIN="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join("tools", "rccl_check.py")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "RCCL_CHECK_OK world=2" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_bench_scale_step_at_one_gpu():
+    """`bench.py --gpus 1 --scale-step`: the N = 1 point of the step `--gpus N` times (refinement step, no exchange), so that
+    the driver's value(N) / (N value(1)) can be the scaling of ONE step."""
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "6", "--warmup", "2", "--repeats", "2", "--scale-step",
+                        "--no-cpu-baseline", "--no-extras"], cwd=ROOT, env=dict(os.environ, GSR_BENCH_NO_PIN="1"), capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["config"]["scale_step"] is True and d["config"]["views_in_flight"] == 1
+    assert "refinement step" in d["config"]["workload"] and d["value"] > 0 and d["config"]["value_spread"]["repeats"] == 2
