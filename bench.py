@@ -264,7 +264,23 @@ def issue_statistics(lib, rs, params, device):
     live = int(np.bitwise_count(live_words).sum())
     kept = np.bitwise_or.reduce(live_words, axis=2)                              # [U, 4]: positions any pixel of the block replays
     trips = int(np.bitwise_count(kept).sum())
+    # Snapshots (one float4 per pixel and unit, written by the forward when the pixel first consumes a candidate of the unit):
+    # NEEDED by the backward = the pixel has a candidate in the unit and its last contributor lies in or behind it (exactly the
+    # snapshots of units the pixel reached before its last contributor); WRITTEN beyond those: a pixel walks on behind its
+    # last contributor until a candidate stops it (T (1 - alpha) < 1e-4) -- if that candidate opens a new unit, one more
+    # snapshot is written that nobody reads (upper estimate: every pixel with a candidate in a later unit writes one).
+    has = words != 0
+    u_local = (np.arange(U) - unit0[tile_of])[:, None, None]
+    last_unit = np.where(nct > 0, (nct - 1) // 64, -1)[tile_of]
+    needed = int((has & (u_local > 0) & (u_local <= last_unit)).sum())
+    later = has & (u_local > 0) & (u_local > last_unit)
+    nz_tiles = np.nonzero(units > 0)[0]
+    extra = int((np.add.reduceat(later.astype(np.int32), unit0[nz_tiles], axis=0) > 0).sum()) if len(nz_tiles) else 0
+    snaps = {"needed_by_backward": needed, "written_upper_estimate": needed + extra,
+             "needed_over_written": round(needed / max(needed + extra, 1), 4),
+             "what": "per (pixel, unit) snapshots of view 0; written = needed + at most one per pixel whose walk went on into a later unit"}
     return {"live_pairs_per_view": live, "bwd_pair_trips_per_view": trips, "bwd_unit_blocks_with_work": int((kept != 0).sum()),
+            "snapshots": snaps,
             "bwd_live_lanes_per_pair_trip": round(live / max(trips, 1), 2), "num_rendered": int(Rn), "units": int(U)}
 
 

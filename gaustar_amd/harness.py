@@ -63,9 +63,32 @@ class NerfCamera:
         proj_t[2, 1] = -float(self.principal_ndc[1])
         full_t = (view_t @ proj_t).astype(np.float32)
         campos = np.asarray(self.c2w, dtype=np.float64)[:3, 3]    # p3d get_camera_center() = camera position
+        if getattr(self, "_center_override", None) is not None:   # (with_extrinsic: the reference's own formula)
+            campos = np.asarray(self._center_override, dtype=np.float64)
         return scene.Camera(W=int(self.width), H=int(self.height), tanfovx=math.tan(fovx * 0.5), tanfovy=math.tan(fovy * 0.5),
                             viewmatrix=np.ascontiguousarray(view_t, dtype=np.float32), projmatrix=np.ascontiguousarray(full_t),
                             campos=campos.astype(np.float32))
+
+    def with_extrinsic(self, extr) -> "NerfCamera":
+        """The camera `overwrite_extr` turns this one into (sugar_model.py:1119-1127 and :1141-1147): `extr` is a [4,4]
+        WORLD-TO-CAMERA matrix in COLMAP axes (X right, Y down, Z forward).  The reference stores R = inverse(extr[:3,:3])
+        and T = extr[:3,3] in its pytorch3d camera with the first two axes negated, negates them back, and hands
+        getWorld2View(R, T) = [R^T | T] to the rasterizer; its camera centre is pytorch3d's -T R^-1 of the stored pair, i.e.
+        -extr[:3,:3]^T ... for a rotation, the camera position.  Intrinsics, image size and clip planes are kept."""
+        E = np.asarray(extr.detach().cpu().numpy() if isinstance(extr, torch.Tensor) else extr, dtype=np.float64).reshape(4, 4)
+        R = np.linalg.inv(E[:3, :3])                          # :1121 (p3d_camera.R, the two sign flips of :1122 / :1143 cancel)
+        T = E[:3, 3].copy()                                   # :1123
+        w2c = np.eye(4)
+        w2c[:3, :3] = R.transpose()                           # getWorld2View: Rt[:3,:3] = R^T, Rt[:3,3] = t
+        w2c[:3, 3] = T
+        c2w = np.linalg.inv(w2c)
+        c2w[:3, 1:3] *= -1                                    # back to the NeRF axes rasterizer_camera() starts from
+        cam = NerfCamera(c2w=c2w[:3, :], fx=self.fx, fy=self.fy, width=self.width, height=self.height, znear=self.znear,
+                         zfar=self.zfar, principal_ndc=self.principal_ndc)
+        # pytorch3d's get_camera_center() of the stored (R, T) pair: C = -T_p3d R_p3d^-1 with R_p3d = R D, T_p3d = T D
+        # (D = diag(-1, -1, 1)) = -T R^-1 -- equal to c2w[:3, 3] for a rigid `extr`, and what the reference uses otherwise
+        cam._center_override = (-(T @ np.linalg.inv(R))).astype(np.float32)
+        return cam
 
     def on_device(self, device):
         """(Camera, viewmatrix, full_proj, campos) with the three tensors resident on `device`, built once."""
@@ -310,13 +333,16 @@ class SurfaceGaussians(nn.Module):
         return torch.cat([self._sh_coordinates_dc, self._sh_coordinates_rest], dim=1)
 
     def get_points_rgb(self, positions=None, camera_centers=None, directions=None, sh_levels=None, sh_coordinates=None):
-        """sugar_model.py:674-718 (one camera centre; the `directions` variant is not provided)."""
-        if directions is not None or camera_centers is None:
-            raise NotImplementedError("get_points_rgb: only the camera_centers form is provided")
-        positions = self.points if positions is None else positions
+        """sugar_model.py:674-718: colours for one camera centre (fused HIP producer) or, when `camera_centers` is None, for
+        the given `directions`, taken as they are (torch operations, producers.points_rgb_from_directions)."""
         sh = self.sh_coordinates if sh_coordinates is None else sh_coordinates
         levels = self.sh_levels if sh_levels is None else int(sh_levels)
-        return producers.points_rgb(positions, camera_centers, sh, levels)
+        if camera_centers is not None:                                        # :698-699 (takes precedence, as in the reference)
+            positions = self.points if positions is None else positions
+            return producers.points_rgb(positions, camera_centers, sh, levels)
+        if directions is not None:                                            # :700-701
+            return producers.points_rgb_from_directions(directions, sh, levels)
+        raise ValueError("Either camera_centers or directions must be provided.")   # :703
 
     # -------------------------------------------------------------------------------- rendering
     def _settings(self, camera: NerfCamera, bg: torch.Tensor, sh_degree: int):
@@ -340,16 +366,21 @@ class SurfaceGaussians(nn.Module):
                                          compute_covariance_in_rasterizer: bool = True, return_2d_radii: bool = False,
                                          quaternions=None, use_solid_surface: bool = False,
                                          use_same_scale_in_all_directions: bool = False, return_opacities: bool = False,
-                                         return_colors: bool = False, positions=None, point_colors=None):
+                                         return_colors: bool = False, positions=None, point_colors=None, overwrite_extr=None):
         """sugar_model.py:1065-1311 with `camera` in place of (nerf_cameras, camera_indices).  Returns the image [H,W,3]
-        or, with return_2d_radii / return_opacities / return_colors, the reference's dict."""
-        if sh_rotations is not None or not compute_covariance_in_rasterizer:
-            raise NotImplementedError("sh_rotations / precomputed 3-D covariances are not part of this counterpart")
+        or, with return_2d_radii / return_opacities / return_colors, the reference's dict.  `overwrite_extr` (a [4,4]
+        world-to-camera matrix, COLMAP axes; :1119-1127, :1141-1147) replaces the camera's pose and keeps its intrinsics;
+        `sh_rotations` ([P,3,3]) turns every view direction before the SH evaluation (:1200-1205);
+        `compute_covariance_in_rasterizer=False` hands the rasterizer R diag(s^2) R^T instead of scales + quaternions
+        (:1237-1260)."""
+        if overwrite_extr is not None:
+            camera = camera.with_extrinsic(overwrite_extr)
         dev = self.device
         bg = torch.zeros(3, device=dev) if bg_color is None else torch.as_tensor(bg_color, dtype=torch.float32, device=dev)
         sh_deg = self.sh_levels - 1 if sh_deg is None else int(sh_deg)
         if (positions is None and point_colors is None and quaternions is None and not compute_color_in_rasterizer
-                and not use_solid_surface and not use_same_scale_in_all_directions
+                and not use_solid_surface and not use_same_scale_in_all_directions and sh_rotations is None
+                and compute_covariance_in_rasterizer
                 and not (return_2d_radii or return_opacities or return_colors)):
             # the plain call (what the refinement loop issues, refine.py:552): the whole render as one autograd node
             img, _ = self.render_channels(camera, bg, sh_deg=sh_deg, depth_channels=0)
@@ -360,8 +391,11 @@ class SurfaceGaussians(nn.Module):
         if point_colors is None:
             if compute_color_in_rasterizer:
                 shs = self.sh_coordinates                                     # :1208
-            else:
+            elif sh_rotations is None:
                 splat_colors = self.get_points_rgb(positions=positions, camera_centers=campos, sh_levels=sh_deg + 1)
+            else:                                                             # :1200-1205
+                dirs = (torch.nn.functional.normalize(positions - campos.view(1, 3), dim=-1).unsqueeze(1) @ sh_rotations)[..., 0, :]
+                splat_colors = self.get_points_rgb(positions=positions, camera_centers=None, directions=dirs, sh_levels=sh_deg + 1)
         else:
             splat_colors = point_colors                                       # :1211
         splat_opacities = self.strengths.view(-1, 1)
@@ -370,9 +404,13 @@ class SurfaceGaussians(nn.Module):
         screenspace_points = torch.zeros(self.n_points, 3, dtype=positions.dtype, requires_grad=True, device=dev)
         if return_2d_radii:
             screenspace_points.retain_grad()
+        cov3D = None
+        if not compute_covariance_in_rasterizer:                              # :1237-1260
+            cov3D = producers.covariance_3d(scales, quaternions)
+            scales = quaternions = None
         rendered_image, radii = GaussianRasterizer(settings)(means3D=positions, means2D=screenspace_points, shs=shs,
                                                             colors_precomp=splat_colors, opacities=splat_opacities,
-                                                            scales=scales, rotations=quaternions, cov3D_precomp=None)
+                                                            scales=scales, rotations=quaternions, cov3D_precomp=cov3D)
         image = rendered_image.transpose(0, 1).transpose(1, 2)                # :1298
         if not (return_2d_radii or return_opacities or return_colors):
             return image

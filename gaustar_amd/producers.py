@@ -297,3 +297,70 @@ def _check_faces(faces: torch.Tensor, n_verts: int) -> None:
         setattr(faces, _FACES_ATTR, (faces._version, n_verts))
     except AttributeError:   # (a tensor subclass with __slots__: checked every call)
         pass
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The `directions=` form of SuGaR.get_points_rgb (sugar_model.py:700-716): colours from GIVEN view directions, used as they
+# are (not re-normalised) -- the form render_image_gaussian_rasterizer takes with `sh_rotations` (sugar_model.py:1200-1205).
+# A rarely used option: plain torch operations on the caller's (device) tensors, autograd included; the constants and
+# polynomials are those of gaustar_utils/spherical_harmonics.py:16-33, :134-171 (= auxiliary.h:22-39 up to degree 3).
+# ------------------------------------------------------------------------------------------------------------------
+_SH_C0 = 0.28209479177387814
+_SH_C1 = 0.4886025119029199
+_SH_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
+_SH_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+          1.445305721320277, -0.5900435899266435)
+_SH_C4 = (2.5033429417967046, -1.7701307697799304, 0.9461746957575601, -0.6690465435572892, 0.10578554691520431,
+          -0.6690465435572892, 0.47308734787878004, -1.7701307697799304, 0.6258357354491761)
+
+
+def sh_basis_torch(deg: int, dirs: torch.Tensor) -> torch.Tensor:
+    """[P, (deg+1)^2] values of the real SH basis polynomials at `dirs` [P,3] (spherical_harmonics.py:134-171; degree <= 4)."""
+    if deg < 0 or deg > 4:
+        raise ValueError("sh degree must be 0..4")
+    x, y, z = dirs[..., 0], dirs[..., 1], dirs[..., 2]
+    b = [torch.full_like(x, _SH_C0)]
+    if deg > 0:
+        b += [-_SH_C1 * y, _SH_C1 * z, -_SH_C1 * x]
+    if deg > 1:
+        xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+        b += [_SH_C2[0] * xy, _SH_C2[1] * yz, _SH_C2[2] * (2.0 * zz - xx - yy), _SH_C2[3] * xz, _SH_C2[4] * (xx - yy)]
+        if deg > 2:
+            b += [_SH_C3[0] * y * (3 * xx - yy), _SH_C3[1] * xy * z, _SH_C3[2] * y * (4 * zz - xx - yy),
+                  _SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy), _SH_C3[4] * x * (4 * zz - xx - yy), _SH_C3[5] * z * (xx - yy),
+                  _SH_C3[6] * x * (xx - 3 * yy)]
+            if deg > 3:
+                b += [_SH_C4[0] * xy * (xx - yy), _SH_C4[1] * yz * (3 * xx - yy), _SH_C4[2] * xy * (7 * zz - 1),
+                      _SH_C4[3] * yz * (7 * zz - 3), _SH_C4[4] * (zz * (35 * zz - 30) + 3), _SH_C4[5] * xz * (7 * zz - 3),
+                      _SH_C4[6] * (xx - yy) * (7 * zz - 1), _SH_C4[7] * xz * (xx - 3 * yy),
+                      _SH_C4[8] * (xx * (xx - 3 * yy) - yy * (3 * xx - yy))]
+    return torch.stack(b, dim=-1)
+
+
+def points_rgb_from_directions(directions: torch.Tensor, sh_coordinates: torch.Tensor, sh_levels: int) -> torch.Tensor:
+    """colors[P,3] = clamp_min(eval_sh(sh_levels-1, sh_coordinates[:, :sh_levels**2], directions) + 0.5, 0) with the
+    directions taken as given (sugar_model.py:702-716)."""
+    n = int(sh_levels) ** 2
+    if sh_coordinates.dim() != 3 or sh_coordinates.size(1) < n or sh_coordinates.size(2) != 3:
+        raise RuntimeError(f"sh_coordinates must be (num_points, >= {n}, 3)")
+    basis = sh_basis_torch(int(sh_levels) - 1, directions)                       # [P, n]
+    return torch.clamp_min((basis.unsqueeze(-1) * sh_coordinates[:, :n]).sum(dim=1) + 0.5, 0.0)
+
+
+def quaternion_to_matrix(q: torch.Tensor) -> torch.Tensor:
+    """pytorch3d.transforms.quaternion_to_matrix (real part first; the published algorithm: two_s = 2 / |q|^2), as
+    render_image_gaussian_rasterizer uses it for `compute_covariance_in_rasterizer=False` (sugar_model.py:1239)."""
+    r, i, j, k = torch.unbind(q, -1)
+    two_s = 2.0 / (q * q).sum(-1)
+    o = torch.stack((1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
+                     two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
+                     two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)), -1)
+    return o.reshape(q.shape[:-1] + (3, 3))
+
+
+def covariance_3d(scales: torch.Tensor, quaternions: torch.Tensor) -> torch.Tensor:
+    """cov3D[P,6] = upper triangle {xx, xy, xz, yy, yz, zz} of R diag(s^2) R^T (sugar_model.py:1237-1257)."""
+    R = quaternion_to_matrix(quaternions)
+    M = R * (scales * scales).unsqueeze(-2)                                      # R diag(s^2)
+    S = M @ R.transpose(-1, -2)
+    return torch.stack((S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]), dim=-1)

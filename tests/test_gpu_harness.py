@@ -188,3 +188,76 @@ def test_one_node_render_with_constant_colours_only(hip_lib):
     ref = m.render_image_gaussian_rasterizer(ncam, bg_color=[0.0, 1.0, 0.0], return_opacities=True)["image"]   # (the composition of nodes)
     assert torch.equal(img[:3].permute(1, 2, 0), ref)
     assert torch.equal(m.render_image_gaussian_rasterizer(ncam, bg_color=[0.0, 1.0, 0.0]), ref)                  # (the plain call: one node)
+
+
+# ------------------------------------------------------------------ the less-travelled arguments (sugar_model.py:1065-1311)
+def test_overwrite_extr_renders_the_other_camera(hip_lib):
+    """render_image_gaussian_rasterizer(camera A, overwrite_extr = world-to-camera of B) == render(camera B)
+    (sugar_model.py:1119-1127, :1141-1147; refined_mesh.py:353 renders from a re-posed camera this way)."""
+    from gaustar_amd import harness, scene
+    m = _model(2, False, seed=5)
+    a = scene.look_at_camera((0.5, 1.6, 2.6), (0.0, 1.2, 0.0), 200, 160, focal_px=170.0)
+    b = scene.look_at_camera((-0.9, 0.8, 2.4), (0.0, 1.2, 0.0), 200, 160, focal_px=170.0)
+    na, nb = harness.nerf_camera_from_scene(a), harness.nerf_camera_from_scene(b)
+    E = torch.from_numpy(np.asarray(b.viewmatrix, np.float32).T.copy()).cuda()
+    with torch.no_grad():
+        want = m.render_image_gaussian_rasterizer(camera=nb, bg_color=[0.1, 0.2, 0.3], sh_deg=3)
+        got = m.render_image_gaussian_rasterizer(camera=na, bg_color=[0.1, 0.2, 0.3], sh_deg=3, overwrite_extr=E)
+        other = m.render_image_gaussian_rasterizer(camera=na, bg_color=[0.1, 0.2, 0.3], sh_deg=3)
+    # (the pose goes through two more float64 inversions: matrices equal to 1e-6, a threshold flip allowed as elsewhere)
+    parity.check_image(got.permute(2, 0, 1).cpu().numpy(), want.permute(2, 0, 1).cpu().numpy(), "overwrite_extr vs camera B", tol=2e-4,
+                       max_outlier_frac=2e-4)
+    assert float((got - other).abs().max()) > 0.05          # and it is not camera A's image
+
+
+def test_sh_rotations_turn_the_view_directions(hip_lib):
+    """sh_rotations = identity gives the plain render's colours; a random rotation per Gaussian gives
+    clamp_min(eval_sh(normalize(p - c) @ R) + 0.5, 0) (sugar_model.py:1200-1205) -- checked against the producer oracle's
+    eval_sh restatement (pinned by the reference's own) -- and gradients reach the SH coefficients and the positions."""
+    from gaustar_amd import harness, scene
+    from oracle import producers_oracle as po
+    m = _model(2, True, seed=6)
+    ncam = harness.nerf_camera_from_scene(scene.look_at_camera((0.4, 1.5, 2.7), (0.0, 1.2, 0.0), 160, 120, focal_px=140.0))
+    P = m.n_points
+    eye = torch.eye(3, device="cuda").expand(P, 3, 3).contiguous()
+    with torch.no_grad():
+        plain = m.render_image_gaussian_rasterizer(camera=ncam, sh_deg=3, return_colors=True)
+        ident = m.render_image_gaussian_rasterizer(camera=ncam, sh_deg=3, sh_rotations=eye, return_colors=True)
+    assert torch.allclose(plain["colors"], ident["colors"], rtol=1e-5, atol=2e-6)
+    assert torch.allclose(plain["image"], ident["image"], rtol=1e-4, atol=1e-4)
+    from scipy.spatial.transform import Rotation
+    Rm = torch.from_numpy(Rotation.random(P, random_state=1).as_matrix().astype(np.float32)).cuda()
+    out = m.render_image_gaussian_rasterizer(camera=ncam, sh_deg=3, sh_rotations=Rm, return_colors=True)
+    _cam, _view, _proj, campos = ncam.on_device(m.device)
+    pts = m.points.detach()
+    dirs = (torch.nn.functional.normalize(pts - campos.view(1, 3), dim=-1).unsqueeze(1) @ Rm)[..., 0, :]
+    sh = m.sh_coordinates.detach().cpu()
+    want = torch.clamp_min(po.eval_sh(3, sh.transpose(-1, -2), dirs.cpu()) + 0.5, 0.0)
+    assert torch.allclose(out["colors"].detach().cpu(), want, rtol=1e-5, atol=5e-6)
+    out["image"].sum().backward()
+    assert m._sh_coordinates_rest.grad is not None and float(m._sh_coordinates_rest.grad.abs().max()) > 0
+    assert m._points.grad is not None and torch.isfinite(m._points.grad).all()
+
+
+def test_covariance_handed_over_instead_of_scales_and_rotations(hip_lib):
+    """compute_covariance_in_rasterizer=False (sugar_model.py:1237-1260): cov3D = R diag(s^2) R^T formed outside and passed
+    as cov3D_precomp renders the same image as scales + quaternions, and gradients flow back through it to the mesh."""
+    from gaustar_amd import harness, scene
+    m = _model(2, False, seed=7)
+    ncam = harness.nerf_camera_from_scene(scene.look_at_camera((0.5, 1.6, 2.6), (0.0, 1.2, 0.0), 200, 160, focal_px=170.0))
+    inside = m.render_image_gaussian_rasterizer(camera=ncam, bg_color=[0.0, 1.0, 0.0], sh_deg=3, return_2d_radii=True)
+    outside = m.render_image_gaussian_rasterizer(camera=ncam, bg_color=[0.0, 1.0, 0.0], sh_deg=3, compute_covariance_in_rasterizer=False,
+                                                 return_2d_radii=True)
+    assert int((inside["radii"] != outside["radii"]).sum()) <= 2
+    parity.check_image(outside["image"].detach().permute(2, 0, 1).cpu().numpy(), inside["image"].detach().permute(2, 0, 1).cpu().numpy(),
+                       "cov3D outside vs inside the rasterizer", tol=2e-4, max_outlier_frac=2e-4)
+    g = {}
+    for name, out in (("in", inside), ("out", outside)):
+        for p in m.parameters():
+            p.grad = None
+        (out["image"] * torch.linspace(0.5, 1.5, 3, device="cuda")).sum().backward()
+        g[name] = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+    assert set(g["in"]) == set(g["out"])
+    for k in g["in"]:
+        a, b = g["out"][k], g["in"][k]
+        assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()) + 1e-7, k
