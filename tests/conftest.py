@@ -16,7 +16,7 @@ def pytest_configure(config):
 
 
 def golden_names():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith(("utils_", "loss_", "producers_", "formats_")))
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith(("utils_", "loss_", "producers_", "formats_", "harness_")))
 
 
 @pytest.fixture(scope="session")

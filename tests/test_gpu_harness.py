@@ -252,10 +252,13 @@ def test_covariance_handed_over_instead_of_scales_and_rotations(hip_lib):
     parity.check_image(outside["image"].detach().permute(2, 0, 1).cpu().numpy(), inside["image"].detach().permute(2, 0, 1).cpu().numpy(),
                        "cov3D outside vs inside the rasterizer", tol=2e-4, max_outlier_frac=2e-4)
     g = {}
-    for name, out in (("in", inside), ("out", outside)):
+    for name, flag in (("in", True), ("out", False)):   # (rendered again: the two renders above share the cached geometry node)
         for p in m.parameters():
             p.grad = None
-        (out["image"] * torch.linspace(0.5, 1.5, 3, device="cuda")).sum().backward()
+        m._geom_cache = None
+        img = m.render_image_gaussian_rasterizer(camera=ncam, bg_color=[0.0, 1.0, 0.0], sh_deg=3, compute_covariance_in_rasterizer=flag,
+                                                 return_2d_radii=True)["image"]
+        (img * torch.linspace(0.5, 1.5, 3, device="cuda")).sum().backward()
         g[name] = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
     assert set(g["in"]) == set(g["out"])
     for k in g["in"]:
