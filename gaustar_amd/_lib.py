@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_longlong, c_si
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSR_LIB_PATH", os.path.join(_HERE, "libgsr_hip.so"))   # override: experiment variants
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 ALLOC_FN = ctypes.CFUNCTYPE(c_void_p, c_void_p, c_size_t)
 
 # name -> (restype, argtypes); mirrors include/gsr.h one to one (tests check both directions).
@@ -75,6 +75,14 @@ SIGNATURES = {
     "gsr_depth_l1_workspace_bytes": (c_size_t, []),
     "gsr_depth_l1": (c_int, [c_int, c_int, c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_longlong, c_float,
                              c_float, c_float, c_void_p, c_void_p, c_void_p, c_longlong, c_longlong, c_void_p]),
+    "gsr_l1_ssim_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_longlong, c_longlong, c_longlong, c_void_p, c_longlong,
+                                     c_longlong, c_longlong, c_float, c_void_p, c_void_p, c_void_p, c_longlong, c_longlong,
+                                     c_longlong, c_void_p]),
+    "gsr_depth_l1_backward": (c_int, [c_int, c_int, c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_longlong, c_float,
+                                      c_float, c_float, c_void_p, c_void_p, c_void_p, c_longlong, c_longlong, c_void_p]),
+    "gsr_rgb_depth_loss": (c_int, [c_int, c_int, c_int, c_void_p, c_longlong, c_longlong, c_longlong, c_void_p, c_longlong,
+                                   c_longlong, c_longlong, c_float, c_void_p, c_int, c_int, c_void_p, c_longlong, c_longlong,
+                                   c_void_p, c_longlong, c_longlong, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "gsr_adam_step": (c_int, [c_longlong, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_double, c_int,
                               c_void_p]),
     "gsr_adam_step_multi": (c_int, [c_int, POINTER(c_longlong), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),

@@ -88,7 +88,7 @@ int fail_msg(const char* msg)
 
 extern "C" {
 
-int gsr_abi_version(void) { return 11; }
+int gsr_abi_version(void) { return 12; }
 
 const char* gsr_last_error(void) { return g_err.c_str(); }
 
@@ -783,6 +783,66 @@ int gsr_depth_l1(int H, int W, const float* pred, long long pred_sy, long long p
         launch_depth_l1(H, W, pred, ps, gt, gs_, max_depth, depth_factor, mask_factor, workspace, loss_out, dL_dpred, qs, st);
     }
     GSR_CHECK_LAUNCH("depth_l1 kernels");
+    return 0;
+}
+
+int gsr_l1_ssim_backward(int C, int H, int W, const float* pred, long long pred_sc, long long pred_sy, long long pred_sx,
+                         const float* gt, long long gt_sc, long long gt_sy, long long gt_sx, float dssim_factor,
+                         const void* workspace, const float* grad_scale, float* dL_dpred, long long grad_sc, long long grad_sy,
+                         long long grad_sx, gsr_stream_t stream)
+{
+    g_err.clear();
+    if (C <= 0 || H <= 0 || W <= 0) return fail_msg("gsr_l1_ssim_backward: image size must be positive");
+    if (C > 65535) return fail_msg("gsr_l1_ssim_backward: too many channels");
+    if (!pred || !gt || !workspace || !dL_dpred) return fail_msg("gsr_l1_ssim_backward: required pointer is null");
+    const long long ps[3] = {pred_sc, pred_sy, pred_sx}, gs_[3] = {gt_sc, gt_sy, gt_sx}, qs[3] = {grad_sc, grad_sy, grad_sx};
+    hipStream_t st = (hipStream_t)stream;
+    {
+        Scope sc(ST_LOSS, st);
+        launch_l1_ssim_grad(C, H, W, pred, ps, gt, gs_, dssim_factor, workspace, grad_scale, dL_dpred, qs, st);
+    }
+    GSR_CHECK_LAUNCH("ssim_grad_kernel");
+    return 0;
+}
+
+int gsr_depth_l1_backward(int H, int W, const float* pred, long long pred_sy, long long pred_sx, const float* gt,
+                          long long gt_sy, long long gt_sx, float max_depth, float depth_factor, float mask_factor,
+                          const float* stats, const float* grad_scale, float* dL_dpred, long long grad_sy, long long grad_sx,
+                          gsr_stream_t stream)
+{
+    g_err.clear();
+    if (H <= 0 || W <= 0) return fail_msg("gsr_depth_l1_backward: image size must be positive");
+    if (!pred || !gt || !stats || !dL_dpred) return fail_msg("gsr_depth_l1_backward: required pointer is null");
+    const long long ps[2] = {pred_sy, pred_sx}, gs_[2] = {gt_sy, gt_sx}, qs[2] = {grad_sy, grad_sx};
+    hipStream_t st = (hipStream_t)stream;
+    {
+        Scope sc(ST_LOSS, st);
+        launch_depth_l1_grad(H, W, pred, ps, gt, gs_, max_depth, depth_factor, mask_factor, stats, grad_scale, dL_dpred, qs, st);
+    }
+    GSR_CHECK_LAUNCH("depth_grad_kernel");
+    return 0;
+}
+
+int gsr_rgb_depth_loss(int C, int H, int W, const float* pred, long long pred_sc, long long pred_sy, long long pred_sx,
+                       const float* gt, long long gt_sc, long long gt_sy, long long gt_sx, float dssim_factor,
+                       void* ssim_workspace, int Hd, int Wd, const float* depth_pred, long long dpred_sy, long long dpred_sx,
+                       const float* depth_gt, long long dgt_sy, long long dgt_sx, float max_depth, float depth_factor,
+                       float mask_factor, void* depth_workspace, float* loss_out, gsr_stream_t stream)
+{
+    g_err.clear();
+    if (C <= 0 || H <= 0 || W <= 0 || Hd <= 0 || Wd <= 0) return fail_msg("gsr_rgb_depth_loss: image size must be positive");
+    if (C > 65535) return fail_msg("gsr_rgb_depth_loss: too many channels");
+    if (!pred || !gt || !ssim_workspace || !depth_pred || !depth_gt || !depth_workspace || !loss_out)
+        return fail_msg("gsr_rgb_depth_loss: required pointer is null");
+    const long long ps[3] = {pred_sc, pred_sy, pred_sx}, gs_[3] = {gt_sc, gt_sy, gt_sx};
+    const long long dps[2] = {dpred_sy, dpred_sx}, dgs[2] = {dgt_sy, dgt_sx};
+    hipStream_t st = (hipStream_t)stream;
+    {
+        Scope sc(ST_LOSS, st);
+        launch_rgb_depth_loss(C, H, W, pred, ps, gt, gs_, dssim_factor, ssim_workspace, Hd, Wd, depth_pred, dps, depth_gt, dgs,
+                              max_depth, depth_factor, mask_factor, depth_workspace, loss_out, st);
+    }
+    GSR_CHECK_LAUNCH("rgb_depth_loss kernels");
     return 0;
 }
 

@@ -220,10 +220,21 @@ size_t l1_ssim_workspace_bytes(int C, int H, int W);
 void launch_l1_ssim(int C, int H, int W, const float* pred, const long long* pred_strides, const float* gt,
                     const long long* gt_strides, float dssim_factor, void* workspace, float* loss_out, float* grad,
                     const long long* grad_strides, hipStream_t st);
+void launch_l1_ssim_grad(int C, int H, int W, const float* pred, const long long* pred_strides, const float* gt,
+                         const long long* gt_strides, float dssim_factor, const void* workspace, const float* scale, float* grad,
+                         const long long* grad_strides, hipStream_t st);
 size_t depth_l1_workspace_bytes();
 void launch_depth_l1(int H, int W, const float* pred, const long long* pred_strides, const float* gt,
                      const long long* gt_strides, float max_depth, float depth_factor, float mask_factor,
                      void* workspace, float* loss_out, float* grad, const long long* grad_strides, hipStream_t st);
+
+void launch_depth_l1_grad(int H, int W, const float* pred, const long long* pred_strides, const float* gt,
+                          const long long* gt_strides, float max_depth, float depth_factor, float mask_factor,
+                          const float* stats, const float* scale, float* grad, const long long* grad_strides, hipStream_t st);
+void launch_rgb_depth_loss(int C, int H, int W, const float* pred, const long long* ps, const float* gt, const long long* gs_, float f,
+                           void* ws_ssim, int Hd, int Wd, const float* dpred, const long long* dps, const float* dgt,
+                           const long long* dgs, float max_depth, float depth_factor, float mask_factor, void* ws_depth,
+                           float* out8, hipStream_t st);
 
 // Optional per-workgroup timeline for tuning (gsr_debug_set_trace): when non-null, the blend kernels store
 // {start, end} of every workgroup (100 MHz wall clock) at trace[2*blockIdx] (forward) / trace[2*(T+blockIdx)].

@@ -7,7 +7,7 @@
 // five convolutions); at 1080p that is several milliseconds around a rasterizer that now takes 0.4.
 //
 // Here: two tiled passes, each a separable 11-tap Gaussian in LDS.
-//   pass 1  x, y tile (+5 halo, zero outside the crop like conv2d's zero padding) -> mu_x, mu_y, E[x^2], E[y^2], E[xy]
+//   pass 1  x, y tile (+5 halo, zero outside the crop like conv2d's zero padding) -> mu_x, mu_y, E[x^2 + y^2], E[xy]
 //           -> SSIM map value S and its three partial derivatives w.r.t. the x-dependent window moments
 //              D1 = dS/dmu_x, D2 = dS/dE[x^2], D3 = dS/dE[xy]   (closed form, below);
 //           per-workgroup partial sums of S and |x - y|.
@@ -23,7 +23,7 @@ constexpr int LR = 5;                 // window radius (window_size 11, loss_uti
 #define GSR_SSIM_TILE_H 16
 #endif
 constexpr int LT = 32;                // output tile width
-constexpr int LTY = GSR_SSIM_TILE_H;  // output tile height (16: 25 KB of LDS per workgroup -> 6 workgroups per CU)
+constexpr int LTY = GSR_SSIM_TILE_H;  // output tile height (16: 22 KB of LDS per workgroup in pass 1 -> 7 workgroups per CU)
 constexpr int LI = LT + 2 * LR;       // input tile width (42)
 constexpr int LIY = LTY + 2 * LR;     // input tile height
 constexpr int LP = LI + 1;            // padded LDS row of the input tile
@@ -39,6 +39,17 @@ __device__ constexpr float GW[11] = {0x1.0d956cp-10f, 0x1.f1fe02p-8f, 0x1.26eb18
                                      0x1.10656p-2f,   0x1.b43c3ep-3f, 0x1.bff0fep-4f, 0x1.26eb18p-5f, 0x1.f1fe02p-8f,
                                      0x1.0d956cp-10f};
 constexpr float SSIM_C1 = 0.01f * 0.01f, SSIM_C2 = 0.03f * 0.03f;   // loss_utils.py:54-55
+// One output of the 11-tap window.  The window is symmetric (GW[k] == GW[10 - k], bit for bit), so the taps are paired:
+// five additions (the cheap instruction class) + six multiply-adds instead of eleven multiply-adds -- the two SSIM kernels
+// are vector-issue-bound on exactly these loops.  (Summation order differs from a left-to-right conv2d by rounding only:
+// tests/test_gpu_losses.py holds the loss to 2e-6 and the gradient to 2e-4 of its maximum against the reference's.)
+__device__ __forceinline__ float win11(const float* v)
+{
+    float s = GW[5] * v[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) s = __builtin_fmaf(GW[k], v[k] + v[10 - k], s);
+    return s;
+}
 
 struct View { const float* p; long long sc, sy, sx; };     // element strides of a [C,H,W]-indexed image
 struct ViewW { float* p; long long sc, sy, sx; };
@@ -59,7 +70,9 @@ __global__ void __launch_bounds__(256)
 ssim_stats_kernel(int H, int W, View x, View y, float* __restrict__ D, float* __restrict__ partials)
 {
     __shared__ float X[LIY * LP], Y[LIY * LP];
-    __shared__ float Hq[5][LIY * LT];
+    // (SSIM reads E[x^2] and E[y^2] only as their SUM -- sigma_x^2 + sigma_y^2 -- so x^2 + y^2 goes through the window as
+    // ONE quantity: four windowed maps instead of the reference's five, loss_utils.py:47-52)
+    __shared__ float Hq[4][LIY * LT];
     __shared__ float red[4];
     const int tid = threadIdx.x;
     const int tx0 = blockIdx.x * LT, ty0 = blockIdx.y * LTY, ch = blockIdx.z;
@@ -101,40 +114,29 @@ ssim_stats_kernel(int H, int W, View x, View y, float* __restrict__ D, float* __
     // reads per output before, 7 now) and its three products are formed once instead of eleven times.
     for (int t = tid; t < LIY * (LT / HS); t += 256) {
         const int r = t / (LT / HS), c0 = (t - r * (LT / HS)) * HS;
-        float a[HS + 10], b[HS + 10], aa[HS + 10], bb[HS + 10], ab[HS + 10];
+        float a[HS + 10], b[HS + 10], sq[HS + 10], ab[HS + 10];
 #pragma unroll
         for (int k = 0; k < HS + 10; k++) {
             a[k] = X[r * LP + c0 + k]; b[k] = Y[r * LP + c0 + k];
-            aa[k] = a[k] * a[k]; bb[k] = b[k] * b[k]; ab[k] = a[k] * b[k];
+            sq[k] = __builtin_fmaf(a[k], a[k], b[k] * b[k]); ab[k] = a[k] * b[k];
         }
 #pragma unroll
         for (int o = 0; o < HS; o++) {
-            float hx = 0.f, hy = 0.f, hxx = 0.f, hyy = 0.f, hxy = 0.f;
-#pragma unroll
-            for (int k = 0; k < 11; k++) {
-                const float w = GW[k];
-                hx += w * a[o + k]; hy += w * b[o + k]; hxx += w * aa[o + k]; hyy += w * bb[o + k]; hxy += w * ab[o + k];
-            }
             const int i = r * LT + c0 + o;
-            Hq[0][i] = hx; Hq[1][i] = hy; Hq[2][i] = hxx; Hq[3][i] = hyy; Hq[4][i] = hxy;
+            Hq[0][i] = win11(a + o); Hq[1][i] = win11(b + o); Hq[2][i] = win11(sq + o); Hq[3][i] = win11(ab + o);
         }
     }
     __syncthreads();
     // vertical: thread = (column c, group of 4 rows); 14 rows of each quantity slide through registers
     const int c = tid & 31, r0 = (tid >> 5) * RPT;
-    float out[5][RPT];
+    float out[4][RPT];
 #pragma unroll
-    for (int q = 0; q < 5; q++) {
+    for (int q = 0; q < 4; q++) {
         float col[RPT + 10];
 #pragma unroll
         for (int k = 0; k < RPT + 10; k++) col[k] = Hq[q][(r0 + k) * LT + c];
 #pragma unroll
-        for (int o = 0; o < RPT; o++) {
-            float s = 0.f;
-#pragma unroll
-            for (int k = 0; k < 11; k++) s += GW[k] * col[o + k];
-            out[q][o] = s;
-        }
+        for (int o = 0; o < RPT; o++) out[q][o] = win11(col + o);
     }
     float l1 = 0.f, ssum = 0.f;
     const size_t plane = (size_t)H * W;
@@ -143,10 +145,11 @@ ssim_stats_kernel(int H, int W, View x, View y, float* __restrict__ D, float* __
         const int gy = ty0 + r0 + o, gx = tx0 + c;
         if (gy < H && gx < W) {
             const float mu1 = out[0][o], mu2 = out[1][o];
-            const float s1 = out[2][o] - mu1 * mu1, s2 = out[3][o] - mu2 * mu2, s12 = out[4][o] - mu1 * mu2;
+            const float musq = mu1 * mu1 + mu2 * mu2;
+            const float s1s2 = out[2][o] - musq, s12 = out[3][o] - mu1 * mu2;   // sigma_x^2 + sigma_y^2, sigma_xy
             // loss_utils.py:57
             const float a1 = 2.f * mu1 * mu2 + SSIM_C1, a2 = 2.f * s12 + SSIM_C2;
-            const float b1 = mu1 * mu1 + mu2 * mu2 + SSIM_C1, b2 = s1 + s2 + SSIM_C2;
+            const float b1 = musq + SSIM_C1, b2 = s1s2 + SSIM_C2;
             const float inv = 1.f / (b1 * b2);
             const float S = a1 * a2 * inv;
             // partials w.r.t. mu_x, E[x^2], E[xy] with s1 = E[x^2] - mu_x^2, s12 = E[xy] - mu_x mu_y
@@ -202,8 +205,12 @@ l1_ssim_finalize_kernel(int n_wg, const float* __restrict__ partials, double inv
 
 // ---------------------------------------------------------------- pass 2
 __global__ void __launch_bounds__(256)
-ssim_grad_kernel(int H, int W, View x, View y, const float* __restrict__ D, float ca, float cb, ViewW g)
+ssim_grad_kernel(int H, int W, View x, View y, const float* __restrict__ D, float ca, float cb, const float* __restrict__ scale,
+                 ViewW g)
 {
+    // (scale: the incoming d(total)/d(loss) as a DEVICE scalar -- autograd's grad_output -- so that the gradient leaves this
+    // kernel final instead of being multiplied once more by an elementwise kernel over the whole image; NULL = 1)
+    if (scale) { const float sc_ = *scale; ca *= sc_; cb *= sc_; }
     __shared__ float T[3][LIY * LP];
     __shared__ float Hq[3][LIY * LT];
     const int tid = threadIdx.x;
@@ -242,11 +249,8 @@ ssim_grad_kernel(int H, int W, View x, View y, const float* __restrict__ D, floa
         for (int k = 0; k < HS + 10; k++) { d0[k] = T[0][r * LP + c0 + k]; d1[k] = T[1][r * LP + c0 + k]; d2[k] = T[2][r * LP + c0 + k]; }
 #pragma unroll
         for (int o = 0; o < HS; o++) {
-            float h0 = 0.f, h1 = 0.f, h2 = 0.f;
-#pragma unroll
-            for (int k = 0; k < 11; k++) { const float w = GW[k]; h0 += w * d0[o + k]; h1 += w * d1[o + k]; h2 += w * d2[o + k]; }
             const int i = r * LT + c0 + o;
-            Hq[0][i] = h0; Hq[1][i] = h1; Hq[2][i] = h2;
+            Hq[0][i] = win11(d0 + o); Hq[1][i] = win11(d1 + o); Hq[2][i] = win11(d2 + o);
         }
     }
     __syncthreads();
@@ -258,12 +262,7 @@ ssim_grad_kernel(int H, int W, View x, View y, const float* __restrict__ D, floa
 #pragma unroll
         for (int k = 0; k < RPT + 10; k++) col[k] = Hq[q][(r0 + k) * LT + c];
 #pragma unroll
-        for (int o = 0; o < RPT; o++) {
-            float s = 0.f;
-#pragma unroll
-            for (int k = 0; k < 11; k++) s += GW[k] * col[o + k];
-            out[q][o] = s;
-        }
+        for (int o = 0; o < RPT; o++) out[q][o] = win11(col + o);
     }
 #pragma unroll
     for (int o = 0; o < RPT; o++) {
@@ -285,21 +284,38 @@ size_t l1_ssim_workspace_bytes(int C, int H, int W)
     return align_up(3 * n * sizeof(float)) + align_up(2 * n_wg * sizeof(float)) + 256;
 }
 
-void launch_l1_ssim(int C, int H, int W, const float* pred, const long long* ps, const float* gt, const long long* gs_,
-                    float f, void* workspace, float* loss_out, float* grad, const long long* gstr, hipStream_t st)
+// pass 1 alone (-> D and the per-workgroup partial sums in `workspace`); returns the number of partial pairs
+static int launch_ssim_stats(int C, int H, int W, const float* pred, const long long* ps, const float* gt, const long long* gs_,
+                             void* workspace, hipStream_t st)
 {
     const size_t n = (size_t)C * H * W;
     float* D = static_cast<float*>(workspace);
     float* partials = reinterpret_cast<float*>(static_cast<char*>(workspace) + align_up(3 * n * sizeof(float)));
     const dim3 grid((W + LT - 1) / LT, (H + LTY - 1) / LTY, C);
-    const int n_wg = (int)(grid.x * grid.y * grid.z);
     const View x{pred, ps[0], ps[1], ps[2]}, y{gt, gs_[0], gs_[1], gs_[2]};
     ssim_stats_kernel<<<grid, 256, 0, st>>>(H, W, x, y, D, partials);
+    return (int)(grid.x * grid.y * grid.z);
+}
+
+// pass 2 alone, from the D maps pass 1 left in `workspace`
+void launch_l1_ssim_grad(int C, int H, int W, const float* pred, const long long* ps, const float* gt, const long long* gs_,
+                         float f, const void* workspace, const float* scale, float* grad, const long long* gstr, hipStream_t st)
+{
+    const size_t n = (size_t)C * H * W;
+    const dim3 grid((W + LT - 1) / LT, (H + LTY - 1) / LTY, C);
+    const View x{pred, ps[0], ps[1], ps[2]}, y{gt, gs_[0], gs_[1], gs_[2]};
+    const ViewW g{grad, gstr[0], gstr[1], gstr[2]};
+    ssim_grad_kernel<<<grid, 256, 0, st>>>(H, W, x, y, static_cast<const float*>(workspace), (1.f - f) / (float)n, f / (float)n, scale, g);
+}
+
+void launch_l1_ssim(int C, int H, int W, const float* pred, const long long* ps, const float* gt, const long long* gs_,
+                    float f, void* workspace, float* loss_out, float* grad, const long long* gstr, hipStream_t st)
+{
+    const size_t n = (size_t)C * H * W;
+    const float* partials = reinterpret_cast<const float*>(static_cast<char*>(workspace) + align_up(3 * n * sizeof(float)));
+    const int n_wg = launch_ssim_stats(C, H, W, pred, ps, gt, gs_, workspace, st);
     l1_ssim_finalize_kernel<<<1, 1024, 0, st>>>(n_wg, partials, 1.0 / (double)n, f, loss_out);
-    if (grad) {
-        const ViewW g{grad, gstr[0], gstr[1], gstr[2]};
-        ssim_grad_kernel<<<grid, 256, 0, st>>>(H, W, x, y, D, (1.f - f) / (float)n, f / (float)n, g);
-    }
+    if (grad) launch_l1_ssim_grad(C, H, W, pred, ps, gt, gs_, f, workspace, nullptr, grad, gstr, st);
 }
 
 // ---------------------------------------------------------------- masked depth / silhouette L1 (refine.py:634-660)
@@ -376,14 +392,15 @@ depth_finalize_kernel(int n_wg, const float* __restrict__ partials, float depth_
 __global__ void __launch_bounds__(256)
 depth_grad_kernel(int H, int W, const float* __restrict__ pred, long long psy, long long psx,
                   const float* __restrict__ gt, long long gsy, long long gsx, float max_depth, float depth_factor,
-                  float mask_factor, const float* __restrict__ stats, float* __restrict__ grad, long long qsy,
-                  long long qsx)
+                  float mask_factor, const float* __restrict__ stats, const float* __restrict__ scale,
+                  float* __restrict__ grad, long long qsy, long long qsx)
 {
     const int yy = (int)blockIdx.y, xx = (int)(blockIdx.x * 256 + threadIdx.x);   // grid = (ceil(W / 256), H): no division
     if (xx >= W) return;
     const float p = pred[yy * psy + xx * psx], g = gt[yy * gsy + xx * gsx];
-    const float cf = depth_factor == 0.f ? 0.f : depth_factor / stats[2];   // a disabled term has no gradient (not 0/0)
-    const float cb = mask_factor == 0.f ? 0.f : mask_factor / stats[3];
+    const float sc_ = scale ? *scale : 1.f;                                  // (device scalar: see ssim_grad_kernel)
+    const float cf = depth_factor == 0.f ? 0.f : sc_ * depth_factor / stats[2];   // a disabled term has no gradient (not 0/0)
+    const float cb = mask_factor == 0.f ? 0.f : sc_ * mask_factor / stats[3];
     float v = 0.f;
     if (g < max_depth) { const float d = p - g; v = cf * (d > 0.f ? 1.f : d < 0.f ? -1.f : 0.f); }
     else if (g > max_depth) { const float d = p - max_depth; v = cb * (d > 0.f ? 1.f : d < 0.f ? -1.f : 0.f); }
@@ -393,6 +410,15 @@ depth_grad_kernel(int H, int W, const float* __restrict__ pred, long long psy, l
 constexpr int DEPTH_WGS = 1024;
 size_t depth_l1_workspace_bytes() { return align_up(4 * DEPTH_WGS * sizeof(float)) + 256; }
 
+void launch_depth_l1_grad(int H, int W, const float* pred, const long long* ps, const float* gt, const long long* gs_,
+                          float max_depth, float depth_factor, float mask_factor, const float* stats, const float* scale,
+                          float* grad, const long long* gstr, hipStream_t st)
+{
+    depth_grad_kernel<<<dim3((unsigned)((W + 255) / 256), (unsigned)H), 256, 0, st>>>(H, W, pred, ps[0], ps[1], gt, gs_[0], gs_[1],
+                                                                  max_depth, depth_factor, mask_factor, stats, scale,
+                                                                  grad, gstr[0], gstr[1]);
+}
+
 void launch_depth_l1(int H, int W, const float* pred, const long long* ps, const float* gt, const long long* gs_,
                      float max_depth, float depth_factor, float mask_factor, void* workspace, float* loss_out,
                      float* grad, const long long* gstr, hipStream_t st)
@@ -401,10 +427,68 @@ void launch_depth_l1(int H, int W, const float* pred, const long long* ps, const
     float* partials = static_cast<float*>(workspace);
     depth_stats_kernel<<<n_wg, 256, 0, st>>>(H, W, pred, ps[0], ps[1], gt, gs_[0], gs_[1], max_depth, partials);
     depth_finalize_kernel<<<1, 256, 0, st>>>(n_wg, partials, depth_factor, mask_factor, loss_out);
-    if (grad)
-        depth_grad_kernel<<<dim3((unsigned)((W + 255) / 256), (unsigned)H), 256, 0, st>>>(H, W, pred, ps[0], ps[1], gt, gs_[0], gs_[1],
-                                                                      max_depth, depth_factor, mask_factor, loss_out,
-                                                                      grad, gstr[0], gstr[1]);
+    if (grad) launch_depth_l1_grad(H, W, pred, ps, gt, gs_, max_depth, depth_factor, mask_factor, loss_out, nullptr, grad, gstr, st);
+}
+
+// ---------------------------------------------------------------- both losses of a refinement iteration, values only
+// One finalize for the two reductions: out = {l1 + dssim loss, l1 mean, ssim mean, depth term, mask term, #fg, #bg, TOTAL}.
+// (As separate ops the iteration paid two single-workgroup finalize kernels and two elementwise additions for the total:
+// four dependent launches of ~5 us each on the stream.)  Same arithmetic and order as the two finalize kernels above.
+__global__ void __launch_bounds__(1024)
+rgb_depth_finalize_kernel(int n_wg, const float* __restrict__ partials, double inv_n, float f, int n_wg_d,
+                          const float* __restrict__ partials_d, float depth_factor, float mask_factor, float* __restrict__ out)
+{
+    __shared__ double r[6][1024];
+    const float2* p2 = reinterpret_cast<const float2*>(partials);
+    double a = 0.0, b = 0.0;
+    int i = threadIdx.x;
+    for (; i + 3 * 1024 < n_wg; i += 4 * 1024) {
+        const float2 v0 = p2[i], v1 = p2[i + 1024], v2 = p2[i + 2048], v3 = p2[i + 3072];
+        a += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+        b += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+    }
+    for (; i < n_wg; i += 1024) { const float2 v = p2[i]; a += (double)v.x; b += (double)v.y; }
+    // the depth partials in the summation order of depth_finalize_kernel: 256 strided accumulators (threads 0..255 here)
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    if (threadIdx.x < 256)
+        for (int k = threadIdx.x; k < n_wg_d; k += 256) {
+            const float4 q = reinterpret_cast<const float4*>(partials_d)[k];
+            v[0] += (double)q.x; v[1] += (double)q.y; v[2] += (double)q.z; v[3] += (double)q.w;
+        }
+    r[0][threadIdx.x] = a; r[1][threadIdx.x] = b;
+#pragma unroll
+    for (int k = 0; k < 4; k++) r[2 + k][threadIdx.x] = v[k];
+    __syncthreads();
+    for (int d = 512; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) r[k][threadIdx.x] += r[k][threadIdx.x + d];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double l1 = r[0][0] * inv_n, s = r[1][0] * inv_n;
+        const float loss = (float)((1.0 - (double)f) * l1 + (double)f * (1.0 - s));   // refine.py:453
+        const float dt = depth_factor == 0.f ? 0.f : (float)((double)depth_factor * (r[2][0] / r[3][0]));
+        const float mt = mask_factor == 0.f ? 0.f : (float)((double)mask_factor * (r[4][0] / r[5][0]));
+        out[0] = loss; out[1] = (float)l1; out[2] = (float)s;
+        out[3] = dt; out[4] = mt; out[5] = (float)r[3][0]; out[6] = (float)r[5][0];
+        out[7] = (loss + dt) + mt;   // (float additions in the order the separate ops formed the total)
+    }
+}
+
+void launch_rgb_depth_loss(int C, int H, int W, const float* pred, const long long* ps, const float* gt, const long long* gs_, float f,
+                           void* ws_ssim, int Hd, int Wd, const float* dpred, const long long* dps, const float* dgt,
+                           const long long* dgs, float max_depth, float depth_factor, float mask_factor, void* ws_depth,
+                           float* out8, hipStream_t st)
+{
+    const size_t n = (size_t)C * H * W;
+    const float* partials = reinterpret_cast<const float*>(static_cast<char*>(ws_ssim) + align_up(3 * n * sizeof(float)));
+    const int n_wg = launch_ssim_stats(C, H, W, pred, ps, gt, gs_, ws_ssim, st);
+    const int n_wg_d = Hd < DEPTH_WGS ? Hd : DEPTH_WGS;
+    float* partials_d = static_cast<float*>(ws_depth);
+    depth_stats_kernel<<<n_wg_d, 256, 0, st>>>(Hd, Wd, dpred, dps[0], dps[1], dgt, dgs[0], dgs[1], max_depth, partials_d);
+    rgb_depth_finalize_kernel<<<1, 1024, 0, st>>>(n_wg, partials, 1.0 / (double)n, f, n_wg_d, partials_d, depth_factor, mask_factor, out8);
 }
 
 }  // namespace gsr

@@ -3,7 +3,8 @@
 Host-side mirror of gaustar_utils/loss_utils.py (`l1_loss`, `ssim`) and of the loss assembly in
 gaustar_trainers/refine.py:451-453 (`(1 - f) * l1 + f * (1 - ssim)`, on the margin-cropped view of
 :584-594) and :634-660 (masked depth + silhouette L1).  Each op is ONE call into libgsr_hip.so that returns
-the loss value AND d loss / d pred; autograd just scales that gradient by the incoming scalar.  The gradient
+the loss value; the gradient pass is a second call made from autograd's backward, which hands the kernels the incoming
+scalar as a DEVICE pointer, so d loss / d pred leaves them final (no elementwise multiply over the image).  The gradient
 w.r.t. the ground-truth image is not provided (the trainer never needs it).
 
 There is no CPU path: CPU tensors raise, like the rasterizer (gaustar_amd/rasterizer.py).
@@ -43,7 +44,19 @@ def _crop(t: torch.Tensor, margin: Optional[Sequence[int]]) -> torch.Tensor:
     return t[..., m2:(-m3 if m3 else None), m0:(-m1 if m1 else None)]
 
 
+def _scale_ptr(g_loss: torch.Tensor, dev):
+    """autograd's incoming d(total)/d(loss) as a float32 device scalar the gradient kernels read (no host sync, and no
+    elementwise multiply over the image afterwards); the tensor is returned to keep it alive over the launch."""
+    g = g_loss
+    if g.dtype != torch.float32 or g.device != dev or g.dim() != 0 or not g.is_contiguous():
+        g = g.detach().to(device=dev, dtype=torch.float32).reshape(()).contiguous()
+    return g, ctypes.c_void_p(g.data_ptr())
+
+
 class _L1DSSIM(torch.autograd.Function):
+    """Forward: the value pass (gsr_l1_ssim without a gradient buffer).  Backward: gsr_l1_ssim_backward from the workspace the
+    value pass left, scaled by the incoming gradient ON THE DEVICE."""
+
     @staticmethod
     def forward(ctx, pred, gt, dssim_factor, margin):
         lib = _lib.load()
@@ -56,33 +69,40 @@ class _L1DSSIM(torch.autograd.Function):
         if H <= 0 or W <= 0:
             raise RuntimeError("the margin leaves an empty image")
         dev = p.device
-        need_grad = ctx.needs_input_grad[0]
         with _host.on_device(dev):
             ws = torch.empty(lib.gsr_l1_ssim_workspace_bytes(C, H, W), dtype=torch.uint8, device=dev)
             out = torch.empty(3, dtype=torch.float32, device=dev)
-            grad_full = gv = None
-            if need_grad:
-                # planar [C,H,W] -- the layout the backward blend reads; zero outside the crop
-                grad_full = (torch.zeros if margin is not None else torch.empty)(p_full.shape, dtype=torch.float32, device=dev)
-                gv = _crop(grad_full, margin)
             _lib.check(lib.gsr_l1_ssim(
                 C, H, W, ctypes.c_void_p(p.data_ptr()), p.stride(0), p.stride(1), p.stride(2),
                 ctypes.c_void_p(g.data_ptr()), g.stride(0), g.stride(1), g.stride(2), float(dssim_factor),
-                ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(out.data_ptr()),
-                ctypes.c_void_p(gv.data_ptr()) if need_grad else None,
-                gv.stride(0) if need_grad else 0, gv.stride(1) if need_grad else 0, gv.stride(2) if need_grad else 0,
-                _stream()), "gsr_l1_ssim")
-        ctx.grad_full = grad_full
-        ctx.pred_shape = pred.shape
+                ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(out.data_ptr()), None, 0, 0, 0, _stream()), "gsr_l1_ssim")
+        if ctx.needs_input_grad[0]:
+            ctx.save_for_backward(p_full, g_full, ws)
+        ctx.cfg = (float(dssim_factor), margin, pred.shape)
         ctx.mark_non_differentiable(out)
         ctx.set_materialize_grads(False)   # no zero-filled "gradient" of the parts vector per backward (one fill kernel)
         return out[0], out
 
     @staticmethod
     def backward(ctx, g_loss, _g_parts):
-        if ctx.grad_full is None or g_loss is None:
+        if not ctx.saved_tensors or g_loss is None:
             return None, None, None, None
-        return (ctx.grad_full * g_loss).reshape(ctx.pred_shape), None, None, None
+        lib = _lib.load()
+        p_full, g_full, ws = ctx.saved_tensors
+        f, margin, pred_shape = ctx.cfg
+        p, g = _crop(p_full, margin), _crop(g_full, margin)
+        C, H, W = (int(v) for v in p.shape)
+        dev = p.device
+        with _host.on_device(dev):
+            # planar [C,H,W] -- the layout the backward blend reads; zero outside the crop
+            grad_full = (torch.zeros if margin is not None else torch.empty)(p_full.shape, dtype=torch.float32, device=dev)
+            gv = _crop(grad_full, margin)
+            keep, sp = _scale_ptr(g_loss, dev)
+            _lib.check(lib.gsr_l1_ssim_backward(
+                C, H, W, ctypes.c_void_p(p.data_ptr()), p.stride(0), p.stride(1), p.stride(2),
+                ctypes.c_void_p(g.data_ptr()), g.stride(0), g.stride(1), g.stride(2), f, ctypes.c_void_p(ws.data_ptr()), sp,
+                ctypes.c_void_p(gv.data_ptr()), gv.stride(0), gv.stride(1), gv.stride(2), _stream()), "gsr_l1_ssim_backward")
+        return grad_full.reshape(pred_shape), None, None, None
 
 
 def l1_dssim_loss(pred: torch.Tensor, gt: torch.Tensor, dssim_factor: float = 0.2,
@@ -120,27 +140,37 @@ class _DepthL1(torch.autograd.Function):
         g = gt if gt.dtype == torch.float32 else gt.float()
         H, W = (int(v) for v in p.shape)
         dev = p.device
-        need_grad = ctx.needs_input_grad[0]
         with _host.on_device(dev):
             ws = torch.empty(lib.gsr_depth_l1_workspace_bytes(), dtype=torch.uint8, device=dev)
             out = torch.empty(4, dtype=torch.float32, device=dev)
-            grad = torch.empty(H, W, dtype=torch.float32, device=dev) if need_grad else None
             _lib.check(lib.gsr_depth_l1(
                 H, W, ctypes.c_void_p(p.data_ptr()), p.stride(0), p.stride(1), ctypes.c_void_p(g.data_ptr()),
                 g.stride(0), g.stride(1), float(max_depth), float(depth_factor), float(mask_factor),
-                ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(out.data_ptr()),
-                ctypes.c_void_p(grad.data_ptr()) if need_grad else None, W if need_grad else 0, 1 if need_grad else 0,
-                _stream()), "gsr_depth_l1")
-        ctx.grad = grad
+                ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(out.data_ptr()), None, 0, 0, _stream()), "gsr_depth_l1")
+        if ctx.needs_input_grad[0]:
+            ctx.save_for_backward(p, g, out)
+        ctx.cfg = (float(max_depth), float(depth_factor), float(mask_factor), pred.dtype)
         ctx.mark_non_differentiable(out)
         ctx.set_materialize_grads(False)   # no zero-filled "gradient" of the parts vector per backward (one fill kernel)
         return out[0] + out[1], out
 
     @staticmethod
     def backward(ctx, g_loss, _g_parts):
-        if ctx.grad is None or g_loss is None:
+        if not ctx.saved_tensors or g_loss is None:
             return None, None, None, None, None
-        return ctx.grad * g_loss, None, None, None, None
+        lib = _lib.load()
+        p, g, out = ctx.saved_tensors
+        max_depth, depth_factor, mask_factor, in_dtype = ctx.cfg
+        H, W = (int(v) for v in p.shape)
+        dev = p.device
+        with _host.on_device(dev):
+            grad = torch.empty(H, W, dtype=torch.float32, device=dev)
+            keep, sp = _scale_ptr(g_loss, dev)
+            _lib.check(lib.gsr_depth_l1_backward(
+                H, W, ctypes.c_void_p(p.data_ptr()), p.stride(0), p.stride(1), ctypes.c_void_p(g.data_ptr()), g.stride(0),
+                g.stride(1), max_depth, depth_factor, mask_factor, ctypes.c_void_p(out.data_ptr()), sp,
+                ctypes.c_void_p(grad.data_ptr()), W, 1, _stream()), "gsr_depth_l1_backward")
+        return grad.to(in_dtype), None, None, None, None
 
 
 def depth_mask_l1_loss(pred_depth: torch.Tensor, gt_depth: torch.Tensor, max_depth: float, depth_factor: float = 1.0,
@@ -152,8 +182,9 @@ def depth_mask_l1_loss(pred_depth: torch.Tensor, gt_depth: torch.Tensor, max_dep
 
 
 class _RGBDepthLoss(torch.autograd.Function):
-    """l1 + dssim on channels 0-2 and masked depth L1 on channel 3 of ONE [6,H,W] render; the gradient comes back as ONE
-    [6,H,W] tensor that both loss kernels wrote into (channels 4-5 zero)."""
+    """l1 + dssim on channels 0-2 and masked depth L1 on channel 3 of ONE [6,H,W] / [4,H,W] render.  Forward: both value
+    passes and ONE reduction kernel (gsr_rgb_depth_loss) -> the total as a device scalar.  Backward: the two gradient passes
+    write d(total)/d(render), scaled by the incoming gradient on the device, into ONE tensor (channels 4-5 zero)."""
 
     @staticmethod
     def forward(ctx, img6, gt_rgb, gt_depth, dssim_factor, margin, max_depth, depth_factor, mask_factor):
@@ -176,41 +207,51 @@ class _RGBDepthLoss(torch.autograd.Function):
         d = x[3]
         Hd, Wd = (int(v) for v in d.shape)
         dev = x.device
-        need_grad = ctx.needs_input_grad[0]
+        vp = lambda t: ctypes.c_void_p(t.data_ptr())
         with _host.on_device(dev):
             ws = torch.empty(lib.gsr_l1_ssim_workspace_bytes(C, H, W), dtype=torch.uint8, device=dev)
             wd = torch.empty(lib.gsr_depth_l1_workspace_bytes(), dtype=torch.uint8, device=dev)
-            out = torch.empty(7, dtype=torch.float32, device=dev)      # {loss, l1, ssim | depth term, mask term, #fg, #bg}
-            grad6 = gv = gdv = None
-            if need_grad:
-                grad6 = torch.empty_like(x, memory_format=torch.contiguous_format)
-                if x.size(0) > 4:
-                    grad6[4:].zero_()
-                if margin is not None:
-                    grad6[:3].zero_()
-                gv, gdv = _crop(grad6[:3], margin), grad6[3]
-            vp = lambda t: ctypes.c_void_p(t.data_ptr())
-            _lib.check(lib.gsr_l1_ssim(
+            out = torch.empty(8, dtype=torch.float32, device=dev)   # {loss, l1, ssim | depth term, mask term, #fg, #bg | total}
+            _lib.check(lib.gsr_rgb_depth_loss(
                 C, H, W, vp(p), p.stride(0), p.stride(1), p.stride(2), vp(g), g.stride(0), g.stride(1), g.stride(2),
-                float(dssim_factor), vp(ws), vp(out), vp(gv) if need_grad else None,
-                gv.stride(0) if need_grad else 0, gv.stride(1) if need_grad else 0, gv.stride(2) if need_grad else 0,
-                _stream()), "gsr_l1_ssim")
-            _lib.check(lib.gsr_depth_l1(
-                Hd, Wd, vp(d), d.stride(0), d.stride(1), vp(gd), gd.stride(0), gd.stride(1), float(max_depth),
-                float(depth_factor), float(mask_factor), vp(wd), ctypes.c_void_p(out.data_ptr() + 12),
-                vp(gdv) if need_grad else None, gdv.stride(0) if need_grad else 0, gdv.stride(1) if need_grad else 0,
-                _stream()), "gsr_depth_l1")
-        ctx.grad6 = grad6
-        ctx.in_dtype = img6.dtype
-        ctx.mark_non_differentiable(out)
+                float(dssim_factor), vp(ws), Hd, Wd, vp(d), d.stride(0), d.stride(1), vp(gd), gd.stride(0), gd.stride(1),
+                float(max_depth), float(depth_factor), float(mask_factor), vp(wd), vp(out), _stream()), "gsr_rgb_depth_loss")
+        if ctx.needs_input_grad[0]:
+            ctx.save_for_backward(x, g_full, gd, ws, out)
+        ctx.cfg = (float(dssim_factor), margin, float(max_depth), float(depth_factor), float(mask_factor), img6.dtype)
+        parts = out[:7]
+        ctx.mark_non_differentiable(parts)
         ctx.set_materialize_grads(False)   # no zero-filled "gradient" of the parts vector per backward (one fill kernel)
-        return out[0] + out[3] + out[4], out
+        return out[7], parts
 
     @staticmethod
     def backward(ctx, g_loss, _g_parts):
-        if ctx.grad6 is None or g_loss is None:
+        if not ctx.saved_tensors or g_loss is None:
             return (None,) * 8
-        return (ctx.grad6 * g_loss).to(ctx.in_dtype), None, None, None, None, None, None, None
+        lib = _lib.load()
+        x, g_full, gd, ws, out = ctx.saved_tensors
+        f, margin, max_depth, depth_factor, mask_factor, in_dtype = ctx.cfg
+        p, g = _crop(x[:3], margin), _crop(g_full, margin)
+        C, H, W = (int(v) for v in p.shape)
+        d = x[3]
+        Hd, Wd = (int(v) for v in d.shape)
+        dev = x.device
+        vp = lambda t: ctypes.c_void_p(t.data_ptr())
+        with _host.on_device(dev):
+            grad6 = torch.empty_like(x, memory_format=torch.contiguous_format)
+            if x.size(0) > 4:
+                grad6[4:].zero_()
+            if margin is not None:
+                grad6[:3].zero_()
+            gv, gdv = _crop(grad6[:3], margin), grad6[3]
+            keep, sp = _scale_ptr(g_loss, dev)
+            _lib.check(lib.gsr_l1_ssim_backward(
+                C, H, W, vp(p), p.stride(0), p.stride(1), p.stride(2), vp(g), g.stride(0), g.stride(1), g.stride(2), f, vp(ws), sp,
+                vp(gv), gv.stride(0), gv.stride(1), gv.stride(2), _stream()), "gsr_l1_ssim_backward")
+            _lib.check(lib.gsr_depth_l1_backward(
+                Hd, Wd, vp(d), d.stride(0), d.stride(1), vp(gd), gd.stride(0), gd.stride(1), max_depth, depth_factor, mask_factor,
+                ctypes.c_void_p(out.data_ptr() + 12), sp, vp(gdv), gdv.stride(0), gdv.stride(1), _stream()), "gsr_depth_l1_backward")
+        return grad6.to(in_dtype), None, None, None, None, None, None, None
 
 
 def rgb_depth_loss(render6: torch.Tensor, gt_rgb: torch.Tensor, gt_depth: torch.Tensor, max_depth: float,

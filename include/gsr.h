@@ -276,6 +276,29 @@ int gsr_depth_l1(int H, int W, const float* pred, long long pred_sy, long long p
                  void* workspace, float* loss_out, float* dL_dpred, long long grad_sy, long long grad_sx,
                  gsr_stream_t stream);
 
+/* The same two losses with the gradient pass as a call of its own (ABI 12), for callers that learn the incoming
+ * d(total)/d(loss) only in their backward pass (autograd's grad_output; refine.py:794 `loss.backward()`):
+ *   gsr_l1_ssim(..., dL_dpred = NULL) / gsr_depth_l1(..., dL_dpred = NULL) / gsr_rgb_depth_loss evaluate the values and leave
+ *   what the gradient needs in `workspace` resp. `loss_out`; gsr_l1_ssim_backward / gsr_depth_l1_backward then write
+ *   grad_scale[0] * d loss / d pred, with grad_scale a DEVICE scalar (NULL = 1) -- no elementwise multiply over the image
+ *   afterwards.  `workspace` / `stats` are the buffers of the value call, unmodified; pred / gt the same images.
+ * gsr_rgb_depth_loss = the value passes of gsr_l1_ssim on an RGB image and of gsr_depth_l1 on a depth image with ONE
+ * reduction kernel: loss_out [8] = {l1 + dssim loss, l1 mean, ssim mean, depth term, mask term, #fg, #bg, total of the
+ * three terms}; loss_out + 3 is the `stats` argument of gsr_depth_l1_backward. */
+int gsr_l1_ssim_backward(int C, int H, int W, const float* pred, long long pred_sc, long long pred_sy, long long pred_sx,
+                         const float* gt, long long gt_sc, long long gt_sy, long long gt_sx, float dssim_factor,
+                         const void* workspace, const float* grad_scale, float* dL_dpred, long long grad_sc, long long grad_sy,
+                         long long grad_sx, gsr_stream_t stream);
+int gsr_depth_l1_backward(int H, int W, const float* pred, long long pred_sy, long long pred_sx, const float* gt,
+                          long long gt_sy, long long gt_sx, float max_depth, float depth_factor, float mask_factor,
+                          const float* stats, const float* grad_scale, float* dL_dpred, long long grad_sy, long long grad_sx,
+                          gsr_stream_t stream);
+int gsr_rgb_depth_loss(int C, int H, int W, const float* pred, long long pred_sc, long long pred_sy, long long pred_sx,
+                       const float* gt, long long gt_sc, long long gt_sy, long long gt_sx, float dssim_factor,
+                       void* ssim_workspace, int Hd, int Wd, const float* depth_pred, long long dpred_sy, long long dpred_sx,
+                       const float* depth_gt, long long dgt_sy, long long dgt_sx, float max_depth, float depth_factor,
+                       float mask_factor, void* depth_workspace, float* loss_out, gsr_stream_t stream);
+
 /* Tuning aid: when device_buffer is non-NULL (4*T uint64), the two blend kernels record the start/end wall
  * clock (100 MHz) of every workgroup: forward at [2*b], backward at [2*(T+b)], b = launch index.  NULL = off. */
 int gsr_debug_set_trace(void* device_buffer);

@@ -129,3 +129,29 @@ def test_rgb_depth_loss_equals_the_two_separate_losses(margin, hip_lib):
     assert abs(float(la) - float(lb)) < 1e-6 and parts.numel() == 7
     assert torch.equal(a.grad[4:], torch.zeros_like(a.grad[4:]))
     assert torch.allclose(a.grad, b.grad, rtol=0, atol=1e-9) and float(a.grad[:4].abs().max()) > 0
+
+
+def test_gradient_pass_scales_on_the_device_and_can_run_twice(hip_lib):
+    """The gradient kernels run in autograd's backward with the incoming gradient as a DEVICE scalar (ABI 12:
+    gsr_l1_ssim_backward / gsr_depth_l1_backward): any scale -- also one that is itself a function of other device values --
+    gives scale x the unit gradient, and the saved workspace survives a second backward over the same graph."""
+    from gaustar_amd import losses
+    g = torch.Generator(device="cuda").manual_seed(12)
+    H, W = 64, 96
+    img = torch.rand(4, H, W, device="cuda", generator=g)
+    img[3] = img[3] * 12.0
+    gt_rgb = torch.rand(3, H, W, device="cuda", generator=g)
+    gt_d = torch.rand(H, W, device="cuda", generator=g) * 14.0
+    a = img.clone().requires_grad_(True)
+    la = losses.rgb_depth_loss(a, gt_rgb, gt_d, 10.0, 0.2, 0.7, 0.3, margin=(2, 3, 1, 4))
+    la.backward(retain_graph=True)
+    unit = a.grad.clone(); a.grad = None
+    w = torch.tensor(3.0, device="cuda", requires_grad=True)
+    (la * w * w).backward()                     # d/dloss = 9, delivered as a device scalar computed by other kernels
+    assert torch.allclose(a.grad, 9.0 * unit, rtol=1e-6, atol=1e-12) and abs(float(w.grad) - 6.0 * float(la)) < 1e-5
+    for fn in (lambda t: losses.l1_dssim_loss(t[:3], gt_rgb, 0.3), lambda t: losses.depth_mask_l1_loss(t[3], gt_d, 10.0, 0.7, 0.3)):
+        b = img.clone().requires_grad_(True)
+        fn(b).backward()
+        u = b.grad.clone(); b.grad = None
+        (fn(b) * -0.25).backward()
+        assert torch.allclose(b.grad, -0.25 * u, rtol=1e-6, atol=1e-12)
