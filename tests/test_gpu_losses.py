@@ -148,10 +148,10 @@ def test_gradient_pass_scales_on_the_device_and_can_run_twice(hip_lib):
     unit = a.grad.clone(); a.grad = None
     w = torch.tensor(3.0, device="cuda", requires_grad=True)
     (la * w * w).backward()                     # d/dloss = 9, delivered as a device scalar computed by other kernels
-    assert torch.allclose(a.grad, 9.0 * unit, rtol=1e-6, atol=1e-12) and abs(float(w.grad) - 6.0 * float(la)) < 1e-5
+    assert torch.allclose(a.grad, 9.0 * unit, rtol=1e-5, atol=1e-9) and abs(float(w.grad) - 6.0 * float(la)) < 1e-5
     for fn in (lambda t: losses.l1_dssim_loss(t[:3], gt_rgb, 0.3), lambda t: losses.depth_mask_l1_loss(t[3], gt_d, 10.0, 0.7, 0.3)):
         b = img.clone().requires_grad_(True)
         fn(b).backward()
         u = b.grad.clone(); b.grad = None
         (fn(b) * -0.25).backward()
-        assert torch.allclose(b.grad, -0.25 * u, rtol=1e-6, atol=1e-12)
+        assert torch.allclose(b.grad, -0.25 * u, rtol=1e-5, atol=1e-9)   # (the scale enters before the two terms are subtracted)
