@@ -83,6 +83,10 @@ SIGNATURES = {
     "gsr_rgb_depth_loss": (c_int, [c_int, c_int, c_int, c_void_p, c_longlong, c_longlong, c_longlong, c_void_p, c_longlong,
                                    c_longlong, c_longlong, c_float, c_void_p, c_int, c_int, c_void_p, c_longlong, c_longlong,
                                    c_void_p, c_longlong, c_longlong, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "gsr_rgb_depth_loss_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_longlong, c_longlong, c_longlong, c_void_p, c_longlong,
+                                            c_longlong, c_longlong, c_float, c_void_p, c_int, c_int, c_void_p, c_longlong, c_longlong,
+                                            c_void_p, c_longlong, c_longlong, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p,
+                                            c_longlong, c_longlong, c_longlong, c_void_p, c_longlong, c_longlong, c_void_p]),
     "gsr_adam_step": (c_int, [c_longlong, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double, c_double, c_int,
                               c_void_p]),
     "gsr_adam_step_multi": (c_int, [c_int, POINTER(c_longlong), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),

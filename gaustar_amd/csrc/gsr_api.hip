@@ -831,7 +831,7 @@ int gsr_rgb_depth_loss(int C, int H, int W, const float* pred, long long pred_sc
 {
     g_err.clear();
     if (C <= 0 || H <= 0 || W <= 0 || Hd <= 0 || Wd <= 0) return fail_msg("gsr_rgb_depth_loss: image size must be positive");
-    if (C > 65535) return fail_msg("gsr_rgb_depth_loss: too many channels");
+    if (C > 65534) return fail_msg("gsr_rgb_depth_loss: too many channels");
     if (!pred || !gt || !ssim_workspace || !depth_pred || !depth_gt || !depth_workspace || !loss_out)
         return fail_msg("gsr_rgb_depth_loss: required pointer is null");
     const long long ps[3] = {pred_sc, pred_sy, pred_sx}, gs_[3] = {gt_sc, gt_sy, gt_sx};
@@ -843,6 +843,31 @@ int gsr_rgb_depth_loss(int C, int H, int W, const float* pred, long long pred_sc
                               max_depth, depth_factor, mask_factor, depth_workspace, loss_out, st);
     }
     GSR_CHECK_LAUNCH("rgb_depth_loss kernels");
+    return 0;
+}
+
+int gsr_rgb_depth_loss_backward(int C, int H, int W, const float* pred, long long pred_sc, long long pred_sy, long long pred_sx,
+                                const float* gt, long long gt_sc, long long gt_sy, long long gt_sx, float dssim_factor,
+                                const void* ssim_workspace, int Hd, int Wd, const float* depth_pred, long long dpred_sy,
+                                long long dpred_sx, const float* depth_gt, long long dgt_sy, long long dgt_sx, float max_depth,
+                                float depth_factor, float mask_factor, const float* loss_out, const float* grad_scale,
+                                float* dL_dpred, long long grad_sc, long long grad_sy, long long grad_sx, float* dL_ddepth,
+                                long long dgrad_sy, long long dgrad_sx, gsr_stream_t stream)
+{
+    g_err.clear();
+    if (C <= 0 || H <= 0 || W <= 0 || Hd <= 0 || Wd <= 0) return fail_msg("gsr_rgb_depth_loss_backward: image size must be positive");
+    if (C > 65534) return fail_msg("gsr_rgb_depth_loss_backward: too many channels");
+    if (!pred || !gt || !ssim_workspace || !depth_pred || !depth_gt || !loss_out || !dL_dpred || !dL_ddepth)
+        return fail_msg("gsr_rgb_depth_loss_backward: required pointer is null");
+    const long long ps[3] = {pred_sc, pred_sy, pred_sx}, gs_[3] = {gt_sc, gt_sy, gt_sx}, qs[3] = {grad_sc, grad_sy, grad_sx};
+    const long long dps[2] = {dpred_sy, dpred_sx}, dgs[2] = {dgt_sy, dgt_sx}, dqs[2] = {dgrad_sy, dgrad_sx};
+    hipStream_t st = (hipStream_t)stream;
+    {
+        Scope sc(ST_LOSS, st);
+        launch_rgb_depth_loss_grad(C, H, W, pred, ps, gt, gs_, dssim_factor, ssim_workspace, Hd, Wd, depth_pred, dps, depth_gt, dgs,
+                                   max_depth, depth_factor, mask_factor, loss_out + 3, grad_scale, dL_dpred, qs, dL_ddepth, dqs, st);
+    }
+    GSR_CHECK_LAUNCH("rgb_depth_loss gradient kernel");
     return 0;
 }
 

@@ -236,6 +236,12 @@ void launch_rgb_depth_loss(int C, int H, int W, const float* pred, const long lo
                            const long long* dgs, float max_depth, float depth_factor, float mask_factor, void* ws_depth,
                            float* out8, hipStream_t st);
 
+void launch_rgb_depth_loss_grad(int C, int H, int W, const float* pred, const long long* ps, const float* gt, const long long* gs_, float f,
+                                const void* ws_ssim, int Hd, int Wd, const float* dpred, const long long* dps, const float* dgt,
+                                const long long* dgs, float max_depth, float depth_factor, float mask_factor, const float* stats,
+                                const float* scale, float* grad, const long long* gstr, float* dgrad, const long long* dgstr,
+                                hipStream_t st);
+
 // Optional per-workgroup timeline for tuning (gsr_debug_set_trace): when non-null, the blend kernels store
 // {start, end} of every workgroup (100 MHz wall clock) at trace[2*blockIdx] (forward) / trace[2*(T+blockIdx)].
 extern uint64_t* g_trace;

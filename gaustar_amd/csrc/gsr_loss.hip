@@ -65,15 +65,69 @@ __device__ __forceinline__ float block_sum_256(float v, float* red)
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// The masked depth loss of the same iteration (refine.py:634-660; kernels further down) can ride along in the two SSIM
+// launches as ONE MORE z-plane of workgroups: as launches of their own its two passes are ~7 us each of mostly launch and
+// drain on the stream.  n_wg == 0: no depth plane.
+struct DepthPlane {
+    int H, W;
+    const float* pred; long long psy, psx;
+    const float* gt; long long gsy, gsx;
+    float max_depth;
+    float* partials; int n_wg;                                   // value pass: [n_wg][4] = {sum_fg, n_fg, sum_bg, n_bg}
+    float depth_factor, mask_factor; const float* stats; const float* scale; float* grad; long long qsy, qsx;   // gradient pass
+};
+
+__device__ __forceinline__ void depth_stats_rows(const DepthPlane& z, int w, int n_wg, float* red)
+{
+    float sf = 0.f, nf = 0.f, sb = 0.f, nb = 0.f;
+    // a workgroup walks whole rows (no 64-bit division per element), four elements of a thread in flight at a time
+    for (int yy = w; yy < z.H; yy += n_wg) {
+        const float* pr = z.pred + yy * z.psy;
+        const float* gr = z.gt + yy * z.gsy;
+        for (int x0 = (int)threadIdx.x; x0 < z.W; x0 += 4 * 256) {
+            float p[4], g[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int xx = x0 + 256 * u;
+                const bool in = xx < z.W;
+                p[u] = in ? pr[xx * z.psx] : 0.f;
+                g[u] = in ? gr[xx * z.gsx] : z.max_depth;   // == max_depth: neither foreground nor background
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (g[u] < z.max_depth) { sf += fabsf(p[u] - g[u]); nf += 1.f; }
+                else if (g[u] > z.max_depth) { sb += fabsf(p[u] - z.max_depth); nb += 1.f; }
+            }
+        }
+    }
+    const float a = block_sum_256(sf, red), b = block_sum_256(nf, red), c = block_sum_256(sb, red), d = block_sum_256(nb, red);
+    if (threadIdx.x == 0) {
+        z.partials[4 * w] = a; z.partials[4 * w + 1] = b; z.partials[4 * w + 2] = c; z.partials[4 * w + 3] = d;
+    }
+}
+
+__device__ __forceinline__ float depth_grad_value(float p, float g, float max_depth, float cf, float cb)
+{
+    float v = 0.f;
+    if (g < max_depth) { const float d = p - g; v = cf * (d > 0.f ? 1.f : d < 0.f ? -1.f : 0.f); }
+    else if (g > max_depth) { const float d = p - max_depth; v = cb * (d > 0.f ? 1.f : d < 0.f ? -1.f : 0.f); }
+    return v;
+}
+
 // ---------------------------------------------------------------- pass 1
 __global__ void __launch_bounds__(256)
-ssim_stats_kernel(int H, int W, View x, View y, float* __restrict__ D, float* __restrict__ partials)
+ssim_stats_kernel(int H, int W, View x, View y, float* __restrict__ D, float* __restrict__ partials, int C_rgb, DepthPlane dz)
 {
     __shared__ float X[LIY * LP], Y[LIY * LP];
     // (SSIM reads E[x^2] and E[y^2] only as their SUM -- sigma_x^2 + sigma_y^2 -- so x^2 + y^2 goes through the window as
     // ONE quantity: four windowed maps instead of the reference's five, loss_utils.py:47-52)
     __shared__ float Hq[4][LIY * LT];
     __shared__ float red[4];
+    if ((int)blockIdx.z == C_rgb) {   // (uniform) the depth plane: the first dz.n_wg workgroups of it each take rows w, w + n_wg, ..
+        const int w = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+        if (w < dz.n_wg) depth_stats_rows(dz, w, dz.n_wg, red);
+        return;
+    }
     const int tid = threadIdx.x;
     const int tx0 = blockIdx.x * LT, ty0 = blockIdx.y * LTY, ch = blockIdx.z;
     const float* xp = x.p + ch * x.sc;
@@ -158,8 +212,8 @@ ssim_stats_kernel(int H, int W, View x, View y, float* __restrict__ D, float* __
             const float d3 = 2.f * a1 * inv;
             const size_t o_ = (size_t)ch * plane + (size_t)gy * W + gx;
             D[o_] = d1;
-            D[(size_t)gridDim.z * plane + o_] = d2;
-            D[2 * (size_t)gridDim.z * plane + o_] = d3;
+            D[(size_t)C_rgb * plane + o_] = d2;
+            D[2 * (size_t)C_rgb * plane + o_] = d3;
             ssum += S;
             l1 += fabsf(X[(r0 + o + LR) * LP + c + LR] - Y[(r0 + o + LR) * LP + c + LR]);
         }
@@ -206,8 +260,19 @@ l1_ssim_finalize_kernel(int n_wg, const float* __restrict__ partials, double inv
 // ---------------------------------------------------------------- pass 2
 __global__ void __launch_bounds__(256)
 ssim_grad_kernel(int H, int W, View x, View y, const float* __restrict__ D, float ca, float cb, const float* __restrict__ scale,
-                 ViewW g)
+                 ViewW g, int C_rgb, DepthPlane dz)
 {
+    if ((int)blockIdx.z == C_rgb) {   // (uniform) the depth plane: every workgroup of it takes rows w, w + (workgroups of a plane), ..
+        const int nwg = (int)(gridDim.x * gridDim.y), w = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+        const float sc_ = dz.scale ? *dz.scale : 1.f;
+        const float cf = dz.depth_factor == 0.f ? 0.f : sc_ * dz.depth_factor / dz.stats[2];   // a disabled term has no gradient
+        const float cbk = dz.mask_factor == 0.f ? 0.f : sc_ * dz.mask_factor / dz.stats[3];
+        for (int yy = w; yy < dz.H; yy += nwg)
+            for (int xx = (int)threadIdx.x; xx < dz.W; xx += 256)
+                dz.grad[yy * dz.qsy + xx * dz.qsx] = depth_grad_value(dz.pred[yy * dz.psy + xx * dz.psx], dz.gt[yy * dz.gsy + xx * dz.gsx],
+                                                                       dz.max_depth, cf, cbk);
+        return;
+    }
     // (scale: the incoming d(total)/d(loss) as a DEVICE scalar -- autograd's grad_output -- so that the gradient leaves this
     // kernel final instead of being multiplied once more by an elementwise kernel over the whole image; NULL = 1)
     if (scale) { const float sc_ = *scale; ca *= sc_; cb *= sc_; }
@@ -215,7 +280,7 @@ ssim_grad_kernel(int H, int W, View x, View y, const float* __restrict__ D, floa
     __shared__ float Hq[3][LIY * LT];
     const int tid = threadIdx.x;
     const int tx0 = blockIdx.x * LT, ty0 = blockIdx.y * LTY, ch = blockIdx.z;
-    const size_t plane = (size_t)H * W, vol = (size_t)gridDim.z * plane;
+    const size_t plane = (size_t)H * W, vol = (size_t)C_rgb * plane;
     constexpr int NL = (LIY * LI + 255) / 256;
     float dv[NL][3];
     constexpr int DR = 256 / LI, DC = 256 % LI;   // (row, column) step per 256 elements, see ssim_stats_kernel
@@ -285,16 +350,27 @@ size_t l1_ssim_workspace_bytes(int C, int H, int W)
 }
 
 // pass 1 alone (-> D and the per-workgroup partial sums in `workspace`); returns the number of partial pairs
+constexpr int DEPTH_WGS = 1024;
+static int depth_plane_wgs(int C, int H, int W, int Hd)   // workgroups of the depth plane's value pass (they walk whole rows)
+{
+    (void)C;
+    const int plane = ((W + LT - 1) / LT) * ((H + LTY - 1) / LTY);
+    const int n = Hd < DEPTH_WGS ? Hd : DEPTH_WGS;
+    return n < plane ? n : plane;
+}
+
 static int launch_ssim_stats(int C, int H, int W, const float* pred, const long long* ps, const float* gt, const long long* gs_,
-                             void* workspace, hipStream_t st)
+                             void* workspace, hipStream_t st, const DepthPlane* depth = nullptr)
 {
     const size_t n = (size_t)C * H * W;
     float* D = static_cast<float*>(workspace);
     float* partials = reinterpret_cast<float*>(static_cast<char*>(workspace) + align_up(3 * n * sizeof(float)));
-    const dim3 grid((W + LT - 1) / LT, (H + LTY - 1) / LTY, C);
+    const dim3 grid((W + LT - 1) / LT, (H + LTY - 1) / LTY, C + (depth ? 1 : 0));
     const View x{pred, ps[0], ps[1], ps[2]}, y{gt, gs_[0], gs_[1], gs_[2]};
-    ssim_stats_kernel<<<grid, 256, 0, st>>>(H, W, x, y, D, partials);
-    return (int)(grid.x * grid.y * grid.z);
+    DepthPlane dz{};
+    if (depth) dz = *depth;
+    ssim_stats_kernel<<<grid, 256, 0, st>>>(H, W, x, y, D, partials, C, dz);
+    return (int)(grid.x * grid.y * C);
 }
 
 // pass 2 alone, from the D maps pass 1 left in `workspace`
@@ -305,7 +381,8 @@ void launch_l1_ssim_grad(int C, int H, int W, const float* pred, const long long
     const dim3 grid((W + LT - 1) / LT, (H + LTY - 1) / LTY, C);
     const View x{pred, ps[0], ps[1], ps[2]}, y{gt, gs_[0], gs_[1], gs_[2]};
     const ViewW g{grad, gstr[0], gstr[1], gstr[2]};
-    ssim_grad_kernel<<<grid, 256, 0, st>>>(H, W, x, y, static_cast<const float*>(workspace), (1.f - f) / (float)n, f / (float)n, scale, g);
+    ssim_grad_kernel<<<grid, 256, 0, st>>>(H, W, x, y, static_cast<const float*>(workspace), (1.f - f) / (float)n, f / (float)n, scale, g,
+                                           C, DepthPlane{});
 }
 
 void launch_l1_ssim(int C, int H, int W, const float* pred, const long long* ps, const float* gt, const long long* gs_,
@@ -328,33 +405,10 @@ depth_stats_kernel(int H, int W, const float* __restrict__ pred, long long psy, 
                    float* __restrict__ partials)
 {
     __shared__ float red[4];
-    float sf = 0.f, nf = 0.f, sb = 0.f, nb = 0.f;
-    // a workgroup walks whole rows (no 64-bit division per element), four elements of a thread in flight at a time
-    for (int yy = (int)blockIdx.x; yy < H; yy += (int)gridDim.x) {
-        const float* pr = pred + yy * psy;
-        const float* gr = gt + yy * gsy;
-        for (int x0 = (int)threadIdx.x; x0 < W; x0 += 4 * 256) {
-            float p[4], g[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int xx = x0 + 256 * u;
-                const bool in = xx < W;
-                p[u] = in ? pr[xx * psx] : 0.f;
-                g[u] = in ? gr[xx * gsx] : max_depth;   // == max_depth: neither foreground nor background
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (g[u] < max_depth) { sf += fabsf(p[u] - g[u]); nf += 1.f; }
-                else if (g[u] > max_depth) { sb += fabsf(p[u] - max_depth); nb += 1.f; }
-            }
-        }
-    }
-    const float a = block_sum_256(sf, red), b = block_sum_256(nf, red), c = block_sum_256(sb, red),
-                d = block_sum_256(nb, red);
-    if (threadIdx.x == 0) {
-        partials[4 * blockIdx.x] = a; partials[4 * blockIdx.x + 1] = b;
-        partials[4 * blockIdx.x + 2] = c; partials[4 * blockIdx.x + 3] = d;
-    }
+    DepthPlane z{};
+    z.H = H; z.W = W; z.pred = pred; z.psy = psy; z.psx = psx; z.gt = gt; z.gsy = gsy; z.gsx = gsx; z.max_depth = max_depth;
+    z.partials = partials;
+    depth_stats_rows(z, (int)blockIdx.x, (int)gridDim.x, red);
 }
 
 __global__ void __launch_bounds__(256)
@@ -401,13 +455,9 @@ depth_grad_kernel(int H, int W, const float* __restrict__ pred, long long psy, l
     const float sc_ = scale ? *scale : 1.f;                                  // (device scalar: see ssim_grad_kernel)
     const float cf = depth_factor == 0.f ? 0.f : sc_ * depth_factor / stats[2];   // a disabled term has no gradient (not 0/0)
     const float cb = mask_factor == 0.f ? 0.f : sc_ * mask_factor / stats[3];
-    float v = 0.f;
-    if (g < max_depth) { const float d = p - g; v = cf * (d > 0.f ? 1.f : d < 0.f ? -1.f : 0.f); }
-    else if (g > max_depth) { const float d = p - max_depth; v = cb * (d > 0.f ? 1.f : d < 0.f ? -1.f : 0.f); }
-    grad[yy * qsy + xx * qsx] = v;
+    grad[yy * qsy + xx * qsx] = depth_grad_value(p, g, max_depth, cf, cb);
 }
 
-constexpr int DEPTH_WGS = 1024;
 size_t depth_l1_workspace_bytes() { return align_up(4 * DEPTH_WGS * sizeof(float)) + 256; }
 
 void launch_depth_l1_grad(int H, int W, const float* pred, const long long* ps, const float* gt, const long long* gs_,
@@ -484,11 +534,31 @@ void launch_rgb_depth_loss(int C, int H, int W, const float* pred, const long lo
 {
     const size_t n = (size_t)C * H * W;
     const float* partials = reinterpret_cast<const float*>(static_cast<char*>(ws_ssim) + align_up(3 * n * sizeof(float)));
-    const int n_wg = launch_ssim_stats(C, H, W, pred, ps, gt, gs_, ws_ssim, st);
-    const int n_wg_d = Hd < DEPTH_WGS ? Hd : DEPTH_WGS;
     float* partials_d = static_cast<float*>(ws_depth);
-    depth_stats_kernel<<<n_wg_d, 256, 0, st>>>(Hd, Wd, dpred, dps[0], dps[1], dgt, dgs[0], dgs[1], max_depth, partials_d);
-    rgb_depth_finalize_kernel<<<1, 1024, 0, st>>>(n_wg, partials, 1.0 / (double)n, f, n_wg_d, partials_d, depth_factor, mask_factor, out8);
+    DepthPlane dz{};
+    dz.H = Hd; dz.W = Wd; dz.pred = dpred; dz.psy = dps[0]; dz.psx = dps[1]; dz.gt = dgt; dz.gsy = dgs[0]; dz.gsx = dgs[1];
+    dz.max_depth = max_depth; dz.partials = partials_d; dz.n_wg = depth_plane_wgs(C, H, W, Hd);
+    const int n_wg = launch_ssim_stats(C, H, W, pred, ps, gt, gs_, ws_ssim, st, &dz);   // the depth sums ride along as a z-plane
+    rgb_depth_finalize_kernel<<<1, 1024, 0, st>>>(n_wg, partials, 1.0 / (double)n, f, dz.n_wg, partials_d, depth_factor, mask_factor, out8);
+}
+
+// both gradient passes in ONE launch (the depth image as one more z-plane of the SSIM gradient kernel)
+void launch_rgb_depth_loss_grad(int C, int H, int W, const float* pred, const long long* ps, const float* gt, const long long* gs_, float f,
+                                const void* ws_ssim, int Hd, int Wd, const float* dpred, const long long* dps, const float* dgt,
+                                const long long* dgs, float max_depth, float depth_factor, float mask_factor, const float* stats,
+                                const float* scale, float* grad, const long long* gstr, float* dgrad, const long long* dgstr,
+                                hipStream_t st)
+{
+    const size_t n = (size_t)C * H * W;
+    const dim3 grid((W + LT - 1) / LT, (H + LTY - 1) / LTY, C + 1);
+    const View x{pred, ps[0], ps[1], ps[2]}, y{gt, gs_[0], gs_[1], gs_[2]};
+    const ViewW g{grad, gstr[0], gstr[1], gstr[2]};
+    DepthPlane dz{};
+    dz.H = Hd; dz.W = Wd; dz.pred = dpred; dz.psy = dps[0]; dz.psx = dps[1]; dz.gt = dgt; dz.gsy = dgs[0]; dz.gsx = dgs[1];
+    dz.max_depth = max_depth; dz.n_wg = 1; dz.depth_factor = depth_factor; dz.mask_factor = mask_factor; dz.stats = stats;
+    dz.scale = scale; dz.grad = dgrad; dz.qsy = dgstr[0]; dz.qsx = dgstr[1];
+    ssim_grad_kernel<<<grid, 256, 0, st>>>(H, W, x, y, static_cast<const float*>(ws_ssim), (1.f - f) / (float)n, f / (float)n, scale, g,
+                                           C, dz);
 }
 
 }  // namespace gsr

@@ -245,12 +245,11 @@ class _RGBDepthLoss(torch.autograd.Function):
                 grad6[:3].zero_()
             gv, gdv = _crop(grad6[:3], margin), grad6[3]
             keep, sp = _scale_ptr(g_loss, dev)
-            _lib.check(lib.gsr_l1_ssim_backward(
-                C, H, W, vp(p), p.stride(0), p.stride(1), p.stride(2), vp(g), g.stride(0), g.stride(1), g.stride(2), f, vp(ws), sp,
-                vp(gv), gv.stride(0), gv.stride(1), gv.stride(2), _stream()), "gsr_l1_ssim_backward")
-            _lib.check(lib.gsr_depth_l1_backward(
+            _lib.check(lib.gsr_rgb_depth_loss_backward(
+                C, H, W, vp(p), p.stride(0), p.stride(1), p.stride(2), vp(g), g.stride(0), g.stride(1), g.stride(2), f, vp(ws),
                 Hd, Wd, vp(d), d.stride(0), d.stride(1), vp(gd), gd.stride(0), gd.stride(1), max_depth, depth_factor, mask_factor,
-                ctypes.c_void_p(out.data_ptr() + 12), sp, vp(gdv), gdv.stride(0), gdv.stride(1), _stream()), "gsr_depth_l1_backward")
+                vp(out), sp, vp(gv), gv.stride(0), gv.stride(1), gv.stride(2), vp(gdv), gdv.stride(0), gdv.stride(1), _stream()),
+                "gsr_rgb_depth_loss_backward")
         return grad6.to(in_dtype), None, None, None, None, None, None, None
 
 

@@ -299,6 +299,16 @@ int gsr_rgb_depth_loss(int C, int H, int W, const float* pred, long long pred_sc
                        const float* depth_gt, long long dgt_sy, long long dgt_sx, float max_depth, float depth_factor,
                        float mask_factor, void* depth_workspace, float* loss_out, gsr_stream_t stream);
 
+/* Both gradient passes of gsr_rgb_depth_loss in ONE launch: loss_out is the [8] vector the value call wrote (its elements
+ * 5 and 6 are the pixel counts the depth gradient divides by), ssim_workspace the value call's, unmodified. */
+int gsr_rgb_depth_loss_backward(int C, int H, int W, const float* pred, long long pred_sc, long long pred_sy, long long pred_sx,
+                                const float* gt, long long gt_sc, long long gt_sy, long long gt_sx, float dssim_factor,
+                                const void* ssim_workspace, int Hd, int Wd, const float* depth_pred, long long dpred_sy,
+                                long long dpred_sx, const float* depth_gt, long long dgt_sy, long long dgt_sx, float max_depth,
+                                float depth_factor, float mask_factor, const float* loss_out, const float* grad_scale,
+                                float* dL_dpred, long long grad_sc, long long grad_sy, long long grad_sx, float* dL_ddepth,
+                                long long dgrad_sy, long long dgrad_sx, gsr_stream_t stream);
+
 /* Tuning aid: when device_buffer is non-NULL (4*T uint64), the two blend kernels record the start/end wall
  * clock (100 MHz) of every workgroup: forward at [2*b], backward at [2*(T+b)], b = launch index.  NULL = off. */
 int gsr_debug_set_trace(void* device_buffer);
