@@ -551,7 +551,9 @@ class ShardedAdam:
         Costs a dictionary look-up per parameter when nothing is pending."""
         if not any(b["ag"] is not None for b in self.buckets):
             return
-        which = range(len(self.buckets)) if params is None else sorted({self._bucket_of[id(p)] for p in params if p is not None})
+        # (parameters this optimiser does not hold -- frozen ones, None placeholders -- have nothing in flight)
+        which = range(len(self.buckets)) if params is None else sorted({self._bucket_of[id(p)] for p in params
+                                                                        if p is not None and id(p) in self._bucket_of})
         from .optim import _bump_version
         for bi in which:
             b = self.buckets[bi]
