@@ -201,7 +201,6 @@ class GradAllReducer:
         return sum(p.numel() for p in self.params) * 4
 
     def close(self) -> None:
-        self.wait_params()
         for h in self._hooks:
             h.remove()
         self._hooks = []
@@ -517,6 +516,7 @@ class ShardedAdam:
                 p.grad.zero_()
 
     def close(self) -> None:
+        self.wait_params()
         for h in self._hooks:
             h.remove()
         self._hooks = []

@@ -113,8 +113,10 @@ def test_single_process_is_a_noop():
     from gaustar_amd import dist as gd
     p = torch.zeros(4, requires_grad=True)
     p.grad = torch.ones(4)
-    gd.GradAllReducer([p])()
+    red = gd.GradAllReducer([p])
+    red()
     assert torch.equal(p.grad, torch.ones(4)) and gd.world_size() == 1 and gd.rank() == 0
+    red.close(); red.close()                  # (idempotent; tools/bench_window.py closes its reducer after every frame)
 
 
 def _sweep_worker(rank, world, port, n, q):
