@@ -609,3 +609,82 @@ def test_lazy_all_gather_is_fenced_gloo_world2():
         assert err < 2e-6 and same, res
         assert pending == [1, 1, 1, 1] and all(stale_seen), res
         assert idx == [0, 1, 2, 3]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# World sizes 3 and 4 (the node has eight GPUs; every box this project has seen has one): shards that cut parameters at
+# other places than the halves do, padding to N equal 16-byte-aligned shards with an odd N, the lazy all-gather and a
+# checkpoint round trip through torch.optim.Adam's format across ranks.
+# ------------------------------------------------------------------------------------------------------------------
+def _sharded_worker_n(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from gaustar_amd import dist as gd
+    gd.init_from_env("gloo")
+    torch.manual_seed(0)
+    shapes = [(1001, 3), (77,), (5000, 2), (9, 4), (333, 5)]
+    ps = [torch.nn.Parameter(torch.randn(*s)) for s in shapes]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    groups = lambda xs: [{"params": [xs[0], xs[4]], "lr": 1e-2}, {"params": [xs[1], xs[2]], "lr": 3e-3}, {"params": [xs[3]], "lr": 1e-3}]
+    mk = lambda xs: gd.ShardedAdam(groups(xs), ready_order=[xs[2], xs[3], xs[0], xs[4], xs[1]], eps=1e-15, bucket_bytes=20_000,
+                                   segment_step=torch_adam_segment, gather_first=[xs[4], xs[1]])
+    opt = mk(ps)
+    ref = torch.optim.Adam(groups(qs), eps=1e-15)
+    w = lambda r: [(i + 1.0) * (r + 1.0) for i in range(5)]
+    n_of = lambda r: 4 if r == 1 else 5                      # rank 1 never produces a gradient for the last parameter of its list
+
+    def one(o, xs, it):
+        o.zero_grad()
+        o.wait_params() if hasattr(o, "wait_params") else None
+        sum(c * (p ** 2).sum() for c, p in list(zip(w(rank), xs))[:n_of(rank)]).backward()
+        if it == 2:
+            (0.5 * xs[2].sum()).backward()
+        o.step()
+
+    def one_ref(it):
+        ref.zero_grad()
+        l = sum(sum(c * (p ** 2).sum() for c, p in list(zip(w(r), qs))[:n_of(r)]) for r in range(world)) / world
+        if it == 2:
+            l = l + 0.5 * qs[2].sum()
+        l.backward()
+        ref.step()
+    for it in range(4):
+        one(opt, ps, it); one_ref(it)
+    pend = opt.pending_gathers()
+    sd = opt.state_dict()                                     # collective; fences the lazy gathers
+    err = max(float((p - q_).abs().max()) for p, q_ in zip(ps, qs))
+    # resume on the same ranks from the checkpoint, and from torch.optim.Adam's own
+    ps2 = [torch.nn.Parameter(q_.detach().clone()) for q_ in qs]
+    opt2 = mk(ps2)
+    opt2.load_state_dict(ref.state_dict())
+    for it in range(4, 6):
+        one(opt, ps, it); one(opt2, ps2, it); one_ref(it)
+    opt.wait_params(); opt2.wait_params()
+    err2 = max(float((p - q_).abs().max()) for p, q_ in zip(ps, qs))
+    err3 = max(float((p - q_).abs().max()) for p, q_ in zip(ps2, qs))
+    flat = torch.cat([p.detach().reshape(-1) for p in ps])
+    alls = [torch.zeros_like(flat) for _ in range(world)]
+    torch.distributed.all_gather(alls, flat)
+    same = all(bool(torch.equal(alls[0], a)) for a in alls)
+    shard_ok = all(b["S"] * world == b["n"] and b["S"] % 4 == 0 for b in opt.buckets)
+    q.put((rank, err, err2, err3, same, shard_ok, pend, sorted(sd["state"]), opt.state_bytes_per_rank(), opt.payload_bytes()))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [3, 4])
+def test_sharded_adam_gloo_world_3_and_4(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker_n, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, err2, err3, same, shard_ok, pend, idx, state_b, payload in res:
+        assert err < 2e-6 and err2 < 3e-6 and err3 < 3e-6 and same and shard_ok, res
+        assert pend >= 1 and idx == [0, 1, 2, 3, 4], res
+        assert state_b < 1.15 * 2 * payload / world, res         # 1/N of the two moments (+ padding)
