@@ -587,6 +587,11 @@ GSR_BWD_SPECIALISE(4, GSR_BWD_WAVES4)
 #ifndef GSR_BWD_WALK_DEFAULT
 #define GSR_BWD_WALK_DEFAULT 0
 #endif
+#ifndef GSR_BWD_PK_DEFAULT
+#define GSR_BWD_PK_DEFAULT 0
+#endif
+bool launch_blend_bwd_pk(int C, int W, int H, int U, const float* bg, ImageState im, BinState b, const float* dL_dpix, float* grad_acc,
+                         hipStream_t st);
 bool launch_blend_bwd_walk(int rows, int C, int W, int H, int U, const float* bg, ImageState im, BinState b, const float* dL_dpix,
                            float* grad_acc, hipStream_t st);
 
@@ -598,6 +603,9 @@ void launch_blend_bwd(int C, int W, int H, int U, const float* bg, const float* 
     // GSR_BWD_WALK=<rows>: the per-lane-walk variant (gsr_blend_bwd_walk.hip), three and four channels
     static const int walk_rows = getenv("GSR_BWD_WALK") ? atoi(getenv("GSR_BWD_WALK")) : GSR_BWD_WALK_DEFAULT;
     if (walk_rows > 0 && launch_blend_bwd_walk(walk_rows, C, W, H, U, bg, im, b, dL_dpix, grad_acc, st)) return;
+    // GSR_BWD_PK=1: two kept instances per trip on packed f32 instructions (gsr_blend_bwd_pk.hip), three channels
+    static const int pk = getenv("GSR_BWD_PK") ? atoi(getenv("GSR_BWD_PK")) : GSR_BWD_PK_DEFAULT;
+    if (pk > 0 && launch_blend_bwd_pk(C, W, H, U, bg, im, b, dL_dpix, grad_acc, st)) return;
     // Residency knob: extra dynamic LDS lowers the number of co-resident units per CU (tuning only).
     static const int pad = getenv("GSR_BWD_LDS_PAD") ? atoi(getenv("GSR_BWD_LDS_PAD")) : 0;
     uint64_t* tr = g_trace ? g_trace + 2 * (size_t)t.T : nullptr;
