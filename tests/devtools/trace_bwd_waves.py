@@ -62,3 +62,12 @@ frac = np.array(frac)
 print("per SIMD sample: mean waves in head %.2f, in body %.2f" % (frac[:, 0].mean(), frac[:, 1].mean()))
 print("histogram of #waves in head per SIMD sample:", hist.tolist())
 print("histogram of #waves in body per SIMD sample:", np.bincount(frac[:, 1], minlength=8).tolist())
+# residency over the span: mean resident waves per SIMD slot in each twentieth of the kernel's span
+edges = np.linspace(0.0, span, 21)
+res = []
+for a, b in zip(edges[:-1], edges[1:]):
+    ov = np.clip(np.minimum(en, b) - np.maximum(st, a), 0.0, None).sum() / (b - a)
+    res.append(ov / len(ids))
+print("resident waves per SIMD by twentieth of the span:", [round(float(x), 2) for x in res])
+order = np.argsort(st)
+print("start time of the last wave %.1f us; waves ending in the last 10 us: %d" % (st.max(), int(np.sum(en > span - 10.0))))
