@@ -221,7 +221,6 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
         totals[2] = nonempty;
         totals[3] = total_seg;
         totals[6] = 0u;           // scatter counts the parts of long lists here
-        totals[7] = 0u;           // blend_fwd counts the entries of the backward's work list here
         totals[5] = view_token;   // scatter compares it with totals[4] (set by a preprocess workgroup that ran out of room)
         seg_off[T] = total_seg;
     }

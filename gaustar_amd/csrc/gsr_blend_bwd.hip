@@ -60,7 +60,7 @@
 #define GSR_BWD_FOR_REPS(CALL)                                                                                                 \
     for (uint32_t rep = 0; rep < GSR_BWD_REP; rep++) {                                                                         \
         const uint32_t vbid = (((blockIdx.x >> 3) * GSR_BWD_REP + rep) << 3) | (blockIdx.x & 7u);                              \
-        CALL;                                                                                                                  \
+        if (vbid < (uint32_t)n_vb) CALL;                                                                                       \
         __builtin_amdgcn_wave_barrier();                                                                                       \
     }
 #ifndef GSR_BWD_SMEM
@@ -79,7 +79,7 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
                  const uint2* __restrict__ masks, const uint32_t* __restrict__ point_list, const float4* __restrict__ rec_a,
                  const float4* __restrict__ rec_b, const RecTail<C>* __restrict__ rec_c, const float* __restrict__ bg,
                  const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-                 const float* __restrict__ dL_dpix, float* __restrict__ grad_acc, uint64_t* __restrict__ trace, uint32_t vbid, uint32_t n_vb, const uint4* __restrict__ work, const uint32_t* __restrict__ work_count)
+                 const float* __restrict__ dL_dpix, float* __restrict__ grad_acc, uint64_t* __restrict__ trace, uint32_t vbid, uint32_t n_vb)
 {
     using L = SlotLayout<C>;
     constexpr int SF = L::FLOATS, NM = L::NM, MOM0 = L::MOM0, SV = snap_vecs(C);
@@ -96,39 +96,25 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     __shared__ __attribute__((aligned(16))) float qf[QCAP * SF];   // queue slots (see SlotLayout)
     __shared__ __attribute__((aligned(16))) float Rm[2 * GRP * RSTRIDE];   // rows 0..7: r, rows 8..15: w, [row][pixel lane]
     // one wave64 per workgroup: unit = (tile, segment), wave = 8x8 block of the tile.
-    // (vbid: the id this call works on -- the workgroup id, or one of GSR_BWD_REP ids a wave works off in turn)
-    // Which (unit, block) it is comes from the work list the forward left (gsr_blend_fwd.hip: only pairs in which some pixel
-    // replays an instance are listed, a quarter of all pairs are not), together with everything the unit has to know about
-    // its tile: ONE scalar trip (the list's length rides along), then EVERY vector load of the unit's head is requested
-    // before the first one is waited for -- pixel state, candidate words of this unit and the next, the two snapshots a
-    // resuming pixel needs, and the unit's 64 instance records, which the forward left in list order (rec_a/b/c).  As a
-    // chain (unit -> tile -> ranges -> n_contrib -> words -> snapshot; words -> list -> id -> geometry) the head of a unit
-    // was six dependent trips to memory, a third of a unit's life, with nothing to issue meanwhile.
-    // XCD-aware placement: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2); XCD x takes runs
-    // of 32 consecutive list entries -- the blocks of a unit (which read the SAME records) and most units of a tile (which
-    // share pixel state and snapshots) meet in one L2.
+    // XCD-aware placement: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the
+    // naive map (unit = id / 4) would put the four blocks of a unit -- which read the SAME instance records -- on
+    // four different L2s.  Instead the four blocks of a unit take four consecutive slots of ONE XCD.
+    // Units of one tile are consecutive and also share their pixels' dL_dpix / T / n_contrib and the tile's final
+    // snapshot, so an XCD takes RUNS of 8 consecutive units: of every 64 units, XCD x owns [8x, 8x + 8).
+    // (vbid: the unit-block this call works on -- the workgroup id, or one of GSR_BWD_REP ids a wave works off in turn)
+    const uint32_t n_units = n_vb >> 2;
     const uint32_t xcd = vbid & 7u, slot = vbid >> 3;
-    const uint32_t wpos = (slot >> 5) * 256u + xcd * 32u + (slot & 31u);
-    const uint32_t wcount = *work_count;
-    uint4 info = work[wpos];                              // (the list is padded to whole runs: always a valid address)
-    uint32_t unit, wave_sel;
-    if (wcount != 0xffffffffu) {
-        if (wpos >= wcount) return;
-        unit = info.w + ((info.z >> 16) & 63u);
-        wave_sel = (info.z >> 24) & 3u;
-        info.z &= 0xffffu;
-    } else {
-        // no list (a view that blended long lists in parts): every (unit, block) pair, the four blocks of a unit in four
-        // consecutive slots of one XCD, runs of 8 units per XCD
-        if (vbid >= n_vb) return;
-        const uint32_t n_units = n_vb >> 2;
-        const uint32_t grp = slot >> 2;                       // index of this (unit) among the XCD's units
-        unit = (grp >> 3) * 64u + xcd * 8u + (grp & 7u);
-        wave_sel = slot & 3u;
-        const uint32_t full = (n_units >> 6) << 6;            // units covered by complete groups of 64
-        if (vbid >= full * 4u) { unit = vbid >> 2; wave_sel = vbid & 3u; }   // ragged tail: plain map
-        info = unit_info[unit];
-    }
+    const uint32_t grp = slot >> 2;                       // index of this (unit) among the XCD's units
+    uint32_t unit = (grp >> 3) * 64u + xcd * 8u + (grp & 7u);
+    uint32_t wave_sel = slot & 3u;
+    const uint32_t full = (n_units >> 6) << 6;            // units covered by complete groups of 64
+    if (vbid >= full * 4u) { unit = vbid >> 2; wave_sel = vbid & 3u; }   // ragged tail: plain map
+    // Everything the unit has to know about its tile in one (scalar) load; then EVERY vector load of the unit's head is
+    // requested before the first one is waited for -- pixel state, candidate words of this unit and the next, the two
+    // snapshots a resuming pixel needs, and the unit's 64 instance records, which the forward left in list order
+    // (rec_a/b/c).  As a chain (unit -> tile -> ranges -> n_contrib -> words -> snapshot; words -> list -> id -> geometry)
+    // the head of a unit was six dependent trips to memory, a third of a unit's life, with nothing to issue meanwhile.
+    const uint4 info = unit_info[unit];
     const int tile = (int)info.x;
     const uint32_t list0 = info.y;
     const int n = (int)info.z;
@@ -664,10 +650,9 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
                  const uint2* __restrict__ masks, const uint32_t* __restrict__ point_list, const float4* __restrict__ rec_a,
                  const float4* __restrict__ rec_b, const RecTail<C>* __restrict__ rec_c, const float* __restrict__ bg,
                  const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-                 const float* __restrict__ dL_dpix, float* __restrict__ grad_acc, uint64_t* __restrict__ trace, int n_vb, const uint4* __restrict__ work,
-                 const uint32_t* __restrict__ work_count)
+                 const float* __restrict__ dL_dpix, float* __restrict__ grad_acc, uint64_t* __restrict__ trace, int n_vb)
 {
-    GSR_BWD_FOR_REPS(blend_bwd_unit<C>(W, H, gx, unit_info, snap, masks, point_list, rec_a, rec_b, rec_c, bg, final_T, n_contrib, dL_dpix, grad_acc, trace, vbid, (uint32_t)n_vb, work, work_count));
+    GSR_BWD_FOR_REPS(blend_bwd_unit<C>(W, H, gx, unit_info, snap, masks, point_list, rec_a, rec_b, rec_c, bg, final_T, n_contrib, dL_dpix, grad_acc, trace, vbid, (uint32_t)n_vb));
 }
 // Three channels: the register allocator is told to stay within six waves per SIMD (80 registers; left alone it takes 82
 // and the kernel runs five: 0.141 vs 0.131 ms on config C).  Six channels (104 registers) would have to spill 20 and lose.
@@ -679,11 +664,10 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
                          const float4* __restrict__ rec_a, const float4* __restrict__ rec_b,                                  \
                          const RecTail<CH>* __restrict__ rec_c, const float* __restrict__ bg,                                 \
                          const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,                           \
-                         const float* __restrict__ dL_dpix, float* __restrict__ grad_acc, uint64_t* __restrict__ trace, int n_vb,   \
-                         const uint4* __restrict__ work, const uint32_t* __restrict__ work_count)                             \
+                         const float* __restrict__ dL_dpix, float* __restrict__ grad_acc, uint64_t* __restrict__ trace, int n_vb) \
     {                                                                                                                         \
         GSR_BWD_FOR_REPS(blend_bwd_unit<CH>(W, H, gx, unit_info, snap, masks, point_list, rec_a, rec_b, rec_c, bg, final_T,      \
-                                            n_contrib, dL_dpix, grad_acc, trace, vbid, (uint32_t)n_vb, work, work_count)); \
+                                            n_contrib, dL_dpix, grad_acc, trace, vbid, (uint32_t)n_vb));                      \
     }
 #ifndef GSR_BWD_LDS_PAD_DEFAULT
 #define GSR_BWD_LDS_PAD_DEFAULT 0
@@ -725,10 +709,10 @@ void launch_blend_bwd(int C, int W, int H, int U, const float* bg, const float* 
     uint64_t* tr = g_trace ? g_trace + 2 * (size_t)t.T : nullptr;
     const auto go = [&](auto tag) {
         constexpr int CC = decltype(tag)::value;
-        const int n_vb = 4 * U, grid = ((n_vb + 255) / 256 * 256 + GSR_BWD_REP - 1) / GSR_BWD_REP;   // (whole runs of the work list)
+        const int n_vb = 4 * U, grid = 8 * ((n_vb + 8 * GSR_BWD_REP - 1) / (8 * GSR_BWD_REP));
         blend_bwd_kernel<CC><<<grid, 64, pad, st>>>(W, H, t.gx, b.unit_info, b.snap, b.masks, b.point_list, b.rec_a, b.rec_b,
                                                     static_cast<const RecTail<CC>*>(b.rec_c), bg, im.final_T, im.n_contrib,
-                                                    dL_dpix, grad_acc, tr, n_vb, b.work, im.totals + 7);
+                                                    dL_dpix, grad_acc, tr, n_vb);
     };
     if (C == 6) go(std::integral_constant<int, 6>{});
     else if (C == 4) go(std::integral_constant<int, 4>{});

@@ -58,22 +58,9 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                  RecTail<C>* __restrict__ rec_c, const uint2* __restrict__ part_list, const uint32_t* __restrict__ totals,
                  float4* __restrict__ part_fin, uint32_t* __restrict__ part_last, uint32_t split_n, bool keep,
                  float4* __restrict__ zero_ptr,
-                 uint32_t zero_n, uint32_t* __restrict__ counters, uint32_t counters_tp, uint64_t* __restrict__ trace,
-                 uint4* __restrict__ work, uint32_t* __restrict__ work_count)
+                 uint32_t zero_n, uint32_t* __restrict__ counters, uint32_t counters_tp, uint64_t* __restrict__ trace)
 {
     const uint64_t t_start = trace ? wall_clock64() : 0;
-    // The backward's work list (gsr_blend_bwd.hip): which (unit, 8x8 block) pairs of this tile have a pixel that replays an
-    // instance there.  A quarter of all pairs have none (the block's pixels saturated in front of the unit, or the unit's 64
-    // instances miss the block); listing the others costs a tile three barriers and saves the backward a wave -- launch,
-    // two trips to memory, a slot for 4 us -- for each of them.  Views that blend long lists in parts build none.
-    __shared__ unsigned long long wl_mask[4];
-    __shared__ uint32_t wl_base;
-    // (uniform over the launch; 64 units per tile is what a pixel's unit mask holds -- a view with a longer list blends it in
-    // parts anyway unless a tuning build says otherwise)
-    const bool wl_want = MODE == 0 && work != nullptr && keep && snap != nullptr;
-    const bool wl_on = wl_want && split_n == 0xffffffffu && totals[1] <= 64u * 64u;
-    if (MODE == 0 && threadIdx.x < 4) wl_mask[threadIdx.x] = 0ull;
-    if (wl_want && !wl_on && blockIdx.x == 0 && threadIdx.x == 0) *work_count = 0xffffffffu;
     if constexpr (MODE == 1) { if (blockIdx.x >= totals[6]) return; }   // parts of this view (scatter_kernel lists them)
     // Side job: the backward's accumulation table (48 B per Gaussian) has to be zero before blend_bwd runs.  When the
     // caller hands it over at forward time every workgroup clears its slice here instead of a separate fill (a 5 us blit
@@ -152,7 +139,6 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     // segment (SNAP_SEG list positions) of the word this pixel consumed last.  A part that is not the tile's first starts
     // "nowhere": the first word of ANY of its units, the first one included, opens a segment and leaves a snapshot
     uint32_t seg_cur = (MODE == 1 && part_c0 != 0u) ? 0xffffffffu : 0u;
-    unsigned long long umask = 0ull;   // units of the tile in which this pixel consumed a candidate word (work list, MODE 0)
 
     // Two-stage software pipeline over the dependent gather (list -> id -> records): ids are fetched two chunks ahead,
     // records and mask words one chunk ahead, so no global-memory latency sits between a chunk's barrier and its walk.
@@ -260,7 +246,6 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                 const uint32_t seg_new = (c0 + (uint32_t)h * 32u) / (uint32_t)SNAP_SEG;
                 if (need && cur != 0u && seg_new != seg_cur) {
                     seg_cur = seg_new;
-                    if (MODE == 0) umask |= 1ull << (seg_new & 63u);
                     store_snapshot<C>(snap + ((size_t)(unit0 + seg_new * (SNAP_SEG / 64)) * 256 + pix_in_tile) * SV, T, Cc);
                 }
             }
@@ -510,34 +495,8 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             fetch_ids(c0 + 2 * CH);
             __syncthreads();
             // (a pixel that is done consumes no words)
-            const uint32_t nzw = done ? 0u : nonempty_words(c0);
-            // (the tile's first unit opens no segment in the walk: the pixel consumes a word of it iff it has one)
-            if (c0 == 0u && (nzw & ((1u << (SNAP_SEG / 32)) - 1u)) != 0u) umask |= 1ull;
-            const bool stopped = walk(c0, nzw);
+            const bool stopped = walk(c0, done ? 0u : nonempty_words(c0));
             done = done || stopped;
-        }
-    }
-    if (wl_on) {
-        // a pixel replays in unit u iff it consumed a word of u and u is not behind its last contributor's unit (every
-        // candidate of an earlier unit lies in front of the last contributor; that one's own unit holds it)
-        umask &= last != 0u ? (2ull << ((last - 1u) >> 6)) - 1ull : 0ull;
-        static_assert(SNAP_SEG == 64, "one bit per unit");
-        __syncthreads();   // wl_mask cleared
-        if (umask != 0ull) atomicOr(&wl_mask[wave], umask);
-        __syncthreads();
-        const unsigned long long m0 = wl_mask[0], m1 = wl_mask[1], m2 = wl_mask[2], m3 = wl_mask[3];
-        const uint32_t total = (uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
-        if (total != 0u) {   // (uniform)
-            if (threadIdx.x == 0) wl_base = atomicAdd(work_count, total);
-            __syncthreads();
-            // unit-major: the blocks of a unit are neighbours in the list (they read the same records); lane = unit
-            const unsigned long long below = (1ull << lane) - 1ull;
-            const uint32_t start = (uint32_t)(__popcll(m0 & below) + __popcll(m1 & below) + __popcll(m2 & below) + __popcll(m3 & below));
-            const uint32_t b0 = (uint32_t)(m0 >> lane) & 1u, b1 = (uint32_t)(m1 >> lane) & 1u, b2 = (uint32_t)(m2 >> lane) & 1u;
-            const unsigned long long mine = wave == 0 ? m0 : wave == 1 ? m1 : wave == 2 ? m2 : m3;
-            const uint32_t before = wave == 0 ? 0u : wave == 1 ? b0 : wave == 2 ? b0 + b1 : b0 + b1 + b2;
-            if ((mine >> lane) & 1ull)
-                work[wl_base + start + before] = make_uint4((uint32_t)tile, list0, n | ((uint32_t)lane << 16) | ((uint32_t)wave << 24), unit0);
         }
     }
     if (inside) {
@@ -569,12 +528,12 @@ static void launch_fwd_c(int W, int H, int R, int U, uint32_t max_count, const f
         blend_fwd_kernel<C, FWD_CHUNK, 1><<<(unsigned)part_capacity(R, U), 256, 0, st>>>(
             W, H, t.gx, im.ranges, im.order, b.point_list, nullptr, g.g0, g.g1, feats, bg, out_color, im.final_T, im.n_contrib,
             im.seg_off, b.masks, b.snap, b.rec_a, b.rec_b, static_cast<RecTail<C>*>(b.rec_c), b.part_list, im.totals, b.part_fin,
-            b.part_last, split_n, keep_masks, nullptr, 0u, nullptr, 0u, nullptr, nullptr, nullptr);
+            b.part_last, split_n, keep_masks, nullptr, 0u, nullptr, 0u, nullptr);
     blend_fwd_kernel<C, FWD_CHUNK, 0><<<t.T, 256, 0, st>>>(
         W, H, t.gx, im.ranges, im.order, b.point_list, sort_small ? b.keys : nullptr, g.g0, g.g1, feats, bg, out_color, im.final_T,
         im.n_contrib, im.seg_off, b.masks, b.snap, b.rec_a, b.rec_b, static_cast<RecTail<C>*>(b.rec_c), b.part_list, im.totals,
         b.part_fin, b.part_last, split_n, keep_masks, static_cast<float4*>(zero_ptr), (uint32_t)(zero_bytes / 16), counters,
-        (uint32_t)shard_stride(t.T), g_trace, b.work, im.totals + 7);
+        (uint32_t)shard_stride(t.T), g_trace);
 }
 
 void launch_blend_fwd(int C, int W, int H, int R, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im,

@@ -75,7 +75,7 @@ struct ImageState {          // per pixel / per tile
     uint2* ranges;           // [T] {start, end} into point_list
     uint32_t* tile_count;    // [NSHARD][Tp] instances per (shard, tile) (atomics in preprocess), Tp = shard_stride(T)
     uint32_t* tile_cursor;   // [NSHARD][Tp] scatter cursors: a tile's bucket is the concatenation of its shards
-    uint32_t* totals;        // [8] ([7]: entries of the backward's work list, BinState::work; 0xffffffff: none was built) {R, max tile count, number of non-empty tiles, U = number of list segments,
+    uint32_t* totals;        // [8] {R, max tile count, number of non-empty tiles, U = number of list segments,
                              //      token of the view whose preprocess could not record every instance (scatter then
                              //      walks the tiles again), token of the current view, number of parts of long lists, -}
     uint32_t* order;         // [T] tile ids, longest instance lists first (32-entry buckets), empty tiles last:
@@ -146,9 +146,6 @@ struct BinState {            // per instance / per segment
     float4* snap;            // [U][256][snap_vecs(C)] per-pixel {T, C0, C1, ...} BEFORE the first instance of segment
                              // u (u not the first segment of its tile; that slot holds the FINAL {T, C...} when the
                              // tile has more than one segment); pixel index = 16*(y - tile_y0) + (x - tile_x0)
-    uint4* work;             // [4 U rounded up to 256] the backward's work list, written by blend_fwd: one entry per (unit, 8x8 block)
-                             // in which some pixel of the block replays an instance -- {tile, first list entry of the tile,
-                             // entries | unit-in-tile << 16 | block << 24, first unit of the tile}; their number: totals[7]
     size_t bytes;
 };
 // Lists above LONG_LIST entries are blended in parts of one forward chunk (gsr_blend_fwd.hip); part_capacity bounds their
@@ -189,7 +186,6 @@ __host__ __device__ inline BinState carve_bin(void* base, int R, int U, int C = 
     s.part_fin = (float4*)(b + o); o = align_up(o + sizeof(float4) * 256 * (size_t)snap_vecs(C) * np);
     s.snap = (float4*)(b + o); o = align_up(o + sizeof(float4) * 256 * (size_t)snap_vecs(C) * (size_t)U);
     s.rec_c = (void*)(b + o); o = align_up(o + rec_tail_bytes(C) * (size_t)R);
-    s.work = (uint4*)(b + o); o = align_up(o + sizeof(uint4) * (((size_t)U * 4 + 255) / 256 * 256));
     s.bytes = o + 256;
     return s;
 }
