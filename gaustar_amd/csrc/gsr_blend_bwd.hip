@@ -42,30 +42,6 @@
 // unit costs ~20 % more than a 3-channel one instead of 2x.  Record of the accumulation table:
 // grad_acc[gaussian][GRAD_RS] = {sum r, sum r dx, sum r dy, sum r dx^2, sum r dx dy, sum r dy^2, c_0 .. c_{C-1}}.
 #include "gsr_bwd_util.h"
-#ifndef GSR_ABL_LIVE_COND
-#define GSR_ABL_LIVE_COND
-#endif
-#ifndef GSR_ABL_FLUSH_COND
-#define GSR_ABL_FLUSH_COND
-#endif
-#ifndef GSR_ABL_LOOP_COND
-#define GSR_ABL_LOOP_COND
-#endif
-#ifndef GSR_ABL_CONTRACT
-#define GSR_ABL_CONTRACT 0   // 1: skip the moment contraction (timing ablation only, wrong gradients)
-#endif
-#ifndef GSR_BWD_REP
-#define GSR_BWD_REP 1   // unit-blocks a wave works off in turn (ids ((b >> 3) * REP + rep) * 8 + (b & 7): same XCD, neighbouring blocks of a unit)
-#endif
-#define GSR_BWD_FOR_REPS(CALL)                                                                                                 \
-    for (uint32_t rep = 0; rep < GSR_BWD_REP; rep++) {                                                                         \
-        const uint32_t vbid = (((blockIdx.x >> 3) * GSR_BWD_REP + rep) << 3) | (blockIdx.x & 7u);                              \
-        if (vbid < (uint32_t)n_vb) CALL;                                                                                       \
-        __builtin_amdgcn_wave_barrier();                                                                                       \
-    }
-#ifndef GSR_BWD_SMEM
-#define GSR_BWD_SMEM 0
-#endif
 #ifndef GSR_BWD_PROJ
 #define GSR_BWD_PROJ 1
 #endif
@@ -79,7 +55,7 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
                  const uint2* __restrict__ masks, const uint32_t* __restrict__ point_list, const float4* __restrict__ rec_a,
                  const float4* __restrict__ rec_b, const RecTail<C>* __restrict__ rec_c, const float* __restrict__ bg,
                  const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-                 const float* __restrict__ dL_dpix, float* __restrict__ grad_acc, uint64_t* __restrict__ trace, uint32_t vbid, uint32_t n_vb)
+                 const float* __restrict__ dL_dpix, float* __restrict__ grad_acc, uint64_t* __restrict__ trace)
 {
     using L = SlotLayout<C>;
     constexpr int SF = L::FLOATS, NM = L::NM, MOM0 = L::MOM0, SV = snap_vecs(C);
@@ -101,14 +77,13 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     // four different L2s.  Instead the four blocks of a unit take four consecutive slots of ONE XCD.
     // Units of one tile are consecutive and also share their pixels' dL_dpix / T / n_contrib and the tile's final
     // snapshot, so an XCD takes RUNS of 8 consecutive units: of every 64 units, XCD x owns [8x, 8x + 8).
-    // (vbid: the unit-block this call works on -- the workgroup id, or one of GSR_BWD_REP ids a wave works off in turn)
-    const uint32_t n_units = n_vb >> 2;
-    const uint32_t xcd = vbid & 7u, slot = vbid >> 3;
+    const uint32_t n_units = gridDim.x >> 2;
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
     const uint32_t grp = slot >> 2;                       // index of this (unit) among the XCD's units
     uint32_t unit = (grp >> 3) * 64u + xcd * 8u + (grp & 7u);
     uint32_t wave_sel = slot & 3u;
     const uint32_t full = (n_units >> 6) << 6;            // units covered by complete groups of 64
-    if (vbid >= full * 4u) { unit = vbid >> 2; wave_sel = vbid & 3u; }   // ragged tail: plain map
+    if (blockIdx.x >= full * 4u) { unit = blockIdx.x >> 2; wave_sel = blockIdx.x & 3u; }   // ragged tail: plain map
     // Everything the unit has to know about its tile in one (scalar) load; then EVERY vector load of the unit's head is
     // requested before the first one is waited for -- pixel state, candidate words of this unit and the next, the two
     // snapshots a resuming pixel needs, and the unit's 64 instance records, which the forward left in list order
@@ -223,7 +198,9 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
 #if GSR_BWD_PROJ
     // dL_dalpha only ever needs accum_rec through its dot product with dL_dpix, and accum_rec' = accum_rec + alpha (c -
     // accum_rec) is linear: carry A = accum_rec . dL_dpix instead of the C channels.  With k = c . dL_dpix:
-    // s = sum_ch (c_ch - accum_rec_ch) dL_dpix_ch = k - A,  A' = A + alpha s  (A = accd below).  C + 2 instructions per live pair instead of 3 C.
+    // s = sum_ch (c_ch - accum_rec_ch) dL_dpix_ch = k - A,  A' = A + alpha s  (A = accd below).  C + 2 instructions per live
+    // pair instead of 3 C, and C - 1 registers less: three channels 80 -> 70 = seven waves per SIMD (59.5 -> 55.4 M vector
+    // instructions per view; GSR_BWD_PROJ=0 is the per-channel form, bit-compatible with rounds 1-3).
     float accd = 0.f;
 #pragma unroll
     for (int ch = 0; ch < C; ch++) accd = __builtin_fmaf(acc[ch], dp[ch], accd);
@@ -341,23 +318,6 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     const bool keep = ((kany >> (63 - lane)) & 1ull) != 0ull;
     const unsigned long long m = __ballot(keep);
     const int cnt_all = __popcll(m);
-#if GSR_BWD_SMEM
-    // The pair loop takes an instance's record straight from the rows the forward left (rec_a/b/c) at a UNIFORM address:
-    // scalar loads into scalar registers, which the vector instructions of the pair read as their one uniform operand --
-    // no queue fill for them, no LDS reads in the loop, no vector registers for the slot (60 instead of 70: eight waves per
-    // SIMD).  Kept positions are the set bits of kany, deepest first (the queue's order); the record of the next kept
-    // position is requested while the current one is evaluated (explicit instructions: left to the compiler the loads reuse
-    // the current record's registers and therefore sink behind its last use -- issued, then waited for at once).
-    unsigned long long mrem = kany;
-    const float4* const ua = rec_a + list0 + s0;
-    const float4* const ub = rec_b + list0 + s0;
-    const RecTail<C>* const uc = rec_c + list0 + s0;
-    const auto next_bit = [&]() {   // (uniform) highest remaining kept position; past the end: position 0, a valid address
-        const int b = mrem ? 63 - __builtin_clzll(mrem) : 0;
-        mrem &= ~(1ull << b);
-        return b;
-    };
-#endif
     // The queue holds QCAP of the batch's up to 64 kept instances at a time (LDS per workgroup decides how many units are
     // resident, and a typical batch keeps ~22): a batch that keeps more is worked off in chunks, back-to-front order intact.
     for (int q0 = 0; q0 < cnt_all; q0 += QCAP) {
@@ -372,11 +332,9 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
 #pragma unroll
         for (int ch = 2; ch < C; ch++) col[ch] = rc.c[ch - 2];
         qs[0] = make_float4(ra.x, ra.y, __uint_as_float(gid), ra.z);      // the conic is already in the exp2 domain
-#if !GSR_BWD_SMEM
         qs[1] = make_float4(ra.w, rb.x, rb.y, __uint_as_float((uint32_t)k));
-#endif
 #pragma unroll
-        for (int v = 2; v < (GSR_BWD_SMEM ? 0 : L::VECS); v++) {
+        for (int v = 2; v < L::VECS; v++) {
             const int c0 = 4 * (v - 2);
             qs[v] = make_float4(c0 < C ? col[c0 < C ? c0 : 0] : 0.f, c0 + 1 < C ? col[c0 + 1 < C ? c0 + 1 : 0] : 0.f,
                                 c0 + 2 < C ? col[c0 + 2 < C ? c0 + 2 : 0] : 0.f,
@@ -396,34 +354,9 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     // (second tile: its w rows hold channel 3 + col / 3 in columns 0, 3, ..)
     const bool wb_take2 = C2 > 0 && kap >= 2 && col < 3 * C2 && (col % 3) == 0;
     float* const wb_ptr2 = &qf[wb_row0 * SF + MOM0 + 6 + C1 + (col < 3 * C2 ? col / 3 : 0)];
-    for (int g0i = 0; g0i < cnt GSR_ABL_LOOP_COND; g0i += GRP) {
+    for (int g0i = 0; g0i < cnt; g0i += GRP) {
         // ---- vector ALU: w and r of GRP instances for this lane's pixel, parked row-wise in LDS.  The slot of the
         // group's first instance is requested here, every further one while its predecessor is being evaluated.
-#if GSR_BWD_SMEM
-        URecRegs<C> unxt;
-        int b_nxt = next_bit();
-        urec_request<C>(unxt, ua, ub, uc, (uint32_t)b_nxt);
-        urec_wait<C>(unxt);
-        static_for<GRP>([&](auto JJ) {
-            constexpr int jj = decltype(JJ)::value;
-            const int j = g0i + jj;
-            float r = 0.f, w = 0.f;
-            // (request and wait in straight-line code outside the j < cnt branch, as for the LDS slots below; past the end of
-            // the chunk the requests go on -- to valid addresses, for nobody.  The wait for the next record sits BEHIND this
-            // pair's arithmetic and in front of its two table stores: lgkmcnt(0) is the only wait scalar loads allow, and
-            // placed after the stores it would wait for them too)
-            const URecRegs<C> ucur = unxt;
-            const int b_cur = b_nxt;
-            if constexpr (jj + 1 < GRP) { b_nxt = next_bit(); urec_request<C>(unxt, ua, ub, uc, (uint32_t)b_nxt); }
-            if (j < cnt) {
-                const float4 A = make_float4(__uint_as_float(ucur.a[0]), __uint_as_float(ucur.a[1]), 0.f, __uint_as_float(ucur.a[2]));
-                const float4 B = make_float4(__uint_as_float(ucur.a[3]), __uint_as_float(ucur.b[0]), __uint_as_float(ucur.b[1]), 0.f);
-                float cc[C];
-                cc[0] = __uint_as_float(ucur.b[2]); cc[1] = __uint_as_float(ucur.b[3]);
-#pragma unroll
-                for (int ch = 2; ch < C; ch++) cc[ch] = __uint_as_float(ucur.c[ch - 2]);
-                const int pos = s0 + b_cur;
-#else
         SlotRegs<L::IN_VECS> nxt;
         // (the group's slot address is pinned in a vector register: as a uniform value the compiler keeps it scalar and
         // copies it into a fresh vector register for every pair)
@@ -448,7 +381,6 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
 #pragma unroll
                 for (int ch = 0; ch < C; ch++) cc[ch] = cur.v[2 + ch / 4][ch % 4];
                 const int pos = (int)__float_as_uint(B.w);
-#endif
                 const float dx = A.x - pxf, dy = A.y - pyf;
                 const float power = pair_exp2_arg(A.w, B.x, B.y, dx, dy);
                 const float G = __builtin_amdgcn_exp2f(power);
@@ -457,10 +389,10 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
                 {
                     // (`if (live)` compiles to s_and_saveexec + s_cbranch_execz: a pair without a live pixel skips the
                     // block; an explicit ballot test around it doubled the branching and cost 13 us per view)
-                    if (live GSR_ABL_LIVE_COND) {
-                        // accum_rec' = alpha c + (1 - alpha) accum_rec written as accum_rec + alpha (c - accum_rec):
-                        // the difference is needed for dL_dalpha anyway (one fma per channel instead of mul + fma);
-                        // T_final * bg . dL_dpix is a per-pixel constant.  14 vector instructions per live pair.
+                    if (live) {
+                        // accum_rec' = alpha c + (1 - alpha) accum_rec written as accum_rec + alpha (c - accum_rec), and
+                        // projected on dL_dpix (see accd above); T_final * bg . dL_dpix is a per-pixel constant.
+                        // 11 vector instructions per live pair at three channels (per-channel form: 14).
                         const float rinv = __builtin_amdgcn_rcpf(1.f - alpha);
                         T = T * rinv;
                         w = alpha * T;
@@ -485,9 +417,6 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
             }
             // (explicit instructions: the wait above counts on exactly these two LDS operations behind every request --
             // the compiler must neither fuse them into one ds_write2 nor move them)
-#if GSR_BWD_SMEM
-            if constexpr (jj + 1 < GRP) urec_wait<C>(unxt);
-#endif
             lds_store_b32<jj * RSTRIDE * 4>(rw_addr, r);
             lds_store_b32<(GRP + jj) * RSTRIDE * 4>(rw_addr, w);
         });
@@ -508,7 +437,7 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
                 ra[4 * qd] = v.x; ra[4 * qd + 1] = v.y; ra[4 * qd + 2] = v.z; ra[4 * qd + 3] = v.w;
             }
         }
-        if constexpr (BF16 && !GSR_ABL_CONTRACT) {
+        if constexpr (BF16) {
             uint32_t kMinusOneLo = 0x0000BF80u, kMinusOneHi = 0xBF800000u;   // bf16 pairs {-1, 0}, {0, -1}
             asm volatile("" : "+v"(kMinusOneLo), "+v"(kMinusOneHi));
 #pragma unroll
@@ -571,7 +500,7 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
             }
             const bool spatial = kap < 2;
             acc0[0] = spatial ? v0 : t0_; acc0[1] = spatial ? v1 : t1_; acc0[2] = spatial ? v2 : t2_; acc0[3] = spatial ? v3 : t3_;
-        } else if constexpr (!GSR_ABL_CONTRACT) {
+        } else {
 #pragma unroll
         for (int t = 0; t < 16; t += 2) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[t], Bf[t], acc0, 0, 0, 0);
@@ -620,7 +549,7 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     // flush: lanes walk the (instance, moment) table row-major, so one atomic instruction covers the consecutive
     // floats of several packed records -- the memory pipeline merges lanes that share a cache line into one
     // request instead of one per float.
-    for (int idx = lane; idx < cnt * NM GSR_ABL_FLUSH_COND; idx += 64) {
+    for (int idx = lane; idx < cnt * NM; idx += 64) {
         const int e = idx / NM, v = idx - e * NM;
         {
             const size_t g = __float_as_uint(qf[e * SF + 2]);
@@ -650,12 +579,12 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
                  const uint2* __restrict__ masks, const uint32_t* __restrict__ point_list, const float4* __restrict__ rec_a,
                  const float4* __restrict__ rec_b, const RecTail<C>* __restrict__ rec_c, const float* __restrict__ bg,
                  const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-                 const float* __restrict__ dL_dpix, float* __restrict__ grad_acc, uint64_t* __restrict__ trace, int n_vb)
+                 const float* __restrict__ dL_dpix, float* __restrict__ grad_acc, uint64_t* __restrict__ trace)
 {
-    GSR_BWD_FOR_REPS(blend_bwd_unit<C>(W, H, gx, unit_info, snap, masks, point_list, rec_a, rec_b, rec_c, bg, final_T, n_contrib, dL_dpix, grad_acc, trace, vbid, (uint32_t)n_vb));
+    blend_bwd_unit<C>(W, H, gx, unit_info, snap, masks, point_list, rec_a, rec_b, rec_c, bg, final_T, n_contrib, dL_dpix, grad_acc, trace);
 }
-// Three channels: the register allocator is told to stay within six waves per SIMD (80 registers; left alone it takes 82
-// and the kernel runs five: 0.141 vs 0.131 ms on config C).  Six channels (104 registers) would have to spill 20 and lose.
+// Three channels: the register allocator is told to stay within six waves per SIMD (80 registers; left alone the per-channel
+// form took 82 and the kernel ran five: 0.141 vs 0.131 ms on config C).  Six channels (104 registers) would have to spill 20 and lose.
 #define GSR_BWD_SPECIALISE(CH, WAVES)                                                                                          \
     template <>                                                                                                               \
     __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))                                      \
@@ -664,16 +593,13 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
                          const float4* __restrict__ rec_a, const float4* __restrict__ rec_b,                                  \
                          const RecTail<CH>* __restrict__ rec_c, const float* __restrict__ bg,                                 \
                          const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,                           \
-                         const float* __restrict__ dL_dpix, float* __restrict__ grad_acc, uint64_t* __restrict__ trace, int n_vb) \
+                         const float* __restrict__ dL_dpix, float* __restrict__ grad_acc, uint64_t* __restrict__ trace)       \
     {                                                                                                                         \
-        GSR_BWD_FOR_REPS(blend_bwd_unit<CH>(W, H, gx, unit_info, snap, masks, point_list, rec_a, rec_b, rec_c, bg, final_T,      \
-                                            n_contrib, dL_dpix, grad_acc, trace, vbid, (uint32_t)n_vb));                      \
+        blend_bwd_unit<CH>(W, H, gx, unit_info, snap, masks, point_list, rec_a, rec_b, rec_c, bg, final_T, n_contrib,         \
+                           dL_dpix, grad_acc, trace);                                                                         \
     }
-#ifndef GSR_BWD_LDS_PAD_DEFAULT
-#define GSR_BWD_LDS_PAD_DEFAULT 0
-#endif
 #ifndef GSR_BWD_WAVES3
-#define GSR_BWD_WAVES3 6
+#define GSR_BWD_WAVES3 6   // (the projected form takes 70 registers and runs seven; 8 = 64 registers spills eight and loses 10 us)
 #endif
 GSR_BWD_SPECIALISE(3, GSR_BWD_WAVES3)
 #ifndef GSR_BWD_WAVES4
@@ -705,14 +631,13 @@ void launch_blend_bwd(int C, int W, int H, int U, const float* bg, const float* 
     static const int pk = getenv("GSR_BWD_PK") ? atoi(getenv("GSR_BWD_PK")) : GSR_BWD_PK_DEFAULT;
     if (pk > 0 && launch_blend_bwd_pk(C, W, H, U, bg, im, b, dL_dpix, grad_acc, st)) return;
     // Residency knob: extra dynamic LDS lowers the number of co-resident units per CU (tuning only).
-    static const int pad = getenv("GSR_BWD_LDS_PAD") ? atoi(getenv("GSR_BWD_LDS_PAD")) : GSR_BWD_LDS_PAD_DEFAULT;
+    static const int pad = getenv("GSR_BWD_LDS_PAD") ? atoi(getenv("GSR_BWD_LDS_PAD")) : 0;
     uint64_t* tr = g_trace ? g_trace + 2 * (size_t)t.T : nullptr;
     const auto go = [&](auto tag) {
         constexpr int CC = decltype(tag)::value;
-        const int n_vb = 4 * U, grid = 8 * ((n_vb + 8 * GSR_BWD_REP - 1) / (8 * GSR_BWD_REP));
-        blend_bwd_kernel<CC><<<grid, 64, pad, st>>>(W, H, t.gx, b.unit_info, b.snap, b.masks, b.point_list, b.rec_a, b.rec_b,
-                                                    static_cast<const RecTail<CC>*>(b.rec_c), bg, im.final_T, im.n_contrib,
-                                                    dL_dpix, grad_acc, tr, n_vb);
+        blend_bwd_kernel<CC><<<4 * U, 64, pad, st>>>(W, H, t.gx, b.unit_info, b.snap, b.masks, b.point_list, b.rec_a, b.rec_b,
+                                                     static_cast<const RecTail<CC>*>(b.rec_c), bg, im.final_T, im.n_contrib,
+                                                     dL_dpix, grad_acc, tr);
     };
     if (C == 6) go(std::integral_constant<int, 6>{});
     else if (C == 4) go(std::integral_constant<int, 4>{});

@@ -118,51 +118,9 @@ __device__ __forceinline__ unsigned long long wave_or_u64_lds(uint32_t scratch_a
            (uint32_t)__builtin_amdgcn_readfirstlane((int)all[0]);
 }
 
-// ---- an instance record in SCALAR registers (gsr_blend_bwd.hip, GSR_BWD_SMEM): rec_a = {x, y, a, b}, rec_b = {c, opacity,
-// colour 0, colour 1}, rec_c = colours 2 ..; requested with explicit s_load instructions from uniform row pointers.
-// Scalar loads return out of order, so the only valid wait is lgkmcnt(0) -- which also covers the LDS stores in flight.
-typedef uint32_t u32x2s __attribute__((ext_vector_type(2)));
-template <int C> struct URecRegs { u32x4 a, b; uint32_t c[C - 2]; };
-template <int C, class RA, class RC>
-__device__ __forceinline__ void urec_request(URecRegs<C>& r, const RA* ua, const RA* ub, const RC* uc, uint32_t pos)
-{
-    const uint32_t off = pos * 16u;
-    asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(r.a) : "s"(ua), "s"(off) : "memory");
-    asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(r.b) : "s"(ub), "s"(off) : "memory");
-    if constexpr (C == 3) {
-        const uint32_t off_c = pos * 4u;
-        asm volatile("s_load_dword %0, %1, %2" : "=&s"(r.c[0]) : "s"(uc), "s"(off_c) : "memory");
-    } else if constexpr (C == 4) {
-        const uint32_t off_c = pos * 8u;
-        u32x2s t;
-        asm volatile("s_load_dwordx2 %0, %1, %2" : "=&s"(t) : "s"(uc), "s"(off_c) : "memory");
-        r.c[0] = t[0]; r.c[1] = t[1];
-    } else {
-        static_assert(C == 6, "");
-        u32x4 t;
-        asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(t) : "s"(uc), "s"(off) : "memory");
-        r.c[0] = t[0]; r.c[1] = t[1]; r.c[2] = t[2]; r.c[3] = t[3];
-    }
-}
-template <int C> __device__ __forceinline__ void urec_wait(URecRegs<C>& r)
-{
-    if constexpr (C == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.a), "+s"(r.b), "+s"(r.c[0]) : : "memory");
-    else if constexpr (C == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.a), "+s"(r.b), "+s"(r.c[0]), "+s"(r.c[1]) : : "memory");
-    else asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.a), "+s"(r.b), "+s"(r.c[0]), "+s"(r.c[1]), "+s"(r.c[2]), "+s"(r.c[3]) : : "memory");
-}
-
-#ifndef GSR_ABL_ATOMIC
-#define GSR_ABL_ATOMIC 0
-#endif
 __device__ __forceinline__ void atomic_add_f32(float* p, float v)
 {
-#if GSR_ABL_ATOMIC == 1     // timing ablations only (wrong gradients): plain store / workgroup-scope atomic
-    *p = v;
-#elif GSR_ABL_ATOMIC == 2
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
 }
 
 #ifndef GSR_BWD_GRP

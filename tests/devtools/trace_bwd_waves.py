@@ -71,3 +71,10 @@ for a, b in zip(edges[:-1], edges[1:]):
 print("resident waves per SIMD by twentieth of the span:", [round(float(x), 2) for x in res])
 order = np.argsort(st)
 print("start time of the last wave %.1f us; waves ending in the last 10 us: %d" % (st.max(), int(np.sum(en > span - 10.0))))
+# by launch order: wave index = row of the trace = unit * 4 + block (units are in tile launch order, longest lists first)
+idx = np.nonzero(ok)[0]
+dec = np.array_split(np.arange(len(idx)), 10)
+print("by tenth of the unit order: mean start / head / body (us), share of waves with work")
+for d in dec:
+    b_ = (en - hd)[d]
+    print("   start %6.1f  head %5.2f  body %5.2f  with work %.2f" % (st[d].mean(), (hd - st)[d].mean(), b_[b_ > 0].mean() if (b_ > 0).any() else 0.0, (b_ > 0).mean()))
