@@ -529,7 +529,9 @@ static void launch_fwd_c(int W, int H, int R, int U, uint32_t max_count, const f
             W, H, t.gx, im.ranges, im.order, b.point_list, nullptr, g.g0, g.g1, feats, bg, out_color, im.final_T, im.n_contrib,
             im.seg_off, b.masks, b.snap, b.rec_a, b.rec_b, static_cast<RecTail<C>*>(b.rec_c), b.part_list, im.totals, b.part_fin,
             b.part_last, split_n, keep_masks, nullptr, 0u, nullptr, 0u, nullptr);
-    blend_fwd_kernel<C, FWD_CHUNK, 0><<<t.T, 256, 0, st>>>(
+    // Residency knob: extra dynamic LDS lowers the number of co-resident tiles per CU (tuning only).
+    static const int pad = getenv("GSR_FWD_LDS_PAD") ? atoi(getenv("GSR_FWD_LDS_PAD")) : 0;
+    blend_fwd_kernel<C, FWD_CHUNK, 0><<<t.T, 256, pad, st>>>(
         W, H, t.gx, im.ranges, im.order, b.point_list, sort_small ? b.keys : nullptr, g.g0, g.g1, feats, bg, out_color, im.final_T,
         im.n_contrib, im.seg_off, b.masks, b.snap, b.rec_a, b.rec_b, static_cast<RecTail<C>*>(b.rec_c), b.part_list, im.totals,
         b.part_fin, b.part_last, split_n, keep_masks, static_cast<float4*>(zero_ptr), (uint32_t)(zero_bytes / 16), counters,
