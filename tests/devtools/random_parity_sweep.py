@@ -8,10 +8,12 @@ import parity
 from gaustar_amd import scene
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+START = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # first case (seeds are 1000 + case: `1 1203` re-runs case 1203 alone)
 fails = 0
 flips = 0
 pair_flips = 0
-for case in range(N):
+noise_rot = 0
+for case in range(START, START + N):
     rng = np.random.default_rng(1000 + case)
     W, H = int(rng.integers(1, 260)), int(rng.integers(1, 200))
     P = int(rng.choice([1, 7, 100, 1500, 6000]))
@@ -64,10 +66,23 @@ for case in range(N):
         # two pixels off by up to alpha*T*c and a gradient difference confined to that pair; anything wider is a failure.
         img_ref = st["color"] if mode not in ("rgb6", "rgb4") else np.concatenate([st["color"], st2["color"]])
         off = int((np.abs(hip["color"] - img_ref).max(0) > 1e-4).sum()) if hip is not None and hip["color"].shape == img_ref.shape else 99
-        if 1 <= off <= 2:
+        # A rotation gradient that is ITSELF rounding noise: the quaternion's gradient is what is left of dL/dR after the
+        # normalisation projects the radial part out, and for a splat with nearly equal in-plane scales that is a difference of
+        # terms five orders above it (case 1203: max|ref| 5e-7 beside dL_dscales of order 1e-2; HIP path and oracle agree to
+        # 6e-11 absolute).  check_grad scales its tolerance by the array's own maximum; here the other arrays set the scale.
+        rot_noise = False
+        if "dL_drotations" in str(e) and hip is not None and mode not in ("rgb6", "rgb4"):
+            scale = max(float(np.abs(np.asarray(g[k])).max()) for k in ("dL_dscales", "dL_dmeans3D"))
+            d = np.abs(np.asarray(hip["dL_drotations"], np.float64) - np.asarray(g["dL_drotations"], np.float64).reshape(hip["dL_drotations"].shape)).max()
+            rot_noise = float(np.abs(np.asarray(g["dL_drotations"])).max()) < 1e-3 * scale and d <= 1e-6 * scale
+        if rot_noise:
+            noise_rot += 1
+            print(f"case {case}: W={W} H={H} P={P} mode={mode}: rotation gradient at rounding-noise level, tolerated ({str(e)[:120]})")
+        elif 1 <= off <= 2:
             pair_flips += 1
             print(f"case {case}: W={W} H={H} P={P} mode={mode}: {off} pixel(s) across a blend threshold, tolerated ({str(e)[:90]})")
         else:
             fails += 1
             print(f"case {case}: W={W} H={H} P={P} mode={mode} deg={deg} sm={sm}: FAIL {str(e)[:200]}")
-print(f"random parity sweep: {N - fails}/{N} passed ({flips} single-radius ulp flips, {pair_flips} single-pair threshold flips tolerated)")
+print(f"random parity sweep: {N - fails}/{N} passed ({flips} single-radius ulp flips, {pair_flips} single-pair threshold flips, "
+      f"{noise_rot} noise-level rotation gradients tolerated)")
