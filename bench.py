@@ -594,7 +594,12 @@ def main():
                         valu = {"insts_per_launch": int(vi), "issue_cycles_per_simd": round(vi * 4 / N_SIMD, 1),
                                 "frac": round(min(1.0, f4), 4), "frac_4_cycle_model_uncapped": round(f4, 4),
                                 "frac_floor_2p4_cycles_each": round(f4 * 2.4 / 4, 4), "unit": "wave64 VALU instructions",
-                                "salu_insts_per_launch": pmc[dom].get("salu_insts")}
+                                "salu_insts_per_launch": pmc[dom].get("salu_insts"),
+                                "what": "share of the SIMDs' cycles the kernel's vector instructions take under a 4-cycle model (what "
+                                        "SQ_ACTIVE_INST_VALU charges) and at 2.4 cycles each; round 4 measured a wave64 fma at 2.5 "
+                                        "cycles with eight waves resident and 9.4 alone (tools/micro/dep_issue.hip) and -21 % "
+                                        "instructions buying -5 % time: the kernel is latency-bound at its residency, read the "
+                                        "floor figure, not the 4-cycle one (DESIGN.md 6)"}
             except Exception:
                 traffic, valu = None, None
         path_gbs = total_b / (ms_per_step * 1e-3) / 1e9 if world == 1 else total_b * world / (ms_per_step * 1e-3) / 1e9
