@@ -42,9 +42,6 @@
 // unit costs ~20 % more than a 3-channel one instead of 2x.  Record of the accumulation table:
 // grad_acc[gaussian][GRAD_RS] = {sum r, sum r dx, sum r dy, sum r dx^2, sum r dx dy, sum r dy^2, c_0 .. c_{C-1}}.
 #include "gsr_bwd_util.h"
-#ifndef GSR_BWD_SWP
-#define GSR_BWD_SWP 0
-#endif
 #ifndef GSR_BWD_PROJ
 #define GSR_BWD_PROJ 1
 #endif
@@ -360,75 +357,6 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     for (int g0i = 0; g0i < cnt; g0i += GRP) {
         // ---- vector ALU: w and r of GRP instances for this lane's pixel, parked row-wise in LDS.  The slot of the
         // group's first instance is requested here, every further one while its predecessor is being evaluated.
-#if GSR_BWD_SWP
-        // Software-pipelined form: the TEST of pair jj + 1 (slot -> exponent -> exp -> alpha -> live mask; a chain of a dozen
-        // dependent instructions that touches nothing of the pixel's running state) sits in one straight-line block with the
-        // LIVE part of pair jj (the chain through T and accd), written without a branch so that the block stays whole: the
-        // scheduler interleaves two independent chains where the loop above offers the SIMD one (a wave alone issues a
-        // dependent instruction every 9.4 cycles, two independent ones in little more; tools/micro/dep_issue.hip).
-        struct Tested { float G, alpha; bool live; float cc[C]; };
-        const auto test_slot = [&](const SlotRegs<L::IN_VECS>& sl) {
-            Tested t;
-            const float4 A = make_float4(sl.v[0][0], sl.v[0][1], sl.v[0][2], sl.v[0][3]);
-            const float4 B = make_float4(sl.v[1][0], sl.v[1][1], sl.v[1][2], sl.v[1][3]);
-#pragma unroll
-            for (int ch = 0; ch < C; ch++) t.cc[ch] = sl.v[2 + ch / 4][ch % 4];
-            const int pos = (int)__float_as_uint(B.w);
-            const float dx = A.x - pxf, dy = A.y - pyf;
-            const float power = pair_exp2_arg(A.w, B.x, B.y, dx, dy);
-            t.G = __builtin_amdgcn_exp2f(power);
-            t.alpha = fminf(ALPHA_MAX, B.z * t.G);
-            t.live = pos < my_lim && power <= 0.0f && t.alpha >= ALPHA_MIN;
-            return t;
-        };
-        const auto live_part = [&](const Tested& t, float& r, float& w) {   // branch-free: a dead lane keeps its state, r = w = 0
-            const float a = t.live ? t.alpha : 0.f;
-            const float rinv = __builtin_amdgcn_rcpf(1.f - a);        // dead: 1
-            T = T * rinv;
-            w = a * T;
-            float kd = t.cc[0] * dp[0];
-#pragma unroll
-            for (int ch = 1; ch < C; ch++) kd = __builtin_fmaf(t.cc[ch], dp[ch], kd);
-            const float s = kd - accd;
-            accd = __builtin_fmaf(a, s, accd);
-            const float rr = t.G * __builtin_fmaf(s, T, -(rinv * tf_bg));
-            r = t.live ? rr : 0.f;
-        };
-        static_assert(GSR_BWD_PROJ, "the software-pipelined loop carries the projected accum_rec");
-        SlotRegs<L::IN_VECS> nxt;
-        uint32_t q_grp = q_base + (uint32_t)(g0i * SF * 4);
-        asm volatile("" : "+v"(q_grp));
-        lds_request<L::IN_VECS, 0>(nxt, q_grp);
-        lds_wait<0>(nxt);
-        Tested tcur;
-        {
-            const SlotRegs<L::IN_VECS> first = nxt;
-            lds_request<L::IN_VECS, SF * 4>(nxt, q_grp);
-            tcur = test_slot(first);                             // (g0i < cnt: the group's first pair exists)
-        }
-        static_for<GRP>([&](auto JJ) {
-            constexpr int jj = decltype(JJ)::value;
-            const int j = g0i + jj;
-            float r = 0.f, w = 0.f;
-            Tested tnext = tcur;
-            if constexpr (jj + 1 < GRP) {
-                lds_wait<(jj == 0 ? 0 : 2)>(nxt);
-                const SlotRegs<L::IN_VECS> cur1 = nxt;
-                if constexpr (jj + 2 < GRP) lds_request<L::IN_VECS, (jj + 2) * SF * 4>(nxt, q_grp);
-                if (j + 1 < cnt) {            // (uniform) the common path: one block, two chains
-                    tnext = test_slot(cur1);
-                    live_part(tcur, r, w);
-                } else if (j < cnt) {
-                    live_part(tcur, r, w);
-                }
-            } else {
-                if (j < cnt) live_part(tcur, r, w);
-            }
-            lds_store_b32<jj * RSTRIDE * 4>(rw_addr, r);
-            lds_store_b32<(GRP + jj) * RSTRIDE * 4>(rw_addr, w);
-            tcur = tnext;
-        });
-#else
         SlotRegs<L::IN_VECS> nxt;
         // (the group's slot address is pinned in a vector register: as a uniform value the compiler keeps it scalar and
         // copies it into a fresh vector register for every pair)
@@ -492,7 +420,6 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
             lds_store_b32<jj * RSTRIDE * 4>(rw_addr, r);
             lds_store_b32<(GRP + jj) * RSTRIDE * 4>(rw_addr, w);
         });
-#endif
         __builtin_amdgcn_wave_barrier();
         // ---- matrix pipe: [16 rows = r and w of GRP instances] x [64 pixels] . [64 pixels x 16 columns].
         // A operand: lane l carries table row (l & 15) and the 16 pixels 16*kap .. 16*kap + 15 -> 16 consecutive floats of
