@@ -78,3 +78,44 @@ print("by tenth of the unit order: mean start / head / body (us), share of waves
 for d in dec:
     b_ = (en - hd)[d]
     print("   start %6.1f  head %5.2f  body %5.2f  with work %.2f" % (st[d].mean(), (hd - st)[d].mean(), b_[b_ > 0].mean() if (b_ > 0).any() else 0.0, (b_ > 0).mean()))
+# what a different launch order could buy: greedy list scheduling of the measured wave lives (start -> end) onto as many slots as
+# were busy on average, in the order launched, sorted longest-first (the best any reordering can do) and shortest-first
+import heapq
+life = (en - st)
+def makespan(order, slots):
+    h = [0.0] * slots
+    heapq.heapify(h)
+    end = 0.0
+    for i in order:
+        t = heapq.heappop(h) + life[i]
+        end = max(end, t)
+        heapq.heappush(h, t)
+    return end
+slots = int(round(res[len(res) // 2] * len(ids)))
+launch = np.argsort(st, kind="stable")
+print(f"list scheduling on {slots} slots: launch order {makespan(launch, slots):.1f} us, longest first {makespan(np.argsort(-life), slots):.1f} us, "
+      f"shortest first {makespan(np.argsort(life), slots):.1f} us; sum of lives / slots = {life.sum() / slots:.1f} us")
+# proxies a launch order could be built from before the backward runs: the tile's list length, the unit's depth in its tile, the
+# entries the unit holds
+rng_t = torch.zeros(T, 2, dtype=torch.int32, device=dev)
+pv = lambda x: ctypes.c_void_p(x.data_ptr())
+lib.gsr_debug_export(gs.P, int(Rn), int(U), W, H, pv(geom), pv(binning), pv(img), None, None, None, None, pv(rng_t), None, None, None, None)
+rg = rng_t.cpu().numpy().astype(np.int64)
+tl = rg[:, 1] - rg[:, 0]
+nun = (tl + 63) // 64
+u_tile = np.repeat(np.arange(T), nun); u_k = np.concatenate([np.arange(c) for c in nun]) if nun.sum() else np.zeros(0, int)
+assert len(u_tile) == U, (len(u_tile), U)
+u_n = tl[u_tile]; u_ent = np.minimum(64, u_n - 64 * u_k)
+w_unit = idx // 4
+for name, key in (("tile length, longest first", -u_n[w_unit] * 100 + u_k[w_unit]), ("unit depth in tile, front units first", u_k[w_unit]),
+                  ("entries of the unit, fullest first", -u_ent[w_unit]), ("front units first, then fullest", u_k[w_unit] * 100 - u_ent[w_unit]),
+                  ("fullest first, then front units", -u_ent[w_unit] * 100 + u_k[w_unit])):
+    print(f"   order by {name}: {makespan(np.argsort(key, kind='stable'), slots):.1f} us")
+print("   mean life by unit depth k = 0, 1, 2, 3, 4+:", [round(float(life[u_k[w_unit] == k].mean()), 1) for k in range(4)], round(float(life[u_k[w_unit] >= 4].mean()), 1),
+      " by entries <=16 / <=32 / <=48 / <64 / 64:", [round(float(life[(u_ent[w_unit] > a) & (u_ent[w_unit] <= b)].mean()), 1) for a, b in ((0, 16), (16, 32), (32, 48), (48, 63), (63, 64))])
+o = np.argsort(-u_ent[w_unit], kind="stable")
+tail_ = o[-slots:]
+print("   fullest first: last generation mean life %.1f, max %.1f, p99 %.1f; entries there min/max %d/%d; count of 64-entry waves %d of %d" % (
+    life[tail_].mean(), life[tail_].max(), np.percentile(life[tail_], 99), u_ent[w_unit][tail_].min(), u_ent[w_unit][tail_].max(), int((u_ent[w_unit] == 64).sum()), len(life)))
+cs = np.cumsum(life[o]) / slots
+print("   cumulative work / slots at 25/50/75/100 %% of that order: %.1f %.1f %.1f %.1f" % tuple(cs[[len(cs) // 4, len(cs) // 2, 3 * len(cs) // 4, -1]]))
