@@ -119,3 +119,20 @@ print("   fullest first: last generation mean life %.1f, max %.1f, p99 %.1f; ent
     life[tail_].mean(), life[tail_].max(), np.percentile(life[tail_], 99), u_ent[w_unit][tail_].min(), u_ent[w_unit][tail_].max(), int((u_ent[w_unit] == 64).sum()), len(life)))
 cs = np.cumsum(life[o]) / slots
 print("   cumulative work / slots at 25/50/75/100 %% of that order: %.1f %.1f %.1f %.1f" % tuple(cs[[len(cs) // 4, len(cs) // 2, 3 * len(cs) // 4, -1]]))
+# stragglers: the slowest 2 % of the waves -- where do they lose their time, and do they share anything?
+thr = np.percentile(life, 98)
+sl = life >= thr
+xcc = (hw >> 32) & 0xf
+print("stragglers (life >= %.1f us, %d waves): head %.1f us (all: %.1f), body %.1f (all with work: %.1f); entries mean %.0f (all %.0f); unit depth mean %.1f (all %.1f)" % (
+    thr, int(sl.sum()), (hd - st)[sl].mean(), (hd - st).mean(), (en - hd)[sl].mean(), body[live].mean(), u_ent[w_unit][sl].mean(), u_ent[w_unit].mean(),
+    u_k[w_unit][sl].mean(), u_k[w_unit].mean()))
+print("   per XCD share of stragglers:", [round(float((xcc[sl] == x).mean()), 3) for x in range(8)], " start time mean %.1f (all %.1f)" % (st[sl].mean(), st.mean()))
+tiles_sl = u_tile[w_unit][sl]
+uq, cn = np.unique(tiles_sl, return_counts=True)
+print("   distinct tiles among stragglers: %d; tiles with >= 4 straggling waves: %d; list length of straggler tiles mean %.0f (all tiles with units: %.0f)" % (
+    len(uq), int((cn >= 4).sum()), tl[uq].mean(), tl[tl > 0].mean()))
+blk = idx % 4
+print("   by block:", [int(((blk == b) & sl).sum()) for b in range(4)], " same (unit) with >= 2 straggling blocks:", int((np.unique(w_unit[sl], return_counts=True)[1] >= 2).sum()))
+print("   per XCD: waves", [int((xcc == x).sum()) for x in range(8)])
+print("   per XCD: sum of lives (ms-us)", [round(float(life[xcc == x].sum()) / 1e3, 1) for x in range(8)], " last end (us)", [round(float(en[xcc == x].max()), 1) for x in range(8)],
+      " last start", [round(float(st[xcc == x].max()), 1) for x in range(8)])
