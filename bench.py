@@ -158,7 +158,9 @@ def one_step(step, rank, world, params, means2D, rasters, dpix):
     return color
 
 
-def timed(fn, steps, world, device, prewarm=2):
+def timed(fn, steps, world, device, prewarm=2, on_timed_start=None):
+    """on_timed_start: called after the untimed first steps have drained, right before the K timed ones (the instrumented
+    passes reset the per-kernel brackets there, so that launches_per_step counts the K timed steps only)."""
     import gc
     gc.collect(); gc.disable()   # (a generation-2 pass of Python's collector stops the host for tens of milliseconds; between timed regions, not inside)
     # (untimed: the collector pass above and whatever ran before this region -- another mode, the other config's workload --
@@ -168,6 +170,8 @@ def timed(fn, steps, world, device, prewarm=2):
     if world > 1:
         tdist.barrier()
     torch.cuda.synchronize(device)
+    if on_timed_start is not None:
+        on_timed_start()
     t0 = time.perf_counter()
     try:
         for s in range(steps):
@@ -322,7 +326,7 @@ def other_config(name, device, lib, steps=20, repeats=3):
     msv = (ctypes.c_float * nst)()
     cnt = (ctypes.c_int * nst)()
     lib.gsr_profile_enable(1)
-    timed(step, steps, 1, device)
+    timed(step, steps, 1, device, on_timed_start=lambda: lib.gsr_profile_read(msv, cnt, 1))   # (brackets of the K timed steps only)
     _lib.check(lib.gsr_profile_read(msv, cnt, 1), "gsr_profile_read")
     lib.gsr_profile_enable(0)
     e = torch.Tensor([])
@@ -538,7 +542,8 @@ def main():
     ms = (ctypes.c_float * nst)()
     cnt = (ctypes.c_int * nst)()
     lib.gsr_profile_enable(1)
-    dt_prof = timed(step, args.steps, world, device)   # (under --scale-step / N > 1 the brackets see the same six rasterizer kernels)
+    # (under --scale-step / N > 1 the brackets see the same six rasterizer kernels; the untimed first steps' brackets are dropped)
+    dt_prof = timed(step, args.steps, world, device, on_timed_start=lambda: lib.gsr_profile_read(ms, cnt, 1))
     _lib.check(lib.gsr_profile_read(ms, cnt, 1), "gsr_profile_read")
     lib.gsr_profile_enable(0)
 
@@ -651,6 +656,16 @@ def main():
         # their own in the counter file and are left out of this sum: < 1 % of a step)
         major = [k for k in kern if kern[k]["launches_per_step"] >= 0.5]
         out["roofline"]["kernels_sum_rocprof_ms_per_step"] = round(sum(rp.values()) * 1e-6, 4) if rp and all(k in rp for k in major) else None
+        # the dominant kernel's fraction spelled out, so that it can be recomputed from the line itself: algorithmic bytes
+        # per launch / mean launch duration / peak -- by this run's HIP events (frac) and by rocprofv3's mean duration of the
+        # same kernel of the same csrc (frac_rocprof; the event brackets add a few microseconds per launch)
+        lps_dom = kern[dom]["launches_per_step"]
+        out["roofline"]["alg_bytes_per_launch"] = int(round(per_kernel_b.get(dom, 0) / lps_dom))
+        out["roofline"]["ms_per_launch"] = kern[dom]["ms_per_launch"]
+        rp_ns = (pmc_ok.get(dom) or {}).get("rocprof_avg_ns") if isinstance(pmc_ok.get(dom), dict) else None
+        out["roofline"]["rocprof_avg_ns"] = rp_ns
+        out["roofline"]["frac_rocprof"] = (round(per_kernel_b.get(dom, 0) / lps_dom / (rp_ns * 1e-9) / 1e9 / HBM_PEAK_GBS, 5)
+                                           if rp_ns else None)
         if world == 1 and not args.no_extras:
             try:
                 iss = issue_statistics(lib, rasters[0].raster_settings, params, device)

@@ -608,28 +608,21 @@ GSR_BWD_SPECIALISE(3, GSR_BWD_WAVES3)
 // Four channels (two B tiles): 85 registers left alone = five waves; held at 80 for six it spills ten and loses (0.146 vs 0.134 ms)
 GSR_BWD_SPECIALISE(4, GSR_BWD_WAVES4)
 
-#ifndef GSR_BWD_WALK_DEFAULT
-#define GSR_BWD_WALK_DEFAULT 0
+// Experiment builds only (python -m gaustar_amd.build --variant NAME --with tools/variants/<file>.hip ...): the extra source
+// defines launch_blend_bwd_variant and gets the first go at the launch; the product library has ONE backward blend.
+#ifdef GSR_BWD_VARIANT
+bool launch_blend_bwd_variant(int C, int W, int H, int U, const float* bg, ImageState im, BinState b, const float* dL_dpix, float* grad_acc,
+                              hipStream_t st);
 #endif
-#ifndef GSR_BWD_PK_DEFAULT
-#define GSR_BWD_PK_DEFAULT 0
-#endif
-bool launch_blend_bwd_pk(int C, int W, int H, int U, const float* bg, ImageState im, BinState b, const float* dL_dpix, float* grad_acc,
-                         hipStream_t st);
-bool launch_blend_bwd_walk(int rows, int C, int W, int H, int U, const float* bg, ImageState im, BinState b, const float* dL_dpix,
-                           float* grad_acc, hipStream_t st);
 
 void launch_blend_bwd(int C, int W, int H, int U, const float* bg, const float* feats, GeomState g, ImageState im,
                       BinState b, const float* dL_dpix, float* grad_acc, hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);
     if (U <= 0) return;
-    // GSR_BWD_WALK=<rows>: the per-lane-walk variant (gsr_blend_bwd_walk.hip), three and four channels
-    static const int walk_rows = getenv("GSR_BWD_WALK") ? atoi(getenv("GSR_BWD_WALK")) : GSR_BWD_WALK_DEFAULT;
-    if (walk_rows > 0 && launch_blend_bwd_walk(walk_rows, C, W, H, U, bg, im, b, dL_dpix, grad_acc, st)) return;
-    // GSR_BWD_PK=1: two kept instances per trip on packed f32 instructions (gsr_blend_bwd_pk.hip), three channels
-    static const int pk = getenv("GSR_BWD_PK") ? atoi(getenv("GSR_BWD_PK")) : GSR_BWD_PK_DEFAULT;
-    if (pk > 0 && launch_blend_bwd_pk(C, W, H, U, bg, im, b, dL_dpix, grad_acc, st)) return;
+#ifdef GSR_BWD_VARIANT
+    if (launch_blend_bwd_variant(C, W, H, U, bg, im, b, dL_dpix, grad_acc, st)) return;
+#endif
     // Residency knob: extra dynamic LDS lowers the number of co-resident units per CU (tuning only).
     static const int pad = getenv("GSR_BWD_LDS_PAD") ? atoi(getenv("GSR_BWD_LDS_PAD")) : 0;
     uint64_t* tr = g_trace ? g_trace + 2 * (size_t)t.T : nullptr;

@@ -1,5 +1,5 @@
-// gsr_bwd_util.h -- helpers shared by the backward blend kernels (gsr_blend_bwd.hip: uniform pair loop;
-// gsr_blend_bwd_walk.hip: per-lane walk): bf16 splits, LDS queue-slot layout, explicit LDS requests, wave-wide OR.
+// gsr_bwd_util.h -- helpers shared by the backward blend kernel (gsr_blend_bwd.hip: uniform pair loop) and the experiment
+// variants under tools/variants/: bf16 splits, LDS queue-slot layout, explicit LDS requests, wave-wide OR.
 #pragma once
 #include "gsr_internal.h"
 #include <cstdlib>

@@ -40,6 +40,14 @@ def test_bench_line_at_one_gpu():
     assert set(rf["kernels"]) >= {"preprocess_kernel", "tile_scan_kernel", "scatter_kernel", "blend_fwd_kernel", "blend_bwd_kernel",
                                   "geom_bwd_kernel"}
     assert rf["kernel"] in ("blend_bwd_kernel", "blend_fwd_kernel") and "host" in d
+    # the fraction follows from the line's own numbers: algorithmic bytes of ONE launch / its mean duration / peak, and the
+    # brackets count the K timed steps only (round 4 divided by 22 / 20 launches per step: timed()'s untimed first steps)
+    for k in ("preprocess_kernel", "scatter_kernel", "blend_fwd_kernel", "blend_bwd_kernel", "geom_bwd_kernel"):
+        assert rf["kernels"][k]["launches_per_step"] == 1.0, (k, rf["kernels"][k])
+    recomputed = rf["alg_bytes_per_launch"] / (rf["ms_per_launch"] * 1e-3) / 8e12
+    assert abs(recomputed - rf["frac"]) <= 2e-3 * rf["frac"], (recomputed, rf["frac"])
+    assert abs(rf["kernels_sum_ms_per_step"] - sum(v["ms_per_launch"] for v in rf["kernels"].values())) < 2e-3
+    assert "frac_rocprof" in rf and (rf["frac_rocprof"] is None or 0.0 < rf["frac_rocprof"] < 1.0)
 
 
 def test_bench_other_configs_leg():
@@ -51,6 +59,7 @@ def test_bench_other_configs_leg():
     o = bench.other_config("B", dev, _lib.load(), steps=4, repeats=2)
     assert o["gaussians"] == 200400 and o["beta_P"] == 464 and o["sh_coeffs_in_kernel"] == 0 and o["num_rendered"] > 100_000
     assert 0.0 < o["path_frac"] < 1.0 and o["dominant_kernel"] in o["kernels"] and o["best_frac"] >= o["dominant_frac"]
+    assert all(v["launches_per_step"] == 1.0 for k_, v in o["kernels"].items() if k_ in ("blend_fwd_kernel", "blend_bwd_kernel"))
     total, per = bench.algorithmic_bytes(200400, o["num_rendered"], 1920, 1080, 0)
     assert o["alg_bytes_per_view"] == int(total)
     t16, _ = bench.algorithmic_bytes(1000, 2000, 64, 64, 16)

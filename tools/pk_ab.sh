@@ -1,7 +1,8 @@
 #!/usr/bin/env bash
 # tools/pk_ab.sh -- the packed-math backward (gsr_blend_bwd_pk.hip, two kept instances per trip on v_pk_*_f32) against the
 # product's scalar pair loop: parity under GSR_BWD_PK=1, instruction counts and an in-process interleaved timing A/B.
-#   python -m gaustar_amd.build --variant pk -DGSR_BWD_PK_DEFAULT=1
+#   python -m gaustar_amd.build --variant pk --with tools/variants/gsr_blend_bwd_pk.hip      (round 5: the kernel lives in tools/variants/)
+#   export GSR_LIB_PATH=$PWD/gaustar_amd/libgsr_hip_pk.so
 #   gpurun -- 'bash tools/pk_ab.sh > gpurun_out/pk_ab.log 2>&1'
 cd "$(dirname "$0")/.."
 echo "== parity, GSR_BWD_PK=1 (parity + multitarget + harness)"

@@ -433,4 +433,12 @@ bool launch_blend_bwd_pk(int C, int W, int H, int U, const float* bg, ImageState
     return true;
 }
 
+// the hook gsr_blend_bwd.hip calls in a -DGSR_BWD_VARIANT build (GSR_BWD_PK=0: the product's pair loop)
+bool launch_blend_bwd_variant(int C, int W, int H, int U, const float* bg, ImageState im, BinState b, const float* dL_dpix, float* grad_acc,
+                              hipStream_t st)
+{
+    static const int pk = getenv("GSR_BWD_PK") ? atoi(getenv("GSR_BWD_PK")) : 1;
+    return pk > 0 && launch_blend_bwd_pk(C, W, H, U, bg, im, b, dL_dpix, grad_acc, st);
+}
+
 }  // namespace gsr

@@ -470,4 +470,12 @@ bool launch_blend_bwd_walk(int rows, int C, int W, int H, int U, const float* bg
     return true;
 }
 
+// the hook gsr_blend_bwd.hip calls in a -DGSR_BWD_VARIANT build; rows from GSR_BWD_WALK (8 / 16 / 32), 0 = the product's pair loop
+bool launch_blend_bwd_variant(int C, int W, int H, int U, const float* bg, ImageState im, BinState b, const float* dL_dpix, float* grad_acc,
+                              hipStream_t st)
+{
+    static const int rows = getenv("GSR_BWD_WALK") ? atoi(getenv("GSR_BWD_WALK")) : 16;
+    return rows > 0 && launch_blend_bwd_walk(rows, C, W, H, U, bg, im, b, dL_dpix, grad_acc, st);
+}
+
 }  // namespace gsr
