@@ -479,17 +479,29 @@ class ShardedAdam:
     def add_param_group(self, param_group: dict) -> None:
         """torch.optim.Optimizer.add_param_group (the reference wrapper forwards to it, sugar_optimizer.py:117-118): the new
         parameters get flat buckets of their own behind the existing ones -- call it on every rank, between steps."""
-        if any(b["rs"] is not None for b in self.buckets):
-            raise RuntimeError("ShardedAdam.add_param_group: a reduction is in flight; call it between step() and the next backward")
+        if any(b["rs"] is not None for b in self.buckets) or any(b["ready"] > 0 for b in self.buckets) or self._fired:
+            raise RuntimeError("ShardedAdam.add_param_group: a reduction is in flight or gradients of this step have already "
+                               "arrived; call it between step() and the next backward")
+        self.wait_params()                      # (lazy gathers of the last step: the layout below must not move under them)
         g = dict(param_group)
         ps = g["params"]
         g["params"] = [ps] if isinstance(ps, torch.Tensor) else list(ps)
         g.setdefault("lr", self._defaults["lr"])
         g.setdefault("betas", self._defaults["betas"])
         g.setdefault("eps", self._defaults["eps"])
+        # validate BEFORE touching any state: a refused group must leave the optimiser as it was
+        seen = set()
+        dev0 = self._order[0].device if self._order else None
         for p in g["params"]:
-            if id(p) in self._group_of:
+            if not isinstance(p, torch.Tensor):
+                raise TypeError("ShardedAdam.add_param_group: parameters must be tensors")
+            if id(p) in self._group_of or id(p) in seen:
                 raise ValueError("some parameters appear in more than one parameter group")
+            if p.dtype != torch.float32:
+                raise ValueError("ShardedAdam: float32 parameters only")
+            if dev0 is not None and p.device != dev0:
+                raise ValueError("ShardedAdam.add_param_group: parameters must live on the optimiser's device")
+            seen.add(id(p))
         self.param_groups.append(g)
         for p in g["params"]:
             self._group_of[id(p)] = g

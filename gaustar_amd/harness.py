@@ -46,7 +46,10 @@ class NerfCamera:
     znear: float = 1e-4
     zfar: float = 100.0
     principal_ndc: Sequence[float] = (0.0, 0.0)   # p3d K[0,0,2], K[0,1,2]; 0 when cx = W/2, cy = H/2 (cameras.py:276-277)
-    _cache: Dict = field(default_factory=dict, repr=False)
+    # camera centre handed to the rasterizer instead of c2w[:3, 3] (with_extrinsic: the reference's -T R^-1 differs from it
+    # for a non-rigid extrinsic); a declared field, so dataclasses.replace / copy / pickle keep it
+    center_override: Optional[np.ndarray] = None
+    _cache: Dict = field(default_factory=dict, repr=False, compare=False)
 
     def rasterizer_camera(self) -> scene.Camera:
         """sugar_model.py:1129-1163: flip to COLMAP axes, invert, R stored transposed, world_view = getWorld2View(R, T)^T,
@@ -63,8 +66,8 @@ class NerfCamera:
         proj_t[2, 1] = -float(self.principal_ndc[1])
         full_t = (view_t @ proj_t).astype(np.float32)
         campos = np.asarray(self.c2w, dtype=np.float64)[:3, 3]    # p3d get_camera_center() = camera position
-        if getattr(self, "_center_override", None) is not None:   # (with_extrinsic: the reference's own formula)
-            campos = np.asarray(self._center_override, dtype=np.float64)
+        if self.center_override is not None:                  # (with_extrinsic: the reference's own formula)
+            campos = np.asarray(self.center_override, dtype=np.float64)
         return scene.Camera(W=int(self.width), H=int(self.height), tanfovx=math.tan(fovx * 0.5), tanfovy=math.tan(fovy * 0.5),
                             viewmatrix=np.ascontiguousarray(view_t, dtype=np.float32), projmatrix=np.ascontiguousarray(full_t),
                             campos=campos.astype(np.float32))
@@ -76,6 +79,10 @@ class NerfCamera:
         getWorld2View(R, T) = [R^T | T] to the rasterizer; its camera centre is pytorch3d's -T R^-1 of the stored pair, i.e.
         -extr[:3,:3]^T ... for a rotation, the camera position.  Intrinsics, image size and clip planes are kept."""
         E = np.asarray(extr.detach().cpu().numpy() if isinstance(extr, torch.Tensor) else extr, dtype=np.float64).reshape(4, 4)
+        key = ("extr", E.tobytes())                          # (the derived camera and its device tensors are built once per pose)
+        hit = self._cache.get(key)
+        if hit is not None:
+            return hit
         R = np.linalg.inv(E[:3, :3])                          # :1121 (p3d_camera.R, the two sign flips of :1122 / :1143 cancel)
         T = E[:3, 3].copy()                                   # :1123
         w2c = np.eye(4)
@@ -83,11 +90,15 @@ class NerfCamera:
         w2c[:3, 3] = T
         c2w = np.linalg.inv(w2c)
         c2w[:3, 1:3] *= -1                                    # back to the NeRF axes rasterizer_camera() starts from
-        cam = NerfCamera(c2w=c2w[:3, :], fx=self.fx, fy=self.fy, width=self.width, height=self.height, znear=self.znear,
-                         zfar=self.zfar, principal_ndc=self.principal_ndc)
         # pytorch3d's get_camera_center() of the stored (R, T) pair: C = -T_p3d R_p3d^-1 with R_p3d = R D, T_p3d = T D
         # (D = diag(-1, -1, 1)) = -T R^-1 -- equal to c2w[:3, 3] for a rigid `extr`, and what the reference uses otherwise
-        cam._center_override = (-(T @ np.linalg.inv(R))).astype(np.float32)
+        cam = NerfCamera(c2w=c2w[:3, :], fx=self.fx, fy=self.fy, width=self.width, height=self.height, znear=self.znear,
+                         zfar=self.zfar, principal_ndc=self.principal_ndc,
+                         center_override=(-(T @ np.linalg.inv(R))).astype(np.float32))
+        if len(self._cache) > 64:                             # (a pose optimised per iteration must not grow the cache for ever)
+            for k_ in [k_ for k_ in self._cache if isinstance(k_, tuple) and k_[0] == "extr"]:
+                del self._cache[k_]
+        self._cache[key] = cam
         return cam
 
     def on_device(self, device):
@@ -277,6 +288,18 @@ class SurfaceGaussians(nn.Module):
             ps += [self._delta_t, self._delta_r]
         return ps
 
+    def _fence(self, *params) -> None:
+        """Readers of parameters outside the fused render: if the optimiser left their all-gather in flight
+        (dist.ShardedAdam(gather_first=...)), order this stream behind it.  No sink, nothing pending: one attribute look-up."""
+        fence = getattr(self.grad_sink, "wait_params", None)
+        if fence is not None:
+            fence(params if params else None)
+
+    def state_dict(self, *a, **kw):
+        """nn.Module.state_dict behind a fence on every lazily gathered parameter (a checkpoint must not read torn shards)."""
+        self._fence()
+        return super().state_dict(*a, **kw)
+
     # -------------------------------------------------------------------------------- the reference's properties
     @property
     def device(self):
@@ -301,6 +324,7 @@ class SurfaceGaussians(nn.Module):
         """(points, scaling, quaternions) from one fused call, shared by the three properties while no parameter
         changes (the reference recomputes each property from scratch on every access)."""
         params = [self._points, self._scales, self._quaternions] + ([self._delta_t, self._delta_r] if self._loose_bind else [])
+        self._fence(*params)
         key = (tuple(p._version for p in params), torch.is_grad_enabled())
         if self._geom_cache is None or self._geom_cache[0] != key:
             out = producers.mesh_bound_gaussians(
@@ -324,12 +348,14 @@ class SurfaceGaussians(nn.Module):
 
     @property
     def strengths(self):              # :442-447
+        self._fence(self.all_densities)
         if self.return_one_densities:
             return torch.ones_like(self.all_densities.view(-1, 1))
         return torch.sigmoid(self.all_densities.view(-1, 1))
 
     @property
     def sh_coordinates(self):         # :449-450
+        self._fence(self._sh_coordinates_dc, self._sh_coordinates_rest)
         return torch.cat([self._sh_coordinates_dc, self._sh_coordinates_rest], dim=1)
 
     def get_points_rgb(self, positions=None, camera_centers=None, directions=None, sh_levels=None, sh_coordinates=None):

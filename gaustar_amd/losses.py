@@ -219,10 +219,13 @@ class _RGBDepthLoss(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             ctx.save_for_backward(x, g_full, gd, ws, out)
         ctx.cfg = (float(dssim_factor), margin, float(max_depth), float(depth_factor), float(mask_factor), img6.dtype)
-        parts = out[:7]
+        # (copies: the returned loss and parts must not alias `out`, which backward reads -- an in-place `loss += reg` or
+        # `parts.mul_()` by the caller is then allowed, as it was before the fused reduction; one 32-byte copy kernel)
+        res = out.clone()
+        parts = res[:7]
         ctx.mark_non_differentiable(parts)
         ctx.set_materialize_grads(False)   # no zero-filled "gradient" of the parts vector per backward (one fill kernel)
-        return out[7], parts
+        return res[7], parts
 
     @staticmethod
     def backward(ctx, g_loss, _g_parts):

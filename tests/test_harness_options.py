@@ -75,3 +75,33 @@ def test_covariance_3d_is_R_S2_Rt():
     S = R_ref @ (s[:, :, None] ** 2 * np.eye(3)) @ R_ref.transpose(0, 2, 1)
     want = np.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], -1)
     assert np.abs(c - want).max() < 1e-12
+
+
+def test_readers_outside_the_fused_render_fence_lazily_gathered_parameters():
+    """with dist.ShardedAdam(gather_first=...) step() leaves the SH / density gathers in flight; `strengths`,
+    `sh_coordinates`, `get_points_rgb` and `state_dict()` must fence the parameters they read (wait_params), as the fused
+    render does for its producers."""
+    from gaustar_amd import harness, scene
+    v, f = scene.icosphere(1, 1.0)
+    m = harness.SurfaceGaussians(torch.from_numpy(v).float(), torch.from_numpy(f).long(), 1, sh_levels=2)
+
+    class Sink:
+        def __init__(self):
+            self.calls = []
+
+        def wait_params(self, params=None):
+            self.calls.append(None if params is None else {id(p) for p in params})
+
+    m.grad_sink = s = Sink()
+    _ = m.strengths
+    assert s.calls[-1] == {id(m.all_densities)}
+    _ = m.sh_coordinates
+    assert s.calls[-1] == {id(m._sh_coordinates_dc), id(m._sh_coordinates_rest)}
+    n = len(s.calls)
+    d = torch.nn.functional.normalize(torch.randn(m.n_points, 3), dim=-1)
+    m.get_points_rgb(directions=d, sh_levels=2)
+    assert len(s.calls) > n and s.calls[-1] == {id(m._sh_coordinates_dc), id(m._sh_coordinates_rest)}
+    m.state_dict()
+    assert s.calls[-1] is None                                   # everything
+    m.grad_sink = None
+    _ = m.strengths                                              # no sink: nothing to call
