@@ -399,6 +399,19 @@ def ref_gpu_baseline(gs, cams, bg, device, views=4):
                     "same workload, one GPU, outside the timed region; includes the wrapper's per-call allocations and syncs"}
 
 
+def parity_leg(gs, cams, bg, device, every=10):
+    """Threshold-flip counts against the reference build (oracle/rig_parity.py, the checker of tests/test_gpu_rig_parity.py) on
+    every `every`-th view of the rig: how many elements per view sit outside the 1e-4 tolerance, and how far."""
+    from oracle import ref, rig_parity
+    if not ref.available():
+        return None
+    s_ = rig_parity.summarise(rig_parity.compare_views(gs, cams, bg, range(0, len(cams), every), device=str(device)))
+    s_["what"] = ("elements per view (image + six gradient tensors) outside tests/parity.py's tolerances against the reference's "
+                  "kernels built for gfx950: pairs on the other side of alpha >= 1/255 or T < 1e-4 (exp2-domain alpha); outside the "
+                  "timed region")
+    return s_
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -737,7 +750,8 @@ def main():
                 rw[2].close(); del rw
             except Exception as ex:
                 out["refinement_step_single_gpu"] = {"error": repr(ex)[:200]}
-            for key, fn in (("ref_gpu_baseline", lambda: ref_gpu_baseline(gs, cams, bg, device)), ("window", window_benchmark)):
+            for key, fn in (("ref_gpu_baseline", lambda: ref_gpu_baseline(gs, cams, bg, device)), ("window", window_benchmark),
+                            ("parity", lambda: parity_leg(gs, cams, bg, device))):
                 try:
                     out[key] = fn()
                 except Exception as ex:
