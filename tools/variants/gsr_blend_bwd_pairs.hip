@@ -30,26 +30,37 @@ namespace gsr {
 #ifndef GSR_PAIRS_Q
 #define GSR_PAIRS_Q 16
 #endif
+#ifndef GSR_PAIRS_RMAX
+#define GSR_PAIRS_RMAX 3
+#endif
 #ifndef GSR_PAIRS_WAVES
-#define GSR_PAIRS_WAVES 2
+#define GSR_PAIRS_WAVES 4   // (120 registers at three rows per group; held at 96 = five waves it spills and loses 100 us)
 #endif
 
 namespace pairs {
 constexpr int Q = GSR_PAIRS_Q;            // kept instances per chunk (a pixel has at most Q pairs per chunk: rank fits four bits)
 static_assert(Q == 8 || Q == 16, "chunk: whole MFMA groups, rank within a pixel in four bits");
 constexpr int ROWB = 144;                 // bytes per table row: 64 pixels of bf16 + 16 (sixteen rows 144 B apart cover all banks)
-constexpr int W_ROWS = Q * ROWB + 128;    // w rows behind the r rows of a plane, shifted by 32 banks
-constexpr int PLANE = W_ROWS + Q * ROWB;  // one bf16 plane: r rows [0, Q), w rows [Q, 2 Q)
-constexpr int TBL = 0, TBL_BYTES = 3 * PLANE;        // hi, mid, lo
-constexpr int REC = TBL + TBL_BYTES;      // Q + 1 records of 48 B: {x, y, a', b'}, {c', opacity, c0, c1}, {c2, row offset, -, gaussian}
+constexpr int W_ROWS = Q * ROWB + 128;    // w rows behind the r rows of the plane, shifted by 32 banks
+constexpr int PLANE = W_ROWS + Q * ROWB;  // the bf16 plane: r rows [0, Q), w rows [Q, 2 Q); filled three times (hi, mid, lo passes)
+constexpr int TBL = 0, TBL_BYTES = PLANE;
+// While a row group is being EVALUATED the plane's bytes hold what only that phase reads: the chunk's pair list and the
+// per-pixel constants.  The group's last gather has been issued before the plane is zeroed (LDS operations of a wave execute
+// in order); a chunk with more rows than one group re-writes both for the next group.
+constexpr int LIST = TBL;                 // pair list: u16 entries {instance lane : 6, pixel : 6, rank : 4}
+constexpr int LIST_BYTES = (Q * 64 + 64 + 8) * 2;   // every pixel x every instance, + a row of slack for the look-ahead read
+constexpr int SPIX = (LIST + LIST_BYTES + 15) & ~15;   // 64 x 32 B: {T_final bg.dL_dpix, x, y, -}, {dL_dpix 0..2, -}
+static_assert(SPIX + 64 * 32 <= TBL + TBL_BYTES || Q == 8, "list + pixel constants must fit the plane");
+constexpr int PHASE1_END = SPIX + 64 * 32;
+constexpr int REC = (TBL + (TBL_BYTES > PHASE1_END ? TBL_BYTES : PHASE1_END) + 15) & ~15;
+                                          // Q + 1 records of 48 B: {x, y, a', b'}, {c', opacity, c0, c1}, {c2, row offset, -, gaussian}
 constexpr int REC_BYTES = (Q + 1) * 48;   //   (the last one: a null record for lanes outside the chunk)
 constexpr int SLOT = REC + REC_BYTES;     // 64 bytes: instance lane -> record slot of the chunk (Q: none)
-constexpr int PIX = (SLOT + 64 + 15) & ~15;   // 64 pixel states of 32 B: {T, A, T_final bg.dL_dpix, x}, {dL_dpix 0..2, y}
-constexpr int LIST = PIX + 64 * 32;       // pair list: u16 entries {instance lane : 6, pixel : 6, rank : 4}
-constexpr int LIST_BYTES = (Q * 64 + 64 + 8) * 2;   // every pixel x every instance, + a row of slack for the look-ahead read
-constexpr int TOTAL = LIST + LIST_BYTES;
-static_assert(PIX % 16 == 0 && REC % 16 == 0 && PLANE % 16 == 0, "16-byte accesses");
+constexpr int DPIX = (SLOT + 64 + 15) & ~15;   // 64 x 8 B: a pixel's running {T, A} (updated from chunk to chunk)
+constexpr int TOTAL = DPIX + 64 * 8;
+static_assert(DPIX % 16 == 0 && REC % 16 == 0 && SPIX % 16 == 0, "16-byte accesses");
 constexpr int SF = 12, MOM0 = 2, NM = 9;  // record floats, first moment float, moments per instance
+constexpr int RMAX = GSR_PAIRS_RMAX;      // rows of a group: evaluated together, as independent instruction streams
 }   // namespace pairs
 
 // x = hi + r1's upper half + r2 exactly (three bf16 values); contraction off: `x` is a product at the call site, and fused into
@@ -61,6 +72,29 @@ __device__ __forceinline__ void bf16_rests(float x, float& r1, float& r2)
     r2 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
 }
 
+__device__ __forceinline__ float bf16_rest_nc(float x)   // x minus its upper 16 bits, never fused into the producer of x
+{
+#pragma clang fp contract(off)
+    return x - __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+}
+// colour rows of the D tile: the three split columns of a channel sit in neighbouring lanes (hi, mid, lo); t = hi + (mid + lo)
+// lands in the first of them (two fused DPP adds per register; as gsr_blend_bwd.hip)
+__device__ __forceinline__ void split_sum4(float v0, float v1, float v2, float v3, float& t0_, float& t1_, float& t2_, float& t3_)
+{
+    float s0_, s1_, s2_, s3_;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %8, %8 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %9, %9 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %10, %10 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %11, %11 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %4, %0, %8 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %5, %1, %9 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %6, %2, %10 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %7, %3, %11 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(s0_), "=&v"(s1_), "=&v"(s2_), "=&v"(s3_), "=&v"(t0_), "=&v"(t1_), "=&v"(t2_), "=&v"(t3_)
+        : "v"(v0), "v"(v1), "v"(v2), "v"(v3));
+}
+
 // One step of the segmented scan of affine maps in a single block (fixed order: the wait states DPP reads need behind the
 // instruction that wrote their source are there by construction, see the comment at the call site).
 #define GSR_PAIRS_STEP(CTRL, COND)                                                       \
@@ -68,6 +102,17 @@ __device__ __forceinline__ void bf16_rests(float x, float& r1, float& r2)
     "v_fmac_f32_dpp %[b], %[b], %[m] " CTRL " bank_mask:0xf\n\t"                        \
     "v_mul_f32_dpp %[t], %[a], %[a] " CTRL " bank_mask:0xf\n\t"                         \
     "v_cndmask_b32_e64 %[a], %[a], %[t], " COND "\n\t"
+// the same step for two / three rows at once, row by row inside every stage (operands a0.. b0.. m0.. t0..)
+#define GSR_PAIRS_M(J, COND) "v_cndmask_b32_e64 %[m" #J "], 0, %[a" #J "], " COND "\n\t"
+#define GSR_PAIRS_F(J, CTRL) "v_fmac_f32_dpp %[b" #J "], %[b" #J "], %[m" #J "] " CTRL " bank_mask:0xf\n\t"
+#define GSR_PAIRS_X(J, CTRL) "v_mul_f32_dpp %[t" #J "], %[a" #J "], %[a" #J "] " CTRL " bank_mask:0xf\n\t"
+#define GSR_PAIRS_A(J, COND) "v_cndmask_b32_e64 %[a" #J "], %[a" #J "], %[t" #J "], " COND "\n\t"
+#define GSR_PAIRS_STEP2(CTRL, C0, C1)                                                                                    \
+    GSR_PAIRS_M(0, C0) GSR_PAIRS_M(1, C1) GSR_PAIRS_F(0, CTRL) GSR_PAIRS_F(1, CTRL) GSR_PAIRS_X(0, CTRL) GSR_PAIRS_X(1, CTRL) \
+    GSR_PAIRS_A(0, C0) GSR_PAIRS_A(1, C1)
+#define GSR_PAIRS_STEP3(CTRL, C0, C1, C2)                                                                                \
+    GSR_PAIRS_M(0, C0) GSR_PAIRS_M(1, C1) GSR_PAIRS_M(2, C2) GSR_PAIRS_F(0, CTRL) GSR_PAIRS_F(1, CTRL) GSR_PAIRS_F(2, CTRL) \
+    GSR_PAIRS_X(0, CTRL) GSR_PAIRS_X(1, CTRL) GSR_PAIRS_X(2, CTRL) GSR_PAIRS_A(0, C0) GSR_PAIRS_A(1, C1) GSR_PAIRS_A(2, C2)
 
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_PAIRS_WAVES, 8)))
 blend_bwd_pairs_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, const float4* __restrict__ snap,
@@ -234,11 +279,9 @@ blend_bwd_pairs_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info
     }
     __builtin_amdgcn_wave_barrier();
 
-    // ---- per-pixel state into LDS (pair lanes gather it by pixel); the null record
+    // ---- a pixel's running {T, A} into LDS (pair lanes gather it by pixel); the null record
     {
-        float4* ps = reinterpret_cast<float4*>(lds + PIX) + 2 * lane;
-        ps[0] = make_float4(T, accd, tf_bg, pxf);
-        ps[1] = make_float4(dp[0], dp[1], dp[2], pyf);
+        reinterpret_cast<float2*>(lds + DPIX)[lane] = make_float2(T, accd);
         if (lane < 3) reinterpret_cast<float4*>(lds + REC + Q * 48)[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // candidate word in "instance lane" order: bit l <-> list position s0 + 63 - l
@@ -256,7 +299,7 @@ blend_bwd_pairs_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info
         const bool more_chunks = q0 + Q < cnt_all;
         const bool inchunk = keep && slot_g >= q0 && slot_g < q0 + Q;
         const unsigned long long mc = __ballot(inchunk);
-        // ---- records of the chunk's instances by slot, lane -> slot map, table zeroed
+        // ---- records of the chunk's instances by slot, lane -> slot map
         {
             const int slot = slot_g - q0;
             lds[SLOT + lane] = (unsigned char)(inchunk ? slot : Q);
@@ -266,11 +309,10 @@ blend_bwd_pairs_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info
                 rs[1] = rb;
                 rs[2] = make_float4(rc.c[0], __uint_as_float((uint32_t)(slot * ROWB)), 0.f, __uint_as_float(gid));
             }
-            float4* t4 = reinterpret_cast<float4*>(lds + TBL);
-            for (int i = lane; i < TBL_BYTES / 16; i += 64) t4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         // ---- pair list of the chunk, pixel-major, deepest first within a pixel
-        uint32_t wl = wrev_lo & (uint32_t)mc, wh = wrev_hi & (uint32_t)(mc >> 32);
+        const uint32_t wl0 = wrev_lo & (uint32_t)mc, wh0 = wrev_hi & (uint32_t)(mc >> 32);
+        uint32_t wl = wl0, wh = wh0;
         const uint32_t c_p = (uint32_t)__builtin_popcount(wl) + (uint32_t)__builtin_popcount(wh);
         uint32_t incl = c_p;
         incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, false);
@@ -280,9 +322,14 @@ blend_bwd_pairs_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info
         incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xa, 0xf, false);
         incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xc, 0xf, false);
         const int N = __builtin_amdgcn_readlane((int)incl, 63);
-        {
+        // (a lambda: a chunk with more rows than one group writes list and pixel constants again after every group's passes)
+        const auto write_phase1 = [&]() {
+            float4* sp = reinterpret_cast<float4*>(lds + SPIX) + 2 * lane;
+            sp[0] = make_float4(tf_bg, pxf, pyf, 0.f);
+            sp[1] = make_float4(dp[0], dp[1], dp[2], 0.f);
             unsigned char* la = lds + LIST + 2u * (incl - c_p);
             uint32_t eb = (uint32_t)lane << 6;           // {pixel, rank 0}
+            wl = wl0; wh = wh0;
             while (wl) {
                 const uint32_t l = (uint32_t)__builtin_ctz(wl);
                 wl &= wl - 1u;
@@ -296,139 +343,188 @@ blend_bwd_pairs_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info
                 la += 2; eb += 0x1000u;
             }
             if (lane == 0) *reinterpret_cast<unsigned short*>(lds + LIST + 2 * N) = 0;   // sentinel: "a new pixel starts here"
-        }
-        __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_wave_barrier();
+        };
+        write_phase1();
 
-        // ---- rows of 64 pairs
-        float a_c = 1.f, b_c = 0.f;                       // inclusive (a, b) of the previous row's last lane (uniform)
+        // ---- version 2: the rows of the chunk in GROUPS of up to RMAX, all rows of a group as independent instruction streams
+        // (gathers of every row requested before the first is used, the scans of the rows interleaved step by step); a group
+        // keeps its (r, w) in registers and fills the ONE bf16 plane three times -- hi, mid, lo parts -- with the contraction's
+        // matrix instructions behind every pass accumulating into the same registers.
         const int n_rows = (N + 63) >> 6;
-        for (int r = 0; r < n_rows; r++) {
-            const int i = 64 * r + lane;
-            const uint32_t e = *reinterpret_cast<const unsigned short*>(lds + LIST + 2 * i);
-            const uint32_t e_next = *reinterpret_cast<const unsigned short*>(lds + LIST + 2 * i + 2);
-            const uint32_t l_i = e & 63u, pixo = (e >> 1) & 0x7e0u, q = e >> 12;
-            const uint32_t slot = lds[SLOT + l_i];
-            const float4* rp = reinterpret_cast<const float4*>(lds + REC + slot * 48);
-            const float4 v0 = rp[0], v1 = rp[1], v2 = rp[2];
-            const float4* pp = reinterpret_cast<const float4*>(lds + PIX + pixo);
-            const float4 P0 = pp[0], P1 = pp[1];
-            const float dx = v0.x - P0.w, dy = v0.y - P1.w;
-            const float power = pair_exp2_arg(v0.z, v0.w, v1.x, dx, dy);
-            const float G = __builtin_amdgcn_exp2f(power);
-            const float alpha = fminf(ALPHA_MAX, v1.y * G);
-            const bool live = i < N && power <= 0.0f && alpha >= ALPHA_MIN;
-            const float ae = live ? alpha : 0.f;
-            float a = 1.f - ae;
-            const float kd = __builtin_fmaf(v2.x, P1.z, __builtin_fmaf(v1.w, P1.y, v1.z * P1.x));
-            float b = ae * kd;
-            // segmented inclusive scan of the affine maps over the row.  A lane combines with lane i - d iff its rank within
-            // its pixel is >= d (the pairs of a pixel are consecutive) and lane i - d exists in the DPP row: qq folds both.
-            // Order of the block: cndmask m | fmac_dpp b | mul_dpp t | cndmask a -- b is DPP-read three instructions after it was
-            // written, a two instructions after (the two wait states a DPP read needs); the leading s_nop covers the first step
-            // and the two wait states a vector read of a vector-written mask register needs on gfx950.
+        const int n_grp8 = (cnt + 7) >> 3;                // MFMA groups of eight instances in this chunk (1 or 2)
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        float a_c = 1.f, b_c = 0.f;                       // inclusive (a, b) of the last lane of the row before (uniform)
+        const int arow = (col < 8 ? 0 : W_ROWS) + (col & 7) * ROWB + 32 * kap;
+        const auto row_group = [&](auto NRtag, const int r0) {
+            constexpr int NR = decltype(NRtag)::value;
+            uint32_t e[NR], e_next[NR], slot[NR], q[NR], pixo[NR], cell[NR];
+            bool live[NR], in_list[NR];
+            float a[NR], b[NR], G[NR], ae[NR], kd[NR], T0[NR], A0[NR], tfbg[NR], rr[NR], ww[NR];
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                const int i = 64 * (r0 + j) + lane;
+                e[j] = *reinterpret_cast<const unsigned short*>(lds + LIST + 2 * i);
+                e_next[j] = *reinterpret_cast<const unsigned short*>(lds + LIST + 2 * i + 2);
+                in_list[j] = i < N;
+            }
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                slot[j] = lds[SLOT + (e[j] & 63u)];
+                pixo[j] = (e[j] >> 1) & 0x7e0u;
+                q[j] = e[j] >> 12;
+            }
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                const float4* rp = reinterpret_cast<const float4*>(lds + REC + slot[j] * 48);
+                const float4 v0 = rp[0], v1 = rp[1];
+                const float2 v2 = *reinterpret_cast<const float2*>(rp + 2);
+                const float4* pp = reinterpret_cast<const float4*>(lds + SPIX + pixo[j]);
+                const float4 S0 = pp[0], P1 = pp[1];                                    // {tf_bg, x, y, -}, {dL_dpix, -}
+                const float2 TA = *reinterpret_cast<const float2*>(lds + DPIX + (pixo[j] >> 2));   // running {T, A}
+                const float dx = v0.x - S0.y, dy = v0.y - S0.z;
+                const float power = pair_exp2_arg(v0.z, v0.w, v1.x, dx, dy);
+                G[j] = __builtin_amdgcn_exp2f(power);
+                const float alpha = fminf(ALPHA_MAX, v1.y * G[j]);
+                live[j] = in_list[j] && power <= 0.0f && alpha >= ALPHA_MIN;
+                ae[j] = live[j] ? alpha : 0.f;
+                a[j] = 1.f - ae[j];
+                kd[j] = __builtin_fmaf(v2.x, P1.z, __builtin_fmaf(v1.w, P1.y, v1.z * P1.x));
+                b[j] = ae[j] * kd[j];
+                T0[j] = TA.x; A0[j] = TA.y; tfbg[j] = S0.x;
+                cell[j] = __float_as_uint(v2.y) + (pixo[j] >> 4);      // row offset + 2 * pixel
+            }
+            // segmented inclusive scans of the affine maps, the NR rows step by step (see version 1 for the step; with the rows
+            // interleaved every DPP read sits at least 2 NR instructions behind the write of its source)
             {
-                const uint32_t qq = min(q, (uint32_t)(lane & 15));
-                const unsigned long long c1 = __ballot(qq >= 1u), c2 = __ballot(qq >= 2u), c4 = __ballot(qq >= 4u), c8 = __ballot(qq >= 8u);
-                const unsigned long long c15 = __ballot(q >= thr15), c31 = __ballot(q >= thr31);
-                float m_, t_;
-                asm volatile("s_nop 1\n\t"
-                             GSR_PAIRS_STEP("row_shr:1 row_mask:0xf", "%[c1]")
-                             GSR_PAIRS_STEP("row_shr:2 row_mask:0xf", "%[c2]")
-                             GSR_PAIRS_STEP("row_shr:4 row_mask:0xf", "%[c4]")
-                             GSR_PAIRS_STEP("row_shr:8 row_mask:0xf", "%[c8]")
-                             GSR_PAIRS_STEP("row_bcast:15 row_mask:0xa", "%[c15]")
-                             GSR_PAIRS_STEP("row_bcast:31 row_mask:0xc", "%[c31]")
-                             : [a] "+v"(a), [b] "+v"(b), [m] "=&v"(m_), [t] "=&v"(t_)
-                             : [c1] "s"(c1), [c2] "s"(c2), [c4] "s"(c4), [c8] "s"(c8), [c15] "s"(c15), [c31] "s"(c31));
+                unsigned long long c1[NR], c2[NR], c4[NR], c8[NR], c15[NR], c31[NR];
+#pragma unroll
+                for (int j = 0; j < NR; j++) {
+                    const uint32_t qq = min(q[j], (uint32_t)(lane & 15));
+                    c1[j] = __ballot(qq >= 1u); c2[j] = __ballot(qq >= 2u); c4[j] = __ballot(qq >= 4u); c8[j] = __ballot(qq >= 8u);
+                    c15[j] = __ballot(q[j] >= thr15); c31[j] = __ballot(q[j] >= thr31);
+                }
+                float m_[NR], t_[NR];
+                if constexpr (NR == 1) {
+                    asm volatile("s_nop 1\n\t"
+                                 GSR_PAIRS_STEP("row_shr:1 row_mask:0xf", "%[c1]") GSR_PAIRS_STEP("row_shr:2 row_mask:0xf", "%[c2]")
+                                 GSR_PAIRS_STEP("row_shr:4 row_mask:0xf", "%[c4]") GSR_PAIRS_STEP("row_shr:8 row_mask:0xf", "%[c8]")
+                                 GSR_PAIRS_STEP("row_bcast:15 row_mask:0xa", "%[c15]") GSR_PAIRS_STEP("row_bcast:31 row_mask:0xc", "%[c31]")
+                                 : [a] "+v"(a[0]), [b] "+v"(b[0]), [m] "=&v"(m_[0]), [t] "=&v"(t_[0])
+                                 : [c1] "s"(c1[0]), [c2] "s"(c2[0]), [c4] "s"(c4[0]), [c8] "s"(c8[0]), [c15] "s"(c15[0]), [c31] "s"(c31[0]));
+                } else if constexpr (NR == 2) {
+                    asm volatile("s_nop 1\n\t"
+                                 GSR_PAIRS_STEP2("row_shr:1 row_mask:0xf", "%[p0]", "%[q0]") GSR_PAIRS_STEP2("row_shr:2 row_mask:0xf", "%[p1]", "%[q1]")
+                                 GSR_PAIRS_STEP2("row_shr:4 row_mask:0xf", "%[p2]", "%[q2]") GSR_PAIRS_STEP2("row_shr:8 row_mask:0xf", "%[p3]", "%[q3]")
+                                 GSR_PAIRS_STEP2("row_bcast:15 row_mask:0xa", "%[p4]", "%[q4]") GSR_PAIRS_STEP2("row_bcast:31 row_mask:0xc", "%[p5]", "%[q5]")
+                                 : [a0] "+v"(a[0]), [b0] "+v"(b[0]), [m0] "=&v"(m_[0]), [t0] "=&v"(t_[0]),
+                                   [a1] "+v"(a[1]), [b1] "+v"(b[1]), [m1] "=&v"(m_[1]), [t1] "=&v"(t_[1])
+                                 : [p0] "s"(c1[0]), [p1] "s"(c2[0]), [p2] "s"(c4[0]), [p3] "s"(c8[0]), [p4] "s"(c15[0]), [p5] "s"(c31[0]),
+                                   [q0] "s"(c1[1]), [q1] "s"(c2[1]), [q2] "s"(c4[1]), [q3] "s"(c8[1]), [q4] "s"(c15[1]), [q5] "s"(c31[1]));
+                } else {
+                    static_assert(NR <= 3, "scan blocks are written for up to three rows");
+                    asm volatile("s_nop 1\n\t"
+                                 GSR_PAIRS_STEP3("row_shr:1 row_mask:0xf", "%[p0]", "%[q0]", "%[s0]") GSR_PAIRS_STEP3("row_shr:2 row_mask:0xf", "%[p1]", "%[q1]", "%[s1]")
+                                 GSR_PAIRS_STEP3("row_shr:4 row_mask:0xf", "%[p2]", "%[q2]", "%[s2]")
+                                 : [a0] "+v"(a[0]), [b0] "+v"(b[0]), [m0] "=&v"(m_[0]), [t0] "=&v"(t_[0]),
+                                   [a1] "+v"(a[1]), [b1] "+v"(b[1]), [m1] "=&v"(m_[1]), [t1] "=&v"(t_[1]),
+                                   [a2] "+v"(a[NR - 1]), [b2] "+v"(b[NR - 1]), [m2] "=&v"(m_[NR - 1]), [t2] "=&v"(t_[NR - 1])
+                                 : [p0] "s"(c1[0]), [p1] "s"(c2[0]), [p2] "s"(c4[0]), [q0] "s"(c1[1]), [q1] "s"(c2[1]), [q2] "s"(c4[1]),
+                                   [s0] "s"(c1[NR - 1]), [s1] "s"(c2[NR - 1]), [s2] "s"(c4[NR - 1]));
+                    asm volatile("s_nop 1\n\t"
+                                 GSR_PAIRS_STEP3("row_shr:8 row_mask:0xf", "%[p0]", "%[q0]", "%[s0]") GSR_PAIRS_STEP3("row_bcast:15 row_mask:0xa", "%[p1]", "%[q1]", "%[s1]")
+                                 GSR_PAIRS_STEP3("row_bcast:31 row_mask:0xc", "%[p2]", "%[q2]", "%[s2]")
+                                 : [a0] "+v"(a[0]), [b0] "+v"(b[0]), [m0] "=&v"(m_[0]), [t0] "=&v"(t_[0]),
+                                   [a1] "+v"(a[1]), [b1] "+v"(b[1]), [m1] "=&v"(m_[1]), [t1] "=&v"(t_[1]),
+                                   [a2] "+v"(a[NR - 1]), [b2] "+v"(b[NR - 1]), [m2] "=&v"(m_[NR - 1]), [t2] "=&v"(t_[NR - 1])
+                                 : [p0] "s"(c8[0]), [p1] "s"(c15[0]), [p2] "s"(c31[0]), [q0] "s"(c8[1]), [q1] "s"(c15[1]), [q2] "s"(c31[1]),
+                                   [s0] "s"(c8[NR - 1]), [s1] "s"(c15[NR - 1]), [s2] "s"(c31[NR - 1]));
+                }
             }
-            // a pixel that began in the previous row: compose with that row's last lane (rank > lane)
+            // per row, in order (the carry runs from row to row): compose with the row before, exclusive maps, T and A, r and w
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                const bool cont = q[j] > (uint32_t)lane;
+                const float m = cont ? a[j] : 0.f;
+                b[j] = __builtin_fmaf(b_c, m, b[j]);
+                a[j] = cont ? a[j] * a_c : a[j];
+                float a_ex = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(a_c), __float_as_int(a[j]), 0x138, 0xf, 0xf, false));
+                float b_ex = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(b_c), __float_as_int(b[j]), 0x138, 0xf, 0xf, false));
+                a_ex = q[j] == 0u ? 1.f : a_ex;
+                b_ex = q[j] == 0u ? 0.f : b_ex;
+                a_c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a[j]), 63));
+                b_c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b[j]), 63));
+                const float A_before = __builtin_fmaf(a_ex, A0[j], b_ex);
+                const float Tn = T0[j] * __builtin_amdgcn_rcpf(a[j]);
+                if (more_chunks && e_next[j] < 0x1000u && in_list[j])
+                    *reinterpret_cast<float2*>(lds + DPIX + (pixo[j] >> 2)) = make_float2(Tn, __builtin_fmaf(a[j], A0[j], b[j]));
+                ww[j] = ae[j] * Tn;
+                const float s_ = kd[j] - A_before;
+                const float rinv = __builtin_amdgcn_rcpf(1.f - ae[j]);
+                rr[j] = G[j] * __builtin_fmaf(s_, Tn, -(rinv * tfbg[j]));
+            }
+            // the plane: every gather of the group has been issued -- zero it (it held the list and the pixel constants), then the
+            // hi / mid / lo passes
             {
-                const bool cont = q > (uint32_t)lane;
-                const float m = cont ? a : 0.f;
-                b = __builtin_fmaf(b_c, m, b);
-                a = cont ? a * a_c : a;
+                __builtin_amdgcn_wave_barrier();
+                float4* t4 = reinterpret_cast<float4*>(lds + TBL);
+#pragma unroll
+                for (int i = 0; i < (TBL_BYTES / 16 + 63) / 64; i++)
+                    if (i * 64 + lane < TBL_BYTES / 16) t4[i * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            // exclusive maps: the inclusive ones of the lane below (lane 0: the carry), identity at a pixel's first pair
-            float a_ex = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(a_c), __float_as_int(a), 0x138, 0xf, 0xf, false));
-            float b_ex = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(b_c), __float_as_int(b), 0x138, 0xf, 0xf, false));
-            a_ex = q == 0u ? 1.f : a_ex;
-            b_ex = q == 0u ? 0.f : b_ex;
-            a_c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
-            b_c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
-            const float A_before = __builtin_fmaf(a_ex, P0.y, b_ex);
-            const float Tn = P0.x * __builtin_amdgcn_rcpf(a);          // T in front of this pair
-            if (more_chunks && e_next < 0x1000u && i < N) {            // last pair of its pixel in this chunk: state for the next
-                *reinterpret_cast<float2*>(lds + PIX + pixo) = make_float2(Tn, __builtin_fmaf(a, P0.y, b));
+#pragma unroll
+            for (int pass = 0; pass < 3; pass++) {
+#pragma unroll
+                for (int j = 0; j < NR; j++) {
+                    if (live[j]) {
+                        unsigned char* tp = lds + TBL + cell[j];
+                        *reinterpret_cast<unsigned short*>(tp) = (unsigned short)(__float_as_uint(rr[j]) >> 16);
+                        *reinterpret_cast<unsigned short*>(tp + W_ROWS) = (unsigned short)(__float_as_uint(ww[j]) >> 16);
+                    }
+                    if (pass < 2) { rr[j] = bf16_rest_nc(rr[j]); ww[j] = bf16_rest_nc(ww[j]); }
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int g = 0; g < 2; g++) {
+                    if (g < n_grp8) {
+                        const unsigned char* ab = lds + TBL + arow + g * 8 * ROWB;
+                        const u32x4 a0_ = *reinterpret_cast<const u32x4*>(ab), a1_ = *reinterpret_cast<const u32x4*>(ab + 16);
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a0_), __builtin_bit_cast(bf16x8, Bp[0]), acc[g], 0, 0, 0);
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1_), __builtin_bit_cast(bf16x8, Bp[1]), acc[g], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-            if (live) {
-                const float w = ae * Tn;
-                const float s = kd - A_before;
-                const float rinv = __builtin_amdgcn_rcpf(1.f - ae);
-                const float rr = G * __builtin_fmaf(s, Tn, -(rinv * P0.z));
-                // exact bf16 splits at the writer (hi + mid + lo == value), three planes, [instance row][pixel]
-                const uint32_t cell = __float_as_uint(v2.y) + (pixo >> 4);       // row offset + 2 * pixel
-                float r1, r2, w1, w2;
-                bf16_rests(rr, r1, r2);
-                bf16_rests(w, w1, w2);
-                unsigned char* tp = lds + TBL + cell;
-                *reinterpret_cast<unsigned short*>(tp) = (unsigned short)(__float_as_uint(rr) >> 16);
-                *reinterpret_cast<unsigned short*>(tp + PLANE) = (unsigned short)(__float_as_uint(r1) >> 16);
-                *reinterpret_cast<unsigned short*>(tp + 2 * PLANE) = (unsigned short)(__float_as_uint(r2) >> 16);
-                *reinterpret_cast<unsigned short*>(tp + W_ROWS) = (unsigned short)(__float_as_uint(w) >> 16);
-                *reinterpret_cast<unsigned short*>(tp + W_ROWS + PLANE) = (unsigned short)(__float_as_uint(w1) >> 16);
-                *reinterpret_cast<unsigned short*>(tp + W_ROWS + 2 * PLANE) = (unsigned short)(__float_as_uint(w2) >> 16);
-            }
+        };
+        for (int r0 = 0; r0 < n_rows; r0 += RMAX) {
+            const int left = n_rows - r0;
+            if (RMAX >= 3 && left >= 3) row_group(std::integral_constant<int, (RMAX >= 3 ? 3 : 1)>{}, r0);
+            else if (RMAX >= 2 && left >= 2) row_group(std::integral_constant<int, (RMAX >= 2 ? 2 : 1)>{}, r0);
+            else row_group(std::integral_constant<int, 1>{}, r0);
+            if (r0 + RMAX < n_rows) write_phase1();       // (rare: a chunk of more than RMAX rows) list and constants again
         }
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- contraction per group of eight instances: A operand rows 0..7 = r, 8..15 = w of the group's instances, read
-        // straight from the bf16 planes (lane: row l & 15, pixels 16 kap + 8 h .. + 7 of half h)
+        // moments of the chunk's instances out of the accumulators (D layout, split-column sums: as gsr_blend_bwd.hip)
         {
-            const int arow = (col < 8 ? 0 : W_ROWS) + (col & 7) * ROWB + 32 * kap;
             const int wb_row0 = 4 * (kap & 1);
             const bool wb_take = kap < 2 ? col < 6 : (col >= 6 && col < 6 + 3 * C && (col % 3) == 0);
             float* const recf = reinterpret_cast<float*>(lds + REC);
             float* const wb_ptr = recf + wb_row0 * SF + MOM0 + (col >= 6 ? 6 + (col - 6) / 3 : col);
-            for (int g0i = 0; g0i < cnt; g0i += 8) {
-                const unsigned char* ab = lds + TBL + arow + g0i * ROWB;
-                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const u32x4 a_hi = *reinterpret_cast<const u32x4*>(ab + 16 * h);
-                    const u32x4 a_mid = *reinterpret_cast<const u32x4*>(ab + PLANE + 16 * h);
-                    const u32x4 a_lo = *reinterpret_cast<const u32x4*>(ab + 2 * PLANE + 16 * h);
-                    const bf16x8 bb = __builtin_bit_cast(bf16x8, Bp[h]);
-                    f32x4& ac = h ? acc1 : acc0;
-                    ac = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_lo), bb, ac, 0, 0, 0);
-                    ac = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_mid), bb, ac, 0, 0, 0);
-                    ac = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_hi), bb, ac, 0, 0, 0);
-                }
-                const auto split_sum = [](float v0_, float v1_, float v2_, float v3_, float& t0_, float& t1_, float& t2_, float& t3_) {
-                    float s0_, s1_, s2_, s3_;
-                    asm("s_nop 1\n\t"
-                        "v_add_f32_dpp %0, %8, %8 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                        "v_add_f32_dpp %1, %9, %9 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                        "v_add_f32_dpp %2, %10, %10 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                        "v_add_f32_dpp %3, %11, %11 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                        "v_add_f32_dpp %4, %0, %8 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                        "v_add_f32_dpp %5, %1, %9 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                        "v_add_f32_dpp %6, %2, %10 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                        "v_add_f32_dpp %7, %3, %11 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-                        : "=&v"(s0_), "=&v"(s1_), "=&v"(s2_), "=&v"(s3_), "=&v"(t0_), "=&v"(t1_), "=&v"(t2_), "=&v"(t3_)
-                        : "v"(v0_), "v"(v1_), "v"(v2_), "v"(v3_));
-                };
-                const float d0 = acc0[0] + acc1[0], d1 = acc0[1] + acc1[1], d2 = acc0[2] + acc1[2], d3 = acc0[3] + acc1[3];
-                float t0_, t1_, t2_, t3_;
-                split_sum(d0, d1, d2, d3, t0_, t1_, t2_, t3_);
-                const bool spatial = kap < 2;
-                const float o0 = spatial ? d0 : t0_, o1 = spatial ? d1 : t1_, o2 = spatial ? d2 : t2_, o3 = spatial ? d3 : t3_;
-                if (wb_take) {
-                    float* const dst = wb_ptr + g0i * SF;
-                    const int left = cnt - g0i - wb_row0;
-                    if (0 < left) dst[0 * SF] = o0;
-                    if (1 < left) dst[1 * SF] = o1;
-                    if (2 < left) dst[2 * SF] = o2;
-                    if (3 < left) dst[3 * SF] = o3;
+            for (int g = 0; g < 2; g++) {
+                if (g < n_grp8) {
+                    const float d0 = acc[g][0], d1 = acc[g][1], d2 = acc[g][2], d3 = acc[g][3];
+                    float t0_, t1_, t2_, t3_;
+                    split_sum4(d0, d1, d2, d3, t0_, t1_, t2_, t3_);
+                    const bool spatial = kap < 2;
+                    const float o0 = spatial ? d0 : t0_, o1 = spatial ? d1 : t1_, o2 = spatial ? d2 : t2_, o3 = spatial ? d3 : t3_;
+                    if (wb_take) {
+                        float* const dst = wb_ptr + g * 8 * SF;
+                        const int left = cnt - g * 8 - wb_row0;
+                        if (0 < left) dst[0 * SF] = o0;
+                        if (1 < left) dst[1 * SF] = o1;
+                        if (2 < left) dst[2 * SF] = o2;
+                        if (3 < left) dst[3 * SF] = o3;
+                    }
                 }
             }
         }
