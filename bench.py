@@ -297,7 +297,19 @@ def other_config(name, device, lib, steps=20, repeats=3):
     HIP-event means with each kernel's share of those bytes, and the fraction of the 8 TB/s roofline for the path and for
     the kernel with the best and the largest figure."""
     from gaustar_amd import rasterizer as rz
-    gs, cam, bg = scene.config_B() if name == "B" else scene.config_D()
+    if name == "C_solid":
+        # config C's geometry rendered the way sugar_model.py:1230-1232 does under use_solid_surface (refined_mesh.py:771, :1130):
+        # the two in-plane scales raised to at least their mean.  The synthetic icosphere's triangles are all alike, so the
+        # in-plane scales first get the spread trained surfels have (log-normal, sigma 1.0, seeded) -- then R >> P, the case SURVEY a7
+        # warns about (sort + blend traffic grow with R).
+        gs, cams_, bg = scene.config_C()
+        cam = cams_[0]
+        sc_ = np.array(gs.scales, dtype=np.float32, copy=True)
+        sc_[:, 1:] *= np.exp(np.random.default_rng(7).normal(0.0, 1.0, size=(gs.P, 1))).astype(np.float32)
+        sc_[:, 1:] = np.maximum(sc_[:, 1:].mean(), sc_[:, 1:])
+        gs.scales = sc_
+    else:
+        gs, cam, bg = scene.config_B() if name == "B" else scene.config_D()
     t = lambda x, g=False: None if x is None else torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(device).requires_grad_(g)
     shs, cols, deg = gs.shs, gs.colors_precomp, gs.sh_degree
     if name == "D_depth":
@@ -724,7 +736,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(gs, cams, bg)
         if world == 1 and not args.no_extras:
             oc = {}
-            for cname in ("B", "D", "D_depth"):
+            for cname in ("B", "D", "D_depth", "C_solid"):
                 try:
                     oc[cname] = other_config(cname, device, lib)
                 except Exception as ex:   # a report leg only

@@ -64,13 +64,20 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     const uint64_t t_start = trace ? wall_clock64() : 0;
     // (bf16 path: 69 registers allow seven waves per SIMD, which the LDS budget only admits with 16 slots -- 5 120 bytes
     // per wave; chunks are whole MFMA groups, so a batch of 28 is grouped 8+8 | 8+4 either way)
+#ifndef GSR_BWD_B2_LDS
+#define GSR_BWD_B2_LDS 1   // four channels: the second B tile (channel 3's three split columns) is read from LDS per group of
+                           // eight instances instead of living in eight registers (86 -> 80 registers = six waves per SIMD)
+#endif
 #ifndef GSR_BWD_QCAP
-#define GSR_BWD_QCAP (GSR_BWD_BF16 && C == 3 ? 16 : 32)
+#define GSR_BWD_QCAP (GSR_BWD_BF16 && (C == 3 || (C == 4 && GSR_BWD_B2_LDS)) ? 16 : 32)
 #endif
     constexpr int QCAP = GSR_BWD_QCAP;
     static_assert(QCAP >= GRP && QCAP <= 64 && QCAP % GRP == 0, "queue capacity: whole MFMA groups, at most one batch");
     __shared__ __attribute__((aligned(16))) float qf[QCAP * SF];   // queue slots (see SlotLayout)
     __shared__ __attribute__((aligned(16))) float Rm[2 * GRP * RSTRIDE];   // rows 0..7: r, rows 8..15: w, [row][pixel lane]
+    // (four channels, GSR_BWD_B2_LDS) second B tile as bf16 [column 0..2 = hi, mid, lo of dL_dpix channel 3][64 pixels] + 32 zero bytes
+    constexpr bool B2L = GSR_BWD_B2_LDS && GSR_BWD_BF16 && GSR_BWD_BF16_TILES2 && C == 4;
+    __shared__ __attribute__((aligned(16))) uint32_t B2s[B2L ? 3 * 32 + 8 : 1];
     // one wave64 per workgroup: unit = (tile, segment), wave = 8x8 block of the tile.
     // XCD-aware placement: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the
     // naive map (unit = id / 4) would put the four blocks of a unit -- which read the SAME instance records -- on
@@ -270,7 +277,8 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     __builtin_amdgcn_wave_barrier();
     float Bf[BF16 ? 1 : 16];
     u32x4 Bp[BF16 ? 2 : 1];
-    u32x4 Bp2[C2 > 0 ? 2 : 1];
+    u32x4 Bp2[C2 > 0 && !B2L ? 2 : 1];
+    uint32_t b2_off = 0;    // (B2L) byte offset of this lane's 16 bytes of half 0 (+ 16: half 1); unused columns read the zero block
     {
         const float4* pd = reinterpret_cast<const float4*>(&Rm[(col < BROWS ? col : BROWS) * BS + 16 * kap]);
         float bv[16];
@@ -290,7 +298,19 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
         }
     }
     __builtin_amdgcn_wave_barrier();
-    if constexpr (C2 > 0) {   // second tile: the same staging once more, rows 0 .. 3 C2 - 1 = (hi, mid, lo) of channels 3 ..
+    if constexpr (C2 > 0 && B2L) {
+        // second tile kept in LDS: every pixel lane parks the three bf16 parts of its dL_dpix channel 3, a lane of the matrix
+        // operand (column col, pixels 16 kap + 8 h ..) reads its eight values back per group
+        static_assert(C2 == 1, "one extra channel");
+        const float d0 = dp[C1], d1 = bf16_rest(d0), d2 = bf16_rest(d1);
+        unsigned short* b2h = reinterpret_cast<unsigned short*>(B2s);
+        b2h[0 * 64 + lane] = (unsigned short)(__float_as_uint(d0) >> 16);
+        b2h[1 * 64 + lane] = (unsigned short)(__float_as_uint(d1) >> 16);
+        b2h[2 * 64 + lane] = (unsigned short)(__float_as_uint(d2) >> 16);
+        if (lane < 8) B2s[3 * 32 + lane] = 0u;
+        b2_off = col < 3 ? (uint32_t)(col * 128 + 32 * kap) : (uint32_t)(3 * 128);
+        __builtin_amdgcn_wave_barrier();
+    } else if constexpr (C2 > 0) {   // second tile: the same staging once more, rows 0 .. 3 C2 - 1 = (hi, mid, lo) of channels 3 ..
 #pragma unroll
         for (int ch = 0; ch < C2; ch++) {
             const float d0 = dp[C1 + ch], d1 = bf16_rest(d0), d2 = bf16_rest(d1);
@@ -464,7 +484,10 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_mid), b, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_hi), b, acc, 0, 0, 0);
                 if constexpr (C2 > 0) {
-                    const bf16x8 b2 = __builtin_bit_cast(bf16x8, Bp2[h]);
+                    u32x4 b2r;
+                    if constexpr (B2L) b2r = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(B2s) + b2_off + 16 * h);
+                    else b2r = Bp2[h];
+                    const bf16x8 b2 = __builtin_bit_cast(bf16x8, b2r);
                     f32x4& bcc = acc2;   // (one chain for both halves: four registers less, and the matrix pipe is far from busy)
                     bcc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_lo), b2, bcc, 0, 0, 0);
                     bcc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_mid), b2, bcc, 0, 0, 0);
@@ -603,9 +626,10 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
 #endif
 GSR_BWD_SPECIALISE(3, GSR_BWD_WAVES3)
 #ifndef GSR_BWD_WAVES4
-#define GSR_BWD_WAVES4 5
+#define GSR_BWD_WAVES4 (GSR_BWD_B2_LDS ? 6 : 5)
 #endif
-// Four channels (two B tiles): 85 registers left alone = five waves; held at 80 for six it spills ten and loses (0.146 vs 0.134 ms)
+// Four channels (two B tiles): 85 registers left alone = five waves; held at 80 for six it spilt ten and lost (0.146 vs 0.134 ms).
+// Round 5: with the second B tile read from LDS per group (GSR_BWD_B2_LDS) it fits 80 registers without scratch = six waves.
 GSR_BWD_SPECIALISE(4, GSR_BWD_WAVES4)
 
 // Experiment builds only (python -m gaustar_amd.build --variant NAME --with tools/variants/<file>.hip ...): the extra source
