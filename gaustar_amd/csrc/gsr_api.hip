@@ -382,7 +382,7 @@ int forward_stage2_impl(int P, int R, int max_tile_instances, int num_segments, 
     if (R > 0) {
         if (!scattered) {   // (the fused forward has launched it behind the scan already)
             Scope sc(ST_SCATTER, st);
-            launch_scatter(P, W, H, (uint32_t)(max_tile_instances > 0 ? max_tile_instances : 0), g, im, b, st);
+            launch_scatter(P, W, H, R, (uint32_t)(max_tile_instances > 0 ? max_tile_instances : 0), g, im, b, st);
             GSR_CHECK_LAUNCH("scatter_kernel");
         }
         {

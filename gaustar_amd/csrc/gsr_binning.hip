@@ -304,7 +304,7 @@ scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __
                uint4* __restrict__ unit_info, const uint32_t* __restrict__ tile_count,
                const uint2* __restrict__ ranges, const uint4* __restrict__ wg_recs, const uint2* __restrict__ wg_tab,
                const uint32_t* __restrict__ wg_nrec, uint32_t* __restrict__ totals, uint2* __restrict__ part_list,
-               uint32_t split_n, void* early_base, size_t early_capacity, int early_C)
+               uint32_t* __restrict__ part_ticket, uint32_t split_n, void* early_base, size_t early_capacity, int early_C)
 {
     if (early_base != nullptr) {
         // (uniform) launched right behind the scan, before the host has seen its totals (gsr_forward_fused): where the
@@ -314,8 +314,8 @@ scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __
         const uint32_t R = totals[0], maxc = totals[1], U = totals[3];
         const BinState eb = carve_bin(early_base, (int)R, (int)U, early_C);
         if (eb.bytes > early_capacity) return;
-        keys = eb.keys; unit_info = eb.unit_info; part_list = eb.part_list;
-        split_n = split_threshold_from(maxc, split_n);
+        keys = eb.keys; unit_info = eb.unit_info; part_list = eb.part_list; part_ticket = eb.part_ticket;
+        split_n = split_threshold_from(maxc, R, split_n);
     }
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -334,6 +334,7 @@ scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __
             const uint32_t np = (n + (uint32_t)FWD_CHUNK - 1u) / (uint32_t)FWD_CHUNK;
             const uint32_t at = atomicAdd(&totals[6], np);
             for (uint32_t k = 0; k < np; k++) part_list[at + k] = make_uint2((uint32_t)idx, k * (uint32_t)FWD_CHUNK);
+            part_ticket[at] = 0u;   // the tile's parts draw tickets here; the last one combines (gsr_blend_fwd.hip)
         }
     }
     if (totals[4] != totals[5]) {   // (uniform) every preprocess workgroup of this view recorded all of its instances
@@ -403,13 +404,13 @@ scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __
                              });
 }
 
-void launch_scatter(int P, int W, int H, uint32_t max_count, GeomState g, ImageState im, BinState b, hipStream_t st)
+void launch_scatter(int P, int W, int H, int R, uint32_t max_count, GeomState g, ImageState im, BinState b, hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);
     const int n = P > t.T ? P : t.T;
     scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(P, t.gx, g.rect, g.g0, g.g1, g.depth, im.tile_cursor, b.keys, t.T,
                                                     im.seg_off, b.unit_info, im.tile_count, im.ranges, g.wg_recs, g.wg_tab,
-                                                    g.wg_nrec, im.totals, b.part_list, split_threshold(max_count), nullptr, 0, 3);
+                                                    g.wg_nrec, im.totals, b.part_list, b.part_ticket, split_threshold(max_count, (uint32_t)(R > 0 ? R : 0)), nullptr, 0, 3);
 }
 
 void launch_scatter_early(int P, int W, int H, int C, GeomState g, ImageState im, void* binning_base, size_t capacity, hipStream_t st)
@@ -418,7 +419,7 @@ void launch_scatter_early(int P, int W, int H, int C, GeomState g, ImageState im
     const int n = P > t.T ? P : t.T;
     scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(P, t.gx, g.rect, g.g0, g.g1, g.depth, im.tile_cursor, nullptr, t.T,
                                                     im.seg_off, nullptr, im.tile_count, im.ranges, g.wg_recs, g.wg_tab,
-                                                    g.wg_nrec, im.totals, nullptr, split_from(), binning_base, capacity, C);
+                                                    g.wg_nrec, im.totals, nullptr, nullptr, split_from(), binning_base, capacity, C);
 }
 
 // ---- per-tile bitonic sort of 64-bit keys in LDS.
@@ -538,16 +539,21 @@ tile_sort_big_kernel(const uint2* __restrict__ ranges, const uint32_t* __restric
 // path (keys are unique).  The passes ping-pong between two buffers; the last one leaves the ids in point_list.
 __global__ void __launch_bounds__(256)
 long_sort_runs_kernel(const uint2* __restrict__ part_list, const uint32_t* __restrict__ totals, const uint2* __restrict__ ranges,
-                      const uint64_t* __restrict__ keys, uint64_t* __restrict__ dst)
+                      const uint64_t* __restrict__ keys, uint64_t* __restrict__ dst, uint32_t* __restrict__ ids_out, uint32_t self_sort_n)
 {
     if (blockIdx.x >= totals[6]) return;
     const uint2 part = part_list[blockIdx.x];
     if ((part.y & (SORT_SMALL_CAP - 1u)) != 0u) return;
     const uint2 rg = ranges[part.x];
     const uint32_t n = rg.y - rg.x, m = min(SORT_SMALL_CAP, n - part.y);
+    if (ids_out == nullptr && n <= self_sort_n) return;   // (its parts sort it themselves inside the forward blend's launch)
     __shared__ __attribute__((aligned(16))) uint64_t s[2 * SORT_SMALL_CAP];
     const uint64_t* gk = keys + rg.x + part.y;
     uint64_t* out = dst + rg.x + part.y;
+    if (ids_out != nullptr) {   // (no merge pass follows: no list of the view exceeds one run -- the ids go straight to the list)
+        sort_small_tile(s, gk, ids_out + rg.x + part.y, m);
+        return;
+    }
     if (m == 1u) { if (threadIdx.x == 0) out[0] = gk[0]; return; }
     if (m <= 512u) sort_tile_merge<2>(s, gk, nullptr, m, out);
     else if (m <= 1024u) sort_tile_merge<4>(s, gk, nullptr, m, out);
@@ -556,12 +562,14 @@ long_sort_runs_kernel(const uint2* __restrict__ part_list, const uint32_t* __res
 
 __global__ void __launch_bounds__(256)
 long_sort_merge_kernel(const uint2* __restrict__ part_list, const uint32_t* __restrict__ totals, const uint2* __restrict__ ranges,
-                       const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, uint32_t* __restrict__ ids_out, uint32_t len)
+                       const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, uint32_t* __restrict__ ids_out, uint32_t len,
+                       uint32_t self_sort_n)
 {
     if (blockIdx.x >= totals[6]) return;
     const uint2 part = part_list[blockIdx.x];
     const uint2 rg = ranges[part.x];
     const uint32_t n = rg.y - rg.x;
+    if (n <= self_sort_n) return;
     const uint32_t o0 = part.y + 2u * threadIdx.x;   // a part is FWD_CHUNK = 512 positions: two outputs per thread
     static_assert(FWD_CHUNK == 512, "two outputs per thread of a 256-thread workgroup");
     if (o0 >= n) return;
@@ -599,7 +607,8 @@ bool tile_sort_launches(int R, uint32_t max_count, bool blend_sorts_small)
 {
     if (R <= 0) return false;
     if (getenv("GSR_DEBUG_SORT_CAP") || getenv("GSR_SORT_LDS") || !blend_sorts_small) return true;
-    return max_count > 2048u;
+    // (a view that splits: the parts of lists up to 2 048 entries sort themselves, longer lists go through the merge passes)
+    return split_threshold(max_count, (uint32_t)R) != 0xffffffffu ? max_count > SORT_SMALL_CAP : max_count > 2048u;
 }
 
 bool launch_tile_sort(int W, int H, int R, int U, uint32_t max_count, ImageState im, BinState b, bool blend_sorts_small, hipStream_t st)
@@ -617,16 +626,21 @@ bool launch_tile_sort(int W, int H, int R, int U, uint32_t max_count, ImageState
     // the forward blend sorts each of these lists right before walking it
     else if (blend_sorts_small) left_small = true;
     else tile_sort_reg_kernel<<<t.T, 256, 0, st>>>(im.ranges, im.order, b.keys, b.point_list);
-    const bool in_parts = split_threshold(max_count) != 0xffffffffu && !lds_sort;
-    if (in_parts) {
+    const bool in_parts = split_threshold(max_count, (uint32_t)(R > 0 ? R : 0)) != 0xffffffffu && !lds_sort;
+    // A view that splits: if no list exceeds 2 048 entries the parts sort their lists themselves inside the blend's launch
+    // (blend_sorts_small; gsr_blend_fwd.hip) and nothing is launched here; otherwise every split list is sorted here, by runs of
+    // 2 048 keys and merge passes over memory.
+    const uint32_t self_sort_n = blend_sorts_small && max_count <= SORT_SMALL_CAP ? SORT_SMALL_CAP : 0u;
+    if (in_parts && max_count > self_sort_n) {
         uint64_t* bufs[2] = {reinterpret_cast<uint64_t*>(b.rec_a), reinterpret_cast<uint64_t*>(b.rec_a) + (size_t)R};   // (free until the forward)
         const unsigned grid = (unsigned)part_capacity(R, U);
-        long_sort_runs_kernel<<<grid, 256, 0, st>>>(b.part_list, im.totals, im.ranges, b.keys, bufs[0]);
+        long_sort_runs_kernel<<<grid, 256, 0, st>>>(b.part_list, im.totals, im.ranges, b.keys, bufs[0],
+                                                    max_count <= SORT_SMALL_CAP ? b.point_list : nullptr, self_sort_n);
         int cur = 0;
         for (uint32_t len = SORT_SMALL_CAP; len < max_count; len <<= 1) {
             const bool last = (len << 1) >= max_count || (len << 1) == 0u;
             long_sort_merge_kernel<<<grid, 256, 0, st>>>(b.part_list, im.totals, im.ranges, bufs[cur], bufs[cur ^ 1],
-                                                         last ? b.point_list : nullptr, len);
+                                                         last ? b.point_list : nullptr, len, self_sort_n);
             cur ^= 1;
             if (last) break;
         }

@@ -39,11 +39,17 @@
 namespace gsr {
 
 
-// MODE 0: one workgroup per tile (launch order = `order`).  Lists up to LONG_LIST entries are sorted and walked here, front
-// to back.  A longer list -- a surface seen edge-on stacks thousands of thin splats onto a tile without saturating it, and
-// a pixel's walk is serial: 11 787 entries took one workgroup 514 us -- has been walked before this launch in PARTS of one
-// chunk (MODE 1, one workgroup per part, every part starting from T = 1, C = 0): this workgroup only COMBINES them in
-// order, T_in C_in -> C_in + T_in C_part, T_in T_part per pixel, re-basing the part's per-unit snapshots the same way.
+// MODE 0: one workgroup per tile (launch order = `order`): the list is sorted and walked here, front to back.  That is every
+// view whose longest list stays below SPLIT_FROM entries.  A longer list -- a surface seen edge-on stacks thousands of thin
+// splats onto a tile without saturating it, and a pixel's walk is serial: 11 787 entries took one workgroup 514 us; config B's
+// two 2 100-entry pole tiles ran alone for 60 us of a 114 us launch -- makes the view SPLIT: MODE 2, ONE launch of
+// part_capacity + T workgroups.  The first part_capacity are PART workers: every list above PART_FROM entries (sorted before
+// the launch) is walked in parts of one chunk, one workgroup per part, every part starting from T = 1, C = 0 and independent of
+// all others.  A part that has stored its result draws a ticket at its tile (release fence, agent-scope atomic); the one that
+// draws the LAST ticket COMBINES the tile's parts in order (acquire fence first) -- T_in C_in -> C_in + T_in C_part,
+// T_in T_part per pixel, re-basing the parts' per-unit snapshots the same way -- and writes the tile's pixels.  Nobody waits for
+// anybody, so no assumption about dispatch order is made; the tile's own workgroup (second part of the grid) does nothing.
+// (MODE 1: the part workers as a launch of their own, without tickets -- kept for the two-launch comparison build.)
 // A part is folded in like that only for pixels that cannot have terminated inside it -- the product of ALL its (1 - alpha)
 // keeps T above 1e-4 (then every prefix does) and the part itself did not stop -- the others walk that one chunk again
 // with their true state, exactly as a short list would (a pixel terminates once, so at most one chunk per pixel).
@@ -56,16 +62,19 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                  float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ seg_off,
                  uint2* __restrict__ masks, float4* __restrict__ snap, float4* __restrict__ rec_a, float4* __restrict__ rec_b,
                  RecTail<C>* __restrict__ rec_c, const uint2* __restrict__ part_list, const uint32_t* __restrict__ totals,
-                 float4* __restrict__ part_fin, uint32_t* __restrict__ part_last, uint32_t split_n, bool keep,
+                 float4* __restrict__ part_fin, uint32_t* __restrict__ part_last, uint32_t* __restrict__ part_ticket,
+                 uint32_t part_grid, bool parts_sort, uint32_t split_n, bool keep,
                  float4* __restrict__ zero_ptr,
                  uint32_t zero_n, uint32_t* __restrict__ counters, uint32_t counters_tp, uint64_t* __restrict__ trace)
 {
     const uint64_t t_start = trace ? wall_clock64() : 0;
-    if constexpr (MODE == 1) { if (blockIdx.x >= totals[6]) return; }   // parts of this view (scatter_kernel lists them)
+    // (MODE 2) the first part_grid workgroups are part workers, the others the tiles in launch order
+    const bool is_part = MODE == 1 || (MODE == 2 && blockIdx.x < part_grid);
+    const uint32_t tile_block = MODE == 2 ? blockIdx.x - part_grid : blockIdx.x;
     // Side job: the backward's accumulation table (48 B per Gaussian) has to be zero before blend_bwd runs.  When the
     // caller hands it over at forward time every workgroup clears its slice here instead of a separate fill (a 5 us blit
     // plus its dispatch) in front of the backward.
-    if (MODE == 0 && zero_ptr != nullptr) {
+    if (MODE != 1 && zero_ptr != nullptr) {
         const uint32_t per = (zero_n + gridDim.x - 1u) / gridDim.x;
         const uint32_t i0 = blockIdx.x * per, i1 = min(zero_n, i0 + per);
         for (uint32_t i = i0 + threadIdx.x; i < i1; i += 256u) zero_ptr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -77,17 +86,18 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     // the walk (below) uses the same bytes for its cross-wave stages.  C = 3 at CH = 512: 34 KB, four workgroups per CU.
     constexpr size_t GC_BYTES = (sizeof(RecTail<C>) * CH + 15) / 16 * 16;
     constexpr size_t REC_BYTES = 32 * CH + GC_BYTES, MK_BYTES = sizeof(uint32_t) * 4 * NH * 64;
-    constexpr size_t SORT_BYTES = MODE == 0 ? 2 * SORT_SMALL_CAP * 8 : 0;
+    constexpr size_t SORT_BYTES = 2 * SORT_SMALL_CAP * 8;
     constexpr size_t LDS_BYTES = REC_BYTES + MK_BYTES > SORT_BYTES ? REC_BYTES + MK_BYTES : SORT_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     float4* const ga = reinterpret_cast<float4*>(smem);
     float4* const gb = ga + CH;
     RecTail<C>* const gc = reinterpret_cast<RecTail<C>*>(smem + 32 * CH);
     uint32_t (*mk)[NH][64] = reinterpret_cast<uint32_t(*)[NH][64]>(smem + REC_BYTES);
+    if (is_part && blockIdx.x >= totals[6]) return;   // parts of this view (scatter_kernel lists them)
     uint32_t part_c0 = 0;
     int tile;
-    if constexpr (MODE == 0) {
-        tile = (int)order[blockIdx.x];
+    if (!is_part) {
+        tile = (int)order[tile_block];
     } else {
         const uint2 part = part_list[blockIdx.x];
         tile = (int)part.x;
@@ -95,7 +105,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     }
     // Second side job (fused forward): this tile's eight shard counters and eight scatter cursors live in a library-owned
     // block that has to be all zero again for the next view's preprocess; scatter, their last reader, is done.
-    if (MODE == 0 && counters != nullptr && threadIdx.x < 2 * NSHARD)
+    if (!is_part && counters != nullptr && threadIdx.x < 2 * NSHARD)
         counters[(size_t)threadIdx.x * counters_tp + tile] = 0u;      // rows 0-7: counts, rows 8-15: cursors ([16][Tp])
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tx = tile % gx, ty = tile / gx;
@@ -111,7 +121,8 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     const uint32_t list0 = __builtin_amdgcn_readfirstlane(rg.x);
     const uint32_t n = __builtin_amdgcn_readfirstlane(rg.y - rg.x);
     const uint32_t unit0 = __builtin_amdgcn_readfirstlane(seg_off[tile]);
-    const bool long_list = n > split_n;   // (wave-uniform) blended in parts: split_n = LONG_LIST in views that split at all
+    const bool long_list = n > split_n;   // (wave-uniform) blended in parts: split_n = PART_FROM in views that split at all
+    if (MODE == 2 && !is_part && long_list) return;   // its parts do everything, the last of them the combine
     // Depth sort of this tile's list, right here (lists up to 2 048 entries; longer ones were sorted by tile_sort_big_kernel
     // before this launch).  As a kernel of its own the sort is latency-bound (key loads, cross-lane exchanges, barriers:
     // 25 us at a fraction of the vector ALU) and the blend then starts from a cold chip; inside the blend kernel one
@@ -121,11 +132,20 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     if (n > 1024u) __builtin_amdgcn_s_setprio(3);
     else if (n > 704u) __builtin_amdgcn_s_setprio(2);
     else if (n > 448u) __builtin_amdgcn_s_setprio(1);
-    if constexpr (MODE == 0) {
+    if (!is_part) {
         if (sort_keys != nullptr) {
             if (n >= 1u && n <= 2048u) sort_small_tile(reinterpret_cast<uint64_t*>(smem), sort_keys + list0, point_list + list0, n);
             __syncthreads();   // ids visible to the four waves; the sort's LDS is free
         }
+    } else if (parts_sort && sort_keys != nullptr && n <= SORT_SMALL_CAP) {
+        // A part sorts the WHOLE list of its tile for itself (every part of the tile writes the same ids to the same places): no
+        // workgroup waits for another before its walk, and no sort launch stands in front of the blend.  Only in views whose
+        // longest list fits the in-kernel sort (parts_sort): a view with a list above 2 048 entries needs launch_tile_sort's merge
+        // passes anyway, and then they sort every split list (config B: blend 85 us behind a 27 us sort launch, against 102 us
+        // with its shorter split lists sorted here five times over; an in-place LDS network for 4 096 keys was tried as well:
+        // 78 stages x 64 KB of LDS traffic, ~45 us per part).
+        sort_small_tile(reinterpret_cast<uint64_t*>(smem), sort_keys + list0, point_list + list0, n);
+        __syncthreads();
     }
     const uint32_t* list = point_list + list0;
     const TransposeConsts tc(lane);
@@ -138,7 +158,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     bool done = !inside;
     // segment (SNAP_SEG list positions) of the word this pixel consumed last.  A part that is not the tile's first starts
     // "nowhere": the first word of ANY of its units, the first one included, opens a segment and leaves a snapshot
-    uint32_t seg_cur = (MODE == 1 && part_c0 != 0u) ? 0xffffffffu : 0u;
+    uint32_t seg_cur = (is_part && part_c0 != 0u) ? 0xffffffffu : 0u;
 
     // Two-stage software pipeline over the dependent gather (list -> id -> records): ids are fetched two chunks ahead,
     // records and mask words one chunk ahead, so no global-memory latency sits between a chunk's barrier and its walk.
@@ -240,7 +260,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             const bool need = cur == 0u;
             cur = need ? nw : cur;
             h = need ? nh : h;
-            if (snaps || MODE == 1) {   // (a part always leaves them: the combining workgroup finds its way by them)
+            if (snaps || is_part) {   // (a part always leaves them: the combining workgroup finds its way by them)
                 // first word of a new segment: the running (T, C) is the pixel's state at the segment's boundary (and at
                 // every boundary it skipped) -- what the backward blend's units resume from (gsr_blend_bwd.hip)
                 const uint32_t seg_new = (c0 + (uint32_t)h * 32u) / (uint32_t)SNAP_SEG;
@@ -299,24 +319,14 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         return stopped;
     };
     // where a part of this tile keeps its per-pixel result: parts are numbered (first unit / 8) + (first list entry of
-    // the tile / LONG_LIST) -- increasing along a tile, and strictly increasing from one long tile to the next, whose
-    // list starts more than LONG_LIST entries later; at most U / 8 + R / LONG_LIST + 1
+    // the tile / PART_FROM) -- increasing along a tile, and strictly increasing from one split tile to the next, whose
+    // list starts more than PART_FROM entries later; at most U / 8 + R / PART_FROM + 1
     const auto part_slot = [&](uint32_t c0) {
-        return ((size_t)((unit0 + (c0 >> 6)) / 8u + list0 / LONG_LIST) * 256 + (size_t)pix_in_tile);
+        return ((size_t)((unit0 + (c0 >> 6)) / 8u + list0 / PART_FROM) * 256 + (size_t)pix_in_tile);
     };
 
-    if constexpr (MODE == 1) {
-        // ---- one part: chunk [part_c0, part_c0 + CH) from T = 1, C = 0
-        fetch_ids(part_c0);
-        fetch_records();
-        park(part_c0, false, true, true);   // (words and records always: the combining workgroup may need them)
-        __syncthreads();
-        const bool stopped = walk(part_c0, done ? 0u : nonempty_words(part_c0));
-        const size_t ps = part_slot(part_c0);
-        store_snapshot<C>(part_fin + ps * SV, T, Cc);
-        part_last[ps] = last | (stopped ? 0x80000000u : 0u);
-        return;
-    } else if (long_list) {
+    // ---- combine the parts of this tile, in list order (MODE 0 has none; MODE 2: the part that drew the last ticket)
+    const auto combine_parts = [&]() {
         // ---- combine the parts, in list order.  Phase A, all pixels in step: a part the pixel certainly passes through is
         // folded in; at the first one it may not, the pixel PARKS with its state at that part's start.
         const float thr = T_EPS * 1.001f;   // (0.1 % of slack for the rounding of the products: a borderline pixel parks)
@@ -483,6 +493,40 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                 }
             }
         }
+    };
+    bool combine = false;
+    if (is_part) {
+        // ---- one part: chunk [part_c0, part_c0 + CH) from T = 1, C = 0
+        fetch_ids(part_c0);
+        fetch_records();
+        park(part_c0, false, true, true);   // (words and records always: the combining workgroup may need them)
+        __syncthreads();
+        const bool stopped = walk(part_c0, done ? 0u : nonempty_words(part_c0));
+        const size_t ps = part_slot(part_c0);
+        store_snapshot<C>(part_fin + ps * SV, T, Cc);
+        part_last[ps] = last | (stopped ? 0x80000000u : 0u);
+        if constexpr (MODE != 2) return;
+        // Ticket: everything this part wrote (result, snapshots, words, records) is released to the device before the ticket
+        // is drawn; whoever draws the last one acquires and sees all parts.  Parts of a tile are consecutive in the part list.
+        __shared__ uint32_t ticket;
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0)
+            ticket = __hip_atomic_fetch_add(&part_ticket[blockIdx.x - part_c0 / (uint32_t)CH], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (ticket + 1u != (n + (uint32_t)CH - 1u) / (uint32_t)CH) return;
+        __threadfence();
+        T = 1.0f;
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) Cc[ch] = 0.f;
+        last = 0;
+        done = !inside;
+        combine = true;
+    } else {
+        combine = MODE == 0 && long_list;
+    }
+    if (combine) {
+        combine_parts();
     } else {
         fetch_ids(0);
         fetch_records();
@@ -498,6 +542,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             const bool stopped = walk(c0, done ? 0u : nonempty_words(c0));
             done = done || stopped;
         }
+    
     }
     if (inside) {
         const size_t pix = (size_t)W * py + px;
@@ -510,9 +555,9 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         // final (T, C), from which the backward derives "colour behind a boundary" = C_final - C_snap
         if (snaps && n > (uint32_t)SNAP_SEG) store_snapshot<C>(snap + ((size_t)unit0 * 256 + pix_in_tile) * SV, T, Cc);
     }
-    if (trace && lane == 0) {   // last wave to finish wins the end stamp
-        if (wave == 0) trace[2 * blockIdx.x] = t_start;
-        atomicMax((unsigned long long*)&trace[2 * blockIdx.x + 1], (unsigned long long)wall_clock64());
+    if (trace && lane == 0 && !is_part) {   // last wave to finish wins the end stamp
+        if (wave == 0) trace[2 * tile_block] = t_start;
+        atomicMax((unsigned long long*)&trace[2 * tile_block + 1], (unsigned long long)wall_clock64());
     }
 }
 
@@ -523,19 +568,27 @@ static void launch_fwd_c(int W, int H, int R, int U, uint32_t max_count, const f
 {
     const Tiles t = tiles_of(W, H);
     // (lists above 2 048 entries were sorted by the big-sort kernels before: launch_tile_sort; scatter_kernel listed the parts)
-    const uint32_t split_n = split_threshold(max_count);
-    if (split_n != 0xffffffffu && U > 0)
-        blend_fwd_kernel<C, FWD_CHUNK, 1><<<(unsigned)part_capacity(R, U), 256, 0, st>>>(
-            W, H, t.gx, im.ranges, im.order, b.point_list, nullptr, g.g0, g.g1, feats, bg, out_color, im.final_T, im.n_contrib,
-            im.seg_off, b.masks, b.snap, b.rec_a, b.rec_b, static_cast<RecTail<C>*>(b.rec_c), b.part_list, im.totals, b.part_fin,
-            b.part_last, split_n, keep_masks, nullptr, 0u, nullptr, 0u, nullptr);
+    const uint32_t split_n = split_threshold(max_count, (uint32_t)(R > 0 ? R : 0));
     // Residency knob: extra dynamic LDS lowers the number of co-resident tiles per CU (tuning only).
     static const int pad = getenv("GSR_FWD_LDS_PAD") ? atoi(getenv("GSR_FWD_LDS_PAD")) : 0;
-    blend_fwd_kernel<C, FWD_CHUNK, 0><<<t.T, 256, pad, st>>>(
-        W, H, t.gx, im.ranges, im.order, b.point_list, sort_small ? b.keys : nullptr, g.g0, g.g1, feats, bg, out_color, im.final_T,
-        im.n_contrib, im.seg_off, b.masks, b.snap, b.rec_a, b.rec_b, static_cast<RecTail<C>*>(b.rec_c), b.part_list, im.totals,
-        b.part_fin, b.part_last, split_n, keep_masks, static_cast<float4*>(zero_ptr), (uint32_t)(zero_bytes / 16), counters,
-        (uint32_t)shard_stride(t.T), g_trace);
+    static const bool two_launches = getenv("GSR_FWD_TWO_LAUNCHES") != nullptr;   // (comparison: the parts as a launch of their own)
+    const auto go = [&](auto mode, unsigned grid, unsigned part_grid) {
+        constexpr int M = decltype(mode)::value;
+        blend_fwd_kernel<C, FWD_CHUNK, M><<<grid, 256, M == 1 ? 0 : pad, st>>>(
+            W, H, t.gx, im.ranges, im.order, b.point_list, sort_small ? b.keys : nullptr, g.g0, g.g1, feats, bg, out_color,
+            im.final_T, im.n_contrib, im.seg_off, b.masks, b.snap, b.rec_a, b.rec_b, static_cast<RecTail<C>*>(b.rec_c), b.part_list,
+            im.totals, b.part_fin, b.part_last, b.part_ticket, part_grid, max_count <= SORT_SMALL_CAP, split_n, keep_masks,
+            M != 1 ? static_cast<float4*>(zero_ptr) : nullptr, M != 1 ? (uint32_t)(zero_bytes / 16) : 0u, M != 1 ? counters : nullptr,
+            (uint32_t)shard_stride(t.T), M != 1 ? g_trace : nullptr);
+    };
+    // (scatter_kernel listed the parts; lists above 2 048 entries were sorted by launch_tile_sort, shorter ones sort themselves)
+    if (split_n != 0xffffffffu && U > 0 && !two_launches) {
+        const unsigned np = (unsigned)part_capacity(R, U);
+        go(std::integral_constant<int, 2>{}, np + (unsigned)t.T, np);
+    } else {
+        if (split_n != 0xffffffffu && U > 0) go(std::integral_constant<int, 1>{}, (unsigned)part_capacity(R, U), 0u);
+        go(std::integral_constant<int, 0>{}, (unsigned)t.T, 0u);
+    }
 }
 
 void launch_blend_fwd(int C, int W, int H, int R, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im,

@@ -140,7 +140,8 @@ struct BinState {            // per instance / per segment
     uint4* unit_info;        // [U] {tile, first list entry of the tile, entries of the tile, first unit of the tile}
     uint2* masks;            // [U][4 blocks][64 lanes] per-pixel 64-bit words over the unit's 64 list positions
                              // {positions 0-31, positions 32-63}; block = 2*by + bx, lane = 8*(y % 8) + (x % 8)
-    uint2* part_list;        // [part_capacity] {tile, first list position} of every part of a list above 2 048 entries
+    uint2* part_list;        // [part_capacity] {tile, first list position} of every part of a list blended in parts
+    uint32_t* part_ticket;   // [part_capacity] at a tile's FIRST part: how many of its parts have finished (scatter zeroes it)
     uint32_t* part_last;     // [part_capacity][256] a part's per-pixel last contributor (bit 31: the part stopped)
     float4* part_fin;        // [part_capacity][256][snap_vecs(C)] a part's per-pixel {T, C...} from T = 1, C = 0
     float4* snap;            // [U][256][snap_vecs(C)] per-pixel {T, C0, C1, ...} BEFORE the first instance of segment
@@ -148,28 +149,43 @@ struct BinState {            // per instance / per segment
                              // tile has more than one segment); pixel index = 16*(y - tile_y0) + (x - tile_x0)
     size_t bytes;
 };
-// Lists above LONG_LIST entries are blended in parts of one forward chunk (gsr_blend_fwd.hip); part_capacity bounds their
-// number.  (GSR_LONG_LIST: a build with a huge value walks every list serially -- the comparison build of the tests' tools.)
+// Lists above LONG_LIST entries are sorted by kernels of their own (the forward blend sorts shorter ones itself, gsr_sort.h).
+// (GSR_LONG_LIST: a build with a huge value walks every list serially -- the comparison build of the tests' tools.)
 #ifndef GSR_LONG_LIST
 #define GSR_LONG_LIST 2048
 #endif
 constexpr uint32_t LONG_LIST = GSR_LONG_LIST;
 static_assert(LONG_LIST >= 2048, "lists up to 2 048 entries are sorted inside the forward kernel, whole");
-__host__ __device__ inline size_t part_capacity(int R, int U) { return (size_t)U / 8 + (size_t)R / 2048 + 2; }
-// Splitting costs a launch in front of the forward blend (its parts run before any tile does), so a view splits only if
-// its longest list would otherwise hold the kernel up -- above SPLIT_FROM entries -- and then every list above LONG_LIST
-// is split; 0xffffffff: nothing is.  (Config B's two 2 100-entry tiles are faster left alone: 0.116 vs 0.144 ms.)
-constexpr uint32_t SPLIT_FROM = 4096;
+// In a view that SPLITS, every list above PART_FROM entries is blended in PARTS of one forward chunk each, by workgroups of their
+// own inside the forward blend's launch; the part that finishes last combines them (gsr_blend_fwd.hip).  part_capacity bounds
+// the number of part slots (a part's slot: (first unit of the part / 8) + (first list entry of its tile / PART_FROM), see there).
+#ifndef GSR_PART_FROM
+#define GSR_PART_FROM 1024
+#endif
+constexpr uint32_t PART_FROM = GSR_PART_FROM > GSR_LONG_LIST ? GSR_LONG_LIST : GSR_PART_FROM;
+static_assert(PART_FROM >= 512, "a part is one forward chunk");
+__host__ __device__ inline size_t part_capacity(int R, int U) { return (size_t)U / 8 + (size_t)R / PART_FROM + 2; }
+// A view splits only if its longest list would otherwise hold the kernel up (a pixel's walk is serial): the list has more than
+// SPLIT_FROM entries AND more than 1/256 of all the view's instances -- then its one workgroup is still walking when the chip's
+// 1 024 workgroup slots have finished everything else (config B: two 2 100-entry pole tiles of 368 k instances ran alone for
+// 60 us of a 114 us launch).  Config C's longest lists (1 300 - 2 060 of ~800 k) end with the chip still busy, and their tiles
+// are mostly OPAQUE: split, every part past a pixel's termination is wasted work and the terminating part is re-walked pixel by
+// pixel from memory (measured: +140 us per split view) -- such views are not split.  0xffffffff: nothing is split.
+// GSR_SPLIT_FROM overrides the first condition and drops the second (tests: 0 = every view with a list above PART_FROM).
+constexpr uint32_t SPLIT_FROM = 1792;
 inline uint32_t split_from()
 {
-    static const uint32_t from = getenv("GSR_SPLIT_FROM") ? (uint32_t)atoi(getenv("GSR_SPLIT_FROM")) : SPLIT_FROM;   // (tests: 0)
-    return from;
+    static const uint32_t from = getenv("GSR_SPLIT_FROM") ? ((uint32_t)atoi(getenv("GSR_SPLIT_FROM")) | 0x80000000u) : SPLIT_FROM;
+    return from;   // (bit 31: set by the environment -- the share-of-R condition is off)
 }
-__host__ __device__ inline uint32_t split_threshold_from(uint32_t max_count, uint32_t from)
+__host__ __device__ inline uint32_t split_threshold_from(uint32_t max_count, uint32_t R, uint32_t from)
 {
-    return max_count > from && max_count > LONG_LIST ? LONG_LIST : 0xffffffffu;
+    const bool forced = (from & 0x80000000u) != 0u;
+    from &= 0x7fffffffu;
+    const bool dominates = forced || (unsigned long long)max_count * 256ull > (unsigned long long)R;
+    return max_count > from && max_count > PART_FROM && dominates ? PART_FROM : 0xffffffffu;
 }
-inline uint32_t split_threshold(uint32_t max_count) { return split_threshold_from(max_count, split_from()); }
+inline uint32_t split_threshold(uint32_t max_count, uint32_t R) { return split_threshold_from(max_count, R, split_from()); }
 __host__ __device__ inline BinState carve_bin(void* base, int R, int U, int C = 3)
 {
     // (everything up to and including `masks` sits at offsets that do not depend on C: the debug exports carve with C = 3)
@@ -182,6 +198,7 @@ __host__ __device__ inline BinState carve_bin(void* base, int R, int U, int C = 
     s.masks = (uint2*)(b + o); o = align_up(o + sizeof(uint2) * 256 * (size_t)U);
     const size_t np = part_capacity(R, U);
     s.part_list = (uint2*)(b + o); o = align_up(o + sizeof(uint2) * np);
+    s.part_ticket = (uint32_t*)(b + o); o = align_up(o + 4 * np);
     s.part_last = (uint32_t*)(b + o); o = align_up(o + 4 * 256 * np);
     s.part_fin = (float4*)(b + o); o = align_up(o + sizeof(float4) * 256 * (size_t)snap_vecs(C) * np);
     s.snap = (float4*)(b + o); o = align_up(o + sizeof(float4) * 256 * (size_t)snap_vecs(C) * (size_t)U);
@@ -261,7 +278,7 @@ void launch_preprocess(int P, int D, int M, const float* means3D, const float* s
                        int H, float tan_fovx, float tan_fovy, int* radii, GeomState g, ImageState im, uint32_t view_token,
                        hipStream_t st);
 void launch_tile_scan(ImageState im, int T, uint32_t* host_totals, uint32_t host_seq, uint32_t view_token, hipStream_t st);
-void launch_scatter(int P, int W, int H, uint32_t max_count, GeomState g, ImageState im, BinState b, hipStream_t st);
+void launch_scatter(int P, int W, int H, int R, uint32_t max_count, GeomState g, ImageState im, BinState b, hipStream_t st);
 // the same launch before the host knows R, U and max_count (gsr_forward_fused): the kernel carves `binning_base` itself from
 // the totals the scan left, and does nothing if the carve would not fit `capacity` bytes
 void launch_scatter_early(int P, int W, int H, int C, GeomState g, ImageState im, void* binning_base, size_t capacity, hipStream_t st);

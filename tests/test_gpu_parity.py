@@ -385,11 +385,14 @@ print("LONG_PATH_OK")
 
 
 def test_lists_blended_in_parts():
-    """Lists above 2 048 entries in a view that splits (GSR_SPLIT_FROM=0 makes every such view split; by default only views
-    with a list above 4 096 entries do): the forward blends them in independent parts of one chunk and a combining
-    workgroup folds the parts together, pixels that may terminate inside a part walking their unit exactly
-    (gsr_blend_fwd.hip).  Translucent stacks (nobody terminates), opaque ones (everybody does, in different parts), and a
-    mix; 3 and 6 channels; against the oracle, and the no-grad forward must stay bit-identical to the differentiable one."""
+    """Lists above PART_FROM = 1 024 entries in a view that splits (GSR_SPLIT_FROM=0 makes every such view split; by default
+    only views with a list above 1 792 entries do): the forward blends them in independent parts of one chunk -- part
+    workers inside the blend's own launch -- and the part that finishes LAST (a ticket per tile, no waiting, no dispatch-order
+    assumption) folds the parts together, pixels that may terminate inside a part walking their unit exactly
+    (gsr_blend_fwd.hip).  Translucent stacks (nobody terminates), opaque ones (everybody does, in different parts), a mix, a
+    list above 16 384 entries (four merge passes of the pre-sort), and a view whose longest list stays below 2 048 (the
+    pre-sort writes the ids itself); against the oracle, and the no-grad forward must stay bit-identical to the
+    differentiable one."""
     import subprocess
     import sys
     code = r'''
@@ -399,7 +402,8 @@ sys.path.insert(0, os.path.join(os.getcwd(), "tests")); sys.path.insert(0, os.ge
 import parity
 from gaustar_amd import scene, GaussianRasterizationSettings, GaussianRasterizer
 for seed, opac, P, half in ((1, (0.004, 0.02), 9000, 0.12), (2, (0.3, 0.99), 9000, 0.12), (3, (0.01, 0.6), 12000, 0.12),
-                            (4, (0.004, 0.01), 20000, 0.02)):     # (the last: one list above 16 384 entries -- four merge passes)
+                            (4, (0.004, 0.01), 20000, 0.02),      # (one list above 16 384 entries -- four merge passes)
+                            (5, (0.01, 0.6), 1700, 0.12)):        # (longest list between 1 024 and 2 048: no merge pass at all)
     rng = np.random.default_rng(seed)
     gs = scene.random_gaussians(P, rng, scale_range=(0.02, 0.06), box=((-half, half), (-half, half), (-0.5, 0.5)))
     gs.opacities[:] = rng.uniform(*opac, (gs.P, 1)).astype(np.float32)
@@ -410,7 +414,7 @@ for seed, opac, P, half in ((1, (0.004, 0.02), 9000, 0.12), (2, (0.3, 0.99), 900
     dpix = rng.normal(size=(3, cam.H, cam.W)).astype(np.float32)
     st, g = parity.run_oracle(kw, dpix)
     longest = int((st["ranges"][:, 1] - st["ranges"][:, 0]).max())
-    assert longest > (16384 if seed == 4 else 2048 + 512), longest
+    assert (1024 + 256 < longest <= 2048) if seed == 5 else longest > (16384 if seed == 4 else 2048 + 512), longest
     hip = parity.run_hip(kw, dpix)
     parity.compare_hip_to(hip, st["color"], st["radii"], g, what="parts seed %d (longest list %d)" % (seed, longest))
     # no-grad forward == differentiable forward, bit for bit
