@@ -67,12 +67,12 @@ def test_scratch_sizes(hip_lib):
     assert 8 * 1920 * 1080 <= i <= 8 * 1920 * 1080 + (8 + 64 + 12) * 8160 + 8192   # ranges, 2x8 shard counters, order, seg_off, totals + view tokens
     assert hip_lib.gsr_grad_scratch_bytes(500_000) == 48 * 500_000 + 256
     # per instance: 8 B key + 4 B id + the forward's 36-byte record in list order (16 + 16 + 4); per unit: a 16-byte unit
-    # table entry + one 64-bit mask word and one snapshot per pixel of the tile; per PART of a list above 2 048 entries (at
-    # most U / 8 + R / 2048 + 2 of them): 8 B in the part list + 4 + 16 B per pixel of the tile
+    # table entry + one 64-bit mask word and one snapshot per pixel of the tile; per PART of a list above 1 024 entries (at
+    # most U / 8 + R / 1024 + 2 of them): 8 B in the part list + a 4-byte ticket + 4 + 16 B per pixel of the tile
     al = lambda x: (x + 255) & ~255
     def expect(R, U, sv=1, tail=4):
-        parts = U // 8 + R // 2048 + 2
-        return (al(8 * R) + al(4 * R) + 2 * al(16 * R) + al(16 * U) + al(8 * 256 * U) + al(8 * parts) + al(4 * 256 * parts)
+        parts = U // 8 + R // 1024 + 2
+        return (al(8 * R) + al(4 * R) + 2 * al(16 * R) + al(16 * U) + al(8 * 256 * U) + al(8 * parts) + al(4 * parts) + al(4 * 256 * parts)
                 + al(16 * sv * 256 * parts) + al(16 * sv * 256 * U) + al(tail * R) + 256)
     assert hip_lib.gsr_binning_bytes(1_000_000, 0) == expect(1_000_000, 0)
     assert hip_lib.gsr_binning_bytes(1_000_000, 1000) == expect(1_000_000, 1000)
