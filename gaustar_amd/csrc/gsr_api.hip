@@ -3,6 +3,7 @@
 // (DGR/cuda_rasterizer/rasterizer_impl.cu:141-153, :198-336, :340-434).
 #include "../../include/gsr.h"
 #include "gsr_internal.h"
+#include "gsr_plan.h"
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -23,6 +24,14 @@ namespace {
 thread_local std::string g_err;
 thread_local uint32_t g_pinned_seq = 0;
 thread_local uint32_t* g_pinned = nullptr;
+// words of the pad: [0..3] stage-1 totals, [4] their sequence number (tile_scan); [8] verdict of a planned preprocess, [9] its
+// sequence number
+constexpr int PAD_WORDS = 64, PAD_VERDICT = 8;
+// ints of a plan_info block (include/gsr.h): [0..4] = {state, R_cap, U_cap, max_cap, slack level}; [PI_HEADER .. +7] the header of
+// a plan as its builder wrote it, [PI_ARRIVED] the builder's sequence number (written behind the header), [PI_PENDING] the
+// sequence number the host expects there (0: no plan under way)
+constexpr int PI_HEADER = 8, PI_ARRIVED = 16, PI_PENDING = 17;
+static_assert(PI_PENDING < GSR_PLAN_INFO_INTS, "plan_info block");
 std::atomic<long long> g_wait_ns{0}, g_waits{0};   // gsr_debug_host_wait   // pinned, device-mapped landing pad for the stage-1 totals (written by tile_scan)
 
 // ---- optional per-kernel timing (gsr_profile_*): HIP events on the launch stream around every stage.
@@ -88,7 +97,7 @@ int fail_msg(const char* msg)
 
 extern "C" {
 
-int gsr_abi_version(void) { return 12; }
+int gsr_abi_version(void) { return 13; }
 
 const char* gsr_last_error(void) { return g_err.c_str(); }
 
@@ -101,6 +110,38 @@ size_t gsr_binning_bytes_mt(int R, int num_segments, int num_channels)
 }
 size_t gsr_binning_bytes(int R, int num_segments) { return gsr_binning_bytes_mt(R, num_segments, 3); }
 size_t gsr_grad_scratch_bytes(int P) { return (size_t)48 * (size_t)(P > 0 ? P : 0) + 256; }
+size_t gsr_plan_bytes(int W, int H) { return (W > 0 && H > 0) ? carve_plan(nullptr, W, H).bytes : 0; }
+
+// plan_info blocks: GSR_PLAN_INFO_INTS ints of pinned, device-mapped host memory each (the device writes a plan's header there),
+// cut from slabs -- a hipHostMalloc per camera would cost a tenth of a millisecond at every camera's first view.
+namespace {
+std::mutex g_pi_mu;
+std::vector<int*> g_pi_free;
+}
+int* gsr_plan_info_new(void)
+{
+    std::lock_guard<std::mutex> lk(g_pi_mu);
+    if (g_pi_free.empty()) {
+        constexpr int PER_SLAB = 512;
+        int* slab = nullptr;
+        if (hipHostMalloc((void**)&slab, sizeof(int) * GSR_PLAN_INFO_INTS * PER_SLAB,
+                          hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        for (int i = PER_SLAB - 1; i >= 0; i--) g_pi_free.push_back(slab + (size_t)i * GSR_PLAN_INFO_INTS);
+    }
+    int* p = g_pi_free.back();
+    g_pi_free.pop_back();
+    memset(p, 0, sizeof(int) * GSR_PLAN_INFO_INTS);
+    return p;
+}
+void gsr_plan_info_free(int* plan_info)
+{
+    if (!plan_info) return;
+    std::lock_guard<std::mutex> lk(g_pi_mu);
+    g_pi_free.push_back(plan_info);
+}
 
 namespace {
 // ---- self-cleaning tile counters (gsr_forward_fused only).  The per-(shard, tile) counters and scatter cursors must be
@@ -112,7 +153,14 @@ namespace {
 // `busy` makes a block exclusive to ONE call from acquire_counters() until its stage 2 has been launched (or the call
 // has bailed out): a second host thread rendering on the same stream meanwhile gets nullptr and falls back to the
 // counters in its own image buffer (one fill per view) instead of interleaving its preprocess with this call's scatter.
-struct Counters { uint32_t* base = nullptr; size_t words = 0; bool clean = false; std::atomic<bool> busy{false}; };
+struct Counters {
+    uint32_t* base = nullptr; size_t words = 0; bool clean = false; std::atomic<bool> busy{false};
+    // The block: [PLAN_SYNC_WORDS words of the planned forward (the flag of a view that outgrew its plan)] [tile counters /
+    // cursors of the current image size].  The sync words come FIRST: where they lie must not depend on the image size -- a
+    // flag left behind at a small image's offset would read as a tile count of a larger image's view.
+    uint32_t* sync() const { return base; }
+    uint32_t* cnt() const { return base ? base + PLAN_SYNC_WORDS : nullptr; }
+};
 std::mutex g_cnt_mu;
 std::map<std::pair<int, hipStream_t>, Counters> g_cnt;
 
@@ -151,21 +199,55 @@ Counters* acquire_counters(hipStream_t st, size_t words)
     return c;
 }
 
-int forward_stage1_impl(int P, int D, int M, const float* means3D, const float* shs, const float* colors_precomp,
-                        const float* opacities, const float* scales, float scale_modifier, const float* rotations,
-                        const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
-                        const float* campos, int W, int H, float tan_fovx, float tan_fovy, int prefiltered, int* radii,
-                        void* geom_buffer, void* image_buffer, int* num_rendered, int* max_tile_instances,
-                        int* num_segments, uint32_t* counters, gsr_stream_t stream, void* early_bin = nullptr,
-                        size_t early_capacity = 0, int early_C = 3)
+// Wait for a kernel's word in the pinned pad: normal waits are far below a millisecond and touch nothing but the pad.  The
+// stream is only consulted (did it finish or fault?) once a wait has lasted 2 ms, then every 2 ms: hipStreamQuery takes
+// runtime locks.  -> 0 and *seen = whether the word showed up (false: the stream retired without it), or an error code.
+int wait_pad_word(const volatile uint32_t* flag, uint32_t seq, hipStream_t st, bool* seen)
 {
-    (void)prefiltered;   // the reference only uses it to trap on a culled point (auxiliary.h:156-160)
-    g_err.clear();
-    if (!num_rendered || !max_tile_instances || !num_segments)
-        return fail_msg("gsr_forward_stage1: null output pointer");
-    *num_rendered = 0;
-    *max_tile_instances = 0;
-    *num_segments = 0;
+    const auto t_wait0 = std::chrono::steady_clock::now();
+    auto next_query = t_wait0 + std::chrono::milliseconds(2);
+    for (uint32_t polls = 1; *flag != seq; polls++) {
+        if ((polls & 1023u) == 0u && std::chrono::steady_clock::now() >= next_query) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) break;              // kernel retired: its stores are visible
+            if (q != hipErrorNotReady) GSR_CHECK(q);   // a fault surfaces here
+            next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+        }
+        __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    *seen = *flag == seq;
+    g_wait_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_wait0).count(),
+                        std::memory_order_relaxed);
+    g_waits.fetch_add(1, std::memory_order_relaxed);
+    return 0;
+}
+
+int ensure_pad()
+{
+    if (!g_pinned) {
+        GSR_CHECK(hipHostMalloc((void**)&g_pinned, 4 * PAD_WORDS, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
+        memset(g_pinned, 0, 4 * PAD_WORDS);
+    }
+    return 0;
+}
+uint32_t next_seq() { return ++g_pinned_seq ? g_pinned_seq : ++g_pinned_seq; }   // never 0 (the pad's initial value)
+uint32_t next_view_token()
+{
+    // Token of a view (never 0, unique in the process): a preprocess workgroup that cannot record all of its instances
+    // stores it in totals[4], the scan stores it in totals[5], and scatter walks the tiles again iff the two are equal.
+    // No word has to be cleared between views, and a stale or uninitialised totals[4] can only select the slower path.
+    static std::atomic<uint32_t> g_view_token{0};
+    uint32_t view_token = ++g_view_token;
+    if (view_token == 0) view_token = ++g_view_token;
+    return view_token;
+}
+
+int check_stage1_args(int P, int D, int M, const float* means3D, const float* shs, const float* colors_precomp,
+                      const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
+                      const float* viewmatrix, const float* projmatrix, const float* campos, int W, int H, const int* radii,
+                      const void* geom_buffer, const void* image_buffer)
+{
     if ((long long)tiles_of(W > 0 ? W : 1, H > 0 ? H : 1).T > 256ll * 1024)
         return fail_msg("gsr_forward_stage1: image too large (more than 262144 tiles)");
     if (W <= 0 || H <= 0) return fail_msg("gsr_forward_stage1: image size must be positive");
@@ -181,6 +263,27 @@ int forward_stage1_impl(int P, int D, int M, const float* means3D, const float* 
         if ((cov3D_precomp == nullptr) == (scales == nullptr || rotations == nullptr))
             return fail_msg("gsr_forward_stage1: provide exactly one of scales+rotations / cov3D_precomp");
     }
+    return 0;
+}
+
+int forward_stage1_impl(int P, int D, int M, const float* means3D, const float* shs, const float* colors_precomp,
+                        const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                        const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                        const float* campos, int W, int H, float tan_fovx, float tan_fovy, int prefiltered, int* radii,
+                        void* geom_buffer, void* image_buffer, int* num_rendered, int* max_tile_instances,
+                        int* num_segments, uint32_t* counters, gsr_stream_t stream, void* early_bin = nullptr,
+                        size_t early_capacity = 0, int early_C = 3)
+{
+    (void)prefiltered;   // the reference only uses it to trap on a culled point (auxiliary.h:156-160)
+    g_err.clear();
+    if (!num_rendered || !max_tile_instances || !num_segments)
+        return fail_msg("gsr_forward_stage1: null output pointer");
+    *num_rendered = 0;
+    *max_tile_instances = 0;
+    *num_segments = 0;
+    if (const int bad = check_stage1_args(P, D, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                          viewmatrix, projmatrix, campos, W, H, radii, geom_buffer, image_buffer))
+        return bad;
     hipStream_t st = (hipStream_t)stream;
     const Tiles t = tiles_of(W, H);
     ImageState im = carve_image(image_buffer, W, H);
@@ -192,12 +295,7 @@ int forward_stage1_impl(int P, int D, int M, const float* means3D, const float* 
         GSR_CHECK(hipMemsetAsync(im.tile_count, 0,
                                  (size_t)((char*)(im.tile_cursor + shard_stride(t.T) * NSHARD) - (char*)im.tile_count), st));
     }
-    // Token of this view (never 0, unique in the process): a preprocess workgroup that cannot record all of its instances
-    // stores it in totals[4], the scan stores it in totals[5], and scatter walks the tiles again iff the two are equal.
-    // No word has to be cleared between views, and a stale or uninitialised totals[4] can only select the slower path.
-    static std::atomic<uint32_t> g_view_token{0};
-    uint32_t view_token = ++g_view_token;
-    if (view_token == 0) view_token = ++g_view_token;
+    const uint32_t view_token = next_view_token();
     if (P > 0) {
         GeomState g = carve_geom(geom_buffer, P);
         {
@@ -212,12 +310,9 @@ int forward_stage1_impl(int P, int D, int M, const float* means3D, const float* 
     // sequence number into it.  The host polls the sequence word instead of blocking in hipStreamSynchronize (whose
     // interrupt wake-up costs tens of microseconds of idle GPU per view); every few thousand polls it asks the stream
     // whether it finished or faulted, so a failed kernel ends the wait with its error.  GSR_SYNC_SPIN=0 -> plain sync.
-    if (!g_pinned) {
-        GSR_CHECK(hipHostMalloc((void**)&g_pinned, 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
-        memset(g_pinned, 0, 64);
-    }
+    if (const int bad = ensure_pad()) return bad;
     static const bool spin = !(getenv("GSR_SYNC_SPIN") && atoi(getenv("GSR_SYNC_SPIN")) == 0);
-    const uint32_t seq = ++g_pinned_seq ? g_pinned_seq : ++g_pinned_seq;   // never 0 (the pad's initial value)
+    const uint32_t seq = next_seq();
     {
         Scope sc(ST_TILE_SCAN, st);
         launch_tile_scan(im, t.T, g_pinned, seq, view_token, st);
@@ -232,23 +327,10 @@ int forward_stage1_impl(int P, int D, int M, const float* means3D, const float* 
         }
         GSR_CHECK_LAUNCH("scatter_kernel");
     }
-    const auto t_wait0 = std::chrono::steady_clock::now();
     if (spin) {
-        // Normal waits are far below a millisecond and touch nothing but the pad.  The stream is only consulted (did it
-        // finish or fault?) once a wait has lasted 2 ms, then every 2 ms: hipStreamQuery takes runtime locks.
-        const volatile uint32_t* flag = g_pinned + 4;
-        auto next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
-        for (uint32_t polls = 1; *flag != seq; polls++) {
-            if ((polls & 1023u) == 0u && std::chrono::steady_clock::now() >= next_query) {
-                const hipError_t q = hipStreamQuery(st);
-                if (q == hipSuccess) break;              // kernel retired: its stores are visible
-                if (q != hipErrorNotReady) GSR_CHECK(q);   // a fault surfaces here
-                next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
-            }
-            __builtin_ia32_pause();
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
-        if (*flag != seq) {
+        bool seen = false;
+        if (const int bad = wait_pad_word(g_pinned + 4, seq, st, &seen)) return bad;
+        if (!seen) {
             // The stream reports the kernel retired but its store into the pad has not shown up: never observed, but a
             // platform where device stores to mapped host memory are not coherent must not yield stale totals -- fetch
             // them with an ordinary copy.
@@ -258,9 +340,6 @@ int forward_stage1_impl(int P, int D, int M, const float* means3D, const float* 
     } else {
         GSR_CHECK(hipStreamSynchronize(st));   // the forward's single host sync (cf. rasterizer_impl.cu:281)
     }
-    g_wait_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_wait0).count(),
-                        std::memory_order_relaxed);
-    g_waits.fetch_add(1, std::memory_order_relaxed);
     *num_rendered = (int)g_pinned[0];
     *max_tile_instances = (int)g_pinned[1];
     *num_segments = (int)g_pinned[3];
@@ -292,8 +371,177 @@ namespace {
 int forward_stage2_impl(int P, int R, int max_tile_instances, int num_segments, int num_channels, int W, int H,
                         const float* background, const float* colors_precomp, void* geom_buffer, void* binning_buffer,
                         void* image_buffer, float* out_color, void* grad_scratch, uint32_t* counters, gsr_stream_t stream,
-                        bool scattered);
+                        bool scattered, const PlanJob* job = nullptr, bool* job_rides = nullptr);
 }
+
+namespace {
+// One planned attempt (gsr_internal.h "planned binning"): preprocess claims bucket slots and writes the keys, the forward blend
+// is queued right behind it, and the host waits for preprocess's verdict only.  *fit = 0: the view did not fit the plan --
+// nothing was blended, the library's counter block is clean again once the queued blend has passed, and the caller takes the
+// exact path.
+int forward_planned_attempt(int P, int D, int M, int C, int need_backward, const float* means3D, const float* shs,
+                            const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                            const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                            const float* projmatrix, const float* campos, int W, int H, float tan_fovx, float tan_fovy,
+                            const float* background, int* radii, void* geom_buffer, void* image_buffer, void* binning_buffer,
+                            void* grad_scratch, float* out_color, void* plan_buffer, const int* plan_info, uint32_t* cursors,
+                            uint32_t* sync_words, hipStream_t st, int* fit)
+{
+    *fit = 0;
+    g_err.clear();
+    if (const int bad = check_stage1_args(P, D, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                          viewmatrix, projmatrix, campos, W, H, radii, geom_buffer, image_buffer))
+        return bad;
+    if (!background || !out_color) return fail_msg("gsr_forward_stage2: required pointer is null");
+    if (C != 3 && !colors_precomp)
+        return fail_msg("gsr_forward_stage2: multi-target renders need precomputed colours [P, num_channels]");
+    if (const int bad = ensure_pad()) return bad;
+    const Tiles t = tiles_of(W, H);
+    ImageState im = carve_image(image_buffer, W, H);
+    GeomState g = carve_geom(geom_buffer, P);
+    BinState b = carve_bin(binning_buffer, plan_info[1], plan_info[2], C);
+    const PlanState pl = carve_plan(plan_buffer, W, H);
+    PlanRun run;
+    run.ranges = pl.ranges; run.seg_off = pl.seg_off; run.order = pl.order;
+    run.cursor = cursors; run.sync = sync_words;
+    run.keys = b.keys; run.unit_info = b.unit_info; run.im_ranges = im.ranges; run.im_seg_off = im.seg_off;
+    run.host_pad = g_pinned + PAD_VERDICT; run.host_seq = next_seq(); run.token = next_view_token();
+    (void)t;
+    {
+        Scope sc(ST_PREPROCESS, st);
+        launch_preprocess_planned(P, D, M, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                                  cov3D_precomp, viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, radii, g, im, run, st);
+    }
+    GSR_CHECK_LAUNCH("preprocess_kernel");
+    const float* feats = colors_precomp ? colors_precomp : g.rgb;
+    {
+        Scope sc(ST_BLEND_FWD, st);
+        launch_blend_fwd_planned(C, W, H, background, feats, g, im, b, out_color, need_backward != 0,
+                                 need_backward ? grad_scratch : nullptr,
+                                 need_backward && grad_scratch ? gsr_grad_scratch_bytes(P) : 0, run, st);
+    }
+    GSR_CHECK_LAUNCH("blend_fwd_kernel");
+    bool seen = false;
+    if (const int bad = wait_pad_word(g_pinned + PAD_VERDICT + 1, run.host_seq, st, &seen)) return bad;
+    if (!seen) {   // (see forward_stage1_impl: never observed; the stream has retired, so a plain read-back is final)
+        uint32_t flag = 0;
+        GSR_CHECK(hipMemcpyAsync(&flag, run.sync + 9 * PLAN_SYNC_STRIDE, 4, hipMemcpyDeviceToHost, st));
+        GSR_CHECK(hipStreamSynchronize(st));
+        *fit = flag != run.token;
+        return 0;
+    }
+    *fit = g_pinned[PAD_VERDICT] == 1u;
+    return 0;
+}
+
+int forward_fused_impl(int P, int D, int M, int num_channels, int need_backward, const float* means3D, const float* shs,
+                       const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                       const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                       const float* projmatrix, const float* campos, int W, int H, float tan_fovx, float tan_fovy,
+                       int prefiltered, const float* background, int* radii, void* geom_buffer, void* image_buffer,
+                       void* binning_buffer, size_t binning_capacity, void* grad_scratch, float* out_color,
+                       int* num_rendered, int* max_tile_instances, int* num_segments, int* blended, void* plan_buffer,
+                       int* plan_info, int* planned, gsr_stream_t stream)
+{
+    if (!blended) { g_err.clear(); return fail_msg("gsr_forward_fused: null output pointer"); }
+    *blended = 0;
+    if (planned) *planned = 0;
+    if (!channels_ok(num_channels)) { g_err.clear(); return fail_msg("gsr_forward_fused: num_channels must be 3, 4 or 6"); }
+    hipStream_t st = (hipStream_t)stream;
+    const bool sane = W > 0 && H > 0 && (long long)tiles_of(W > 0 ? W : 1, H > 0 ? H : 1).T <= 256ll * 1024 && image_buffer && P > 0;
+    const size_t cnt_words = sane ? 2 * (size_t)shard_stride(tiles_of(W, H).T) * NSHARD : 0;
+    Counters* own = sane ? acquire_counters(st, cnt_words + PLAN_SYNC_WORDS) : nullptr;
+    CountersLease lease{own};
+    const bool keeps_plan = plan_buffer != nullptr && plan_info != nullptr && sane;
+    if (keeps_plan && plan_info[PI_PENDING] != 0) {
+        // The plan an earlier view of this camera left behind: its header arrives in the caller's pinned words [PI_HEADER ..]
+        // some tens of microseconds into that view's forward blend; nobody waited for it then.  Normally it is long there.
+        bool seen = false;
+        if (const int bad = wait_pad_word(reinterpret_cast<volatile uint32_t*>(plan_info) + PI_ARRIVED, (uint32_t)plan_info[PI_PENDING],
+                                          st, &seen))
+            return bad;
+        const uint32_t* h = reinterpret_cast<const uint32_t*>(plan_info) + PI_HEADER;
+        plan_info[0] = seen ? (h[0] == 1u ? 1 : -1) : 0;
+        if (seen) { plan_info[1] = (int)h[2]; plan_info[2] = (int)h[3]; plan_info[3] = (int)h[4]; }
+        plan_info[PI_PENDING] = 0;
+    }
+    if (keeps_plan && own && plan_info[0] == 1 && plan_info[1] > 0 && plan_info[2] > 0 && binning_buffer &&
+        num_rendered && max_tile_instances && num_segments && (split_from() & 0x80000000u) == 0u &&
+        gsr_binning_bytes_mt(plan_info[1], plan_info[2], num_channels) <= binning_capacity) {
+        int fit = 0;
+        const int rc = forward_planned_attempt(P, D, M, num_channels, need_backward, means3D, shs, colors_precomp, opacities, scales,
+                                               scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, W, H,
+                                               tan_fovx, tan_fovy, background, radii, geom_buffer, image_buffer, binning_buffer,
+                                               grad_scratch, out_color, plan_buffer, plan_info, own->cnt(), own->sync(), st, &fit);
+        if (rc != 0) return rc;
+        if (fit) {
+            *num_rendered = plan_info[1];
+            *num_segments = plan_info[2];
+            *max_tile_instances = plan_info[3];
+            *blended = 1;
+            *planned = planned ? 1 : 0;
+            own->clean = true;   // every tile's workgroup of the forward blend hands its cursor back zeroed
+            return 0;
+        }
+        // the view outgrew its plan: the exact path below renders it (the queued blend leaves the block clean) and re-plans, with
+        // twice the slack
+        plan_info[0] = 0;
+        plan_info[4] = plan_info[4] < 3 ? (plan_info[4] < 0 ? 0 : plan_info[4]) + 1 : 3;
+        if (planned) *planned = -1;
+    }
+    static const bool early_ok = !(getenv("GSR_EARLY_SCATTER") && atoi(getenv("GSR_EARLY_SCATTER")) == 0);
+    const bool early = early_ok && sane && binning_buffer != nullptr && binning_capacity > 0;
+    const int rc = forward_stage1_impl(P, D, M, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                                       cov3D_precomp, viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, prefiltered,
+                                       radii, geom_buffer, image_buffer, num_rendered, max_tile_instances, num_segments,
+                                       own ? own->cnt() : nullptr, stream, early ? binning_buffer : nullptr, binning_capacity,
+                                       num_channels);
+    if (rc != 0) return rc;   // (own stays marked dirty: re-filled on its next use)
+    // The plan this view leaves behind is built by one extra workgroup of its forward blend (gsr_plan.h).  Nobody waits for
+    // it: the header lands in the caller's pinned plan_info words and is adopted by the next call with this plan (above).
+    // Not built when a plan exists (plan_info[0] == 1 was handled above; a misfit has reset it to 0), when the camera is known
+    // to be unplannable (-1: the caller asks again by resetting it to 0), when this view's longest list cannot be planned, or
+    // when stage 2 is left to the caller.
+    PlanJob job{};
+    bool job_rides = false;
+    if (keeps_plan && plan_info[0] == 0) {
+        if ((uint32_t)*max_tile_instances + 16u > PLAN_MAX_LIST) {
+            plan_info[0] = -1;
+        } else if (*num_rendered > 0) {
+            const Tiles t = tiles_of(W, H);
+            const PlanState pl = carve_plan(plan_buffer, W, H);
+            job.enabled = 1u; job.T = t.T; job.gx = t.gx; job.gy = t.gy;
+            job.header = pl.header; job.ranges = pl.ranges; job.seg_off = pl.seg_off; job.order = pl.order;
+            job.split_from_word = split_from();
+            job.level = (uint32_t)(plan_info[4] < 0 ? 0 : plan_info[4] > 3 ? 3 : plan_info[4]);
+            job.host_pad = reinterpret_cast<uint32_t*>(plan_info) + PI_HEADER; job.host_seq = next_seq();
+        }
+    }
+    if (gsr_binning_bytes_mt(*num_rendered, *num_segments, num_channels) > binning_capacity || (*num_rendered > 0 && !binning_buffer)) {
+        // the guess was too small: the caller allocates exactly and runs stage 2 itself -- over the image buffer's own
+        // counters, so they get this call's counts (cursors are still zero) and the library's block is filled again
+        if (own) {
+            ImageState im = carve_image(image_buffer, W, H);
+            GSR_CHECK(hipMemcpyAsync(im.tile_count, own->cnt(), 4 * cnt_words / 2, hipMemcpyDeviceToDevice, st));
+            GSR_CHECK(hipMemsetAsync(im.tile_cursor, 0, 4 * cnt_words / 2, st));
+            GSR_CHECK(hipMemsetAsync(own->cnt(), 0, 4 * cnt_words / 2, st));
+            own->clean = true;
+        }
+        return 0;
+    }
+    const int rc2 = forward_stage2_impl(P, *num_rendered, *max_tile_instances, need_backward ? *num_segments : -*num_segments,
+                                        num_channels, W, H, background, colors_precomp, geom_buffer, binning_buffer,
+                                        image_buffer, out_color, need_backward ? grad_scratch : nullptr,
+                                        own ? own->cnt() : nullptr, stream, early, job.enabled ? &job : nullptr, &job_rides);
+    if (rc2 == 0) {
+        *blended = 1;
+        if (own) own->clean = true;   // the forward blend zeroes every tile's counters and cursors
+    }
+    if (rc2 != 0) return rc2;
+    if (job_rides) plan_info[PI_PENDING] = (int)job.host_seq;
+    return 0;
+}
+}  // namespace
 
 int gsr_forward_fused(int P, int D, int M, int num_channels, int need_backward, const float* means3D, const float* shs,
                       const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
@@ -303,43 +551,27 @@ int gsr_forward_fused(int P, int D, int M, int num_channels, int need_backward, 
                       void* binning_buffer, size_t binning_capacity, void* grad_scratch, float* out_color,
                       int* num_rendered, int* max_tile_instances, int* num_segments, int* blended, gsr_stream_t stream)
 {
-    if (!blended) { g_err.clear(); return fail_msg("gsr_forward_fused: null output pointer"); }
-    *blended = 0;
-    if (!channels_ok(num_channels)) { g_err.clear(); return fail_msg("gsr_forward_fused: num_channels must be 3, 4 or 6"); }
-    hipStream_t st = (hipStream_t)stream;
-    const bool sane = W > 0 && H > 0 && (long long)tiles_of(W > 0 ? W : 1, H > 0 ? H : 1).T <= 256ll * 1024 && image_buffer && P > 0;
-    const size_t cnt_words = sane ? 2 * (size_t)shard_stride(tiles_of(W, H).T) * NSHARD : 0;
-    Counters* own = sane ? acquire_counters(st, cnt_words) : nullptr;
-    CountersLease lease{own};
-    static const bool early_ok = !(getenv("GSR_EARLY_SCATTER") && atoi(getenv("GSR_EARLY_SCATTER")) == 0);
-    const bool early = early_ok && sane && binning_buffer != nullptr && binning_capacity > 0;
-    const int rc = forward_stage1_impl(P, D, M, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
-                                       cov3D_precomp, viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, prefiltered,
-                                       radii, geom_buffer, image_buffer, num_rendered, max_tile_instances, num_segments,
-                                       own ? own->base : nullptr, stream, early ? binning_buffer : nullptr, binning_capacity,
-                                       num_channels);
-    if (rc != 0) return rc;   // (own stays marked dirty: re-filled on its next use)
-    if (gsr_binning_bytes_mt(*num_rendered, *num_segments, num_channels) > binning_capacity || (*num_rendered > 0 && !binning_buffer)) {
-        // the guess was too small: the caller allocates exactly and runs stage 2 itself -- over the image buffer's own
-        // counters, so they get this call's counts (cursors are still zero) and the library's block is filled again
-        if (own) {
-            ImageState im = carve_image(image_buffer, W, H);
-            GSR_CHECK(hipMemcpyAsync(im.tile_count, own->base, 4 * cnt_words / 2, hipMemcpyDeviceToDevice, st));
-            GSR_CHECK(hipMemsetAsync(im.tile_cursor, 0, 4 * cnt_words / 2, st));
-            GSR_CHECK(hipMemsetAsync(own->base, 0, 4 * cnt_words / 2, st));
-            own->clean = true;
-        }
-        return 0;
-    }
-    const int rc2 = forward_stage2_impl(P, *num_rendered, *max_tile_instances, need_backward ? *num_segments : -*num_segments,
-                                        num_channels, W, H, background, colors_precomp, geom_buffer, binning_buffer,
-                                        image_buffer, out_color, need_backward ? grad_scratch : nullptr,
-                                        own ? own->base : nullptr, stream, early);
-    if (rc2 == 0) {
-        *blended = 1;
-        if (own) own->clean = true;   // the forward blend zeroes every tile's counters and cursors
-    }
-    return rc2;
+    return forward_fused_impl(P, D, M, num_channels, need_backward, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+                              rotations, cov3D_precomp, viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, prefiltered,
+                              background, radii, geom_buffer, image_buffer, binning_buffer, binning_capacity, grad_scratch,
+                              out_color, num_rendered, max_tile_instances, num_segments, blended, nullptr, nullptr, nullptr, stream);
+}
+
+int gsr_forward_planned(int P, int D, int M, int num_channels, int need_backward, const float* means3D, const float* shs,
+                        const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                        const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                        const float* projmatrix, const float* campos, int W, int H, float tan_fovx, float tan_fovy,
+                        int prefiltered, const float* background, int* radii, void* geom_buffer, void* image_buffer,
+                        void* binning_buffer, size_t binning_capacity, void* grad_scratch, float* out_color,
+                        int* num_rendered, int* max_tile_instances, int* num_segments, int* blended, void* plan_buffer,
+                        int* plan_info, int* planned, gsr_stream_t stream)
+{
+    if (!plan_buffer || !plan_info || !planned) { g_err.clear(); return fail_msg("gsr_forward_planned: null plan pointer"); }
+    return forward_fused_impl(P, D, M, num_channels, need_backward, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+                              rotations, cov3D_precomp, viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, prefiltered,
+                              background, radii, geom_buffer, image_buffer, binning_buffer, binning_capacity, grad_scratch,
+                              out_color, num_rendered, max_tile_instances, num_segments, blended, plan_buffer, plan_info, planned,
+                              stream);
 }
 
 int gsr_forward_stage2(int P, int R, int max_tile_instances, int num_segments, int W, int H, const float* background,
@@ -355,7 +587,7 @@ namespace {
 int forward_stage2_impl(int P, int R, int max_tile_instances, int num_segments, int num_channels, int W, int H,
                         const float* background, const float* colors_precomp, void* geom_buffer, void* binning_buffer,
                         void* image_buffer, float* out_color, void* grad_scratch, uint32_t* counters, gsr_stream_t stream,
-                        bool scattered)
+                        bool scattered, const PlanJob* job, bool* job_rides)
 {
     g_err.clear();
     if (W <= 0 || H <= 0) return fail_msg("gsr_forward_stage2: image size must be positive");
@@ -401,7 +633,7 @@ int forward_stage2_impl(int P, int R, int max_tile_instances, int num_segments, 
         Scope sc(ST_BLEND_FWD, st);
         launch_blend_fwd(C, W, H, R > 0 ? R : 0, num_segments, (uint32_t)(max_tile_instances > 0 ? max_tile_instances : 0), background, feats, g, im, b,
                          out_color, !forward_only, grad_scratch,
-                         grad_scratch ? gsr_grad_scratch_bytes(P > 0 ? P : 0) : 0, counters, sort_in_blend, st);
+                         grad_scratch ? gsr_grad_scratch_bytes(P > 0 ? P : 0) : 0, counters, sort_in_blend, st, job, job_rides);
     }
     GSR_CHECK_LAUNCH("blend_fwd_kernel");
     return 0;

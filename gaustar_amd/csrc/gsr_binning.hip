@@ -9,49 +9,13 @@
 // STABLE radix sort yields because duplicateWithKeys emits instances in id order.
 #include "gsr_internal.h"
 #include "gsr_sort.h"
+#include "gsr_plan.h"
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
 
 namespace gsr {
 
-// ---- wave64 inclusive scan (sum) on the DPP network: three row shifts of the input, two masked row shifts, two row
-// broadcasts -- seven fused adds.  (As a ladder of six __shfl_up steps it was six dependent ds_bpermute round trips per
-// scan; the kernel is ONE workgroup, so its time is the sum of such chains: tile_scan's "two wave scans + barrier" phase
-// took 2.8 us of the kernel's 11.4, phase stamps of a GSR_SCAN_TRACE build.)
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x, int /*lane*/)
-{
-    const auto dpp = [](uint32_t v, auto ctrl, auto row_mask, auto bank_mask) {
-        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, decltype(row_mask)::value,
-                                                     decltype(bank_mask)::value, true);   // lanes without a source add 0
-    };
-    using std::integral_constant;
-    uint32_t v = x + dpp(x, integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{});   // row_shr:1
-    v += dpp(x, integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{});               // row_shr:2
-    v += dpp(x, integral_constant<int, 0x113>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{});               // row_shr:3
-    v += dpp(v, integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xe>{});               // row_shr:4
-    v += dpp(v, integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xc>{});               // row_shr:8
-    v += dpp(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{}, integral_constant<int, 0xf>{});               // row_bcast:15
-    v += dpp(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{}, integral_constant<int, 0xf>{});               // row_bcast:31
-    return v;
-}
-// max over the wave, complete in lane 63 (same ladder; counts are unsigned, so a missing source contributes 0)
-__device__ __forceinline__ uint32_t wave_max_to_lane63(uint32_t x)
-{
-    const auto dpp = [](uint32_t v, auto ctrl, auto row_mask, auto bank_mask) {
-        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, decltype(row_mask)::value,
-                                                     decltype(bank_mask)::value, true);
-    };
-    using std::integral_constant;
-    uint32_t v = max(x, dpp(x, integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{}));
-    v = max(v, dpp(x, integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{}));
-    v = max(v, dpp(x, integral_constant<int, 0x113>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{}));
-    v = max(v, dpp(v, integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xe>{}));
-    v = max(v, dpp(v, integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xc>{}));
-    v = max(v, dpp(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{}, integral_constant<int, 0xf>{}));
-    v = max(v, dpp(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{}, integral_constant<int, 0xf>{}));
-    return v;
-}
 // Barrier of the scan kernel: LDS traffic only.  __syncthreads() also waits for the global stores in flight (ranges,
 // segment offsets, totals, the pinned host pad) -- a store's full latency, 2 - 3 us, at each of the kernel's barriers, although
 // nothing in the kernel ever reads those back.

@@ -102,6 +102,7 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     const int n = (int)info.z;
     const uint32_t unit0 = info.w;
     const int s0 = (int)(unit - unit0) * 64;           // this unit covers list positions [s0, s1)
+    if (s0 >= n) return;   // (a planned view numbers its units by bucket CAPACITY: this one lies past the list's end)
     const int wave = (int)wave_sel, lane = threadIdx.x;
     const int tx = tile % gx, ty = tile / gx;
     const int sx = tx * TILE + (wave & 1) * SUB, sy = ty * TILE + (wave >> 1) * SUB;

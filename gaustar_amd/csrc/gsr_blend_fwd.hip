@@ -34,6 +34,7 @@
 #include "gsr_internal.h"
 #include "gsr_mask.h"
 #include "gsr_sort.h"
+#include "gsr_plan.h"
 #include <cstdlib>
 
 namespace gsr {
@@ -53,7 +54,13 @@ namespace gsr {
 // A part is folded in like that only for pixels that cannot have terminated inside it -- the product of ALL its (1 - alpha)
 // keeps T above 1e-4 (then every prefix does) and the part itself did not stop -- the others walk that one chunk again
 // with their true state, exactly as a short list would (a pixel terminates once, so at most one chunk per pixel).
-template <int C, int CH, int MODE>
+// PLANNED (MODE 0 only; gsr_internal.h "planned binning"): `ranges` / `order` / `seg_off` are the PLAN's -- {first entry,
+// capacity} of the tile's bucket, the plan's launch order, the bucket's first unit --, the list's length is what preprocess
+// claimed on the tile's cursor, and the list is always sorted here (a planned bucket holds at most 2 048 entries).  The tile's
+// workgroup also writes the backward's unit table for ALL units of the bucket (a unit past the list's end is an empty work
+// item there), leaves {first, first + count} in the image state like the exact path's scan, and hands the cursor back zeroed.
+// A view that did not fit its plan (flag word == this view's token) is left alone: the host renders it the exact way.
+template <int C, int CH, int MODE, bool PLANNED = false>
 __global__ void __launch_bounds__(256)
 blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ order,
                  uint32_t* point_list, const uint64_t* __restrict__ sort_keys, const float4* __restrict__ g0,
@@ -65,12 +72,17 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
                  float4* __restrict__ part_fin, uint32_t* __restrict__ part_last, uint32_t* __restrict__ part_ticket,
                  uint32_t part_grid, bool parts_sort, uint32_t split_n, bool keep,
                  float4* __restrict__ zero_ptr,
-                 uint32_t zero_n, uint32_t* __restrict__ counters, uint32_t counters_tp, uint64_t* __restrict__ trace)
+                 uint32_t zero_n, uint32_t* __restrict__ counters, uint32_t counters_tp, uint64_t* __restrict__ trace,
+                 PlanRun plan, PlanJob job)
 {
+    static_assert(!PLANNED || MODE == 0, "planned views are never split");
     const uint64_t t_start = trace ? wall_clock64() : 0;
     // (MODE 2) the first part_grid workgroups are part workers, the others the tiles in launch order
     const bool is_part = MODE == 1 || (MODE == 2 && blockIdx.x < part_grid);
-    const uint32_t tile_block = MODE == 2 ? blockIdx.x - part_grid : blockIdx.x;
+    // (MODE 0, exact path, the caller keeps a plan for this camera: workgroup 0 -- dispatched first -- builds the plan of the
+    // camera's next view instead of blending a tile, gsr_plan.h; the tiles follow from workgroup 1 on)
+    const bool has_job = MODE == 0 && !PLANNED && job.enabled != 0u;
+    const uint32_t tile_block = MODE == 2 ? blockIdx.x - part_grid : blockIdx.x - (has_job ? 1u : 0u);
     // Side job: the backward's accumulation table (48 B per Gaussian) has to be zero before blend_bwd runs.  When the
     // caller hands it over at forward time every workgroup clears its slice here instead of a separate fill (a 5 us blit
     // plus its dispatch) in front of the backward.
@@ -93,6 +105,13 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     float4* const gb = ga + CH;
     RecTail<C>* const gc = reinterpret_cast<RecTail<C>*>(smem + 32 * CH);
     uint32_t (*mk)[NH][64] = reinterpret_cast<uint32_t(*)[NH][64]>(smem + REC_BYTES);
+    if constexpr (MODE == 0 && !PLANNED) {
+        static_assert(LDS_BYTES >= 4 * PLAN_LDS_T, "the plan job stages the tile counts in the kernel's LDS");
+        if (has_job && blockIdx.x == 0) {
+            plan_build_block<256>(job, ranges, order, reinterpret_cast<uint32_t*>(smem));
+            return;
+        }
+    }
     if (is_part && blockIdx.x >= totals[6]) return;   // parts of this view (scatter_kernel lists them)
     uint32_t part_c0 = 0;
     int tile;
@@ -119,8 +138,27 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     // (wave-uniform values are pinned to scalar registers: the per-chunk bookkeeping below then runs on the scalar unit)
     const uint2 rg = ranges[tile];
     const uint32_t list0 = __builtin_amdgcn_readfirstlane(rg.x);
-    const uint32_t n = __builtin_amdgcn_readfirstlane(rg.y - rg.x);
+    uint32_t n_ = rg.y - rg.x;
+    if constexpr (PLANNED) {
+        uint32_t* const cur = plan.cursor + (size_t)tile * PLAN_CURSOR_STRIDE;
+        const bool misfit = plan.sync[9 * PLAN_SYNC_STRIDE] == plan.token;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            // the verdict on the view, for the host (which waits for nothing else): first thing the first workgroup does
+            plan.host_pad[0] = misfit ? 2u : 1u;
+            __hip_atomic_store(&plan.host_pad[1], plan.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        n_ = *cur;
+        __syncthreads();                          // every wave has read the count
+        if (threadIdx.x == 0 && n_ != 0u) *cur = 0u;
+        if (misfit) return;
+    }
+    const uint32_t n = __builtin_amdgcn_readfirstlane(n_);
     const uint32_t unit0 = __builtin_amdgcn_readfirstlane(seg_off[tile]);
+    if constexpr (PLANNED) {
+        if (threadIdx.x == 0) { plan.im_ranges[tile] = make_uint2(list0, list0 + n); plan.im_seg_off[tile] = unit0; }
+        if (keep)
+            for (uint32_t u = threadIdx.x; u < (rg.y >> 6); u += 256u) plan.unit_info[unit0 + u] = make_uint4((uint32_t)tile, list0, n, unit0);
+    }
     const bool long_list = n > split_n;   // (wave-uniform) blended in parts: split_n = PART_FROM in views that split at all
     if (MODE == 2 && !is_part && long_list) return;   // its parts do everything, the last of them the combine
     // Depth sort of this tile's list, right here (lists up to 2 048 entries; longer ones were sorted by tile_sort_big_kernel
@@ -564,7 +602,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
 template <int C>
 static void launch_fwd_c(int W, int H, int R, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im,
                          BinState b, float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, uint32_t* counters,
-                         bool sort_small, hipStream_t st)
+                         bool sort_small, const PlanJob* job, hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);
     // (lists above 2 048 entries were sorted by the big-sort kernels before: launch_tile_sort; scatter_kernel listed the parts)
@@ -579,7 +617,7 @@ static void launch_fwd_c(int W, int H, int R, int U, uint32_t max_count, const f
             im.final_T, im.n_contrib, im.seg_off, b.masks, b.snap, b.rec_a, b.rec_b, static_cast<RecTail<C>*>(b.rec_c), b.part_list,
             im.totals, b.part_fin, b.part_last, b.part_ticket, part_grid, max_count <= SORT_SMALL_CAP, split_n, keep_masks,
             M != 1 ? static_cast<float4*>(zero_ptr) : nullptr, M != 1 ? (uint32_t)(zero_bytes / 16) : 0u, M != 1 ? counters : nullptr,
-            (uint32_t)shard_stride(t.T), M != 1 ? g_trace : nullptr);
+            (uint32_t)shard_stride(t.T), M != 1 ? g_trace : nullptr, PlanRun{}, M == 0 && job ? *job : PlanJob{});
     };
     // (scatter_kernel listed the parts; lists above 2 048 entries were sorted by launch_tile_sort, shorter ones sort themselves)
     if (split_n != 0xffffffffu && U > 0 && !two_launches) {
@@ -587,17 +625,44 @@ static void launch_fwd_c(int W, int H, int R, int U, uint32_t max_count, const f
         go(std::integral_constant<int, 2>{}, np + (unsigned)t.T, np);
     } else {
         if (split_n != 0xffffffffu && U > 0) go(std::integral_constant<int, 1>{}, (unsigned)part_capacity(R, U), 0u);
-        go(std::integral_constant<int, 0>{}, (unsigned)t.T, 0u);
+        if (split_n != 0xffffffffu && U > 0) job = nullptr;   // (the parts ran as a launch of their own: no plan for such a view)
+        go(std::integral_constant<int, 0>{}, (unsigned)t.T + (job && job->enabled ? 1u : 0u), 0u);
     }
 }
 
+template <int C>
+static void launch_fwd_planned_c(int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
+                                 float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, PlanRun plan, hipStream_t st)
+{
+    const Tiles t = tiles_of(W, H);
+    static const int pad = getenv("GSR_FWD_LDS_PAD") ? atoi(getenv("GSR_FWD_LDS_PAD")) : 0;
+    blend_fwd_kernel<C, FWD_CHUNK, 0, true><<<(unsigned)t.T, 256, pad, st>>>(
+        W, H, t.gx, plan.ranges, plan.order, b.point_list, b.keys, g.g0, g.g1, feats, bg, out_color, im.final_T, im.n_contrib,
+        plan.seg_off, b.masks, b.snap, b.rec_a, b.rec_b, static_cast<RecTail<C>*>(b.rec_c), b.part_list, im.totals, b.part_fin,
+        b.part_last, b.part_ticket, 0u, false, 0xffffffffu, keep_masks, static_cast<float4*>(zero_ptr), (uint32_t)(zero_bytes / 16),
+        nullptr, 0u, g_trace, plan, PlanJob{});
+}
+
+void launch_blend_fwd_planned(int C, int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
+                              float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, PlanRun plan, hipStream_t st)
+{
+    if (C == 6) launch_fwd_planned_c<6>(W, H, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, plan, st);
+    else if (C == 4) launch_fwd_planned_c<4>(W, H, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, plan, st);
+    else launch_fwd_planned_c<3>(W, H, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, plan, st);
+}
+
+// job (may be null): the plan of the camera's next view, built by one extra workgroup of a MODE 0 launch -- *job_rides says
+// whether this view's launch carried it (a view that splits its long lists does not: such a view is not plannable anyway)
 void launch_blend_fwd(int C, int W, int H, int R, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im,
                       BinState b, float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, uint32_t* counters,
-                      bool sort_small, hipStream_t st)
+                      bool sort_small, hipStream_t st, const PlanJob* job, bool* job_rides)
 {
-    if (C == 6) launch_fwd_c<6>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, sort_small, st);
-    else if (C == 4) launch_fwd_c<4>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, sort_small, st);
-    else launch_fwd_c<3>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, sort_small, st);
+    const bool splits = split_threshold(max_count, (uint32_t)(R > 0 ? R : 0)) != 0xffffffffu && U > 0;
+    if (splits || !job || !job->enabled) job = nullptr;
+    if (job_rides) *job_rides = job != nullptr;
+    if (C == 6) launch_fwd_c<6>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, sort_small, job, st);
+    else if (C == 4) launch_fwd_c<4>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, sort_small, job, st);
+    else launch_fwd_c<3>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, sort_small, job, st);
 }
 
 }  // namespace gsr

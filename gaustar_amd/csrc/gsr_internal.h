@@ -207,6 +207,67 @@ __host__ __device__ inline BinState carve_bin(void* base, int R, int U, int C = 
     return s;
 }
 
+// ---------------------------------------------------------------- planned binning (gsr_forward_planned)
+// A PLAN fixes where every tile's bucket lies BEFORE the view is rendered: {first entry, capacity} per tile, the first UNIT of
+// the tile (capacity / 64 units each) and a launch order -- built from the exact tile counts of an earlier view of the same
+// camera (gsr_plan.h: one extra workgroup of that view's forward blend).  With a plan the forward has neither scan nor scatter nor a host
+// round trip on its critical path: preprocess claims bucket slots with one returning atomic per (workgroup, tile) on the
+// tile's cursor and writes the sort keys itself; a tile's list is [first, first + cursor) and the forward blend reads the
+// cursor.  Units are numbered in BUCKET space (a tile owns capacity / 64 consecutive unit ids whatever its count turns out to
+// be), so masks / snapshots / the backward's unit table need no prefix sum over the actual counts either; a unit past its
+// tile's last entry is an empty work item of the backward (one scalar load, then the wave leaves).
+// A view that does not fit its plan (a bucket overflows, a workgroup runs out of table or record space) raises the plan's
+// flag; the forward blend behind it then does nothing but report that to the host -- which waits for this verdict only, written
+// by the blend's first workgroup as it starts -- and the host renders the view the exact way (scan + scatter) and rebuilds the
+// plan from it.
+// Only views whose longest list stays in the forward blend's own sort (<= 2 048 entries, not split) are planned.
+constexpr int PLAN_HDR = 16;              // header words: {valid, T, R_cap, U_cap, max_cap, non-empty tiles of the source view, R of it, -}
+constexpr int PLAN_CURSOR_STRIDE = 8;     // words between the cursors of neighbouring tiles: four tiles per 128-byte line
+constexpr uint32_t PLAN_MAX_LIST = 2048;  // == SORT_SMALL_CAP: a planned list is sorted inside the forward blend
+struct PlanState {
+    uint32_t* header;        // [PLAN_HDR]
+    uint2* ranges;           // [T] {first entry of the tile's bucket, capacity (a multiple of 64, 0: the tile may hold nothing)}
+    uint32_t* seg_off;       // [T+1] first unit of the tile's bucket (exclusive prefix of capacity / 64)
+    uint32_t* order;         // [T] launch order of the tiles (the source view's: longest lists first)
+    size_t bytes;
+};
+inline PlanState carve_plan(void* base, int W, int H)
+{
+    PlanState s; size_t o = 0; char* b = (char*)base;
+    const size_t T = (size_t)tiles_of(W, H).T;
+    s.header = (uint32_t*)(b + o); o = align_up(o + 4 * PLAN_HDR);
+    s.ranges = (uint2*)(b + o); o = align_up(o + 8 * T);
+    s.seg_off = (uint32_t*)(b + o); o = align_up(o + 4 * (T + 1));
+    s.order = (uint32_t*)(b + o); o = align_up(o + 4 * T);
+    s.bytes = o + 256;
+    return s;
+}
+// Words the planned forward keeps in the library's per-stream block behind the tile counters: the flag word (at
+// 9 * PLAN_SYNC_STRIDE: the token of the last view that did not fit its plan; tokens are never 0 and never repeat).
+constexpr int PLAN_SYNC_STRIDE = 32;
+constexpr int PLAN_SYNC_WORDS = PLAN_SYNC_STRIDE * 10;
+struct PlanRun {             // what the planned kernels get besides the exact path's arguments (by value)
+    const uint2* ranges;     // plan
+    const uint32_t* seg_off;
+    const uint32_t* order;
+    uint32_t* cursor;        // [T * PLAN_CURSOR_STRIDE] entries claimed per tile (library block, zero before preprocess)
+    uint32_t* sync;          // [PLAN_SYNC_WORDS] tickets + flag (library block)
+    uint64_t* keys;          // the binning buffer's key array (capacity R_cap)
+    uint4* unit_info;        // the binning buffer's unit table (capacity U_cap): written by the forward blend, tile by tile
+    uint2* im_ranges;        // the image state's ranges / seg_off: the forward blend leaves {first, first + count} and the
+    uint32_t* im_seg_off;    //   tile's first unit there as the exact path's scan would (debug exports read them)
+    uint32_t* host_pad;      // pinned, device-mapped: {verdict (1 fits, 2 does not), sequence number}, written by the forward blend
+    uint32_t host_seq;
+    uint32_t token;          // this view's token
+};
+void launch_preprocess_planned(int P, int D, int M, const float* means3D, const float* shs, const float* colors_precomp,
+                               const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                               const float* cov3D_precomp, const float* view, const float* proj, const float* campos, int W,
+                               int H, float tan_fovx, float tan_fovy, int* radii, GeomState g, ImageState im, PlanRun plan,
+                               hipStream_t st);
+void launch_blend_fwd_planned(int C, int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
+                              float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, PlanRun plan, hipStream_t st);
+
 // producers of rasterizer inputs (gsr_producers.hip)
 void launch_adam(long long n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float step_size,
                  float one_minus_b1, float b2, float one_minus_b2, float eps, float bc2s, hipStream_t st);
@@ -294,9 +355,10 @@ inline int front_of_order(int R, int T)
     const long long bound = ((long long)(R > 0 ? R : 0) / 2017 + 1 + 255) / 256 * 256;
     return (int)(bound < (long long)T ? bound : (long long)T);
 }
+struct PlanJob;   // gsr_plan.h
 void launch_blend_fwd(int C, int W, int H, int R, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im,
                       BinState b, float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, uint32_t* counters,
-                      bool sort_small, hipStream_t st);
+                      bool sort_small, hipStream_t st, const PlanJob* job = nullptr, bool* job_rides = nullptr);
 void launch_blend_bwd(int C, int W, int H, int U, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
                       const float* dL_dpix, float* grad_acc, hipStream_t st);
 void launch_geom_bwd(int P, int D, int M, const float* means3D, const float* shs, const float* scales,

@@ -15,6 +15,12 @@
 
 namespace gsr {
 
+// PLANNED (gsr_forward_planned): the tiles' buckets are laid out already (gsr_internal.h, "planned binning").  The walk is the
+// same; the records stay in LDS ({lane, table slot, offset} in one word), the workgroup's one memory atomic per occupied slot
+// goes to the tile's CURSOR and returns where the workgroup's span starts inside the tile's bucket, and the keys are written
+// right here -- what scatter_kernel does behind a scan in the exact path.  A span that does not fit its bucket, a full table or
+// a full record array raise the plan's flag (nothing is written outside a bucket).
+template <bool PLANNED>
 __global__ void __launch_bounds__(256)
 preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
                   const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
@@ -25,13 +31,17 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
                   float4* __restrict__ g0, float4* __restrict__ g1, float* __restrict__ depth,
                   ushort4* __restrict__ rect, float* __restrict__ rgb, uint32_t* __restrict__ tile_count,
                   uint4* __restrict__ wg_recs, uint2* __restrict__ wg_tab, uint32_t* __restrict__ wg_nrec,
-                  uint32_t* __restrict__ totals, uint32_t view_token)
+                  uint32_t* __restrict__ totals, uint32_t view_token, PlanRun plan)
 {
     constexpr int AGG_SLOTS = WG_TAB_SLOTS;
     __shared__ uint32_t agg_key[AGG_SLOTS], agg_cnt[AGG_SLOTS];
     __shared__ uint32_t tab_full;   // set by the first group that finds no slot: later groups do not probe at all
+    constexpr uint32_t WAVE_CAP = WG_REC_CAP / 4;
+    __shared__ uint32_t rec_lds[PLANNED ? WG_REC_CAP : 1];   // (PLANNED) records {lane << 16 | slot << 8 | offset}, a quarter per wave
+    __shared__ uint32_t depth_lds[PLANNED ? 256 : 1];        // (PLANNED) every thread's depth bits
+    __shared__ uint32_t misfit;                              // (PLANNED) this workgroup found something that does not fit the plan
     for (int i = threadIdx.x; i < AGG_SLOTS; i += blockDim.x) { agg_key[i] = 0xffffffffu; agg_cnt[i] = 0u; }
-    if (threadIdx.x == 0) tab_full = 0u;
+    if (threadIdx.x == 0) { tab_full = 0u; misfit = 0u; }
     __syncthreads();
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -155,7 +165,6 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
     // workgroup) marks the VIEW with its token: counting stays exact, and scatter falls back to walking the tiles.
     uint32_t* const my_row = tile_count + (size_t)(blockIdx.x & (NSHARD - 1)) * shard_stride(gx * gy);
     const unsigned long long lt = (1ull << lane) - 1ull;
-    constexpr uint32_t WAVE_CAP = WG_REC_CAP / 4;
     uint4* const wave_recs = wg_recs + (size_t)blockIdx.x * WG_REC_CAP + (size_t)(threadIdx.x >> 6) * WAVE_CAP;
     uint32_t n_wave = 0;   // (wave-uniform) records of this wave so far
     // (No wave-level grouping of the lanes by tile here: with the LDS table in front of memory every lane simply takes its
@@ -180,16 +189,60 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
             }
             if (slot != 0xffffffffu) {
                 off = atomicAdd(&agg_cnt[slot], 1u);
+            } else if constexpr (PLANNED) {   // table full around this hash: the view does not fit its plan
+                tab_full = 1u;
+                misfit = 1u;
             } else {   // table full around this hash: count directly, flag the view
                 atomicAdd(&my_row[tile], 1u);
                 tab_full = 1u;
                 totals[4] = view_token;
             }
             const uint32_t pos = n_wave + (uint32_t)__popcll(act & lt);
-            if (pos < WAVE_CAP) wave_recs[pos] = make_uint4((uint32_t)idx, __float_as_uint(my_depth), slot, off);
+            if constexpr (PLANNED) {
+                // (a Gaussian meets a tile once, so an offset inside a workgroup's span is below 256)
+                if (pos < WAVE_CAP && slot != 0xffffffffu)
+                    rec_lds[(threadIdx.x >> 6) * WAVE_CAP + pos] = ((uint32_t)lane << 16) | (slot << 8) | off;
+            } else {
+                if (pos < WAVE_CAP) wave_recs[pos] = make_uint4((uint32_t)idx, __float_as_uint(my_depth), slot, off);
+            }
         }
         n_wave += (uint32_t)__popcll(act);
     }
+    if constexpr (PLANNED) {
+        depth_lds[threadIdx.x] = __float_as_uint(my_depth);
+        if (lane == 0 && n_wave > WAVE_CAP) misfit = 1u;
+        __syncthreads();
+        // one returning atomic per occupied slot on the tile's cursor: where this workgroup's span starts inside the bucket
+        // (agg_key is reused for the absolute position of the span; 0xffffffff: the slot is empty or its span does not fit)
+        static_assert(AGG_SLOTS == 256, "one thread per table slot");
+        {
+            const uint32_t tile = agg_key[threadIdx.x];
+            uint32_t at = 0xffffffffu;
+            if (tile != 0xffffffffu) {
+                const uint2 bucket = plan.ranges[tile];
+                const uint32_t cnt = agg_cnt[threadIdx.x];
+                const uint32_t old = atomicAdd(&plan.cursor[(size_t)tile * PLAN_CURSOR_STRIDE], cnt);
+                if (old + cnt <= bucket.y) at = bucket.x + old;
+                else misfit = 1u;
+            }
+            agg_key[threadIdx.x] = at;
+        }
+        __syncthreads();
+        {
+            const uint32_t wv = threadIdx.x >> 6;
+            const uint32_t nr = min(n_wave, WAVE_CAP);
+            const uint32_t gbase = (uint32_t)(idx - lane);
+            for (uint32_t i = lane; i < nr; i += 64u) {
+                const uint32_t r = rec_lds[wv * WAVE_CAP + i];
+                const uint32_t src = r >> 16, at = agg_key[(r >> 8) & 255u];
+                if (at != 0xffffffffu)
+                    plan.keys[at + (r & 255u)] = ((uint64_t)depth_lds[wv * 64u + src] << 32) | (gbase + src);
+            }
+        }
+        // A misfit raises the plan's flag (the token of this view: unique, so the word never has to be cleared).  Nobody reads it
+        // before the next kernel: the forward blend, queued right behind, reports the verdict to the host and leaves the view alone.
+        if (threadIdx.x == 0 && misfit) atomicExch(plan.sync + 9 * PLAN_SYNC_STRIDE, plan.token);
+    } else {
     if (lane == 0) {
         wg_nrec[blockIdx.x * 4 + (threadIdx.x >> 6)] = n_wave;
         if (n_wave > WAVE_CAP) totals[4] = view_token;
@@ -200,6 +253,7 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
         uint2 e = make_uint2(0xffffffffu, 0u);
         if (agg_key[i] != 0xffffffffu) e = make_uint2(agg_key[i], atomicAdd(&my_row[agg_key[i]], agg_cnt[i]));
         tab[i] = e;
+    }
     }
 }
 
@@ -212,11 +266,27 @@ void launch_preprocess(int P, int D, int M, const float* means3D, const float* s
     const Tiles t = tiles_of(W, H);
     const float focal_y = H / (2.0f * tan_fovy), focal_x = W / (2.0f * tan_fovx);   // rasterizer_impl.cu:222-223
     const size_t lds = colors_precomp ? 0 : sh_stage_bytes(M, 4);
-    preprocess_kernel<<<(P + 255) / 256, 256, lds, st>>>(P, D, M, means3D, shs, colors_precomp, opacities, scales,
+    preprocess_kernel<false><<<(P + 255) / 256, 256, lds, st>>>(P, D, M, means3D, shs, colors_precomp, opacities, scales,
                                                        scale_modifier, rotations, cov3D_precomp, view, proj, campos, W,
                                                        H, tan_fovx, tan_fovy, focal_x, focal_y, t.gx, t.gy, radii,
                                                        g.g0, g.g1, g.depth, g.rect, g.rgb, im.tile_count, g.wg_recs, g.wg_tab,
-                                                       g.wg_nrec, im.totals, view_token);
+                                                       g.wg_nrec, im.totals, view_token, PlanRun{});
+}
+
+void launch_preprocess_planned(int P, int D, int M, const float* means3D, const float* shs, const float* colors_precomp,
+                               const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                               const float* cov3D_precomp, const float* view, const float* proj, const float* campos, int W,
+                               int H, float tan_fovx, float tan_fovy, int* radii, GeomState g, ImageState im, PlanRun plan,
+                               hipStream_t st)
+{
+    const Tiles t = tiles_of(W, H);
+    const float focal_y = H / (2.0f * tan_fovy), focal_x = W / (2.0f * tan_fovx);
+    const size_t lds = colors_precomp ? 0 : sh_stage_bytes(M, 4);
+    preprocess_kernel<true><<<(P + 255) / 256, 256, lds, st>>>(P, D, M, means3D, shs, colors_precomp, opacities, scales,
+                                                      scale_modifier, rotations, cov3D_precomp, view, proj, campos, W,
+                                                      H, tan_fovx, tan_fovy, focal_x, focal_y, t.gx, t.gy, radii,
+                                                      g.g0, g.g1, g.depth, g.rect, g.rgb, im.tile_count, g.wg_recs, g.wg_tab,
+                                                      g.wg_nrec, im.totals, plan.token, plan);
 }
 
 // rasterizer_impl.cu:54-66 (checkFrustum): present = view-space z > 0.2.

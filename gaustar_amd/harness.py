@@ -150,7 +150,7 @@ class _RenderMeshBound(torch.autograd.Function):
         if fence is not None:
             fence((p_dc, p_rest, p_dens))
         colors, opac = producers._sh_forward_raw(points, st.campos, dc, rest, D, M, view, cfg["depth_channels"], dens)
-        need_bwd = any(ctx.needs_input_grad)
+        need_bwd = any(ctx.needs_input_grad) and cfg.get("grad", True)
         box = []
         out = _rasterizer.rasterize_gaussians_native(
             st.bg, points, colors, opac, scaling, quats, st.scale_modifier, None, st.viewmatrix, st.projmatrix, st.tanfovx,
@@ -473,6 +473,7 @@ class SurfaceGaussians(nn.Module):
                "lo": float("-inf") if self.min_gaussian_scale is None else float(self.min_gaussian_scale),
                "hi": float("inf") if self.max_gaussian_scale is None else float(self.max_gaussian_scale), "sh_levels": sh_deg + 1,
                "sink": getattr(self, "grad_sink", None),
+               "grad": torch.is_grad_enabled(),   # (Function.forward cannot tell: see rasterizer._CALL)
                "params": (self._points, self._scales, self._quaternions, self.all_densities, self._sh_coordinates_dc,
                           self._sh_coordinates_rest, self._delta_t if self._loose_bind else None,
                           self._delta_r if self._loose_bind else None)}

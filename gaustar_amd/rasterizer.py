@@ -14,6 +14,7 @@ memory.  No CPU fallback exists: tensors must be on a HIP device and the extensi
 """
 from __future__ import annotations
 
+import collections
 import ctypes
 import os
 import threading
@@ -105,12 +106,59 @@ def _require_gpu(t: torch.Tensor, what: str):
 _BINNING_HINT: dict = {}
 _HINT_LOCK = threading.Lock()   # trainer thread + evaluation thread may render on one device
 _FUSED = os.environ.get("GSR_FUSED_FORWARD", "1") != "0"   # 0: always stage 1, allocate exactly, stage 2
+# Plans (include/gsr.h, gsr_forward_planned): per camera the layout of its tiles' buckets, left behind by one view for the
+# next view of that camera.  A camera is recognised by the storage of its view matrix (the reference keeps one tensor per
+# camera: cameras.py:276-310 builds them once, sugar_model.py:1173-1187 hands them over every iteration) on a given stream
+# -- or by an explicit `plan_key`.  A plan is a hint: a wrong or stale one costs the exact path, never a wrong pixel.
+_PLANNED = os.environ.get("GSR_PLANNED", "1") != "0"
+_PLAN_SLOTS = int(os.environ.get("GSR_PLAN_SLOTS", "2048"))
+_PLANS: "collections.OrderedDict" = collections.OrderedDict()   # key -> _Plan
+_PLAN_RETRY = 32   # a camera whose view could not be planned (a list too long for the in-kernel sort) is asked again after this many views
+PLAN_STATS = {"planned": 0, "exact": 0, "misfit": 0}            # views binned by a plan / without one / that outgrew theirs
+
+
+class _Plan:
+    """One camera's plan: the device buffer, the pinned plan_info block the library reads and writes (include/gsr.h), and the
+    binding's own bookkeeping (views to render without asking, misfits in a row, views seen while unplannable)."""
+    __slots__ = ("buf", "info", "skip", "misfits", "idle", "_lib")
+
+    def __init__(self, lib, nbytes, byte_opts):
+        self.buf = torch.empty(nbytes, **byte_opts)
+        self.info = lib.gsr_plan_info_new()
+        if not self.info:
+            raise RuntimeError("gsr_plan_info_new failed")
+        self.skip, self.misfits, self.idle, self._lib = 0, 0, 0, lib
+
+    def __del__(self):
+        try:
+            self._lib.gsr_plan_info_free(self.info)
+        except Exception:
+            pass
+
+
+def _plan_entry(key, lib, nbytes, byte_opts):
+    with _HINT_LOCK:
+        ent = _PLANS.get(key)
+        if ent is not None and ent.buf.numel() == nbytes:
+            _PLANS.move_to_end(key)
+            return ent
+        ent = _Plan(lib, nbytes, byte_opts)
+        _PLANS[key] = ent
+        while len(_PLANS) > _PLAN_SLOTS:
+            _PLANS.popitem(last=False)
+        return ent
+
+
+def drop_plans():
+    """Forget every camera's plan (the next view of each renders the exact way and re-plans)."""
+    with _HINT_LOCK:
+        _PLANS.clear()
 
 
 def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rotations, scale_modifier,
                                cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
                                image_width, sh, degree, campos, prefiltered, debug, need_backward=True,
-                               scratch_box=None):
+                               scratch_box=None, use_plan=None, plan_key=None):
     """-> (num_rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer), like
     RasterizeGaussiansCUDA (DGR/rasterize_points.cu:35-115), plus two more elements: the longest
     per-tile instance list (informational) and the number of list segments (backward work units)."""
@@ -128,6 +176,8 @@ def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rot
                     torch.zeros(0, dtype=torch.int32, device=dev), torch.empty(0, **byte_opts),
                     torch.empty(0, **byte_opts), torch.empty(0, **byte_opts), 0, 0)
         means3D = _dev_f32(means3D, dev)
+        # (the camera's identity for its plan: where the caller keeps the view matrix -- taken before .contiguous() copies it)
+        vm_key = (viewmatrix.untyped_storage().data_ptr(), viewmatrix.storage_offset()) if plan_key is None else None
         background, viewmatrix, projmatrix, campos = (_dev_f32(x, dev) for x in (background, viewmatrix, projmatrix, campos))
         colors, opacity, scales, rotations, cov3D_precomp, sh = (
             _dev_f32(x, dev) for x in (colors, opacity, scales, rotations, cov3D_precomp, sh))
@@ -151,15 +201,48 @@ def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rot
         scratch = None
         if need_backward and scratch_box is not None and hint > 0:
             scratch = torch.empty(lib.gsr_grad_scratch_bytes(P), **byte_opts)
-        _lib.check(lib.gsr_forward_fused(
-            P, int(degree), M, C, int(bool(need_backward)), _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity),
-            _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix),
-            _ptr(campos), W, H, float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(background), _ptr(radii),
-            _ptr(geom), _ptr(img), _ptr(binning), hint, _ptr(scratch), _ptr(out_color), ctypes.byref(R),
-            ctypes.byref(maxc), ctypes.byref(nseg), ctypes.byref(blended), st), "gsr_forward_fused")
+        head = (P, int(degree), M, C, int(bool(need_backward)), _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity),
+                _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix),
+                _ptr(campos), W, H, float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(background), _ptr(radii),
+                _ptr(geom), _ptr(img), _ptr(binning), hint, _ptr(scratch), _ptr(out_color), ctypes.byref(R),
+                ctypes.byref(maxc), ctypes.byref(nseg), ctypes.byref(blended))
+        plan = None
+        if (_PLANNED if use_plan is None else use_plan) and _FUSED and not debug:
+            # (a camera's differentiable renders and its forward-only ones -- ground-truth / evaluation sweeps, often of another
+            # model -- keep separate plans)
+            key = (dev.index, int(st or 0), W, H, bool(need_backward), plan_key if plan_key is not None else vm_key)
+            plan = _plan_entry(key, lib, int(lib.gsr_plan_bytes(W, H)), byte_opts)
+            if plan.skip > 0:         # (a camera whose views keep outgrowing their plans: left alone for a while)
+                plan.skip -= 1
+                plan = None
+        if plan is None:
+            _lib.check(lib.gsr_forward_fused(*head, st), "gsr_forward_fused")
+        else:
+            planned = ctypes.c_int(0)
+            info = plan.info
+            _lib.check(lib.gsr_forward_planned(*head, _ptr(plan.buf), info, ctypes.byref(planned), st), "gsr_forward_planned")
+            if planned.value == 1:
+                PLAN_STATS["planned"] += 1
+                plan.misfits = 0
+            else:
+                PLAN_STATS["exact"] += 1
+                if planned.value == -1:
+                    # the view outgrew its plan (the library has raised the slack level and re-plans).  Misfits in a row -- a
+                    # close-up whose workgroups run out of table space misfits under ANY plan -- pause planning for this
+                    # camera: 2, 4, .. 64 views
+                    PLAN_STATS["misfit"] += 1
+                    plan.misfits += 1
+                    if plan.misfits >= 2:
+                        plan.skip = min(64, 1 << (plan.misfits - 1))
+                if info[0] == -1:     # unplannable (longest list above the in-kernel sort): ask again after _PLAN_RETRY views
+                    plan.idle += 1
+                    if plan.idle >= _PLAN_RETRY:
+                        info[0], plan.idle = 0, 0
         if scratch is not None and blended.value:
             scratch_box.append(scratch)   # cleared by the forward blend: good for exactly one backward
         need = int(lib.gsr_binning_bytes_mt(R.value, nseg.value, C))
+        if plan is not None and plan.info[0] == 1:   # room for the plan's capacities, so that the next view of this camera can use it
+            need = max(need, int(lib.gsr_binning_bytes_mt(plan.info[1], plan.info[2], C)))
         # The hint only moves in steps of 32 MB and only comes down when a view needs less than a QUARTER of it (then it
         # halves): every change of the size is a new block for the caching allocator -- a hipMalloc of a few hundred MB costs
         # tens of milliseconds -- and a hint that shrank by 10 % whenever a view needed less than half of it made a rig of
@@ -257,10 +340,21 @@ def mark_visible_native(means3D, viewmatrix, projmatrix):
 # --------------------------------------------------------------------------------------------
 # The reference's Python layer, unchanged in shape.
 # --------------------------------------------------------------------------------------------
+# Whether the caller records a graph at all: inside autograd.Function.forward grad mode is always off and
+# ctx.needs_input_grad says True for every input that requires grad even under torch.no_grad(), so the mode is noted
+# here, at call time.  A render under no_grad() (ground-truth and evaluation sweeps, refined_mesh.py:733-775) can never be
+# differentiated: it runs forward-only (no per-unit snapshots or candidate words are written) and keeps a plan of its own.
+_CALL = threading.local()
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
-    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+    _CALL.grad = torch.is_grad_enabled()
+    try:
+        return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                         cov3Ds_precomp, raster_settings)
+    finally:
+        _CALL.grad = True
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -274,16 +368,17 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raster_settings.image_height, raster_settings.image_width, sh, raster_settings.sh_degree,
                 raster_settings.campos, raster_settings.prefiltered, raster_settings.debug)
         box = []   # receives the backward's accumulation table when the forward cleared it on the side
+        need_backward = any(ctx.needs_input_grad) and getattr(_CALL, "grad", True)
         if raster_settings.debug:
             cpu_args = cpu_deep_copy_tuple(args)   # copy them before they can be corrupted (ref :83-90)
             try:
-                out = rasterize_gaussians_native(*args, need_backward=any(ctx.needs_input_grad), scratch_box=box)
+                out = rasterize_gaussians_native(*args, need_backward=need_backward, scratch_box=box)
             except Exception as ex:
                 torch.save(cpu_args, "snapshot_fw.dump")
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                 raise ex
         else:
-            out = rasterize_gaussians_native(*args, need_backward=any(ctx.needs_input_grad), scratch_box=box)
+            out = rasterize_gaussians_native(*args, need_backward=need_backward, scratch_box=box)
         num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, _max_tile, num_segments = out
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered

@@ -118,6 +118,42 @@ int gsr_forward_fused(int P, int D, int M, int num_channels, int need_backward, 
                       void* binning_buffer, size_t binning_capacity, void* grad_scratch, float* out_color,
                       int* num_rendered, int* max_tile_instances, int* num_segments, int* blended, gsr_stream_t stream);
 
+/* PLANNED forward (ABI 13): gsr_forward_fused for a camera that is rendered again and again (a training rig: every camera
+ * once per epoch, gaustar_trainers/refine.py:534-548).  The caller keeps, per camera, a device buffer of gsr_plan_bytes(W, H)
+ * bytes and a plan_info block from gsr_plan_info_new() = {state, R_cap, U_cap, max_cap, slack level, ...} (all zero at first).  A call with plan_info[0] == 0
+ * renders the exact way (as gsr_forward_fused) and leaves a PLAN behind (built by one extra workgroup of that view's forward
+ * blend; nobody waits for it: the next call with this plan_info adopts it): per tile the place and capacity of its bucket of
+ * instances (this view's count + 1/8, at least 16 -- times 2^level --, rounded up to whole 64-entry units), the tile's first unit and a launch
+ * order; plan_info is updated.  A call with plan_info[0] == 1 bins BY THE PLAN: preprocess claims bucket slots and writes the
+ * sort keys itself, the forward blend is queued right behind it, and the host only waits for preprocess's verdict -- no
+ * tile-offset scan, no scatter pass and no host round trip between the stages (what replaces
+ * DGR/cuda_rasterizer/rasterizer_impl.cu:277-317 -- InclusiveSum, the num_rendered read-back, duplicateWithKeys,
+ * identifyTileRanges -- for such a view).  *planned = 1 then, and the sizes the backward needs are the plan's CAPACITIES:
+ * *num_rendered = R_cap, *num_segments = U_cap (binning_capacity must hold gsr_binning_bytes_mt(R_cap, U_cap, num_channels),
+ * otherwise the call takes the exact path); images and gradients are those of the exact path bit for bit (a tile's list is
+ * the same sorted list; only where it lies differs).  A view that does not fit its plan (a bucket overflows: the Gaussians
+ * have moved since the plan was made) is detected by preprocess before anything is blended; the same call then renders it the
+ * exact way and re-plans with the slack level raised by one, at most 3 (*planned = -1; 0: no plan was tried).  Only views whose longest list stays within the forward blend's own sort (2 048
+ * entries incl. slack) and that would not be split are planned (plan_info[0] stays 0 otherwise).  A plan is a HINT: any plan of
+ * the right image size is safe for any view -- a bad one costs the fallback, never a wrong pixel.  Needs the library's
+ * per-stream counter block (gsr_forward_fused's), otherwise exact.  All other arguments as gsr_forward_fused. */
+#define GSR_PLAN_INFO_INTS 32
+size_t gsr_plan_bytes(int W, int H);
+/* A plan_info block: GSR_PLAN_INFO_INTS ints of pinned, device-mapped host memory, zeroed (the builder of a plan writes its
+ * header there from the device; ordinary host memory will not do).  [0] state: 0 no plan, 1 valid, -1 this camera's views cannot
+ * be planned (reset to 0 to have the next view try again); [1..3] R_cap, U_cap, max_cap of a valid plan; [4] slack level
+ * (0..3); the rest belongs to the library.  Free with gsr_plan_info_free once no call using it is in flight. */
+int* gsr_plan_info_new(void);
+void gsr_plan_info_free(int* plan_info);
+int gsr_forward_planned(int P, int D, int M, int num_channels, int need_backward, const float* means3D, const float* shs,
+                        const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                        const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                        const float* projmatrix, const float* campos, int W, int H, float tan_fovx, float tan_fovy,
+                        int prefiltered, const float* background, int* radii, void* geom_buffer, void* image_buffer,
+                        void* binning_buffer, size_t binning_capacity, void* grad_scratch, float* out_color,
+                        int* num_rendered, int* max_tile_instances, int* num_segments, int* blended, void* plan_buffer,
+                        int* plan_info, int* planned, gsr_stream_t stream);
+
 /* Frees what the library keeps for (current device, stream) -- the tile-counter block of gsr_forward_fused -- e.g.
  * before the stream is destroyed.  Fails if a gsr_forward_fused on that stream is in flight on another thread. */
 int gsr_release_stream_state(gsr_stream_t stream);

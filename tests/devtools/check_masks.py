@@ -38,7 +38,8 @@ def render(gs, cam, bg, need_backward):
     out = R.rasterize_gaussians_native(t(bg), t(gs.means3D), e if sh_mode else t(gs.colors_precomp), t(gs.opacities), t(gs.scales),
                                        t(gs.rotations), 1.0, e, t(cam.viewmatrix), t(cam.projmatrix), cam.tanfovx,
                                        cam.tanfovy, cam.H, cam.W, t(gs.shs) if sh_mode else e, int(gs.sh_degree) if sh_mode else 0,
-                                       t(cam.campos), False, False, need_backward=need_backward)
+                                       t(cam.campos), False, False, need_backward=need_backward,
+                                       use_plan=False)   # (compact unit numbering: U is recomputed from the ranges below)
     Rn, color, radii, geom, binning, img, maxc, _ = out
     lib = _lib.load()
     P, W, H = len(gs.means3D), cam.W, cam.H

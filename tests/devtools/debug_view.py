@@ -35,7 +35,7 @@ e = torch.Tensor([])
 P, W, H = gs.P, cam.W, cam.H
 out = R.rasterize_gaussians_native(t(bg), t(gs.means3D), t(gs.colors_precomp), t(gs.opacities), t(gs.scales),
                                    t(gs.rotations), 1.0, e, t(cam.viewmatrix), t(cam.projmatrix), cam.tanfovx,
-                                   cam.tanfovy, H, W, e, 0, t(cam.campos), False, False)
+                                   cam.tanfovy, H, W, e, 0, t(cam.campos), False, False, use_plan=False)
 Rn, c2, r2, geom, binning, img, maxc, nseg = out
 print("R ref", Rr, "R ours", Rn, "max tile", maxc, "radii mismatch", (r2.cpu().numpy() != radii).sum())
 T = ((W + 15) // 16) * ((H + 15) // 16)

@@ -37,12 +37,17 @@ def test_bench_line_at_one_gpu():
     assert abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-3            # value = views per second of the median region
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0.0 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
-    assert set(rf["kernels"]) >= {"preprocess_kernel", "tile_scan_kernel", "scatter_kernel", "blend_fwd_kernel", "blend_bwd_kernel",
-                                  "geom_bwd_kernel"}
+    # (views binned by their camera's plan launch neither scan nor scatter: config.binning says how many were)
+    assert set(rf["kernels"]) >= {"preprocess_kernel", "blend_fwd_kernel", "blend_bwd_kernel", "geom_bwd_kernel"}
+    bn = c["binning"]
+    assert bn["planned_views"] + bn["exact_views"] > 0 and bn["misfits"] == 0
+    if bn["exact_views"] == 0:   # cameras 0-5 of the rig are all plannable
+        assert "tile_scan_kernel" not in rf["kernels"] and "scatter_kernel" not in rf["kernels"]
+        assert d["exact_binning"]["ms_per_step"] > 0.0   # (6-step regions are too noisy to order the two figures: profiles/ has them)
     assert rf["kernel"] in ("blend_bwd_kernel", "blend_fwd_kernel") and "host" in d
     # the fraction follows from the line's own numbers: algorithmic bytes of ONE launch / its mean duration / peak, and the
     # brackets count the K timed steps only (round 4 divided by 22 / 20 launches per step: timed()'s untimed first steps)
-    for k in ("preprocess_kernel", "scatter_kernel", "blend_fwd_kernel", "blend_bwd_kernel", "geom_bwd_kernel"):
+    for k in ("preprocess_kernel", "blend_fwd_kernel", "blend_bwd_kernel", "geom_bwd_kernel"):
         assert rf["kernels"][k]["launches_per_step"] == 1.0, (k, rf["kernels"][k])
     recomputed = rf["alg_bytes_per_launch"] / (rf["ms_per_launch"] * 1e-3) / 8e12
     assert abs(recomputed - rf["frac"]) <= 2e-3 * rf["frac"], (recomputed, rf["frac"])

@@ -56,7 +56,8 @@ def test_hip_internal_state_matches_reference(name, hip_lib):
     out = R.rasterize_gaussians_native(t(kw["bg"]), t(kw["means3D"]), opt("colors_precomp"), t(kw["opacities"]),
                                        opt("scales"), opt("rotations"), kw["scale_modifier"], opt("cov3D_precomp"),
                                        t(kw["view"]), t(kw["proj"]), kw["tanfovx"], kw["tanfovy"], H, W, opt("shs"),
-                                       kw["sh_degree"], t(kw["campos"]), False, False)
+                                       kw["sh_degree"], t(kw["campos"]), False, False,
+                                       use_plan=False)   # (the checks below read the exact path's compact lists and unit numbering)
     Rn, color, radii, geom, binning, img, maxc, nseg = out
     assert 0 < Rn <= int(d["out_num_rendered"]) and 0 < maxc <= Rn
     T = ((W + 15) // 16) * ((H + 15) // 16)

@@ -69,6 +69,9 @@ def run(a):
                 d = img[3].clone()
                 d[d >= MAX_DEPTH - 1e-3] = 2 * MAX_DEPTH
                 gts.append((img[:3].clone(), d))
+        if os.environ.get("GSR_WINDOW_PLAN_DEBUG"):
+            from gaustar_amd import rasterizer as _rzd
+            print(f"[window] frame {fi} after ground truth: {_rzd.PLAN_STATS}", file=sys.stderr)
         groups = [{"params": [model._points], "lr": 2e-4},
                   {"params": [model._sh_coordinates_dc, model._sh_coordinates_rest], "lr": 5e-3},
                   {"params": [model._scales, model._quaternions, model.all_densities], "lr": 5e-3}]
@@ -112,6 +115,9 @@ def run(a):
             model.grad_sink = None
         marks[a.iters].record()
         torch.cuda.synchronize(); t_total += time.perf_counter() - t0
+        if os.environ.get("GSR_WINDOW_PLAN_DEBUG"):
+            from gaustar_amd import rasterizer as _rzd
+            print(f"[window] frame {fi} after iterations: {_rzd.PLAN_STATS}", file=sys.stderr)
         gc.enable()
         w_ns, w_n = ctypes.c_longlong(0), ctypes.c_longlong(0)
         _lib.load().gsr_debug_host_wait(ctypes.byref(w_ns), ctypes.byref(w_n), 1)
@@ -127,6 +133,8 @@ def run(a):
         torch.distributed.barrier()
     extra = {} if world == 1 else {"world": world, "exchange": getattr(a, "exchange", "sharded"), "allreduce_payload_MB": round(payload / 1e6, 1), "buckets_issued_during_backward": early,
                                   "views_per_iteration": world}
+    from gaustar_amd import rasterizer as _rz
+    extra["plan_stats"] = dict(_rz.PLAN_STATS)
     return {**extra, "gaussians": N, "image": [a.width, a.height], "cameras": len(ncams), "frames": frames, "iterations": n_it,
             "iterations_per_s": round(n_it / t_total, 1), "ms_per_iteration": round(t_total / n_it * 1e3, 3),
             # the steady state: median over all iterations of the time between their start marks on the stream (the wall

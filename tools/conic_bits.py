@@ -15,7 +15,7 @@ t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
 lib = _lib.load()
 e = torch.Tensor([])
 m3, op, cols, sc, rot = t(gs.means3D), t(gs.opacities), t(gs.colors_precomp), t(gs.scales), t(gs.rotations)
-out = R.rasterize_gaussians_native(t(bg), m3, cols, op, sc, rot, 1.0, e, t(cam.viewmatrix), t(cam.projmatrix), cam.tanfovx, cam.tanfovy, cam.H, cam.W, e, 0, t(cam.campos), False, False)
+out = R.rasterize_gaussians_native(t(bg), m3, cols, op, sc, rot, 1.0, e, t(cam.viewmatrix), t(cam.projmatrix), cam.tanfovx, cam.tanfovy, cam.H, cam.W, e, 0, t(cam.campos), False, False, use_plan=False)
 Rn, _, radii, geom, binning, img, maxc, U = out
 P, W, H = gs.P, cam.W, cam.H
 T = ((W + 15) // 16) * ((H + 15) // 16)

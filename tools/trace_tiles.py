@@ -27,7 +27,7 @@ for _ in range(3):
     c, r = rast(m3, m2, op, None, cols, sc, rot, None); c.backward(dp)
 e = torch.Tensor([])
 out = R.rasterize_gaussians_native(t(bg), m3.detach(), cols.detach(), op.detach(), sc.detach(), rot.detach(), 1.0, e,
-                                   t(cam.viewmatrix), t(cam.projmatrix), cam.tanfovx, cam.tanfovy, H, W, e, 0, t(cam.campos), False, False)
+                                   t(cam.viewmatrix), t(cam.projmatrix), cam.tanfovx, cam.tanfovy, H, W, e, 0, t(cam.campos), False, False, use_plan=False)
 Rn, _, _, geom, binning, img, maxc, U = out
 trace = torch.zeros(2 * T + 2 * U, dtype=torch.int64, device=dev)
 lib.gsr_debug_set_trace(ctypes.c_void_p(trace.data_ptr()))
