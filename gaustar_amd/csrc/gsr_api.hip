@@ -1130,6 +1130,12 @@ int gsr_release_stream_state(gsr_stream_t stream)
     return 0;
 }
 
+int gsr_debug_set_bwd_order(const void* device_order)
+{
+    gsr::g_bwd_order = static_cast<const uint32_t*>(device_order);
+    return 0;
+}
+
 int gsr_debug_set_trace(void* device_buffer)
 {
     gsr::g_trace = static_cast<uint64_t*>(device_buffer);

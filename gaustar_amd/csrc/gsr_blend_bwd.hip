@@ -55,7 +55,8 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
                  const uint2* __restrict__ masks, const uint32_t* __restrict__ point_list, const float4* __restrict__ rec_a,
                  const float4* __restrict__ rec_b, const RecTail<C>* __restrict__ rec_c, const float* __restrict__ bg,
                  const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-                 const float* __restrict__ dL_dpix, float* __restrict__ grad_acc, uint64_t* __restrict__ trace)
+                 const float* __restrict__ dL_dpix, float* __restrict__ grad_acc, uint64_t* __restrict__ trace,
+                 const uint32_t* __restrict__ order)
 {
     using L = SlotLayout<C>;
     constexpr int SF = L::FLOATS, NM = L::NM, MOM0 = L::MOM0, SV = snap_vecs(C);
@@ -91,6 +92,8 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     uint32_t wave_sel = slot & 3u;
     const uint32_t full = (n_units >> 6) << 6;            // units covered by complete groups of 64
     if (blockIdx.x >= full * 4u) { unit = blockIdx.x >> 2; wave_sel = blockIdx.x & 3u; }   // ragged tail: plain map
+    // (a launch ORDER of the units, when there is one: position in the dispatch sequence -> unit; see launch_blend_bwd)
+    if (order != nullptr) unit = order[unit];
     // Everything the unit has to know about its tile in one (scalar) load; then EVERY vector load of the unit's head is
     // requested before the first one is waited for -- pixel state, candidate words of this unit and the next, the two
     // snapshots a resuming pixel needs, and the unit's 64 instance records, which the forward left in list order
@@ -603,9 +606,10 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
                  const uint2* __restrict__ masks, const uint32_t* __restrict__ point_list, const float4* __restrict__ rec_a,
                  const float4* __restrict__ rec_b, const RecTail<C>* __restrict__ rec_c, const float* __restrict__ bg,
                  const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-                 const float* __restrict__ dL_dpix, float* __restrict__ grad_acc, uint64_t* __restrict__ trace)
+                 const float* __restrict__ dL_dpix, float* __restrict__ grad_acc, uint64_t* __restrict__ trace,
+                 const uint32_t* __restrict__ order)
 {
-    blend_bwd_unit<C>(W, H, gx, unit_info, snap, masks, point_list, rec_a, rec_b, rec_c, bg, final_T, n_contrib, dL_dpix, grad_acc, trace);
+    blend_bwd_unit<C>(W, H, gx, unit_info, snap, masks, point_list, rec_a, rec_b, rec_c, bg, final_T, n_contrib, dL_dpix, grad_acc, trace, order);
 }
 // Three channels: the register allocator is told to stay within six waves per SIMD (80 registers; left alone the per-channel
 // form took 82 and the kernel ran five: 0.141 vs 0.131 ms on config C).  Six channels (104 registers) would have to spill 20 and lose.
@@ -617,10 +621,11 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
                          const float4* __restrict__ rec_a, const float4* __restrict__ rec_b,                                  \
                          const RecTail<CH>* __restrict__ rec_c, const float* __restrict__ bg,                                 \
                          const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,                           \
-                         const float* __restrict__ dL_dpix, float* __restrict__ grad_acc, uint64_t* __restrict__ trace)       \
+                         const float* __restrict__ dL_dpix, float* __restrict__ grad_acc, uint64_t* __restrict__ trace,       \
+                         const uint32_t* __restrict__ order)                                                                  \
     {                                                                                                                         \
         blend_bwd_unit<CH>(W, H, gx, unit_info, snap, masks, point_list, rec_a, rec_b, rec_c, bg, final_T, n_contrib,         \
-                           dL_dpix, grad_acc, trace);                                                                         \
+                           dL_dpix, grad_acc, trace, order);                                                                  \
     }
 #ifndef GSR_BWD_WAVES3
 #define GSR_BWD_WAVES3 6   // (the projected form takes 70 registers and runs seven; 8 = 64 registers spills eight and loses 10 us)
@@ -640,6 +645,8 @@ bool launch_blend_bwd_variant(int C, int W, int H, int U, const float* bg, Image
                               hipStream_t st);
 #endif
 
+const uint32_t* g_bwd_order = nullptr;   // (experiments: gsr_debug_set_bwd_order)
+
 void launch_blend_bwd(int C, int W, int H, int U, const float* bg, const float* feats, GeomState g, ImageState im,
                       BinState b, const float* dL_dpix, float* grad_acc, hipStream_t st)
 {
@@ -655,7 +662,7 @@ void launch_blend_bwd(int C, int W, int H, int U, const float* bg, const float* 
         constexpr int CC = decltype(tag)::value;
         blend_bwd_kernel<CC><<<4 * U, 64, pad, st>>>(W, H, t.gx, b.unit_info, b.snap, b.masks, b.point_list, b.rec_a, b.rec_b,
                                                      static_cast<const RecTail<CC>*>(b.rec_c), bg, im.final_T, im.n_contrib,
-                                                     dL_dpix, grad_acc, tr);
+                                                     dL_dpix, grad_acc, tr, g_bwd_order);
     };
     if (C == 6) go(std::integral_constant<int, 6>{});
     else if (C == 4) go(std::integral_constant<int, 4>{});

@@ -323,6 +323,7 @@ void launch_rgb_depth_loss_grad(int C, int H, int W, const float* pred, const lo
 // Optional per-workgroup timeline for tuning (gsr_debug_set_trace): when non-null, the blend kernels store
 // {start, end} of every workgroup (100 MHz wall clock) at trace[2*blockIdx] (forward) / trace[2*(T+blockIdx)].
 extern uint64_t* g_trace;
+extern const uint32_t* g_bwd_order;   // experiments: a launch order of the backward's units (gsr_debug_set_bwd_order)
 
 // ---------------------------------------------------------------- kernel launchers (one per .hip file)
 struct Camera {              // passed by value to kernels (lands in SGPRs / kernarg)

@@ -348,6 +348,8 @@ int gsr_rgb_depth_loss_backward(int C, int H, int W, const float* pred, long lon
 /* Tuning aid: when device_buffer is non-NULL (4*T uint64), the two blend kernels record the start/end wall
  * clock (100 MHz) of every workgroup: forward at [2*b], backward at [2*(T+b)], b = launch index.  NULL = off. */
 int gsr_debug_set_trace(void* device_buffer);
+/* Experiments: a launch order for the backward blend's units ([num_segments] unit ids by dispatch position; NULL: none). */
+int gsr_debug_set_bwd_order(const void* device_order);
 
 /* Per-kernel timing for benchmarks (no reference counterpart; the reference has no profiling hooks,
  * SURVEY.md section 5).  While enabled, every stage this thread launches is bracketed by HIP events

@@ -51,7 +51,8 @@ for k, c in kern.items():
 # 1 - 4 us per stage, so the sum of ITS means exceeds the step; the sum of these does not
 for l in out:
     m = re.match(r'"gsr::(\w+?)(?:<[^"]*)?",(\d+),(\d+),([\d.]+),', l)
-    if m and m.group(1) in res:
+    # (a kernel with two instantiations in the run -- exact and planned binning -- is represented by the one launched more often)
+    if m and m.group(1) in res and int(m.group(2)) > res[m.group(1)].get("rocprof_calls", 0):
         res[m.group(1)]["rocprof_avg_ns"] = float(m.group(4))
         res[m.group(1)]["rocprof_calls"] = int(m.group(2))
 res["_source"] = f"profiles/{name}_pmc.txt (2*FETCH_SIZE + WRITE_SIZE, KiB; see tools/summarize_profiles.py)"
