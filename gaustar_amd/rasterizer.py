@@ -112,6 +112,12 @@ _FUSED = os.environ.get("GSR_FUSED_FORWARD", "1") != "0"   # 0: always stage 1, 
 # -- or by an explicit `plan_key`.  A plan is a hint: a wrong or stale one costs the exact path, never a wrong pixel.
 _PLANNED = os.environ.get("GSR_PLANNED", "1") != "0"
 _PLAN_SLOTS = int(os.environ.get("GSR_PLAN_SLOTS", "2048"))
+# Slack level a camera's first plan is made with (include/gsr.h: capacity = count + max(16, count / 8) << level).  Differentiable
+# renders belong to a training loop whose Gaussians move between a camera's visits: level 2 (count + max(64, count / 2)) -- in the
+# windowed refinement loop (tools/bench_window.py, 3 visits per camera and frame) levels 0 / 1 / 2 / 3 leave 400 / 317 / 133 / 42
+# views outgrowing their plans, and on a static scene the larger buckets cost the backward 1.5 us of empty units.  Forward-only
+# renders (sweeps of a fixed model): level 0.  A view that outgrows its plan raises its camera's level by one.
+_PLAN_LEVEL_ENV = os.environ.get("GSR_PLAN_LEVEL")
 _PLANS: "collections.OrderedDict" = collections.OrderedDict()   # key -> _Plan
 _PLAN_RETRY = 32   # a camera whose view could not be planned (a list too long for the in-kernel sort) is asked again after this many views
 PLAN_STATS = {"planned": 0, "exact": 0, "misfit": 0}            # views binned by a plan / without one / that outgrew theirs
@@ -122,12 +128,13 @@ class _Plan:
     binding's own bookkeeping (views to render without asking, misfits in a row, views seen while unplannable)."""
     __slots__ = ("buf", "info", "skip", "misfits", "idle", "_lib")
 
-    def __init__(self, lib, nbytes, byte_opts):
+    def __init__(self, lib, nbytes, byte_opts, level):
         self.buf = torch.empty(nbytes, **byte_opts)
         self.info = lib.gsr_plan_info_new()
         if not self.info:
             raise RuntimeError("gsr_plan_info_new failed")
         self.skip, self.misfits, self.idle, self._lib = 0, 0, 0, lib
+        self.info[4] = level
 
     def __del__(self):
         try:
@@ -136,13 +143,13 @@ class _Plan:
             pass
 
 
-def _plan_entry(key, lib, nbytes, byte_opts):
+def _plan_entry(key, lib, nbytes, byte_opts, level):
     with _HINT_LOCK:
         ent = _PLANS.get(key)
         if ent is not None and ent.buf.numel() == nbytes:
             _PLANS.move_to_end(key)
             return ent
-        ent = _Plan(lib, nbytes, byte_opts)
+        ent = _Plan(lib, nbytes, byte_opts, level)
         _PLANS[key] = ent
         while len(_PLANS) > _PLAN_SLOTS:
             _PLANS.popitem(last=False)
@@ -211,7 +218,8 @@ def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rot
             # (a camera's differentiable renders and its forward-only ones -- ground-truth / evaluation sweeps, often of another
             # model -- keep separate plans)
             key = (dev.index, int(st or 0), W, H, bool(need_backward), plan_key if plan_key is not None else vm_key)
-            plan = _plan_entry(key, lib, int(lib.gsr_plan_bytes(W, H)), byte_opts)
+            plan = _plan_entry(key, lib, int(lib.gsr_plan_bytes(W, H)), byte_opts,
+                               int(_PLAN_LEVEL_ENV) if _PLAN_LEVEL_ENV is not None else (2 if need_backward else 0))
             if plan.skip > 0:         # (a camera whose views keep outgrowing their plans: left alone for a while)
                 plan.skip -= 1
                 plan = None
