@@ -24,6 +24,9 @@ namespace {
 thread_local std::string g_err;
 thread_local uint32_t g_pinned_seq = 0;
 thread_local uint32_t* g_pinned = nullptr;
+// what stage 1 of this thread's last view told the host besides its three outputs: the number of PARTS the view's long lists
+// are blended in (tile_scan counts them); stage 2 of the same view picks the forward blend's launch shape by it
+thread_local struct { int R, maxc, nseg, parts; } g_last_stage1 = {-1, -1, -1, -1};
 // words of the pad: [0..3] stage-1 totals, [4] their sequence number (tile_scan); [8] verdict of a planned preprocess, [9] its
 // sequence number
 constexpr int PAD_WORDS = 64, PAD_VERDICT = 8;
@@ -343,6 +346,7 @@ int forward_stage1_impl(int P, int D, int M, const float* means3D, const float* 
     *num_rendered = (int)g_pinned[0];
     *max_tile_instances = (int)g_pinned[1];
     *num_segments = (int)g_pinned[3];
+    g_last_stage1 = {*num_rendered, *max_tile_instances, *num_segments, spin ? (int)g_pinned[5] : -1};
     return 0;
 }
 }  // namespace
@@ -629,11 +633,13 @@ int forward_stage2_impl(int P, int R, int max_tile_instances, int num_segments, 
         GSR_CHECK_LAUNCH("tile_sort_kernel");
     }
     const float* feats = colors_precomp ? colors_precomp : g.rgb;
+    const int num_parts = (g_last_stage1.R == R && g_last_stage1.maxc == max_tile_instances && g_last_stage1.nseg == num_segments)
+                              ? g_last_stage1.parts : -1;   // (-1: stage 1 of another view, or of another thread)
     {
         Scope sc(ST_BLEND_FWD, st);
         launch_blend_fwd(C, W, H, R > 0 ? R : 0, num_segments, (uint32_t)(max_tile_instances > 0 ? max_tile_instances : 0), background, feats, g, im, b,
                          out_color, !forward_only, grad_scratch,
-                         grad_scratch ? gsr_grad_scratch_bytes(P > 0 ? P : 0) : 0, counters, sort_in_blend, st, job, job_rides);
+                         grad_scratch ? gsr_grad_scratch_bytes(P > 0 ? P : 0) : 0, counters, sort_in_blend, st, job, job_rides, num_parts);
     }
     GSR_CHECK_LAUNCH("blend_fwd_kernel");
     return 0;

@@ -45,9 +45,10 @@ template <int PER>
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges,
                  uint32_t* __restrict__ totals, uint32_t* __restrict__ host_totals, uint32_t host_seq,
-                 uint32_t* __restrict__ order, uint32_t* __restrict__ seg_off, uint32_t view_token)
+                 uint32_t* __restrict__ order, uint32_t* __restrict__ seg_off, uint32_t view_token, uint32_t split_from_word)
 {
     static_assert((NSHARD & (NSHARD - 1)) == 0, "shard = workgroup index & (NSHARD - 1)");
+    __shared__ uint32_t parts_lds;   // parts (forward chunks) of the lists this view blends in parts: the host picks the launch shape by it
     __shared__ uint32_t wave_sum[16];
     __shared__ uint32_t wave_seg[16];
     __shared__ uint32_t wave_max[16];
@@ -63,6 +64,7 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
 #endif
     SCAN_STAMP();
     for (int i = tid; i < NHIST; i += 1024) hist[i] = 0;
+    if (tid == 0) parts_lds = 0u;
     // PER > 0: this thread's PER tiles live in registers.  PER == 0 (images above 8 192 tiles): the thread owns
     // ceil(T / 1024) consecutive tiles and re-reads their counters (L2-resident) in each of the three passes.
     constexpr bool IN_REGS = PER > 0;
@@ -129,6 +131,8 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
     uint32_t run = woff + incl - sum;
     uint32_t run_seg = woff_seg + incl_seg - segs;
     uint32_t n_empty = 0;   // empty tiles dominate: count them privately, one LDS atomic per thread
+    const uint32_t split_n = split_threshold_from(gmax, total, split_from_word);
+    uint32_t my_parts = 0;
     if constexpr (PER == 8) {
         // the 8 ranges (64 B) and 8 segment offsets (32 B) of a thread leave as 16-byte stores; the image-state carve
         // pads both arrays, and tiles >= T carry empty ranges that nobody reads
@@ -139,6 +143,7 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
             sg[k] = run_seg;
             rs[k + 1] = rs[k] + c[k];
             run_seg += (c[k] + (uint32_t)SEG - 1u) / (uint32_t)SEG;
+            if (t0 + k < T && c[k] > split_n) my_parts += (c[k] + (uint32_t)FWD_CHUNK - 1u) / (uint32_t)FWD_CHUNK;
             if (t0 + k < T) {
                 if (c[k] == 0) n_empty++;
                 else atomicAdd(&hist[length_bucket(c[k]) * NCOPY + copy], 1u);
@@ -167,16 +172,19 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
             seg_off[t] = run_seg;
             run += ck;
             run_seg += (ck + (uint32_t)SEG - 1u) / (uint32_t)SEG;
+            if (ck > split_n) my_parts += (ck + (uint32_t)FWD_CHUNK - 1u) / (uint32_t)FWD_CHUNK;
             if (ck == 0) n_empty++;
             else atomicAdd(&hist[length_bucket(ck) * NCOPY + copy], 1u);
         }
     }
     }
     if (n_empty) atomicAdd(&hist[(NBUCKET - 1) * NCOPY + copy], n_empty);
+    if (my_parts) atomicAdd(&parts_lds, my_parts);
     lds_barrier();
     SCAN_STAMP();   // ranges / seg_off stored, histogram counted
-    uint32_t nonempty = 0;   // (thread 0)
+    uint32_t nonempty = 0, n_parts = 0;   // (thread 0)
     if (tid == 0) {
+        n_parts = parts_lds;
         uint32_t empty = 0;
         for (int i = 0; i < NCOPY; i++) empty += hist[(NBUCKET - 1) * NCOPY + i];
         nonempty = (uint32_t)T - empty;
@@ -234,6 +242,7 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
     // host does not need the totals sooner: what it launches with them is stream-ordered behind scatter anyway.
     if (tid == 0 && host_totals) {
         *reinterpret_cast<uint4*>(host_totals) = make_uint4(total, gmax, nonempty, total_seg);
+        host_totals[5] = n_parts;
         __hip_atomic_store(&host_totals[4], host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 #ifdef GSR_SCAN_TRACE
@@ -248,9 +257,9 @@ tile_scan_kernel(int T, const uint32_t* __restrict__ tile_count, uint2* __restri
 void launch_tile_scan(ImageState im, int T, uint32_t* host_totals, uint32_t host_seq, uint32_t view_token, hipStream_t st)
 {
     if (T <= 8 * 1024)          // up to 1920x1088: counts stay in registers
-        tile_scan_kernel<8><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.totals, host_totals, host_seq, im.order, im.seg_off, view_token);
+        tile_scan_kernel<8><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.totals, host_totals, host_seq, im.order, im.seg_off, view_token, split_from());
     else                        // any larger grid (gsr_forward_stage1 caps T at 262 144 = 8k x 8k)
-        tile_scan_kernel<0><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.totals, host_totals, host_seq, im.order, im.seg_off, view_token);
+        tile_scan_kernel<0><<<1, 1024, 0, st>>>(T, im.tile_count, im.ranges, im.totals, host_totals, host_seq, im.order, im.seg_off, view_token, split_from());
 }
 
 // Every (Gaussian, tile) instance's sort key goes to its slot of the tile's bucket.  Workgroup b serves the 256 Gaussians
@@ -304,7 +313,7 @@ scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __
     if (totals[4] != totals[5]) {   // (uniform) every preprocess workgroup of this view recorded all of its instances
         if ((size_t)blockIdx.x * 256 >= (size_t)P) return;
         __shared__ uint32_t slot_base[WG_TAB_SLOTS];
-        static_assert(WG_TAB_SLOTS == 256, "one thread per table slot");
+        static_assert(WG_TAB_SLOTS % 256 == 0, "whole rounds of the workgroup's 256 threads");
         // (the record count of this wave's quarter and its first batch of records are requested HERE, together with the
         // table row: behind the barrier they were the third and fourth dependent trip to memory of a workgroup that makes
         // four -- table -> tile start and shard counts -> count -> records.  A wave's quarter always exists, so the
@@ -314,17 +323,23 @@ scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __
         const uint4* const recs_ = wg_recs + (size_t)blockIdx.x * WG_REC_CAP + (size_t)wv_ * WAVE_CAP_;
         const uint32_t nr_ = wg_nrec[blockIdx.x * 4 + wv_];
         const uint4 r0_ = recs_[lane];
-        const uint2 e = wg_tab[(size_t)blockIdx.x * WG_TAB_SLOTS + threadIdx.x];
-        if (e.x != 0xffffffffu) {
-            // all seven lower-shard counts are requested together (a loop with `if (s < shard)` compiles to dependent trips)
-            uint32_t cnt[NSHARD - 1];
-            const uint32_t start = ranges[e.x].x;
+        uint2 e_[WG_TAB_SLOTS / 256];
 #pragma unroll
-            for (int s_ = 0; s_ < NSHARD - 1; s_++) cnt[s_] = tile_count[s_ * Tp + e.x];
-            uint32_t base = start + e.y;
+        for (int q = 0; q < WG_TAB_SLOTS / 256; q++) e_[q] = wg_tab[(size_t)blockIdx.x * WG_TAB_SLOTS + q * 256 + threadIdx.x];
 #pragma unroll
-            for (int s_ = 0; s_ < NSHARD - 1; s_++) base += s_ < shard ? cnt[s_] : 0u;
-            slot_base[threadIdx.x] = base;
+        for (int q = 0; q < WG_TAB_SLOTS / 256; q++) {
+            const uint2 e = e_[q];
+            if (e.x != 0xffffffffu) {
+                // all seven lower-shard counts are requested together (a loop with `if (s < shard)` compiles to dependent trips)
+                uint32_t cnt[NSHARD - 1];
+                const uint32_t start = ranges[e.x].x;
+#pragma unroll
+                for (int s_ = 0; s_ < NSHARD - 1; s_++) cnt[s_] = tile_count[s_ * Tp + e.x];
+                uint32_t base = start + e.y;
+#pragma unroll
+                for (int s_ = 0; s_ < NSHARD - 1; s_++) base += s_ < shard ? cnt[s_] : 0u;
+                slot_base[q * 256 + threadIdx.x] = base;
+            }
         }
         __syncthreads();
         // every wave takes the records of the preprocess wave at its position (its quarter of the array)

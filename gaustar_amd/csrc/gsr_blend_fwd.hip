@@ -602,14 +602,21 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
 template <int C>
 static void launch_fwd_c(int W, int H, int R, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im,
                          BinState b, float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, uint32_t* counters,
-                         bool sort_small, const PlanJob* job, hipStream_t st)
+                         bool sort_small, const PlanJob* job, int num_parts, hipStream_t st)
 {
     const Tiles t = tiles_of(W, H);
     // (lists above 2 048 entries were sorted by the big-sort kernels before: launch_tile_sort; scatter_kernel listed the parts)
     const uint32_t split_n = split_threshold(max_count, (uint32_t)(R > 0 ? R : 0));
     // Residency knob: extra dynamic LDS lowers the number of co-resident tiles per CU (tuning only).
     static const int pad = getenv("GSR_FWD_LDS_PAD") ? atoi(getenv("GSR_FWD_LDS_PAD")) : 0;
-    static const bool two_launches = getenv("GSR_FWD_TWO_LAUNCHES") != nullptr;   // (comparison: the parts as a launch of their own)
+    // A part that has stored its result releases it to the device before it draws its ticket -- a write-back of its XCD's L2 --,
+    // which is nothing for a view with a handful of parts (config B: 10) and a storm for one with a thousand (config D, lists of
+    // up to 11 800 entries, every list above 1 024 split: blend_fwd 524 us in one launch against 199 us with the parts as a
+    // launch of their own, whose end is the release).  So: in one launch up to PARTS_IN_LAUNCH parts, two launches above.
+    // (num_parts < 0: the caller did not run stage 1 right before -- decide by the longest list.)
+    constexpr int PARTS_IN_LAUNCH = 64;
+    static const char* e_two = getenv("GSR_FWD_TWO_LAUNCHES");   // (comparison builds: 1 = always two launches, 0 = never)
+    const bool two_launches = e_two ? e_two[0] != '0' : (num_parts >= 0 ? num_parts > PARTS_IN_LAUNCH : max_count > 4096u);
     const auto go = [&](auto mode, unsigned grid, unsigned part_grid) {
         constexpr int M = decltype(mode)::value;
         blend_fwd_kernel<C, FWD_CHUNK, M><<<grid, 256, M == 1 ? 0 : pad, st>>>(
@@ -655,14 +662,14 @@ void launch_blend_fwd_planned(int C, int W, int H, const float* bg, const float*
 // whether this view's launch carried it (a view that splits its long lists does not: such a view is not plannable anyway)
 void launch_blend_fwd(int C, int W, int H, int R, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im,
                       BinState b, float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, uint32_t* counters,
-                      bool sort_small, hipStream_t st, const PlanJob* job, bool* job_rides)
+                      bool sort_small, hipStream_t st, const PlanJob* job, bool* job_rides, int num_parts)
 {
     const bool splits = split_threshold(max_count, (uint32_t)(R > 0 ? R : 0)) != 0xffffffffu && U > 0;
     if (splits || !job || !job->enabled) job = nullptr;
     if (job_rides) *job_rides = job != nullptr;
-    if (C == 6) launch_fwd_c<6>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, sort_small, job, st);
-    else if (C == 4) launch_fwd_c<4>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, sort_small, job, st);
-    else launch_fwd_c<3>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, sort_small, job, st);
+    if (C == 6) launch_fwd_c<6>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, sort_small, job, num_parts, st);
+    else if (C == 4) launch_fwd_c<4>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, sort_small, job, num_parts, st);
+    else launch_fwd_c<3>(W, H, R, U, max_count, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, counters, sort_small, job, num_parts, st);
 }
 
 }  // namespace gsr

@@ -41,7 +41,17 @@ struct GeomState {           // per Gaussian
     uint32_t* wg_nrec;       // [ceil(P / 256)][4] records each wave produced (more than its quarter: the view is flagged)
     size_t bytes;
 };
-constexpr int WG_REC_CAP = 1024, WG_TAB_SLOTS = 256;
+// (table: open addressing on the tile id, a power of two and a multiple of the workgroup's 256 threads; records: a quarter per wave)
+#ifndef GSR_WG_TAB_SLOTS
+#define GSR_WG_TAB_SLOTS 256
+#endif
+#ifndef GSR_WG_REC_CAP
+#define GSR_WG_REC_CAP 1024
+#endif
+constexpr int WG_REC_CAP = GSR_WG_REC_CAP, WG_TAB_SLOTS = GSR_WG_TAB_SLOTS;
+static_assert(WG_TAB_SLOTS >= 256 && (WG_TAB_SLOTS & (WG_TAB_SLOTS - 1)) == 0 && WG_TAB_SLOTS <= 65536 && WG_REC_CAP % 256 == 0, "");
+constexpr int WG_TAB_LOG2 = WG_TAB_SLOTS == 256 ? 8 : WG_TAB_SLOTS == 512 ? 9 : WG_TAB_SLOTS == 1024 ? 10 : WG_TAB_SLOTS == 2048 ? 11 : 12;
+static_assert((1 << WG_TAB_LOG2) == WG_TAB_SLOTS, "table sizes 256 .. 4096");
 inline GeomState carve_geom(void* base, int P)
 {
     GeomState s; size_t o = 0; char* b = (char*)base;
@@ -359,7 +369,7 @@ inline int front_of_order(int R, int T)
 struct PlanJob;   // gsr_plan.h
 void launch_blend_fwd(int C, int W, int H, int R, int U, uint32_t max_count, const float* bg, const float* feats, GeomState g, ImageState im,
                       BinState b, float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, uint32_t* counters,
-                      bool sort_small, hipStream_t st, const PlanJob* job = nullptr, bool* job_rides = nullptr);
+                      bool sort_small, hipStream_t st, const PlanJob* job = nullptr, bool* job_rides = nullptr, int num_parts = -1);
 void launch_blend_bwd(int C, int W, int H, int U, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
                       const float* dL_dpix, float* grad_acc, hipStream_t st);
 void launch_geom_bwd(int P, int D, int M, const float* means3D, const float* shs, const float* scales,

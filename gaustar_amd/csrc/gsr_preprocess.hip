@@ -37,7 +37,7 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
     __shared__ uint32_t agg_key[AGG_SLOTS], agg_cnt[AGG_SLOTS];
     __shared__ uint32_t tab_full;   // set by the first group that finds no slot: later groups do not probe at all
     constexpr uint32_t WAVE_CAP = WG_REC_CAP / 4;
-    __shared__ uint32_t rec_lds[PLANNED ? WG_REC_CAP : 1];   // (PLANNED) records {lane << 16 | slot << 8 | offset}, a quarter per wave
+    __shared__ uint32_t rec_lds[PLANNED ? WG_REC_CAP : 1];   // (PLANNED) records {lane << 24 | slot << 8 | offset}, a quarter per wave
     __shared__ uint32_t depth_lds[PLANNED ? 256 : 1];        // (PLANNED) every thread's depth bits
     __shared__ uint32_t misfit;                              // (PLANNED) this workgroup found something that does not fit the plan
     for (int i = threadIdx.x; i < AGG_SLOTS; i += blockDim.x) { agg_key[i] = 0xffffffffu; agg_cnt[i] = 0u; }
@@ -179,8 +179,7 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
             uint32_t slot = 0xffffffffu, off = 0u;
             // (multiplicative hash: a workgroup's ~90 tiles are runs of consecutive ids in rows gx apart, which
             // `tile & 255` folds onto each other into long probe chains)
-            uint32_t h = ((uint32_t)tile * 0x9E3779B1u) >> 24;
-            static_assert(AGG_SLOTS == 256, "hash keeps the top 8 bits");
+            uint32_t h = ((uint32_t)tile * 0x9E3779B1u) >> (32 - WG_TAB_LOG2);   // (the top bits)
             const int max_probe = tab_full ? 0 : 24;
             for (int probe = 0; probe < max_probe; probe++) {
                 const uint32_t prev = atomicCAS(&agg_key[h], 0xffffffffu, (uint32_t)tile);
@@ -200,8 +199,9 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
             const uint32_t pos = n_wave + (uint32_t)__popcll(act & lt);
             if constexpr (PLANNED) {
                 // (a Gaussian meets a tile once, so an offset inside a workgroup's span is below 256)
-                if (pos < WAVE_CAP && slot != 0xffffffffu)
-                    rec_lds[(threadIdx.x >> 6) * WAVE_CAP + pos] = ((uint32_t)lane << 16) | (slot << 8) | off;
+                // (an instance that found no table slot still takes its place in the record array -- as a record nobody acts on)
+                if (pos < WAVE_CAP)
+                    rec_lds[(threadIdx.x >> 6) * WAVE_CAP + pos] = slot != 0xffffffffu ? (((uint32_t)lane << 24) | (slot << 8) | off) : 0xffffffffu;
             } else {
                 if (pos < WAVE_CAP) wave_recs[pos] = make_uint4((uint32_t)idx, __float_as_uint(my_depth), slot, off);
             }
@@ -214,18 +214,17 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
         __syncthreads();
         // one returning atomic per occupied slot on the tile's cursor: where this workgroup's span starts inside the bucket
         // (agg_key is reused for the absolute position of the span; 0xffffffff: the slot is empty or its span does not fit)
-        static_assert(AGG_SLOTS == 256, "one thread per table slot");
-        {
-            const uint32_t tile = agg_key[threadIdx.x];
+        for (int i = threadIdx.x; i < AGG_SLOTS; i += 256) {
+            const uint32_t tile = agg_key[i];
             uint32_t at = 0xffffffffu;
             if (tile != 0xffffffffu) {
                 const uint2 bucket = plan.ranges[tile];
-                const uint32_t cnt = agg_cnt[threadIdx.x];
+                const uint32_t cnt = agg_cnt[i];
                 const uint32_t old = atomicAdd(&plan.cursor[(size_t)tile * PLAN_CURSOR_STRIDE], cnt);
                 if (old + cnt <= bucket.y) at = bucket.x + old;
                 else misfit = 1u;
             }
-            agg_key[threadIdx.x] = at;
+            agg_key[i] = at;
         }
         __syncthreads();
         {
@@ -234,7 +233,8 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
             const uint32_t gbase = (uint32_t)(idx - lane);
             for (uint32_t i = lane; i < nr; i += 64u) {
                 const uint32_t r = rec_lds[wv * WAVE_CAP + i];
-                const uint32_t src = r >> 16, at = agg_key[(r >> 8) & 255u];
+                if (r == 0xffffffffu) continue;
+                const uint32_t src = r >> 24, at = agg_key[(r >> 8) & 0xffffu];
                 if (at != 0xffffffffu)
                     plan.keys[at + (r & 255u)] = ((uint64_t)depth_lds[wv * 64u + src] << 32) | (gbase + src);
             }

@@ -76,8 +76,9 @@ def test_full_size_pipelines_equal_serial_renders(config_c, V):
             for k in g_s:
                 parity.check_grad(g_p[k].cpu().numpy(), g_s[k].cpu().numpy(), f"pipelines V={V} round {rnd} view {VIEWS[i]} {k}",
                                   tol=1e-5, small_tol=None)
-    # the hint did what the rounds were set up for: grew from nothing, stayed, came down from 16x, grew from 32 MB
-    assert hints[0] >= steady // 2 and hints[1] == hints[0] and hints[2] < 16 * steady and hints[3] > (32 << 20), hints
+    # the hint did what the rounds were set up for: grew from nothing, stayed (or made room for the capacities of the plans
+    # round 0 left behind: gsr_forward_planned), came down from 16x, grew from 32 MB
+    assert hints[0] >= steady // 2 and hints[0] <= hints[1] <= 2 * hints[0] and hints[2] < 16 * steady and hints[3] > (32 << 20), hints
 
 
 def test_a_pipelined_full_size_view_against_reference_build(config_c):
