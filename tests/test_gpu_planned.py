@@ -146,3 +146,27 @@ def test_plans_of_many_cameras_and_small_scene():
             planned += r[3]["planned"]
             assert r[3]["misfit"] == 0
     assert planned >= len(views), planned     # most cameras of the rig are plannable, each for two epochs
+
+
+def test_giant_splats_under_a_plan_do_not_corrupt_anything():
+    """Config C under use_solid_surface-like scales (sugar_model.py:1230-1232; bench.py's C_solid): a few splats cover thousands
+    of tiles, workgroups run out of table slots and record space.  Round 5 found the planned preprocess acting on records it
+    had never written for instances without a table slot (a wild store); every such view must come out as the exact path's."""
+    from gaustar_amd import rasterizer as rz, scene
+    dev = torch.device("cuda:0")
+    gs, cams, bg = scene.config_C()
+    cam = cams[0]
+    sc = np.array(gs.scales, dtype=np.float32, copy=True)
+    sc[:, 1:] *= np.exp(np.random.default_rng(7).normal(0.0, 1.0, size=(gs.P, 1))).astype(np.float32)
+    sc[:, 1:] = np.maximum(sc[:, 1:].mean(), sc[:, 1:])
+    gs.scales = sc
+    ps, cam_t, bg_t, dpix = _inputs(dev, gs, cam, bg)
+    rz.drop_plans()
+    exact = _render(dev, ps, cam_t, bg_t, cam, dpix, use_plan=False)
+    seen = {"planned": 0, "exact": 0, "misfit": 0}
+    for _ in range(6):
+        r = _render(dev, ps, cam_t, bg_t, cam, dpix)
+        for k in seen:
+            seen[k] += r[3][k]
+        _check_same(r, exact, "giant splats")
+    assert seen["planned"] + seen["misfit"] >= 1, seen    # a plan was tried at least once
