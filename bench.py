@@ -780,6 +780,15 @@ def main():
             except OSError:
                 pass
             out["cpu_baseline"] = cpu_baseline(gs, cams, bg)
+            if pinned:   # back to the cores the GPU figures above were measured on: the legs below are GPU figures too
+                try:
+                    for tid in os.listdir("/proc/self/task"):
+                        try:
+                            os.sched_setaffinity(int(tid), pinned)
+                        except OSError:
+                            pass
+                except OSError:
+                    pass
         if world == 1 and not args.no_extras:
             oc = {}
             for cname in ("B", "D", "D_depth", "C_solid"):
