@@ -361,7 +361,9 @@ scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __
         key = ((uint64_t)__float_as_uint(depth[idx]) << 32) | (uint32_t)idx;
         if (!(r.z > r.x && r.w > r.y)) b.z = -1.f;
     }
-    for_each_tile_aggregated(r, a.x, a.y, a.z, a.w, b.x, b.z, gx, lane,
+    // (giant splats are placed by the whole wave below, exactly as preprocess counted them: gsr_internal.h CoopSplat)
+    const bool big = b.z >= 0.0f && rect_is_big(r);
+    for_each_tile_aggregated(big ? make_ushort4(0, 0, 0, 0) : r, a.x, a.y, a.z, a.w, b.x, b.z, gx, lane,
                              [&](int tile, bool is_leader, int group, int rank, int leader_lane) {
                                  uint32_t base = 0;
                                  if (is_leader) {
@@ -381,6 +383,24 @@ scatter_kernel(int P, int gx, const ushort4* __restrict__ rect, const float4* __
                                  base = __shfl(base, leader_lane, 64);
                                  if (tile >= 0) keys[base + (uint32_t)rank] = key;
                              });
+    for (unsigned long long bigs = __ballot(big); bigs != 0ull; bigs &= bigs - 1ull) {
+        const int src = __ffsll((unsigned long long)bigs) - 1;
+        const CoopSplat cs(r, a.x, a.y, a.z, a.w, b.x, b.z, src);
+        const uint64_t src_key = ((uint64_t)(uint32_t)__shfl((int)(key >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)key, src, 64);
+        for (int base0 = 0; base0 < cs.n; base0 += 64) {
+            const int tile = cs.tile(base0, lane, gx);
+            if (tile >= 0) {   // (every lane has a tile of its own: one returning atomic each on the shard's cursor)
+                uint32_t cnt[NSHARD - 1];
+                const uint32_t start = ranges[tile].x;
+#pragma unroll
+                for (int s_ = 0; s_ < NSHARD - 1; s_++) cnt[s_] = tile_count[s_ * Tp + tile];
+                uint32_t at = start + atomicAdd(&tile_cursor[shard * Tp + tile], 1u);
+#pragma unroll
+                for (int s_ = 0; s_ < NSHARD - 1; s_++) at += s_ < shard ? cnt[s_] : 0u;
+                keys[at] = src_key;
+            }
+        }
+    }
 }
 
 void launch_scatter(int P, int W, int H, int R, uint32_t max_count, GeomState g, ImageState im, BinState b, hipStream_t st)

@@ -797,6 +797,36 @@ struct TileWalker {
         return true;
     }
 };
+// Rects above COOP_TILES tiles are not walked by their own lane but by the whole wave, lane k testing tile base + k of the rect:
+// one lane testing a giant splat's thousands of tiles one after the other WAS the kernel for views with a few such splats
+// (config C under solid-surface scales, sugar_model.py:1230-1232: preprocess 761 us, scatter 1 365 us; real captures always hold
+// some).  The same test (block_min_half_quad against tau) on the same tiles as TileWalker, so counts and places agree.
+constexpr int COOP_TILES = 32;
+__device__ __forceinline__ bool rect_is_big(ushort4 r)
+{
+    return r.z > r.x && r.w > r.y && ((int)r.z - (int)r.x) * ((int)r.w - (int)r.y) > COOP_TILES;
+}
+struct CoopSplat {
+    int x0, y0, w, n; float px, py, ca, cb, cc, tau;
+    // the splat of lane `src`, to every lane of the wave
+    __device__ __forceinline__ CoopSplat(ushort4 r, float px_, float py_, float ca_, float cb_, float cc_, float tau_, int src)
+    {
+        const int rx = __shfl((int)r.x, src, 64), ry = __shfl((int)r.y, src, 64), rz = __shfl((int)r.z, src, 64), rw = __shfl((int)r.w, src, 64);
+        x0 = rx; y0 = ry; w = rz - rx; n = w * (rw - ry);
+        px = __shfl(px_, src, 64); py = __shfl(py_, src, 64); ca = __shfl(ca_, src, 64); cb = __shfl(cb_, src, 64);
+        cc = __shfl(cc_, src, 64); tau = __shfl(tau_, src, 64);
+    }
+    // this lane's tile of the round starting at rect position `base`, or -1
+    __device__ __forceinline__ int tile(int base, int lane, int gx) const
+    {
+        const int k = base + lane;
+        if (k >= n) return -1;
+        const int dy = k / w, ty = y0 + dy, tx = x0 + (k - dy * w);
+        const float X0 = (float)(tx * TILE) - px, Y0 = (float)(ty * TILE) - py;
+        const bool hit = block_min_half_quad(ca, cb, cc, X0, X0 + (float)(TILE - 1), Y0, Y0 + (float)(TILE - 1)) <= tau;
+        return hit ? ty * gx + tx : -1;
+    }
+};
 template <class F>
 __device__ __forceinline__ void for_each_tile_aggregated(ushort4 rect, float px, float py, float ca, float cb,
                                                          float cc, float tau, int gx, int lane, F f)

@@ -170,11 +170,10 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
     // (No wave-level grouping of the lanes by tile here: with the LDS table in front of memory every lane simply takes its
     // own place with one returning LDS atomic -- same-address lanes serialise inside that one instruction, which is far
     // cheaper than the ballot loop that used to elect a leader per distinct tile.)
-    TileWalker walker(out_rect, px, py, conic_a, conic_b, conic_c, tau, gx, lane);
-    while (true) {
-        const int tile = walker.next_tile();
+    // one round of the walk: every lane brings a reachable tile of the splat of lane `src` (or -1); -> whether any lane had one
+    const auto visit = [&](int tile, uint32_t src, uint32_t src_idx, uint32_t src_depth) -> bool {
         const unsigned long long act = __ballot(tile >= 0);
-        if (act == 0ull) break;
+        if (act == 0ull) return false;
         if (tile >= 0) {
             uint32_t slot = 0xffffffffu, off = 0u;
             // (multiplicative hash: a workgroup's ~90 tiles are runs of consecutive ids in rows gx apart, which
@@ -201,12 +200,23 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
                 // (a Gaussian meets a tile once, so an offset inside a workgroup's span is below 256)
                 // (an instance that found no table slot still takes its place in the record array -- as a record nobody acts on)
                 if (pos < WAVE_CAP)
-                    rec_lds[(threadIdx.x >> 6) * WAVE_CAP + pos] = slot != 0xffffffffu ? (((uint32_t)lane << 24) | (slot << 8) | off) : 0xffffffffu;
+                    rec_lds[(threadIdx.x >> 6) * WAVE_CAP + pos] = slot != 0xffffffffu ? ((src << 24) | (slot << 8) | off) : 0xffffffffu;
             } else {
-                if (pos < WAVE_CAP) wave_recs[pos] = make_uint4((uint32_t)idx, __float_as_uint(my_depth), slot, off);
+                if (pos < WAVE_CAP) wave_recs[pos] = make_uint4(src_idx, src_depth, slot, off);
             }
         }
         n_wave += (uint32_t)__popcll(act);
+        return true;
+    };
+    // lanes with ordinary rects walk their own tiles in step; giant splats are then walked by the whole wave, one after the other
+    const bool big = tau >= 0.0f && rect_is_big(out_rect);
+    TileWalker walker(big ? make_ushort4(0, 0, 0, 0) : out_rect, px, py, conic_a, conic_b, conic_c, tau, gx, lane);
+    while (visit(walker.next_tile(), (uint32_t)lane, (uint32_t)idx, __float_as_uint(my_depth))) {}
+    for (unsigned long long bigs = __ballot(big); bigs != 0ull; bigs &= bigs - 1ull) {
+        const int src = __ffsll((unsigned long long)bigs) - 1;
+        const CoopSplat cs(out_rect, px, py, conic_a, conic_b, conic_c, tau, src);
+        const uint32_t src_idx = (uint32_t)__shfl(idx, src, 64), src_depth = (uint32_t)__shfl((int)__float_as_uint(my_depth), src, 64);
+        for (int base = 0; base < cs.n; base += 64) visit(cs.tile(base, lane, gx), (uint32_t)src, src_idx, src_depth);
     }
     if constexpr (PLANNED) {
         depth_lds[threadIdx.x] = __float_as_uint(my_depth);

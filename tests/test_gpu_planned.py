@@ -43,7 +43,7 @@ def _render(dev, ps, cam_t, bg_t, cam, dpix=None, use_plan=None, channels=3, nee
     return color.clone(), radii.clone(), grads, delta, (R, nseg)
 
 
-def _check_same(a, b, what):
+def _check_same(a, b, what, gtol=2e-5):
     assert torch.equal(a[0], b[0]), f"{what}: images differ, max {float((a[0] - b[0]).abs().max())}"
     assert torch.equal(a[1], b[1]), f"{what}: radii differ"
     if a[2] is not None:
@@ -53,7 +53,7 @@ def _check_same(a, b, what):
                 continue
             scale = float(gb.abs().max())
             err = float((ga - gb).abs().max())
-            assert err <= 2e-5 * scale + 1e-30, f"{what}: gradient {i} differs by {err} of max {scale}"
+            assert err <= gtol * scale + 1e-30, f"{what}: gradient {i} differs by {err} of max {scale}"
 
 
 def _inputs(dev, gs, cam, bg, channels=3):
@@ -163,10 +163,14 @@ def test_giant_splats_under_a_plan_do_not_corrupt_anything():
     ps, cam_t, bg_t, dpix = _inputs(dev, gs, cam, bg)
     rz.drop_plans()
     exact = _render(dev, ps, cam_t, bg_t, cam, dpix, use_plan=False)
+    # (a giant splat's gradient is a float-atomic sum over tens of thousands of pixels: two runs of the SAME path differ by the
+    # order of those additions -- that spread, measured here, is the yardstick; images and radii must be equal outright)
+    again = _render(dev, ps, cam_t, bg_t, cam, dpix, use_plan=False)
+    noise = max(float((ga - gb).abs().max() / gb.abs().max()) for ga, gb in zip(again[2], exact[2]) if ga is not None and ga.numel())
     seen = {"planned": 0, "exact": 0, "misfit": 0}
     for _ in range(6):
         r = _render(dev, ps, cam_t, bg_t, cam, dpix)
         for k in seen:
             seen[k] += r[3][k]
-        _check_same(r, exact, "giant splats")
+        _check_same(r, exact, "giant splats", gtol=max(2e-5, 8.0 * noise))
     assert seen["planned"] + seen["misfit"] >= 1, seen    # a plan was tried at least once
