@@ -114,6 +114,12 @@ def test_fused_forward_and_new_entry_points_validate_without_gpu(hip_lib):
     rc = hip_lib.gsr_forward_fused(10, 0, 0, 3, 1, *([null] * 5), 1.0, *([null] * 5), 64, 64, 0.5, 0.5, 0, *([null] * 5), 0, null,
                                    null, *outs, null, null)
     assert rc != 0 and b"null output" in hip_lib.gsr_last_error()
+    # planned forward (ABI 13): its three plan pointers are required; with them and null arrays the same validation as fused fires
+    pl = ctypes.c_int(7)
+    rc = hip_lib.gsr_forward_planned(10, 0, 0, 3, 1, *([null] * 5), 1.0, *([null] * 5), 64, 64, 0.5, 0.5, 0, *([null] * 5), 0, null,
+                                     null, *outs, ctypes.byref(bl), null, None, ctypes.byref(pl), null)
+    assert rc != 0 and b"null plan" in hip_lib.gsr_last_error()
+    assert hip_lib.gsr_plan_bytes(1920, 1080) >= 16 * 8160 and hip_lib.gsr_plan_bytes(0, 5) == 0
     # backward_mt: the extra flag does not relax the pointer checks; P == 0 stays a no-op success
     rc = hip_lib.gsr_backward_mt(5, 0, 0, 0, 0, 3, null, 8, 8, *([null] * 4), 1.0, *([null] * 5), 0.5, 0.5, *([null] * 14), 1, null)
     assert rc != 0 and hip_lib.gsr_last_error()

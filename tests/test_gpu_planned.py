@@ -174,3 +174,43 @@ def test_giant_splats_under_a_plan_do_not_corrupt_anything():
             seen[k] += r[3][k]
         _check_same(r, exact, "giant splats", gtol=max(2e-5, 8.0 * noise))
     assert seen["planned"] + seen["misfit"] >= 1, seen    # a plan was tried at least once
+
+
+@pytest.mark.parametrize("name", ["sh3_random", "cov3d_precomp", "mesh_sphere", "edge_cases", "depth_color_bg10"])
+def test_golden_cases_under_a_plan(name):
+    """The golden cases of tests/golden (outputs of the reference's own kernels) rendered three times with the same camera
+    tensors: the third render is binned by the plan the first left (where the case is plannable) and must still match the
+    golden image / radii / gradients as strictly as the first -- in-kernel SH, precomputed covariances, edge cases included."""
+    import parity
+    from gaustar_amd import rasterizer as rz
+    kw, d = parity.load_golden(name)
+    rz.drop_plans()
+    dev = torch.device("cuda:0")
+    t = lambda x: None if x is None else torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
+    e = torch.Tensor([])
+    opt = lambda k: t(kw[k]) if kw.get(k) is not None else e
+    fixed = dict(bg=t(kw["bg"]), view=t(kw["view"]), proj=t(kw["proj"]), campos=t(kw["campos"]))
+    args = dict(means3D=t(kw["means3D"]), colors=opt("colors_precomp"), op=t(kw["opacities"]), scales=opt("scales"), rot=opt("rotations"),
+                cov=opt("cov3D_precomp"), shs=opt("shs"))
+    dpix = t(d["in_dL_dpix"])
+    outs, planned = [], 0
+    for _ in range(4):
+        before = dict(rz.PLAN_STATS)
+        o = rz.rasterize_gaussians_native(fixed["bg"], args["means3D"], args["colors"], args["op"], args["scales"], args["rot"],
+                                          kw["scale_modifier"], args["cov"], fixed["view"], fixed["proj"], kw["tanfovx"], kw["tanfovy"],
+                                          kw["H"], kw["W"], args["shs"], kw["sh_degree"], fixed["campos"], False, False)
+        g = rz.rasterize_gaussians_backward_native(fixed["bg"], args["means3D"], o[2], args["colors"], args["scales"], args["rot"],
+                                                   kw["scale_modifier"], args["cov"], fixed["view"], fixed["proj"], kw["tanfovx"],
+                                                   kw["tanfovy"], dpix, args["shs"], kw["sh_degree"], fixed["campos"], o[3], o[0], o[4], o[5],
+                                                   False, num_segments=o[7])
+        torch.cuda.synchronize()
+        planned += rz.PLAN_STATS["planned"] - before["planned"]
+        outs.append((o[1].clone(), o[2].clone(), [None if x is None else x.clone() for x in g]))
+    first, last = outs[0], outs[-1]
+    assert torch.equal(first[0], last[0]) and torch.equal(first[1], last[1]), name
+    for ga, gb in zip(first[2], last[2]):
+        if ga is None or ga.numel() == 0:
+            continue
+        assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max()) + 1e-30, name
+    parity.check_image(last[0].cpu().numpy(), d["out_color"], f"{name} under a plan")
+    assert planned >= 1 or name in ("edge_cases",), (name, planned)
