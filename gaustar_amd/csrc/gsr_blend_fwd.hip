@@ -167,13 +167,30 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     // tile's sort overlaps the other resident tiles' blending, and the sorted ids are read back while still in L2.
     // The kernel's span is its longest tile (a pixel's walk is serial), and co-resident waves share a SIMD's issue slots:
     // long lists get issue priority -- from their sort on -- so that they do not also run at 1/7 speed.
+#ifdef GSR_FWD_PHASES   // devtool build: wave 0's stamps {start, sorted, then per chunk: parked + words done, walked} behind the traces
+    uint64_t* const ph = (trace && !is_part && threadIdx.x == 0) ? trace + 2 * (size_t)gridDim.x + 2 * 65536 + (size_t)tile_block * 16 : nullptr;
+    int ph_i = 0;
+#define FWD_PHASE() do { if (ph && ph_i < 16) ph[ph_i++] = wall_clock64(); } while (0)
+    if (ph) { ph[ph_i++] = t_start; }
+    FWD_PHASE();
+#else
+#define FWD_PHASE() do { } while (0)
+#endif
     if (n > 1024u) __builtin_amdgcn_s_setprio(3);
     else if (n > 704u) __builtin_amdgcn_s_setprio(2);
     else if (n > 448u) __builtin_amdgcn_s_setprio(1);
+    // (the sorted keys are still in LDS when the tile asks for the ids of its first two chunks: read there, they spare the walk's
+    // first dependent trip to memory -- the ids were written to the list a moment ago, for the later chunks and the backward)
+    const uint64_t* ids_lds = nullptr;
     if (!is_part) {
         if (sort_keys != nullptr) {
-            if (n >= 1u && n <= 2048u) sort_small_tile(reinterpret_cast<uint64_t*>(smem), sort_keys + list0, point_list + list0, n);
+#ifdef GSR_FWD_PHASES
+            if (n >= 1u && n <= 2048u) ids_lds = sort_small_tile(reinterpret_cast<uint64_t*>(smem), sort_keys + list0, point_list + list0, n, [&]() { FWD_PHASE(); });
+#else
+            if (n >= 1u && n <= 2048u) ids_lds = sort_small_tile(reinterpret_cast<uint64_t*>(smem), sort_keys + list0, point_list + list0, n);
+#endif
             __syncthreads();   // ids visible to the four waves; the sort's LDS is free
+            FWD_PHASE();
         }
     } else if (parts_sort && sort_keys != nullptr && n <= SORT_SMALL_CAP) {
         // A part sorts the WHOLE list of its tile for itself (every part of the tile writes the same ids to the same places): no
@@ -207,7 +224,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
 #pragma unroll
         for (int q = 0; q < PT; q++) {
             const uint32_t k = c0 + q * 256 + threadIdx.x;
-            gid_nxt[q] = k < n ? list[k] : 0xffffffffu;
+            gid_nxt[q] = k < n ? (ids_lds != nullptr ? (uint32_t)ids_lds[k] : list[k]) : 0xffffffffu;
         }
     };
     const auto fetch_records = [&]() {
@@ -569,6 +586,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         fetch_ids(0);
         fetch_records();
         fetch_ids(CH);
+        ids_lds = nullptr;   // (the first park below overwrites those bytes)
         for (uint32_t c0 = 0; c0 < n; c0 += CH) {
             // every pixel of the tile saturated: stop (also the barrier that frees the LDS of the previous chunk)
             if (__syncthreads_or(!done) == 0) break;
@@ -576,9 +594,11 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             fetch_records();
             fetch_ids(c0 + 2 * CH);
             __syncthreads();
+            FWD_PHASE();
             // (a pixel that is done consumes no words)
             const bool stopped = walk(c0, done ? 0u : nonempty_words(c0));
             done = done || stopped;
+            FWD_PHASE();
         }
     
     }

@@ -127,22 +127,41 @@ __device__ __forceinline__ void run64_stages(uint64_t (&v)[1], int lane)
 }
 
 // (out: the sorted Gaussian ids; out_keys, if given instead: the sorted keys themselves -- runs of a longer list)
-template <int E>
-__device__ __forceinline__ void sort_tile_merge(uint64_t* __restrict__ s, const uint64_t* __restrict__ gk,
-                                                uint32_t* __restrict__ out, uint32_t n, uint64_t* __restrict__ out_keys = nullptr)
+struct NoStamp { __device__ __forceinline__ void operator()() const {} };
+// -> where the sorted keys lie in LDS when the function returns (valid until the caller reuses the bytes)
+template <int E, class STAMP = NoStamp>
+__device__ __forceinline__ const uint64_t* sort_tile_merge(uint64_t* __restrict__ s, const uint64_t* __restrict__ gk,
+                                                uint32_t* __restrict__ out, uint32_t n, uint64_t* __restrict__ out_keys = nullptr,
+                                                STAMP stamp = STAMP())
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint64_t* A = s;
     uint64_t* B = s + SORT_SMALL_CAP;
     const uint32_t n_runs = (n + 63u) >> 6;
-    for (uint32_t r = wave; r < n_runs; r += 4u) {
-        const uint32_t i = r * 64u + lane;
-        uint64_t v[1] = {i < n ? gk[i] : ~0ull};
-        run64_stages<2, 1>(v, (int)lane);
-        A[i] = v[0];
+    // (a wave's up to E runs: all keys are requested before the first run is sorted -- one trip to memory, not one per run)
+    uint64_t kv[E];
+#pragma unroll
+    for (int q = 0; q < E; q++) {
+        const uint32_t i = (wave + 4u * (uint32_t)q) * 64u + lane;
+        kv[q] = i < n ? gk[i] : ~0ull;
+    }
+#pragma unroll
+    for (int q = 0; q < E; q++) {
+        const uint32_t r = wave + 4u * (uint32_t)q;
+        if (r < n_runs) {   // (wave-uniform)
+            uint64_t v[1] = {kv[q]};
+            run64_stages<2, 1>(v, (int)lane);
+            A[r * 64u + lane] = v[0];
+        }
     }
     __syncthreads();
+    stamp();
     const uint32_t o0 = tid * (uint32_t)E;                       // this thread's output positions [o0, o0 + E) on every level
+    // Round 5: the levels are built for few DEPENDENT trips to LDS -- under three other tiles' walks a dependent ds_read costs
+    // ~400 cycles, and a 1 300-entry list spent 18.7 us here (a quarter of the forward's longest tile) on 5 levels x (11 binary
+    // search steps + 8 sequential merge steps).  Now: a 4-ary search along the merge path (three probes = six independent reads
+    // per step, log4 steps), then the next E keys of BOTH runs in one go (2 E independent reads) and the merge in registers:
+    // min(a[i], b[E-1-i]) is a bitonic sequence holding the E smallest of the 2 E, three (log2 E) compare-exchange stages sort it.
     for (uint32_t len = 64u; len < n; len <<= 1) {
         uint64_t res[E];
         if (o0 < n) {
@@ -154,41 +173,63 @@ __device__ __forceinline__ void sort_tile_merge(uint64_t* __restrict__ s, const 
             const uint32_t d = o0 - base;
             uint32_t lo = d > lb ? d - lb : 0u, hi = min(d, la);
             while (lo < hi) {                                   // merge path: how many of the first d outputs come from a
-                const uint32_t mid = (lo + hi) >> 1;
-                if (a[mid] < b[d - 1u - mid]) lo = mid + 1u; else hi = mid;
+                const uint32_t span = hi - lo;
+                const uint32_t m1 = lo + (span >> 2), m2 = lo + (span >> 1), m3 = lo + ((3u * span) >> 2);
+                const uint64_t a1 = a[m1], b1 = b[d - 1u - m1], a2 = a[m2], b2 = b[d - 1u - m2], a3 = a[m3], b3 = b[d - 1u - m3];
+                const bool p1 = a1 < b1, p2 = a2 < b2, p3 = a3 < b3;   // monotone: true ... true false ... false
+                if (!p1) hi = m1;
+                else if (!p2) { lo = m1 + 1u; hi = m2; }
+                else if (!p3) { lo = m2 + 1u; hi = m3; }
+                else lo = m3 + 1u;
             }
-            uint32_t ai = lo, bi = d - lo;
-            uint64_t ka = ai < la ? a[ai] : ~0ull, kb = bi < lb ? b[bi] : ~0ull;
+            const uint32_t ai = lo, bi = d - lo;
+            uint64_t ka[E], kb[E];
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                const bool take_a = bi >= lb || (ai < la && ka < kb);
-                res[e] = take_a ? ka : kb;
-                if (take_a) { ai++; ka = ai < la ? a[ai] : ~0ull; }
-                else { bi++; kb = bi < lb ? b[bi] : ~0ull; }
+                ka[e] = ai + (uint32_t)e < la ? a[ai + e] : ~0ull;
+                kb[e] = bi + (uint32_t)e < lb ? b[bi + e] : ~0ull;
+            }
+#pragma unroll
+            for (int e = 0; e < E; e++) res[e] = ka[e] < kb[E - 1 - e] ? ka[e] : kb[E - 1 - e];
+#pragma unroll
+            for (int j = E / 2; j > 0; j >>= 1) {
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    if ((e & j) == 0) {
+                        const uint64_t x = res[e], y = res[e | j];
+                        const bool gt = x > y;
+                        res[e] = gt ? y : x;
+                        res[e | j] = gt ? x : y;
+                    }
+                }
             }
 #pragma unroll
             for (int e = 0; e < E; e++)
                 if (o0 + (uint32_t)e < n) B[o0 + e] = res[e];
         }
         __syncthreads();                                        // level done: B complete, nobody reads A any more
+        stamp();
         uint64_t* t = A; A = B; B = t;
     }
     if (out_keys != nullptr) { for (uint32_t i = tid; i < n; i += 256u) out_keys[i] = A[i]; }
     else { for (uint32_t i = tid; i < n; i += 256u) out[i] = (uint32_t)A[i]; }
+    return A;
 }
 
 // One tile of 1 .. 2 048 keys, 256 threads, s = 2 * SORT_SMALL_CAP * 8 bytes of LDS.
 // Must be called by all 256 threads of the workgroup (it contains workgroup barriers).
-__device__ __forceinline__ void sort_small_tile(uint64_t* __restrict__ s, const uint64_t* __restrict__ gk,
-                                                uint32_t* __restrict__ out, uint32_t n)
+// -> the sorted keys in LDS (nullptr for a single key), see sort_tile_merge
+template <class STAMP = NoStamp>
+__device__ __forceinline__ const uint64_t* sort_small_tile(uint64_t* __restrict__ s, const uint64_t* __restrict__ gk,
+                                                           uint32_t* __restrict__ out, uint32_t n, STAMP stamp = STAMP())
 {
     if (n == 1) {
         if (threadIdx.x == 0) out[0] = (uint32_t)gk[0];
-        return;
+        return nullptr;
     }
-    if (n <= 512u) sort_tile_merge<2>(s, gk, out, n);
-    else if (n <= 1024u) sort_tile_merge<4>(s, gk, out, n);
-    else sort_tile_merge<8>(s, gk, out, n);
+    if (n <= 512u) return sort_tile_merge<2>(s, gk, out, n, nullptr, stamp);
+    if (n <= 1024u) return sort_tile_merge<4>(s, gk, out, n, nullptr, stamp);
+    return sort_tile_merge<8>(s, gk, out, n, nullptr, stamp);
 }
 
 }  // namespace gsr
