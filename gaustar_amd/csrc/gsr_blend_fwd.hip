@@ -305,6 +305,112 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     // remaining bits, (nh, nw) = the next non-empty word, read one step ahead, nz = the non-empty words behind it.
     // Everything but the snapshot store is branch-free: lanes need a new word in different trips, and a conditional block
     // that almost every trip enters for a few lanes costs more than selects for all.  Returns whether the pixel stopped.
+#ifndef GSR_FWD_PIPE
+#define GSR_FWD_PIPE 1
+#endif
+#if GSR_FWD_PIPE
+    // Round 5: the gather of the NEXT candidate's record is requested before the arithmetic of the current one (explicit
+    // ds_reads: where they are issued is the point).  A lane's state is kept EAGER for that: (h, cur) = the word being consumed --
+    // non-empty at every trip's start unless the lane is out of candidates --, (nh, nw) = the next non-empty word, already in a
+    // register, nz = the non-empty words behind it; a trip that takes a word's last bit moves on to the next word at its END,
+    // so the next candidate's position is known at the start of every trip.  The walk of a tile's slowest block is a chain of
+    // trips (tools/fwd_phases.py); this takes the LDS round trip out of every link.
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    using TailRegs = std::conditional_t<sizeof(RecTail<C>) == 4, float, std::conditional_t<sizeof(RecTail<C>) == 8, f32x2_, f32x4_>>;
+    struct RecRegs { f32x4_ a, b; TailRegs k; };
+    const uint32_t ga_addr = (uint32_t)(size_t)ga, gc_addr = (uint32_t)(size_t)gc;
+    const auto request = [&](RecRegs& r, uint32_t slot) {
+        const uint32_t ad = ga_addr + slot * 16u;
+        asm volatile("ds_read_b128 %0, %1" : "=&v"(r.a) : "v"(ad) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(r.b) : "v"(ad), "n"(16 * CH) : "memory");
+        const uint32_t ak = gc_addr + slot * (uint32_t)sizeof(RecTail<C>);
+        if constexpr (sizeof(RecTail<C>) == 4) asm volatile("ds_read_b32 %0, %1" : "=&v"(r.k) : "v"(ak) : "memory");
+        else if constexpr (sizeof(RecTail<C>) == 8) asm volatile("ds_read_b64 %0, %1" : "=&v"(r.k) : "v"(ak) : "memory");
+        else asm volatile("ds_read_b128 %0, %1" : "=&v"(r.k) : "v"(ak) : "memory");
+    };
+    const auto walk = [&](uint32_t c0, uint32_t nz) {
+        const uint32_t mk_lane = (uint32_t)(size_t)&mk[wave][0][lane];   // LDS byte address of this lane's word 0 (+ 256 per word)
+        uint32_t cur = 0, nw = 0;
+        int h = 0, nh = 0;
+        bool stopped = false;
+        if (nz != 0u) { h = __builtin_ctz(nz); cur = mk[wave][h][lane]; nz &= nz - 1u; }
+        if (nz != 0u) { nh = __builtin_ctz(nz); nw = mk[wave][nh][lane]; nz &= nz - 1u; }
+        uint32_t slot = (uint32_t)(h * 32 + __builtin_ctz(cur | 0x80000000u));
+        RecRegs rec0, rec1;
+        request(rec0, slot);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rec0.a), "+v"(rec0.b), "+v"(rec0.k) : : "memory");
+        // one trip: the candidate whose record is in `rec`; the next candidate's record is requested into `nxt`
+        const auto trip = [&](RecRegs& rec, RecRegs& nxt) {
+            const bool act = cur != 0u;   // a lane without a candidate evaluates some record and drops it
+            if (snaps || is_part) {   // (a part always leaves them: the combining workgroup finds its way by them)
+                // first word of a new segment: the running (T, C) is the pixel's state at the segment's boundary (and at
+                // every boundary it skipped) -- what the backward blend's units resume from (gsr_blend_bwd.hip)
+                const uint32_t seg_new = (c0 + (uint32_t)h * 32u) / (uint32_t)SNAP_SEG;
+                if (act && seg_new != seg_cur) {
+                    seg_cur = seg_new;
+                    store_snapshot<C>(snap + ((size_t)(unit0 + seg_new * (SNAP_SEG / 64)) * 256 + pix_in_tile) * SV, T, Cc);
+                }
+            }
+            // where the next candidate lies: behind the current one in this word, or the first of the next word
+            const uint32_t rest = cur & (cur - 1u);
+            const bool exhausted = rest == 0u;
+            const uint32_t ncur = exhausted ? nw : rest;
+            const int nh2 = exhausted ? nh : h;
+            const uint32_t nslot = (uint32_t)(nh2 * 32 + __builtin_ctz(ncur | 0x80000000u));
+            // the word behind the look-ahead word and the next candidate's record: requested here, used after the arithmetic
+            const int t = __builtin_ctz(nz | 0x80000000u) & (NH - 1);
+            uint32_t wnext;
+            asm volatile("ds_read_b32 %0, %1" : "=v"(wnext) : "v"(mk_lane + (uint32_t)t * 256u) : "memory");
+            request(nxt, nslot);
+            asm volatile("" : "+v"(rec.a), "+v"(rec.b), "+v"(rec.k));   // (the arithmetic below stays behind the requests)
+            float col[C];
+            col[0] = rec.b[2]; col[1] = rec.b[3];
+            if constexpr (C == 3) col[2] = rec.k;
+            else {
+#pragma unroll
+                for (int ch = 2; ch < C; ch++) col[ch] = rec.k[ch - 2];
+            }
+            const float dx = rec.a[0] - pxf, dy = rec.a[1] - pyf;
+            const float power = pair_exp2_arg(rec.a[2], rec.a[3], rec.b[0], dx, dy);   // exp2 domain, see conic_to_exp2
+            const float alpha = fminf(ALPHA_MAX, rec.b[1] * __builtin_amdgcn_exp2f(power));
+            const bool ok = act && power <= 0.0f && alpha >= ALPHA_MIN;
+            const float test_T = T * (1.0f - alpha);
+            const bool stop = ok && test_T < T_EPS;
+            const bool upd = ok != stop;   // stop implies ok
+            const float w = upd ? alpha * T : 0.0f;
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) Cc[ch] += col[ch] * w;
+            T = upd ? test_T : T;
+            last = upd ? c0 + slot + 1u : last;
+            // (the trip's results are operands of the wait: the compiler otherwise sinks most of the arithmetic BEHIND it)
+            if constexpr (C == 3)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wnext), "+v"(nxt.a), "+v"(nxt.b), "+v"(nxt.k), "+v"(T), "+v"(last), "+v"(Cc[0]), "+v"(Cc[1]), "+v"(Cc[2]) : : "memory");
+            else if constexpr (C == 4)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wnext), "+v"(nxt.a), "+v"(nxt.b), "+v"(nxt.k), "+v"(T), "+v"(last), "+v"(Cc[0]), "+v"(Cc[1]), "+v"(Cc[2]), "+v"(Cc[3]) : : "memory");
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wnext), "+v"(nxt.a), "+v"(nxt.b), "+v"(nxt.k), "+v"(T), "+v"(last), "+v"(Cc[0]), "+v"(Cc[1]), "+v"(Cc[2]), "+v"(Cc[3]), "+v"(Cc[4]), "+v"(Cc[5]) : : "memory");
+            cur = ncur;
+            h = nh2;
+            nw = exhausted ? (nz != 0u ? wnext : 0u) : nw;
+            nh = exhausted ? t : nh;
+            nz = exhausted ? (nz & (nz - 1u)) : nz;
+            // a pixel that terminates drops the rest of its candidates
+            stopped = stopped || stop;
+            cur = stop ? 0u : cur;
+            nw = stop ? 0u : nw;
+            nz = stop ? 0u : nz;
+            slot = nslot;
+        };
+        // (two trips per loop iteration on two register sets: no copies of the prefetched record; the second trip of an
+        // iteration may find every lane out of candidates -- it then blends nothing)
+        while (__ballot(cur != 0u) != 0ull) {
+            trip(rec0, rec1);
+            trip(rec1, rec0);
+        }
+        return stopped;
+    };
+#else
     const auto walk = [&](uint32_t c0, uint32_t nz) {
         const uint32_t mk_lane = (uint32_t)(size_t)&mk[wave][0][lane];   // LDS byte address of this lane's word 0 (+ 256 per word)
         uint32_t cur = 0, nw = 0;
@@ -373,6 +479,7 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
         }
         return stopped;
     };
+#endif
     // where a part of this tile keeps its per-pixel result: parts are numbered (first unit / 8) + (first list entry of
     // the tile / PART_FROM) -- increasing along a tile, and strictly increasing from one split tile to the next, whose
     // list starts more than PART_FROM entries later; at most U / 8 + R / PART_FROM + 1
