@@ -176,9 +176,27 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
 #else
 #define FWD_PHASE() do { } while (0)
 #endif
-    if (n > 1024u) __builtin_amdgcn_s_setprio(3);
-    else if (n > 704u) __builtin_amdgcn_s_setprio(2);
-    else if (n > 448u) __builtin_amdgcn_s_setprio(1);
+#ifndef GSR_FWD_SORT_STAGGER
+#define GSR_FWD_SORT_STAGGER 1
+#endif
+    const auto prio_by_length = [&]() {
+        if (n > 1024u) __builtin_amdgcn_s_setprio(3);
+        else if (n > 704u) __builtin_amdgcn_s_setprio(2);
+        else if (n > 448u) __builtin_amdgcn_s_setprio(1);
+    };
+#if GSR_FWD_SORT_STAGGER
+    // (the launch order's first thousand tiles are its longest and all sort at once, four per CU, on one LDS pipe; distinct
+    // priorities for the sort by the tile's quarter of the launch order let a CU's sorters finish one after the other and move
+    // on to phases with another resource mix: blend_fwd 86.5 -> 85.0 us)
+    switch ((tile_block >> 8) & 3u) {
+        case 0: __builtin_amdgcn_s_setprio(3); break;
+        case 1: __builtin_amdgcn_s_setprio(2); break;
+        case 2: __builtin_amdgcn_s_setprio(1); break;
+        default: __builtin_amdgcn_s_setprio(0); break;
+    }
+#else
+    prio_by_length();
+#endif
     // (the sorted keys are still in LDS when the tile asks for the ids of its first two chunks: read there, they spare the walk's
     // first dependent trip to memory -- the ids were written to the list a moment ago, for the later chunks and the backward)
     const uint64_t* ids_lds = nullptr;
@@ -192,6 +210,9 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
             __syncthreads();   // ids visible to the four waves; the sort's LDS is free
             FWD_PHASE();
         }
+#if GSR_FWD_SORT_STAGGER
+        prio_by_length();
+#endif
     } else if (parts_sort && sort_keys != nullptr && n <= SORT_SMALL_CAP) {
         // A part sorts the WHOLE list of its tile for itself (every part of the tile writes the same ids to the same places): no
         // workgroup waits for another before its walk, and no sort launch stands in front of the blend.  Only in views whose

@@ -172,6 +172,10 @@ __device__ __forceinline__ const uint64_t* sort_tile_merge(uint64_t* __restrict_
             const uint64_t* b = A + base + len;
             const uint32_t d = o0 - base;
             uint32_t lo = d > lb ? d - lb : 0u, hi = min(d, la);
+#ifndef GSR_SORT_KARY
+#define GSR_SORT_KARY 4
+#endif
+#if GSR_SORT_KARY == 4
             while (lo < hi) {                                   // merge path: how many of the first d outputs come from a
                 const uint32_t span = hi - lo;
                 const uint32_t m1 = lo + (span >> 2), m2 = lo + (span >> 1), m3 = lo + ((3u * span) >> 2);
@@ -182,6 +186,12 @@ __device__ __forceinline__ const uint64_t* sort_tile_merge(uint64_t* __restrict_
                 else if (!p3) { lo = m2 + 1u; hi = m3; }
                 else lo = m3 + 1u;
             }
+#else
+            while (lo < hi) {                                   // merge path: how many of the first d outputs come from a
+                const uint32_t mid = (lo + hi) >> 1;
+                if (a[mid] < b[d - 1u - mid]) lo = mid + 1u; else hi = mid;
+            }
+#endif
             const uint32_t ai = lo, bi = d - lo;
             uint64_t ka[E], kb[E];
 #pragma unroll
