@@ -41,12 +41,14 @@ struct GeomState {           // per Gaussian
     uint32_t* wg_nrec;       // [ceil(P / 256)][4] records each wave produced (more than its quarter: the view is flagged)
     size_t bytes;
 };
-// (table: open addressing on the tile id, a power of two and a multiple of the workgroup's 256 threads; records: a quarter per wave)
+// (table: open addressing on the tile id, a power of two and a multiple of the workgroup's 256 threads; records: a quarter per wave.
+// 512 slots / 2 048 records since round 5: at 4K a workgroup's 256 Gaussians meet four times the tiles they meet at 1080p, and a
+// view whose workgroups run out of either takes the slower tile-walking scatter and cannot be planned; config C: unchanged)
 #ifndef GSR_WG_TAB_SLOTS
-#define GSR_WG_TAB_SLOTS 256
+#define GSR_WG_TAB_SLOTS 512
 #endif
 #ifndef GSR_WG_REC_CAP
-#define GSR_WG_REC_CAP 1024
+#define GSR_WG_REC_CAP 2048
 #endif
 constexpr int WG_REC_CAP = GSR_WG_REC_CAP, WG_TAB_SLOTS = GSR_WG_TAB_SLOTS;
 static_assert(WG_TAB_SLOTS >= 256 && (WG_TAB_SLOTS & (WG_TAB_SLOTS - 1)) == 0 && WG_TAB_SLOTS <= 65536 && WG_REC_CAP % 256 == 0, "");

@@ -59,10 +59,10 @@ def test_library_loads_and_exports_every_symbol(hip_lib):
 
 def test_scratch_sizes(hip_lib):
     # 44 B/Gaussian geometry state + 12 B SH-colour slot + what a 256-Gaussian preprocess workgroup leaves for scatter
-    # (1 024 instance records of 16 B, a 256-slot tile table of 8 B, four counts), 8 B/pixel (+ alignment slack)
+    # (2 048 instance records of 16 B, a 512-slot tile table of 8 B, four counts), 8 B/pixel (+ alignment slack)
     g = hip_lib.gsr_geom_bytes(500_000)
     nwg = (500_000 + 255) // 256
-    assert 56 * 500_000 + nwg * (16 * 1024 + 8 * 256 + 16) <= g <= 56 * 500_000 + nwg * (16 * 1024 + 8 * 256 + 16) + 8192
+    assert 56 * 500_000 + nwg * (16 * 2048 + 8 * 512 + 16) <= g <= 56 * 500_000 + nwg * (16 * 2048 + 8 * 512 + 16) + 8192
     i = hip_lib.gsr_image_bytes(1920, 1080)
     assert 8 * 1920 * 1080 <= i <= 8 * 1920 * 1080 + (8 + 64 + 12) * 8160 + 8192   # ranges, 2x8 shard counters, order, seg_off, totals + view tokens
     assert hip_lib.gsr_grad_scratch_bytes(500_000) == 48 * 500_000 + 256
