@@ -100,6 +100,7 @@ SIGNATURES = {
     "gsr_adam_step_multi": (c_int, [c_int, POINTER(c_longlong), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                     POINTER(c_void_p), POINTER(c_double), c_double, c_double, c_double, c_int, c_void_p]),
     "gsr_debug_set_bwd_order": (c_int, [c_void_p]),
+    "gsr_debug_preprocess_occupancy": (c_int, [POINTER(c_int), POINTER(c_int)]),
     "gsr_debug_set_trace": (c_int, [c_void_p]),
     "gsr_num_stages": (c_int, []),
     "gsr_stage_name": (c_char_p, [c_int]),

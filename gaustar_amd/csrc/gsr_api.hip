@@ -1136,6 +1136,12 @@ int gsr_release_stream_state(gsr_stream_t stream)
     return 0;
 }
 
+int gsr_debug_preprocess_occupancy(int* exact, int* planned)
+{
+    gsr::preprocess_occupancy(exact, planned);
+    return 0;
+}
+
 int gsr_debug_set_bwd_order(const void* device_order)
 {
     gsr::g_bwd_order = static_cast<const uint32_t*>(device_order);

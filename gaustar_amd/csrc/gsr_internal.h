@@ -381,6 +381,7 @@ void launch_geom_bwd(int P, int D, int M, const float* means3D, const float* shs
                      float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
                      float* dL_drot, hipStream_t st);
 void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t st);
+void preprocess_occupancy(int* exact, int* planned);   // tuning: resident workgroups per CU of the two preprocess kernels
 
 // ---------------------------------------------------------------- shared device math
 #ifdef __HIPCC__

@@ -20,8 +20,11 @@ namespace gsr {
 // goes to the tile's CURSOR and returns where the workgroup's span starts inside the tile's bucket, and the keys are written
 // right here -- what scatter_kernel does behind a scan in the exact path.  A span that does not fit its bucket, a full table or
 // a full record array raise the plan's flag (nothing is written outside a bucket).
+// (at most 80 scalar registers: with 82-96 the hardware admits SEVEN 256-thread workgroups per CU where the occupancy API and the
+// compiler say eight -- MI355X_MICROARCH.md "Residency" --, config C's 1 920 workgroups then run as 1 792 + a second generation of
+// 128 that starts when the first ones leave: the planned kernel, at 85, ended at 31.6 us with its workgroups living 18)
 template <bool PLANNED>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
 preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
                   const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                   const float* __restrict__ scales, float scale_modifier, const float* __restrict__ rotations,
@@ -46,6 +49,14 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool valid = idx < P;
+#ifdef GSR_PRE_PHASES   // devtool build (planned variant): thread 0's stamps go to the head of the workgroup's unused record area
+    uint64_t* const ph = (PLANNED && threadIdx.x == 0) ? reinterpret_cast<uint64_t*>(wg_recs + (size_t)blockIdx.x * WG_REC_CAP) : nullptr;
+    int ph_i = 0;
+#define PRE_PHASE() do { if (ph) ph[ph_i++] = wall_clock64(); } while (0)
+#else
+#define PRE_PHASE() do { } while (0)
+#endif
+    PRE_PHASE();
     // SH mode: the wave's 64 coefficient rows come in through LDS (coalesced), see sh_stage_load
     extern __shared__ float sh_lds[];
     float* my_sh = nullptr;
@@ -151,6 +162,7 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
         radii[idx] = out_radius;
         rect[idx] = out_rect;
     }
+    PRE_PHASE();   // inputs loaded, projected, state stored
     // All 64 lanes take part (lanes without work carry an empty rect).
     // The wave-level groups are merged once more per WORKGROUP in a small LDS table (open addressing on the tile id)
     // before they reach memory: the 256 Gaussians of a workgroup are neighbours on the mesh and hit the same dozen
@@ -218,10 +230,12 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
         const uint32_t src_idx = (uint32_t)__shfl(idx, src, 64), src_depth = (uint32_t)__shfl((int)__float_as_uint(my_depth), src, 64);
         for (int base = 0; base < cs.n; base += 64) visit(cs.tile(base, lane, gx), (uint32_t)src, src_idx, src_depth);
     }
+    PRE_PHASE();   // tiles walked (this wave)
     if constexpr (PLANNED) {
         depth_lds[threadIdx.x] = __float_as_uint(my_depth);
         if (lane == 0 && n_wave > WAVE_CAP) misfit = 1u;
         __syncthreads();
+        PRE_PHASE();   // every wave has walked
         // one returning atomic per occupied slot on the tile's cursor: where this workgroup's span starts inside the bucket
         // (agg_key is reused for the absolute position of the span; 0xffffffff: the slot is empty or its span does not fit)
         for (int i = threadIdx.x; i < AGG_SLOTS; i += 256) {
@@ -237,6 +251,7 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
             agg_key[i] = at;
         }
         __syncthreads();
+        PRE_PHASE();   // cursor atomics returned
         {
             const uint32_t wv = threadIdx.x >> 6;
             const uint32_t nr = min(n_wave, WAVE_CAP);
@@ -251,6 +266,7 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
         }
         // A misfit raises the plan's flag (the token of this view: unique, so the word never has to be cleared).  Nobody reads it
         // before the next kernel: the forward blend, queued right behind, reports the verdict to the host and leaves the view alone.
+        PRE_PHASE();   // keys stored (this wave)
         if (threadIdx.x == 0 && misfit) atomicExch(plan.sync + 9 * PLAN_SYNC_STRIDE, plan.token);
     } else {
     if (lane == 0) {
@@ -297,6 +313,13 @@ void launch_preprocess_planned(int P, int D, int M, const float* means3D, const 
                                                       H, tan_fovx, tan_fovy, focal_x, focal_y, t.gx, t.gy, radii,
                                                       g.g0, g.g1, g.depth, g.rect, g.rgb, im.tile_count, g.wg_recs, g.wg_tab,
                                                       g.wg_nrec, im.totals, plan.token, plan);
+}
+
+// (tuning: resident workgroups per CU the runtime computes for the two preprocess kernels)
+void preprocess_occupancy(int* exact, int* planned)
+{
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(exact, preprocess_kernel<false>, 256, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(planned, preprocess_kernel<true>, 256, 0);
 }
 
 // rasterizer_impl.cu:54-66 (checkFrustum): present = view-space z > 0.2.

@@ -350,6 +350,8 @@ int gsr_rgb_depth_loss_backward(int C, int H, int W, const float* pred, long lon
 int gsr_debug_set_trace(void* device_buffer);
 /* Experiments: a launch order for the backward blend's units ([num_segments] unit ids by dispatch position; NULL: none). */
 int gsr_debug_set_bwd_order(const void* device_order);
+/* Tuning: workgroups per CU the runtime grants the exact / the planned preprocess kernel. */
+int gsr_debug_preprocess_occupancy(int* exact, int* planned);
 
 /* Per-kernel timing for benchmarks (no reference counterpart; the reference has no profiling hooks,
  * SURVEY.md section 5).  While enabled, every stage this thread launches is bracketed by HIP events
