@@ -465,6 +465,8 @@ int forward_fused_impl(int P, int D, int M, int num_channels, int need_backward,
                                           st, &seen))
             return bad;
         const uint32_t* h = reinterpret_cast<const uint32_t*>(plan_info) + PI_HEADER;
+        // (a header that is not this image's -- another size's, or not a header at all -- is no plan)
+        if (seen && (h[1] != (uint32_t)tiles_of(W, H).T || h[3] != h[2] >> 6 || (h[2] & 63u) != 0u)) seen = false;
         plan_info[0] = seen ? (h[0] == 1u ? 1 : -1) : 0;
         if (seen) { plan_info[1] = (int)h[2]; plan_info[2] = (int)h[3]; plan_info[3] = (int)h[4]; }
         plan_info[PI_PENDING] = 0;

@@ -151,13 +151,18 @@ def _plan_entry(key, lib, nbytes, byte_opts, level):
             return ent
         ent = _Plan(lib, nbytes, byte_opts, level)
         _PLANS[key] = ent
-        while len(_PLANS) > _PLAN_SLOTS:
-            _PLANS.popitem(last=False)
+        if len(_PLANS) > _PLAN_SLOTS:
+            # (a plan's builder may still be on its way to the pinned block of the entry that goes: let the device finish first)
+            torch.cuda.synchronize()
+            while len(_PLANS) > _PLAN_SLOTS:
+                _PLANS.popitem(last=False)
         return ent
 
 
 def drop_plans():
     """Forget every camera's plan (the next view of each renders the exact way and re-plans)."""
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()   # (no plan builder may still be writing into a pinned block that is about to be recycled)
     with _HINT_LOCK:
         _PLANS.clear()
 
