@@ -4,6 +4,7 @@
 #include "../../include/gsr.h"
 #include "gsr_internal.h"
 #include "gsr_plan.h"
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -454,7 +455,9 @@ int forward_fused_impl(int P, int D, int M, int num_channels, int need_backward,
     hipStream_t st = (hipStream_t)stream;
     const bool sane = W > 0 && H > 0 && (long long)tiles_of(W > 0 ? W : 1, H > 0 ? H : 1).T <= 256ll * 1024 && image_buffer && P > 0;
     const size_t cnt_words = sane ? 2 * (size_t)shard_stride(tiles_of(W, H).T) * NSHARD : 0;
-    Counters* own = sane ? acquire_counters(st, cnt_words + PLAN_SYNC_WORDS) : nullptr;
+    // (the planned forward reads the same block as one cursor per tile, PLAN_CURSOR_STRIDE words apart)
+    const size_t blk_words = sane ? std::max(cnt_words, (size_t)tiles_of(W, H).T * PLAN_CURSOR_STRIDE) : 0;
+    Counters* own = sane ? acquire_counters(st, blk_words + PLAN_SYNC_WORDS) : nullptr;
     CountersLease lease{own};
     const bool keeps_plan = plan_buffer != nullptr && plan_info != nullptr && sane;
     if (keeps_plan && plan_info[PI_PENDING] != 0) {

@@ -234,7 +234,13 @@ __host__ __device__ inline BinState carve_bin(void* base, int R, int U, int C = 
 // plan from it.
 // Only views whose longest list stays in the forward blend's own sort (<= 2 048 entries, not split) are planned.
 constexpr int PLAN_HDR = 16;              // header words: {valid, T, R_cap, U_cap, max_cap, non-empty tiles of the source view, R of it, -}
-constexpr int PLAN_CURSOR_STRIDE = 8;     // words between the cursors of neighbouring tiles: four tiles per 128-byte line
+#ifndef GSR_PLAN_CURSOR_STRIDE
+#define GSR_PLAN_CURSOR_STRIDE 32
+#endif
+// words between the cursors of neighbouring tiles: ONE cursor per 128-byte line.  Memory-side atomics serialise per line: config C's
+// planned preprocess (190 k returning atomics, 23 per tile, all workgroups in that phase at once) takes 44.0 / 32.3 / 31.5 / 26.1 / 25.4 us
+// at 2 / 8 / 16 / 32 / 64 words (HIP events, same box)
+constexpr int PLAN_CURSOR_STRIDE = GSR_PLAN_CURSOR_STRIDE;
 constexpr uint32_t PLAN_MAX_LIST = 2048;  // == SORT_SMALL_CAP: a planned list is sorted inside the forward blend
 struct PlanState {
     uint32_t* header;        // [PLAN_HDR]
@@ -262,7 +268,7 @@ struct PlanRun {             // what the planned kernels get besides the exact p
     const uint2* ranges;     // plan
     const uint32_t* seg_off;
     const uint32_t* order;
-    uint32_t* cursor;        // [T * PLAN_CURSOR_STRIDE] entries claimed per tile (library block, zero before preprocess)
+    uint32_t* cursor;        // [T * PLAN_CURSOR_STRIDE] entries claimed per tile (library block, zero before preprocess; 1 MB at 1080p)
     uint32_t* sync;          // [PLAN_SYNC_WORDS] tickets + flag (library block)
     uint64_t* keys;          // the binning buffer's key array (capacity R_cap)
     uint4* unit_info;        // the binning buffer's unit table (capacity U_cap): written by the forward blend, tile by tile
