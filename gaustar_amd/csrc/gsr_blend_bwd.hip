@@ -69,15 +69,21 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
 #define GSR_BWD_B2_LDS 1   // four channels: the second B tile (channel 3's three split columns) is read from LDS per group of
                            // eight instances instead of living in eight registers (86 -> 80 registers = six waves per SIMD)
 #endif
+#ifndef GSR_BWD_PACK4
+#define GSR_BWD_PACK4 1    // four channels in ONE B tile: channels 0, 1 keep three split columns, channels 2, 3 take two (hi + the
+                           // rest rounded to bf16: 16 mantissa bits of dL_dpix, relative error <= 2^-17 on dL_dcolor[2], [3]
+                           // only -- the alpha path reads dL_dpix on the vector ALU); no second tile, no second accumulator
+#endif
 #ifndef GSR_BWD_QCAP
-#define GSR_BWD_QCAP (GSR_BWD_BF16 && (C == 3 || (C == 4 && GSR_BWD_B2_LDS)) ? 16 : 32)
+#define GSR_BWD_QCAP (GSR_BWD_BF16 && (C == 3 || (C == 4 && (GSR_BWD_B2_LDS || GSR_BWD_PACK4))) ? 16 : 32)
 #endif
     constexpr int QCAP = GSR_BWD_QCAP;
     static_assert(QCAP >= GRP && QCAP <= 64 && QCAP % GRP == 0, "queue capacity: whole MFMA groups, at most one batch");
     __shared__ __attribute__((aligned(16))) float qf[QCAP * SF];   // queue slots (see SlotLayout)
     __shared__ __attribute__((aligned(16))) float Rm[2 * GRP * RSTRIDE];   // rows 0..7: r, rows 8..15: w, [row][pixel lane]
     // (four channels, GSR_BWD_B2_LDS) second B tile as bf16 [column 0..2 = hi, mid, lo of dL_dpix channel 3][64 pixels] + 32 zero bytes
-    constexpr bool B2L = GSR_BWD_B2_LDS && GSR_BWD_BF16 && GSR_BWD_BF16_TILES2 && C == 4;
+    constexpr bool PACK4 = GSR_BWD_PACK4 && GSR_BWD_BF16 && C == 4;
+    constexpr bool B2L = GSR_BWD_B2_LDS && GSR_BWD_BF16 && GSR_BWD_BF16_TILES2 && C == 4 && !PACK4;
     __shared__ __attribute__((aligned(16))) uint32_t B2s[B2L ? 3 * 32 + 8 : 1];
     // one wave64 per workgroup: unit = (tile, segment), wave = 8x8 block of the tile.
     // XCD-aware placement: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the
@@ -250,12 +256,13 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     // channels 3 .. C-1 take a second B tile (their split columns 0 .. 3 (C - 3) - 1) fed with the SAME split A operand:
     // six more matrix issues per eight instances, no further splitting.
     // (measured, config C: four channels 0.140 -> 0.134 ms; six channels gain nothing -- 0.158 either way -- and stay on f32)
-    constexpr bool BF16 = GSR_BWD_BF16 && (C == 3 || (GSR_BWD_BF16_TILES2 && C == 4));
-    constexpr int C1 = BF16 ? (C < 3 ? C : 3) : C, C2 = BF16 ? C - C1 : 0;
-    constexpr int BROWS = BF16 ? 6 + 3 * C1 : 6 + C;
+    constexpr bool BF16 = GSR_BWD_BF16 && (C == 3 || ((GSR_BWD_BF16_TILES2 || PACK4) && C == 4));
+    constexpr int C1 = BF16 ? (PACK4 ? 4 : C < 3 ? C : 3) : C, C2 = BF16 ? C - C1 : 0;
+    constexpr int BROWS = BF16 ? (PACK4 ? 16 : 6 + 3 * C1) : 6 + C;
+    // (PACK4: columns 6-8 = channel 0, 9-11 = channel 1, 12-13 = channel 2, 14-15 = channel 3; all sixteen in use, no zero row)
     constexpr int BS = RSTRIDE;   // row stride of the staging rows: with 64 the sixteen columns a 16-lane group reads sit in the same
                               // four banks (a 16-way conflict on each of the four reads below); 68 spreads them over all 64
-    static_assert((BROWS + 1) * BS <= 2 * GRP * RSTRIDE, "B-operand staging must fit the r|w table");
+    static_assert((BROWS + (PACK4 ? 0 : 1)) * BS <= 2 * GRP * RSTRIDE, "B-operand staging must fit the r|w table");
     {
         const float xr = (float)(lane & 7) - 3.5f, yr = (float)(lane >> 3) - 3.5f;
         Rm[0 * BS + lane] = 1.0f;
@@ -268,6 +275,11 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
 #pragma unroll
             for (int ch = 0; ch < C1; ch++) {
                 const float d1 = bf16_rest(dp[ch]), d2 = bf16_rest(d1);
+                if (PACK4 && ch >= 2) {
+                    Rm[(12 + 2 * (ch - 2)) * BS + lane] = dp[ch];
+                    Rm[(13 + 2 * (ch - 2)) * BS + lane] = __uint_as_float(__float_as_uint(d1) + 0x8000u);   // rounded, not cut
+                    continue;
+                }
                 Rm[(6 + 3 * ch) * BS + lane] = dp[ch];      // (the operand takes the upper halves: hi, mid, lo)
                 Rm[(7 + 3 * ch) * BS + lane] = d1;
                 Rm[(8 + 3 * ch) * BS + lane] = d2;
@@ -276,7 +288,7 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
 #pragma unroll
             for (int ch = 0; ch < C; ch++) Rm[(6 + ch) * BS + lane] = dp[ch];
         }
-        Rm[BROWS * BS + lane] = 0.f;
+        if constexpr (!PACK4) Rm[BROWS * BS + lane] = 0.f;
     }
     __builtin_amdgcn_wave_barrier();
     float Bf[BF16 ? 1 : 16];
@@ -284,7 +296,7 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     u32x4 Bp2[C2 > 0 && !B2L ? 2 : 1];
     uint32_t b2_off = 0;    // (B2L) byte offset of this lane's 16 bytes of half 0 (+ 16: half 1); unused columns read the zero block
     {
-        const float4* pd = reinterpret_cast<const float4*>(&Rm[(col < BROWS ? col : BROWS) * BS + 16 * kap]);
+        const float4* pd = reinterpret_cast<const float4*>(&Rm[(PACK4 || col < BROWS ? col : BROWS) * BS + 16 * kap]);
         float bv[16];
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) {
@@ -373,8 +385,10 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
     static_assert(GRP == 8, "the write-back below assumes rows 0-7 = r, 8-15 = w");
     const int wb_row0 = 4 * (kap & 1);
     // (bf16 path: the colour moment of channel ch is the sum of columns 6 + 3 ch .. + 2, gathered into the first of them)
-    const bool wb_take = kap < 2 ? col < 6 : BF16 ? (col >= 6 && col < 6 + 3 * C1 && (col % 3) == 0) : (col >= 6 && col < NM);
-    float* const wb_ptr = &qf[wb_row0 * SF + MOM0 + (BF16 && col >= 6 ? 6 + (col - 6) / 3 : col)];
+    const bool wb_take = kap < 2 ? col < 6
+                       : PACK4   ? (col == 6 || col == 9 || col == 12 || col == 14)
+                       : BF16    ? (col >= 6 && col < 6 + 3 * C1 && (col % 3) == 0) : (col >= 6 && col < NM);
+    float* const wb_ptr = &qf[wb_row0 * SF + MOM0 + (PACK4 && col >= 12 ? 8 + (col - 12) / 2 : BF16 && col >= 6 ? 6 + (col - 6) / 3 : col)];
     // (second tile: its w rows hold channel 3 + col / 3 in columns 0, 3, ..)
     const bool wb_take2 = C2 > 0 && kap >= 2 && col < 3 * C2 && (col % 3) == 0;
     float* const wb_ptr2 = &qf[wb_row0 * SF + MOM0 + 6 + C1 + (col < 3 * C2 ? col / 3 : 0)];
@@ -503,8 +517,8 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
             // hi + (mid + lo) -- two fused DPP adds per register, smallest parts first.  One block, so that the two
             // wait states a DPP read needs behind the instruction that wrote its source are there by construction: the
             // leading s_nop covers the compiler's adds, every t reads an s written four instructions earlier)
-            const auto split_sum = [](float v0, float v1, float v2, float v3, float& t0_, float& t1_, float& t2_, float& t3_) {
-                float s0_, s1_, s2_, s3_;
+            const auto split_sum = [](float v0, float v1, float v2, float v3, float& t0_, float& t1_, float& t2_, float& t3_,
+                                      float& s0_, float& s1_, float& s2_, float& s3_) {
                 asm("s_nop 1\n\t"
                     "v_add_f32_dpp %0, %8, %8 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                     "v_add_f32_dpp %1, %9, %9 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -518,12 +532,16 @@ blend_bwd_unit(int W, int H, int gx, const uint4* __restrict__ unit_info, const 
                     : "v"(v0), "v"(v1), "v"(v2), "v"(v3));
             };
             const float v0 = acc0[0] + acc1[0], v1 = acc0[1] + acc1[1], v2 = acc0[2] + acc1[2], v3 = acc0[3] + acc1[3];
-            float t0_, t1_, t2_, t3_;
-            split_sum(v0, v1, v2, v3, t0_, t1_, t2_, t3_);
+            float t0_, t1_, t2_, t3_, p0_, p1_, p2_, p3_;
+            split_sum(v0, v1, v2, v3, t0_, t1_, t2_, t3_, p0_, p1_, p2_, p3_);
             if constexpr (C2 > 0) {
-                float u0, u1, u2, u3;
-                split_sum(acc2[0], acc2[1], acc2[2], acc2[3], u0, u1, u2, u3);
+                float u0, u1, u2, u3, q0_, q1_, q2_, q3_;
+                split_sum(acc2[0], acc2[1], acc2[2], acc2[3], u0, u1, u2, u3, q0_, q1_, q2_, q3_);
                 acc2[0] = u0; acc2[1] = u1; acc2[2] = u2; acc2[3] = u3;
+            }
+            if constexpr (PACK4) {   // the two-column channels stop at hi + rest
+                const bool two = col >= 12;
+                t0_ = two ? p0_ : t0_; t1_ = two ? p1_ : t1_; t2_ = two ? p2_ : t2_; t3_ = two ? p3_ : t3_;
             }
             const bool spatial = kap < 2;
             acc0[0] = spatial ? v0 : t0_; acc0[1] = spatial ? v1 : t1_; acc0[2] = spatial ? v2 : t2_; acc0[3] = spatial ? v3 : t3_;
@@ -632,7 +650,7 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
 #endif
 GSR_BWD_SPECIALISE(3, GSR_BWD_WAVES3)
 #ifndef GSR_BWD_WAVES4
-#define GSR_BWD_WAVES4 (GSR_BWD_B2_LDS ? 6 : 5)
+#define GSR_BWD_WAVES4 (GSR_BWD_PACK4 || GSR_BWD_B2_LDS ? 6 : 5)   // (PACK4: asked for six the compiler stops at 72 registers = seven waves, no scratch; asked for seven it spills 16 bytes)
 #endif
 // Four channels (two B tiles): 85 registers left alone = five waves; held at 80 for six it spilt ten and lost (0.146 vs 0.134 ms).
 // Round 5: with the second B tile read from LDS per group (GSR_BWD_B2_LDS) it fits 80 registers without scratch = six waves.
