@@ -92,15 +92,24 @@ __device__ __forceinline__ void plan_build_block(const PlanJob& job, const uint2
     const int T = job.T, gx = job.gx, gy = job.gy;
     const uint32_t level = job.level;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per = (T + NT - 1) / NT;
-    const int t0 = tid * per;
+    // This workgroup shares its CU with tiles of the blend: what it costs the launch is the length of its own chain, so every
+    // access to memory is lane-consecutive (a wave owns ROWS of 64 consecutive tiles; the first version gave a thread 32
+    // consecutive tiles -- 64 lines per load / store instruction -- and took 105 us inside a blend of 89) and its waves
+    // run at the highest priority.
+    __builtin_amdgcn_s_setprio(3);
     const bool staged = T <= PLAN_LDS_T;
-    if (staged) {
-        for (int t = tid; t < T; t += NT) { const uint2 r = im_ranges[t]; cnt_lds[t] = r.y - r.x; }
-        __syncthreads();
+    uint32_t vmax = 0, ne = 0, sum_n = 0;
+    for (int t = tid; t < T; t += NT) {
+        const uint2 r = im_ranges[t];
+        const uint32_t n = r.y - r.x;
+        if (staged) cnt_lds[t] = min(n, 0xffffu);       // low half: the count (clipped: above 2 048 the plan is invalid anyway)
+        sum_n += n;
+        vmax = max(vmax, n);
+        ne += n != 0u ? 1u : 0u;
     }
+    if (staged) __syncthreads();
     const auto count_of = [&](int t) -> uint32_t {
-        if (staged) return cnt_lds[t];
+        if (staged) return cnt_lds[t] & 0xffffu;
         const uint2 r = im_ranges[t];
         return r.y - r.x;
     };
@@ -117,15 +126,17 @@ __device__ __forceinline__ void plan_build_block(const PlanJob& job, const uint2
         }
         return plan_capacity(n, near, level);
     };
-    uint32_t sum_cap = 0, vmax = 0, ne = 0, sum_n = 0;
-    for (int k = 0; k < per; k++) {
-        const int t = t0 + k;
+    const int rows = (T + 63) >> 6, rpw = (rows + NW - 1) / NW;      // rows of 64 tiles; rows per wave
+    const int r0 = wave * rpw, r1 = min(rows, r0 + rpw);
+    // pass 1: this wave's capacities (kept in the upper half of the staged word: a neighbour's look-up reads the lower half,
+    // which the store does not change) and their sum
+    uint32_t sum_cap = 0;
+    for (int r = r0; r < r1; r++) {
+        const int t = 64 * r + lane;
         if (t < T) {
-            const uint32_t n = count_of(t);
-            sum_cap += cap_of(t);
-            sum_n += n;
-            vmax = max(vmax, n);
-            ne += n != 0u ? 1u : 0u;
+            const uint32_t c = cap_of(t);
+            if (staged) cnt_lds[t] = (cnt_lds[t] & 0xffffu) | (c << 16);
+            sum_cap += c;
         }
     }
     const uint32_t incl_cap = wave_incl_scan(sum_cap, lane);
@@ -141,16 +152,20 @@ __device__ __forceinline__ void plan_build_block(const PlanJob& job, const uint2
         total_ne += ws_ne[w];
         total_n += ws_n[w];
     }
-    uint32_t run = woff + incl_cap - sum_cap;
-    for (int k = 0; k < per; k++) {
-        const int t = t0 + k;
-        if (t < T) {
-            const uint32_t cap = cap_of(t);
-            job.ranges[t] = make_uint2(run, cap);
-            job.seg_off[t] = run >> 6;     // (capacities are whole units: the unit prefix is the entry prefix / 64)
+    // pass 2: one wave scan per row, the running base carried in a scalar
+    uint32_t run = woff;
+    for (int r = r0; r < r1; r++) {
+        const int t = 64 * r + lane;
+        const bool in = t < T;
+        const uint32_t cap = !in ? 0u : staged ? cnt_lds[t] >> 16 : cap_of(t);
+        const uint32_t incl = wave_incl_scan(cap, lane);
+        if (in) {
+            const uint32_t first = run + incl - cap;
+            job.ranges[t] = make_uint2(first, cap);
+            job.seg_off[t] = first >> 6;     // (capacities are whole units: the unit prefix is the entry prefix / 64)
             job.order[t] = order_in[t];
-            run += cap;
         }
+        run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
     if (tid == 0) {
         const uint32_t max_cap = plan_capacity(gmax, false, level);
