@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_longlong, c_si
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSR_LIB_PATH", os.path.join(_HERE, "libgsr_hip.so"))   # override: experiment variants
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 ALLOC_FN = ctypes.CFUNCTYPE(c_void_p, c_void_p, c_size_t)
 
 # name -> (restype, argtypes); mirrors include/gsr.h one to one (tests check both directions).
@@ -72,10 +72,10 @@ SIGNATURES = {
     "gsr_sh_colors_split_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "gsr_mesh_gaussians": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
-                                   c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                   c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "gsr_mesh_gaussians_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                            c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "gsr_l1_ssim_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gsr_l1_ssim": (c_int, [c_int, c_int, c_int, c_void_p, c_longlong, c_longlong, c_longlong, c_void_p, c_longlong,
                             c_longlong, c_longlong, c_float, c_void_p, c_void_p, c_void_p, c_longlong, c_longlong,

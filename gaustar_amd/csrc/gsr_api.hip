@@ -101,7 +101,7 @@ int fail_msg(const char* msg)
 
 extern "C" {
 
-int gsr_abi_version(void) { return 13; }
+int gsr_abi_version(void) { return 14; }
 
 const char* gsr_last_error(void) { return g_err.c_str(); }
 
@@ -940,10 +940,15 @@ int gsr_adam_step(long long n, float* param, const float* grad, float* exp_avg, 
 int gsr_mesh_gaussians(int F, int G, const float* verts, const long long* faces, const float* bary,
                        const float* raw_scales, const float* raw_complex, float thickness, float min_scale,
                        float max_scale, const float* delta_t, const float* delta_r, float* points, float* scaling,
-                       float* quaternions, gsr_stream_t stream)
+                       float* quaternions, float* clear_dL_dverts, int V, gsr_stream_t stream)
 {
     g_err.clear();
-    if (F <= 0) return 0;
+    if (V < 0) return fail_msg("gsr_mesh_gaussians: negative V");
+    const long long clear_n = clear_dL_dverts ? 3ll * V : 0ll;
+    if (F <= 0) {
+        if (clear_n > 0) launch_zero_f32(clear_dL_dverts, (size_t)clear_n, (hipStream_t)stream);
+        return 0;
+    }
     if (G <= 0 || G > 64) return fail_msg("gsr_mesh_gaussians: Gaussians per face must be 1..64");
     if (!verts || !faces || !bary || !raw_scales || !raw_complex || !points || !scaling || !quaternions)
         return fail_msg("gsr_mesh_gaussians: required pointer is null");
@@ -951,7 +956,7 @@ int gsr_mesh_gaussians(int F, int G, const float* verts, const long long* faces,
     {
         Scope sc(ST_PRODUCERS, st);
         launch_mesh_gaussians(F, G, verts, faces, bary, raw_scales, raw_complex, thickness, min_scale, max_scale, delta_t,
-                              delta_r, points, scaling, quaternions, st);
+                              delta_r, points, scaling, quaternions, clear_dL_dverts, clear_n, st);
     }
     GSR_CHECK_LAUNCH("mesh_gaussians_fwd_kernel");
     return 0;
@@ -961,13 +966,14 @@ int gsr_mesh_gaussians_backward(int F, int G, int V, const float* verts, const l
                                 const float* raw_scales, const float* raw_complex, float min_scale, float max_scale,
                                 const float* delta_r, const float* dL_dpoints, const float* dL_dscaling,
                                 const float* dL_dquaternions, float* dL_dverts, float* dL_draw_scales,
-                                float* dL_draw_complex, float* dL_ddelta_t, float* dL_ddelta_r, gsr_stream_t stream)
+                                float* dL_draw_complex, float* dL_ddelta_t, float* dL_ddelta_r, int dL_dverts_cleared,
+                                gsr_stream_t stream)
 {
     g_err.clear();
     if (V < 0) return fail_msg("gsr_mesh_gaussians_backward: negative V");
     if (V > 0 && !dL_dverts) return fail_msg("gsr_mesh_gaussians_backward: dL_dverts is null");
     hipStream_t st = (hipStream_t)stream;
-    if (V > 0) launch_zero_f32(dL_dverts, 3 * (size_t)V, st);
+    if (V > 0 && !dL_dverts_cleared) launch_zero_f32(dL_dverts, 3 * (size_t)V, st);
     if (F <= 0) return 0;
     if (G <= 0 || G > 64) return fail_msg("gsr_mesh_gaussians_backward: Gaussians per face must be 1..64");
     if (!verts || !faces || !bary || !raw_scales || !raw_complex || !dL_draw_scales || !dL_draw_complex)

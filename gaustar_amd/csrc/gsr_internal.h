@@ -304,7 +304,7 @@ void launch_adam_multi(const AdamBatch& b, float one_minus_b1, float b2, float o
 void launch_mesh_gaussians(int F, int G, const float* verts, const long long* faces, const float* bary,
                            const float* raw_scales, const float* raw_complex, float thickness, float min_scale,
                            float max_scale, const float* delta_t, const float* delta_r, float* points, float* scaling,
-                           float* quats, hipStream_t st);
+                           float* quats, float* clear, long long clear_n, hipStream_t st);
 void launch_mesh_gaussians_bwd(int F, int G, const float* verts, const long long* faces, const float* bary,
                                const float* raw_scales, const float* raw_complex, float min_scale, float max_scale,
                                const float* delta_r, const float* dL_dpoints, const float* dL_dscaling,

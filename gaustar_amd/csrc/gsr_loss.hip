@@ -486,7 +486,8 @@ void launch_depth_l1(int H, int W, const float* pred, const long long* ps, const
 // four dependent launches of ~5 us each on the stream.)  Same arithmetic and order as the two finalize kernels above.
 __global__ void __launch_bounds__(1024)
 rgb_depth_finalize_kernel(int n_wg, const float* __restrict__ partials, double inv_n, float f, int n_wg_d,
-                          const float* __restrict__ partials_d, float depth_factor, float mask_factor, float* __restrict__ out)
+                          const float* __restrict__ partials_d, float depth_factor, float mask_factor, float* __restrict__ out,
+                          float* __restrict__ out_keep)
 {
     __shared__ double r[6][1024];
     const float2* p2 = reinterpret_cast<const float2*>(partials);
@@ -524,6 +525,10 @@ rgb_depth_finalize_kernel(int n_wg, const float* __restrict__ partials, double i
         out[0] = loss; out[1] = (float)l1; out[2] = (float)s;
         out[3] = dt; out[4] = mt; out[5] = (float)r[3][0]; out[6] = (float)r[5][0];
         out[7] = (loss + dt) + mt;   // (float additions in the order the separate ops formed the total)
+        // the same eight numbers once more in the workspace's tail: what the gradient passes read, so that the caller can hand
+        // `out` to its user outright (a 32-byte device copy in front of it was a 4.7 us kernel on the stream)
+        if (out_keep)
+            for (int k = 0; k < 8; k++) out_keep[k] = out[k];
     }
 }
 
@@ -539,7 +544,8 @@ void launch_rgb_depth_loss(int C, int H, int W, const float* pred, const long lo
     dz.H = Hd; dz.W = Wd; dz.pred = dpred; dz.psy = dps[0]; dz.psx = dps[1]; dz.gt = dgt; dz.gsy = dgs[0]; dz.gsx = dgs[1];
     dz.max_depth = max_depth; dz.partials = partials_d; dz.n_wg = depth_plane_wgs(C, H, W, Hd);
     const int n_wg = launch_ssim_stats(C, H, W, pred, ps, gt, gs_, ws_ssim, st, &dz);   // the depth sums ride along as a z-plane
-    rgb_depth_finalize_kernel<<<1, 1024, 0, st>>>(n_wg, partials, 1.0 / (double)n, f, dz.n_wg, partials_d, depth_factor, mask_factor, out8);
+    float* keep = reinterpret_cast<float*>(static_cast<char*>(ws_ssim) + l1_ssim_workspace_bytes(C, H, W) - 256);
+    rgb_depth_finalize_kernel<<<1, 1024, 0, st>>>(n_wg, partials, 1.0 / (double)n, f, dz.n_wg, partials_d, depth_factor, mask_factor, out8, keep);
 }
 
 // both gradient passes in ONE launch (the depth image as one more z-plane of the SSIM gradient kernel)

@@ -159,6 +159,17 @@ __device__ __forceinline__ void plan_build_block(const PlanJob& job, const uint2
         const bool in = t < T;
         const uint32_t cap = !in ? 0u : staged ? cnt_lds[t] >> 16 : cap_of(t);
         const uint32_t incl = wave_incl_scan(cap, lane);
+#ifdef GSR_PLAN_DIAG   // (devtool build) how this view's counts sit in the plan being replaced: host pad words 10 .. 13 =
+                       // tiles over a zero bucket, tiles over a non-zero bucket, entries over, the worst count / capacity in 1/64
+        if (in && job.host_pad) {
+            const uint32_t old = job.ranges[t].y, n = count_of(t);
+            if (n > old) {
+                atomicAdd(&job.host_pad[old == 0u ? 10 : 11], 1u);
+                atomicAdd(&job.host_pad[12], n - old);
+                if (old) atomicMax(&job.host_pad[13], n * 64u / old);
+            }
+        }
+#endif
         if (in) {
             const uint32_t first = run + incl - cap;
             job.ranges[t] = make_uint2(first, cap);

@@ -224,9 +224,11 @@ mesh_gaussians_fwd_kernel(int F, int G, const float* __restrict__ verts, const l
                           const float* __restrict__ bary, const float* __restrict__ raw_scales,
                           const float* __restrict__ raw_complex, float thickness, float min_scale, float max_scale,
                           const float* __restrict__ delta_t, const float* __restrict__ delta_r,
-                          float* __restrict__ points, float* __restrict__ scaling, float* __restrict__ quats)
+                          float* __restrict__ points, float* __restrict__ scaling, float* __restrict__ quats,
+                          float* __restrict__ clear, long long clear_n)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    for (long long i = f; i < clear_n; i += (long long)gridDim.x * blockDim.x) clear[i] = 0.f;   // (side job, see gsr.h)
     if (f >= F) return;
     const FaceFrame Ff = face_frame(verts, faces, (size_t)f);
     for (int g = 0; g < G; g++) {
@@ -347,9 +349,13 @@ mesh_gaussians_fwd8_kernel(int F, int G, const float* __restrict__ verts, const 
                            const float* __restrict__ bary, const float* __restrict__ raw_scales,
                            const float* __restrict__ raw_complex, float thickness, float min_scale, float max_scale,
                            const float* __restrict__ delta_t, const float* __restrict__ delta_r,
-                           float* __restrict__ points, float* __restrict__ scaling, float* __restrict__ quats)
+                           float* __restrict__ points, float* __restrict__ scaling, float* __restrict__ quats,
+                           float* __restrict__ clear, long long clear_n)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    // side job: the vertex-gradient accumulator of the backward to come is cleared here (as a fill of its own in front of
+    // the backward it was a 4.8 us launch on the stream for 0.5 MB)
+    for (long long i = t; i < clear_n; i += (long long)gridDim.x * blockDim.x) clear[i] = 0.f;
     const int f = t / LPF, g = t - f * LPF;
     if (f >= F || g >= G) return;
     const size_t n = (size_t)f * G + g;
@@ -493,17 +499,18 @@ mesh_gaussians_bwd8_kernel(int F, int G, const float* __restrict__ verts, const 
 void launch_mesh_gaussians(int F, int G, const float* verts, const long long* faces, const float* bary,
                            const float* raw_scales, const float* raw_complex, float thickness, float min_scale,
                            float max_scale, const float* delta_t, const float* delta_r, float* points, float* scaling,
-                           float* quats, hipStream_t st)
+                           float* quats, float* clear, long long clear_n, hipStream_t st)
 {
     if (G <= LPF) {
         const long long lanes = (long long)F * LPF;
         mesh_gaussians_fwd8_kernel<<<(unsigned)((lanes + 255) / 256), 256, 0, st>>>(F, G, verts, faces, bary, raw_scales, raw_complex,
                                                                                     thickness, min_scale, max_scale, delta_t, delta_r,
-                                                                                    points, scaling, quats);
+                                                                                    points, scaling, quats, clear, clear_n);
         return;
     }
     mesh_gaussians_fwd_kernel<<<(F + 127) / 128, 128, 0, st>>>(F, G, verts, faces, bary, raw_scales, raw_complex, thickness,
-                                                              min_scale, max_scale, delta_t, delta_r, points, scaling, quats);
+                                                              min_scale, max_scale, delta_t, delta_r, points, scaling, quats, clear,
+                                                              clear_n);
 }
 
 void launch_mesh_gaussians_bwd(int F, int G, const float* verts, const long long* faces, const float* bary,

@@ -145,12 +145,14 @@ class _RenderMeshBound(torch.autograd.Function):
         p_verts, p_rs, p_rc, p_dens, p_dc, p_rest, p_dt, p_dr = cfg["params"]
         if fence is not None:
             fence((p_verts, p_rs, p_rc, p_dt, p_dr))
+        need_bwd = any(ctx.needs_input_grad) and cfg.get("grad", True)
+        # (without a gradient sink the backward's vertex-gradient accumulator is made here and cleared by the forward's launch)
+        ctx.d_verts = torch.empty_like(v) if need_bwd and ctx.needs_input_grad[0] and cfg.get("sink") is None else None
         points, scaling, quats = producers._mesh_forward_raw(v, cfg["faces"], cfg["bary"], rs, rc, cfg["thickness"], cfg["lo"],
-                                                             cfg["hi"], dt, dr)
+                                                             cfg["hi"], dt, dr, clear=ctx.d_verts)
         if fence is not None:
             fence((p_dc, p_rest, p_dens))
         colors, opac = producers._sh_forward_raw(points, st.campos, dc, rest, D, M, view, cfg["depth_channels"], dens)
-        need_bwd = any(ctx.needs_input_grad) and cfg.get("grad", True)
         box = []
         out = _rasterizer.rasterize_gaussians_native(
             st.bg, points, colors, opac, scaling, quats, st.scale_modifier, None, st.viewmatrix, st.projmatrix, st.tanfovx,
@@ -192,8 +194,11 @@ class _RenderMeshBound(torch.autograd.Function):
         if sink is not None:
             sink.written([p for p, o in ((p_dc, o_dc), (p_rest, o_rest if M > 1 else None), (p_dens, o_dens)) if o is not None])
         o_mesh = (buf(p_verts), buf(p_rs), buf(p_rc), buf(p_dt), buf(p_dr))
+        pre, ctx.d_verts = getattr(ctx, "d_verts", None), None      # (cleared by the forward: good for one backward)
+        cleared = o_mesh[0] is None and pre is not None
         d_verts, d_rs, d_rc, d_dt, d_dr = producers._mesh_backward_raw(v, cfg["faces"], cfg["bary"], rs, rc, dr, cfg["lo"], cfg["hi"],
-                                                                       has_dt, d_points, d_scaling, d_quats, out=o_mesh)
+                                                                       has_dt, d_points, d_scaling, d_quats,
+                                                                       out=(pre,) + o_mesh[1:] if cleared else o_mesh, verts_cleared=cleared)
         if sink is not None:
             sink.written([p for p, o in zip((p_verts, p_rs, p_rc, p_dt, p_dr), o_mesh) if o is not None and p is not None])
         # (sink views go back to autograd as FRESH tensor objects: AccumulateGrad adopts an incoming gradient as p.grad only

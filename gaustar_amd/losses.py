@@ -217,22 +217,22 @@ class _RGBDepthLoss(torch.autograd.Function):
                 float(dssim_factor), vp(ws), Hd, Wd, vp(d), d.stride(0), d.stride(1), vp(gd), gd.stride(0), gd.stride(1),
                 float(max_depth), float(depth_factor), float(mask_factor), vp(wd), vp(out), _stream()), "gsr_rgb_depth_loss")
         if ctx.needs_input_grad[0]:
-            ctx.save_for_backward(x, g_full, gd, ws, out)
+            ctx.save_for_backward(x, g_full, gd, ws)
         ctx.cfg = (float(dssim_factor), margin, float(max_depth), float(depth_factor), float(mask_factor), img6.dtype)
-        # (copies: the returned loss and parts must not alias `out`, which backward reads -- an in-place `loss += reg` or
-        # `parts.mul_()` by the caller is then allowed, as it was before the fused reduction; one 32-byte copy kernel)
-        res = out.clone()
-        parts = res[:7]
+        # (the returned loss and parts must not alias what backward reads -- an in-place `loss += reg` or `parts.mul_()` by the
+        # caller is allowed --: the reduction kernel leaves a second copy of the eight numbers in the workspace's tail
+        # (include/gsr.h), which is what backward is handed; `out` goes to the caller outright, no copy kernel)
+        parts = out[:7]
         ctx.mark_non_differentiable(parts)
         ctx.set_materialize_grads(False)   # no zero-filled "gradient" of the parts vector per backward (one fill kernel)
-        return res[7], parts
+        return out[7], parts
 
     @staticmethod
     def backward(ctx, g_loss, _g_parts):
         if not ctx.saved_tensors or g_loss is None:
             return (None,) * 8
         lib = _lib.load()
-        x, g_full, gd, ws, out = ctx.saved_tensors
+        x, g_full, gd, ws = ctx.saved_tensors
         f, margin, max_depth, depth_factor, mask_factor, in_dtype = ctx.cfg
         p, g = _crop(x[:3], margin), _crop(g_full, margin)
         C, H, W = (int(v) for v in p.shape)
@@ -251,7 +251,8 @@ class _RGBDepthLoss(torch.autograd.Function):
             _lib.check(lib.gsr_rgb_depth_loss_backward(
                 C, H, W, vp(p), p.stride(0), p.stride(1), p.stride(2), vp(g), g.stride(0), g.stride(1), g.stride(2), f, vp(ws),
                 Hd, Wd, vp(d), d.stride(0), d.stride(1), vp(gd), gd.stride(0), gd.stride(1), max_depth, depth_factor, mask_factor,
-                vp(out), sp, vp(gv), gv.stride(0), gv.stride(1), gv.stride(2), vp(gdv), gdv.stride(0), gdv.stride(1), _stream()),
+                ctypes.c_void_p(ws.data_ptr() + ws.numel() - 256), sp, vp(gv), gv.stride(0), gv.stride(1), gv.stride(2), vp(gdv),
+                gdv.stride(0), gdv.stride(1), _stream()),
                 "gsr_rgb_depth_loss_backward")
         return grad6.to(in_dtype), None, None, None, None, None, None, None
 

@@ -197,8 +197,10 @@ def points_colors_split(positions: torch.Tensor, camera_centers: torch.Tensor, s
                                     densities)
 
 
-def _mesh_forward_raw(v, fc, bc, rs, rc, thickness, lo, hi, dt, dr):
-    """The mesh producer on prepared tensors (float32 / int64, contiguous, detached, one device) -> (points, scaling, quats)."""
+def _mesh_forward_raw(v, fc, bc, rs, rc, thickness, lo, hi, dt, dr, clear=None):
+    """The mesh producer on prepared tensors (float32 / int64, contiguous, detached, one device) -> (points, scaling, quats).
+    clear: a contiguous float32 [V,3] tensor the launch also sets to zero -- the backward's vertex-gradient accumulator, handed
+    to _mesh_backward_raw as out[0] with verts_cleared=True."""
     lib = _lib.load()
     dev = v.device
     F, G = int(fc.size(0)), int(bc.size(0))
@@ -208,11 +210,12 @@ def _mesh_forward_raw(v, fc, bc, rs, rc, thickness, lo, hi, dt, dr):
     quats = torch.empty(N, 4, dtype=torch.float32, device=dev)
     with _host.on_device(dev):
         _lib.check(lib.gsr_mesh_gaussians(F, G, _p(v), _p(fc), _p(bc), _p(rs), _p(rc), float(thickness), lo, hi, _op(dt),
-                                          _op(dr), _p(points), _p(scaling), _p(quats), _stream()), "gsr_mesh_gaussians")
+                                          _op(dr), _p(points), _p(scaling), _p(quats), _op(clear), int(v.size(0)), _stream()),
+                   "gsr_mesh_gaussians")
     return points, scaling, quats
 
 
-def _mesh_backward_raw(v, fc, bc, rs, rc, dr, lo, hi, has_dt, g_points, g_scaling, g_quats, out=(None,) * 5):
+def _mesh_backward_raw(v, fc, bc, rs, rc, dr, lo, hi, has_dt, g_points, g_scaling, g_quats, out=(None,) * 5, verts_cleared=False):
     """-> (d_verts, d_raw_scales, d_raw_complex, d_delta_t or None, d_delta_r or None); absent output gradients are None.
     out: contiguous float32 tensors to write the five gradients into instead of fresh ones."""
     lib = _lib.load()
@@ -226,7 +229,8 @@ def _mesh_backward_raw(v, fc, bc, rs, rc, dr, lo, hi, has_dt, g_points, g_scalin
     with _host.on_device(dev):
         _lib.check(lib.gsr_mesh_gaussians_backward(
             F, G, V, _p(v), _p(fc), _p(bc), _p(rs), _p(rc), lo, hi, _op(dr), _op(g_points), _op(g_scaling), _op(g_quats),
-            _p(d_verts), _p(d_rs), _p(d_rc), _op(d_dt), _op(d_dr), _stream()), "gsr_mesh_gaussians_backward")
+            _p(d_verts), _p(d_rs), _p(d_rc), _op(d_dt), _op(d_dr), int(bool(verts_cleared and out[0] is not None)), _stream()),
+            "gsr_mesh_gaussians_backward")
     return d_verts, d_rs, d_rc, d_dt, d_dr
 
 
@@ -250,7 +254,9 @@ class _MeshGaussians(torch.autograd.Function):
             raise RuntimeError(f"delta_t must be ({N}, 3) and delta_r ({N}, 4)")
         lo = float("-inf") if min_scale is None else float(min_scale)
         hi = float("inf") if max_scale is None else float(max_scale)
-        points, scaling, quats = _mesh_forward_raw(v, fc, bc, rs, rc, thickness, lo, hi, dt, dr)
+        # (the backward's vertex-gradient accumulator is cleared by the forward's launch; good for ONE backward)
+        ctx.d_verts = torch.empty_like(v) if ctx.needs_input_grad[0] else None
+        points, scaling, quats = _mesh_forward_raw(v, fc, bc, rs, rc, thickness, lo, hi, dt, dr, clear=ctx.d_verts)
         ctx.save_for_backward(v, fc, bc, rs, rc, dr)
         ctx.dims = (lo, hi, dt is not None)
         return points, scaling, quats
@@ -260,8 +266,9 @@ class _MeshGaussians(torch.autograd.Function):
         v, fc, bc, rs, rc, dr = ctx.saved_tensors
         lo, hi, has_dt = ctx.dims
         c = lambda t: None if t is None else t.to(torch.float32).contiguous()
+        pre, ctx.d_verts = ctx.d_verts, None
         d_verts, d_rs, d_rc, d_dt, d_dr = _mesh_backward_raw(v, fc, bc, rs, rc, dr, lo, hi, has_dt, c(g_points), c(g_scaling),
-                                                             c(g_quats))
+                                                             c(g_quats), out=(pre, None, None, None, None), verts_cleared=pre is not None)
         return d_verts, None, None, d_rs, d_rc, None, None, None, d_dt, d_dr
 
 

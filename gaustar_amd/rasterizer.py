@@ -17,6 +17,7 @@ from __future__ import annotations
 import collections
 import ctypes
 import os
+import sys
 import threading
 from typing import NamedTuple
 
@@ -120,6 +121,7 @@ _PLAN_SLOTS = int(os.environ.get("GSR_PLAN_SLOTS", "2048"))
 _PLAN_LEVEL_ENV = os.environ.get("GSR_PLAN_LEVEL")
 _PLANS: "collections.OrderedDict" = collections.OrderedDict()   # key -> _Plan
 _PLAN_RETRY = 32   # a camera whose view could not be planned (a list too long for the in-kernel sort) is asked again after this many views
+_PLAN_DIAG = bool(os.environ.get("GSR_PLAN_DIAG"))
 PLAN_STATS = {"planned": 0, "exact": 0, "misfit": 0}            # views binned by a plan / without one / that outgrew theirs
 
 
@@ -245,6 +247,11 @@ def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rot
                     # camera: 2, 4, .. 64 views
                     PLAN_STATS["misfit"] += 1
                     plan.misfits += 1
+                    if _PLAN_DIAG:    # (devtool: -DGSR_PLAN_DIAG build) how the view sat in the plan it outgrew
+                        torch.cuda.synchronize()
+                        print(f"[plan] misfit grad={need_backward} level={info[4]} tiles over empty buckets {info[18]}, over "
+                              f"non-empty {info[19]}, entries over {info[20]}, worst count/capacity {info[21] / 64:.2f}", file=sys.stderr)
+                        info[18] = info[19] = info[20] = info[21] = 0
                     if plan.misfits >= 2:
                         plan.skip = min(64, 1 << (plan.misfits - 1))
                 if info[0] == -1:     # unplannable (longest list above the in-kernel sort): ask again after _PLAN_RETRY views

@@ -276,16 +276,20 @@ int gsr_sh_colors_split_backward(int P, int D, int M, const float* positions, co
  *   delta_r [F*G,4] are the loose-bind offsets and may be NULL; min_scale / max_scale: -inf / +inf for "none".
  * gsr_mesh_gaussians_backward is its autograd backward: dL_dverts [V,3] is zeroed and accumulated inside;
  * dL_draw_scales, dL_draw_complex (and dL_ddelta_t, dL_ddelta_r when non-NULL) are written outright; any of
- * the three incoming gradients may be NULL (= zero). */
+ * the three incoming gradients may be NULL (= zero).
+ * (ABI 14) clear_dL_dverts / V of the forward: when non-NULL, the forward's launch also sets those [V,3] floats to zero -- the
+ * accumulator of the backward to come, which is then called with dL_dverts_cleared = 1 and skips its own fill (a launch of its
+ * own on the stream for 0.5 MB).  NULL / dL_dverts_cleared = 0: as before. */
 int gsr_mesh_gaussians(int F, int G, const float* verts, const long long* faces, const float* bary,
                        const float* raw_scales, const float* raw_complex, float thickness, float min_scale,
                        float max_scale, const float* delta_t, const float* delta_r, float* points, float* scaling,
-                       float* quaternions, gsr_stream_t stream);
+                       float* quaternions, float* clear_dL_dverts, int V, gsr_stream_t stream);
 int gsr_mesh_gaussians_backward(int F, int G, int V, const float* verts, const long long* faces, const float* bary,
                                 const float* raw_scales, const float* raw_complex, float min_scale, float max_scale,
                                 const float* delta_r, const float* dL_dpoints, const float* dL_dscaling,
                                 const float* dL_dquaternions, float* dL_dverts, float* dL_draw_scales,
-                                float* dL_draw_complex, float* dL_ddelta_t, float* dL_ddelta_r, gsr_stream_t stream);
+                                float* dL_draw_complex, float* dL_ddelta_t, float* dL_ddelta_r, int dL_dverts_cleared,
+                                gsr_stream_t stream);
 
 /* ---- Image-space losses either side of the rasterizer.
  * gsr_l1_ssim replaces  (1 - f) * l1_loss(pred, gt) + f * (1 - ssim(pred, gt))  (gaustar_trainers/refine.py:451-453
@@ -320,7 +324,9 @@ int gsr_depth_l1(int H, int W, const float* pred, long long pred_sy, long long p
  *   afterwards.  `workspace` / `stats` are the buffers of the value call, unmodified; pred / gt the same images.
  * gsr_rgb_depth_loss = the value passes of gsr_l1_ssim on an RGB image and of gsr_depth_l1 on a depth image with ONE
  * reduction kernel: loss_out [8] = {l1 + dssim loss, l1 mean, ssim mean, depth term, mask term, #fg, #bg, total of the
- * three terms}; loss_out + 3 is the `stats` argument of gsr_depth_l1_backward. */
+ * three terms}; loss_out + 3 is the `stats` argument of gsr_depth_l1_backward.  (ABI 14) The same eight floats are also left
+ * in ssim_workspace at byte gsr_l1_ssim_workspace_bytes(C, H, W) - 256: gsr_rgb_depth_loss_backward's loss_out may point
+ * there, so that a caller can hand loss_out itself to its user (who may modify it) and keep only the workspace. */
 int gsr_l1_ssim_backward(int C, int H, int W, const float* pred, long long pred_sc, long long pred_sy, long long pred_sx,
                          const float* gt, long long gt_sc, long long gt_sy, long long gt_sx, float dssim_factor,
                          const void* workspace, const float* grad_scale, float* dL_dpred, long long grad_sc, long long grad_sy,

@@ -56,6 +56,7 @@ def run(a):
     target = harness.SurfaceGaussians(verts, faces, 6, 3).to(dev)
     target.load_state_dict(model.state_dict())
     frames, n_it, per_it = [], 0, []
+    one = torch.ones((), device=dev)
     host_wait_ns = 0
     pts_start = model.points.detach().clone()
     t_total = 0.0
@@ -98,7 +99,7 @@ def run(a):
                 opt.zero_grad(set_to_none=True)
                 img = render(model, ncams[ci], bg4)
                 loss = losses.rgb_depth_loss(img, gts[ci][0], gts[ci][1], MAX_DEPTH, 0.2, 1.0, 0.5)
-                loss.backward()
+                loss.backward(one)                 # (the seed is handed over: a bare backward() fills a ones_like per call, 4.5 us on the stream)
                 if reducer is not None:
                     reducer()                      # the hook in front of sugar_optimizer.py:99-101
                 opt.step()

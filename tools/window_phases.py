@@ -29,7 +29,8 @@ torch.cat = timed("  torch.cat", torch.cat)
 torch.sigmoid = timed("  torch.sigmoid", torch.sigmoid)
 _bw = torch.Tensor.backward
 torch.Tensor.backward = timed("backward (autograd engine, all backward launches)", _bw)
-r = bench_window.run(argparse.Namespace(frames=2, iters=100, level=6, width=1920, height=1080, cameras=160))
+TINY = os.environ.get("WINDOW_PHASES_SIZE") == "tiny"   # tiny: negligible GPU work -- what is timed is the host alone
+r = bench_window.run(argparse.Namespace(frames=2, iters=100, level=2 if TINY else 6, width=160 if TINY else 1920, height=96 if TINY else 1080, cameras=160))
 print({k: r[k] for k in ("median_ms_per_iteration", "host_wait_ms_per_iteration")})
 tot = 0.0
 for k, v in acc.items():
@@ -37,6 +38,8 @@ for k, v in acc.items():
     tot += float(np.median(v))
     print(f"{k:75s} median {np.median(v):.3f} ms  p90 {np.percentile(v, 90):.3f}")
 print("sum of medians", round(tot, 3))
+if TINY:
+    raise SystemExit(0)
 
 # ---- the forward's parts, one at a time (same model; each call timed on the host, GPU idle in between) ----
 from gaustar_amd import GaussianRasterizer, harness, producers, scene
