@@ -165,14 +165,18 @@ def test_giant_splats_under_a_plan_do_not_corrupt_anything():
     exact = _render(dev, ps, cam_t, bg_t, cam, dpix, use_plan=False)
     # (a giant splat's gradient is a float-atomic sum over tens of thousands of pixels: two runs of the SAME path differ by the
     # order of those additions -- that spread, measured here, is the yardstick; images and radii must be equal outright)
-    again = _render(dev, ps, cam_t, bg_t, cam, dpix, use_plan=False)
-    noise = max(float((ga - gb).abs().max() / gb.abs().max()) for ga, gb in zip(again[2], exact[2]) if ga is not None and ga.numel())
+    # (tests/devtools/stress_giant.py: 150 exact renders spread up to 1.5e-2 of the largest scale gradient; one pair of runs as the
+    # yardstick let the test fail once in five runs of the whole suite -- four pairs, and a wider factor)
+    noise = 0.0
+    for _ in range(4):
+        again = _render(dev, ps, cam_t, bg_t, cam, dpix, use_plan=False)
+        noise = max(noise, max(float((ga - gb).abs().max() / gb.abs().max()) for ga, gb in zip(again[2], exact[2]) if ga is not None and ga.numel()))
     seen = {"planned": 0, "exact": 0, "misfit": 0}
     for _ in range(6):
         r = _render(dev, ps, cam_t, bg_t, cam, dpix)
         for k in seen:
             seen[k] += r[3][k]
-        _check_same(r, exact, "giant splats", gtol=max(2e-5, 8.0 * noise))
+        _check_same(r, exact, "giant splats", gtol=max(2e-5, 16.0 * noise))
     assert seen["planned"] + seen["misfit"] >= 1, seen    # a plan was tried at least once
 
 
