@@ -51,8 +51,67 @@ __device__ __forceinline__ float win11(const float* v)
     return s;
 }
 
+// Pass 1 on packed f32 (v_pk_fma_f32 / v_pk_add_f32: two results per instruction): the four windowed maps travel as two PAIRS,
+// (x, y) and (x^2 + y^2, x y) -- the same fused operations in the same order per component as the scalar form (the loss value
+// comes out bit-identical; the D maps differ in last bits where the compiler contracts the closed-form partials differently);
+// the input tile is parked as (x, y) pairs, the row sums as pairs.  The kernel is vector-issue-bound (SQ_INSTS_VALU 34.7 M per
+// launch = 56 us of its 63), four fifths of it these windows: 63 -> 55 us.  (The gradient kernel was tried the same way --
+// (D1, D2) as a pair -- and did not move: with the XCD-aware tile map below it is bound by its reads, 63 -> 40 us.)
+#ifndef GSR_SSIM_PK
+#define GSR_SSIM_PK 1
+#endif
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 win11_2(const f2* v)
+{
+    f2 s = GW[5] * v[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) s = __builtin_elementwise_fma((f2)(GW[k]), v[k] + v[10 - k], s);
+    return s;
+}
+
 struct View { const float* p; long long sc, sy, sx; };     // element strides of a [C,H,W]-indexed image
 struct ViewW { float* p; long long sc, sy, sx; };
+// Which (channel, tile) a workgroup of the SSIM kernels takes.  Workgroups go round-robin over the 8 XCDs in dispatch order
+// (x fastest, then y, then z) and every XCD has its own L2: with the plain map the four neighbours of a tile -- whose 5-pixel
+// halos it re-reads, 2.1x the image in all -- sit on other L2s.  Instead XCD k owns a CONTIGUOUS run of the C * tiles ids
+// (row-major tiles, channel-major): neighbours in a row share an L2 and run close in time.
+__device__ __forceinline__ void xcd_tile(int C_rgb, int& tx, int& ty, int& ch)
+{
+    const int gxn = (int)gridDim.x, n = gxn * (int)gridDim.y, N = C_rgb * n;
+    const int L = ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * gxn + (int)blockIdx.x;
+    const int xcd = L & 7, j = L >> 3, q = N >> 3, r = N & 7;
+    const int id = xcd * q + min(xcd, r) + j;
+    ch = id / n;
+    const int t = id - ch * n;
+    ty = t / gxn; tx = t - ty * gxn;
+}
+// FAST instantiations of the two SSIM kernels: every image (and the D maps) spans less than 4 GB with non-negative strides, so
+// an element is a uniform 64-bit base (the channel's plane) + a 32-bit byte offset in a vector register -- one add per element
+// instead of a 64-bit multiply-add chain -- and halo / out-of-image elements read element 0 and are masked afterwards: loads
+// without branches.  (Static count of the generic kernels: 964 / 531 vector instructions of which 426 / 218 are the windows'
+// arithmetic; 64-bit address arithmetic and one exec-mask branch per conditional load were most of the rest.)
+template <typename T> __device__ __forceinline__ T ld32(const T* base, uint32_t byte_off)
+{
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+// offset of a masked element: 0 when the element lies outside.  (Opaque to the optimiser on purpose: it turns
+// load(in ? off : 0) into in ? load(off) : load(0), i.e. back into one exec-mask branch per load.)
+__device__ __forceinline__ uint32_t masked_off(bool in, uint32_t byte_off)
+{
+    uint32_t o = in ? byte_off : 0u;
+    asm volatile("" : "+v"(o));
+    return o;
+}
+template <typename T> __device__ __forceinline__ void st32(T* base, uint32_t byte_off, T v)
+{
+    *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+static bool view_fits_32(const float* p, const long long* s, int C, int H, int W)
+{
+    if (s[0] < 0 || s[1] < 0 || s[2] < 0) return false;
+    const long long last = (long long)(C - 1) * s[0] + (long long)(H - 1) * s[1] + (long long)(W - 1) * s[2];
+    return p != nullptr && last < (1ll << 29);
+}
 
 __device__ __forceinline__ float block_sum_256(float v, float* red)
 {
@@ -115,13 +174,19 @@ __device__ __forceinline__ float depth_grad_value(float p, float g, float max_de
 }
 
 // ---------------------------------------------------------------- pass 1
+template <bool FAST>
 __global__ void __launch_bounds__(256)
 ssim_stats_kernel(int H, int W, View x, View y, float* __restrict__ D, float* __restrict__ partials, int C_rgb, DepthPlane dz)
 {
+#if GSR_SSIM_PK
+    __shared__ f2 XY[LIY * LP];          // (x, y) per element of the input tile
+    __shared__ f2 Hq2[2][LIY * LT];      // row sums: [0] = (x, y), [1] = (x^2 + y^2, x y)
+#else
     __shared__ float X[LIY * LP], Y[LIY * LP];
     // (SSIM reads E[x^2] and E[y^2] only as their SUM -- sigma_x^2 + sigma_y^2 -- so x^2 + y^2 goes through the window as
     // ONE quantity: four windowed maps instead of the reference's five, loss_utils.py:47-52)
     __shared__ float Hq[4][LIY * LT];
+#endif
     __shared__ float red[4];
     if ((int)blockIdx.z == C_rgb) {   // (uniform) the depth plane: the first dz.n_wg workgroups of it each take rows w, w + n_wg, ..
         const int w = (int)(blockIdx.y * gridDim.x + blockIdx.x);
@@ -129,13 +194,23 @@ ssim_stats_kernel(int H, int W, View x, View y, float* __restrict__ D, float* __
         return;
     }
     const int tid = threadIdx.x;
-    const int tx0 = blockIdx.x * LT, ty0 = blockIdx.y * LTY, ch = blockIdx.z;
+    int tbx, tby, ch;
+    xcd_tile(C_rgb, tbx, tby, ch);
+    const int tx0 = tbx * LT, ty0 = tby * LTY;
     const float* xp = x.p + ch * x.sc;
     const float* yp = y.p + ch * y.sc;
     // all of a thread's tile loads are issued before the first one is consumed (a rolled loop paid one full memory
     // latency per iteration: 5.8 of the workgroup's 9.6 us)
     constexpr int NL = (LIY * LI + 255) / 256;
     float xv[NL], yv[NL];
+    const auto park = [&](int i, float xe, float ye) {
+#if GSR_SSIM_PK
+        f2 e; e.x = xe; e.y = ye;
+        XY[i] = e;
+#else
+        X[i] = xe; Y[i] = ye;
+#endif
+    };
     // element i = tid + 256 k of the LIY x LI input tile: (row, column) advance by (256 / LI, 256 % LI) per k with at most
     // one carry -- one division per thread instead of one per element, and one 64-bit address per thread plus deltas
     constexpr int DR = 256 / LI, DC = 256 % LI;
@@ -143,29 +218,87 @@ ssim_stats_kernel(int H, int W, View x, View y, float* __restrict__ D, float* __
     const int lr0 = tid / LI, lc0 = tid - lr0 * LI;
     const long long xb = (long long)(ty0 + lr0 - LR) * x.sy + (long long)(tx0 + lc0 - LR) * x.sx;
     const long long yb = (long long)(ty0 + lr0 - LR) * y.sy + (long long)(tx0 + lc0 - LR) * y.sx;
+    if constexpr (FAST) {
+        const int xsy = (int)x.sy, xsx = (int)x.sx, ysy = (int)y.sy, ysx = (int)y.sx;
+        const int x0 = (ty0 + lr0 - LR) * xsy + (tx0 + lc0 - LR) * xsx, y0 = (ty0 + lr0 - LR) * ysy + (tx0 + lc0 - LR) * ysx;
+        const int xA = DR * xsy + DC * xsx, xB = xsy - LI * xsx, yA = DR * ysy + DC * ysx, yB = ysy - LI * ysx;   // (uniform)
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int wrap = lc0 + k * DC >= LI ? 1 : 0;
+            const int r = lr0 + k * DR + wrap, c = lc0 + k * DC - wrap * LI;
+            const int gy = ty0 + r - LR, gx = tx0 + c - LR;
+            const bool in = ((k + 1) * 256 <= LIY * LI || tid + k * 256 < LIY * LI) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const int xo = x0 + k * xA + (wrap ? xB : 0), yo = y0 + k * yA + (wrap ? yB : 0);
+            xv[k] = ld32(xp, masked_off(in, (uint32_t)xo * 4u));
+            yv[k] = ld32(yp, masked_off(in, (uint32_t)yo * 4u));
+        }
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int wrap = lc0 + k * DC >= LI ? 1 : 0;
+            const int r = lr0 + k * DR + wrap, c = lc0 + k * DC - wrap * LI;
+            const int gy = ty0 + r - LR, gx = tx0 + c - LR;
+            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            if ((k + 1) * 256 <= LIY * LI || tid + k * 256 < LIY * LI) {
+                park(r * LP + c, in ? xv[k] : 0.f, in ? yv[k] : 0.f);
+            }
+        }
+    } else {
 #pragma unroll
     for (int k = 0; k < NL; k++) {
         const int wrap = lc0 + k * DC >= LI ? 1 : 0;
         const int r = lr0 + k * DR + wrap, c = lc0 + k * DC - wrap * LI;
         const int gy = ty0 + r - LR, gx = tx0 + c - LR;
-        const bool in = tid + k * 256 < LIY * LI && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const bool in = ((k + 1) * 256 <= LIY * LI || tid + k * 256 < LIY * LI) && gy >= 0 && gy < H && gx >= 0 && gx < W;
         const int dr = k * DR + wrap, dc = k * DC - wrap * LI;
         xv[k] = in ? xp[xb + dr * x.sy + dc * x.sx] : 0.f;
         yv[k] = in ? yp[yb + dr * y.sy + dc * y.sx] : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < NL; k++) {
-        if (tid + k * 256 < LIY * LI) {
+        if ((k + 1) * 256 <= LIY * LI || tid + k * 256 < LIY * LI) {
             const int wrap = lc0 + k * DC >= LI ? 1 : 0;
             const int r = lr0 + k * DR + wrap, c = lc0 + k * DC - wrap * LI;
-            X[r * LP + c] = xv[k];
-            Y[r * LP + c] = yv[k];
+            park(r * LP + c, xv[k], yv[k]);
         }
+    }
     }
     __syncthreads();
     // horizontal: LIY rows x 32 columns, five windowed quantities.  A thread takes HS consecutive columns of a row: their
     // HS + 10 inputs slide through registers, so an input is read from LDS once per task instead of once per tap (22 LDS
     // reads per output before, 7 now) and its three products are formed once instead of eleven times.
+#if GSR_SSIM_PK
+    for (int t = tid; t < LIY * (LT / HS); t += 256) {
+        const int r = t / (LT / HS), c0 = (t - r * (LT / HS)) * HS;
+        f2 e[HS + 10], q[HS + 10];
+#pragma unroll
+        for (int k = 0; k < HS + 10; k++) {
+            e[k] = XY[r * LP + c0 + k];
+            const f2 m = e[k].yx * e[k].yy;                        // (y y, x y)
+            q[k].x = __builtin_fmaf(e[k].x, e[k].x, m.x);          // x x + y y, as the scalar form rounds it
+            q[k].y = m.y;
+        }
+#pragma unroll
+        for (int o = 0; o < HS; o++) {
+            const int i = r * LT + c0 + o;
+            Hq2[0][i] = win11_2(e + o); Hq2[1][i] = win11_2(q + o);
+        }
+    }
+    __syncthreads();
+    // vertical: thread = (column c, group of RPT rows); RPT + 10 rows of each pair slide through registers
+    const int c = tid & 31, r0 = (tid >> 5) * RPT;
+    float out[4][RPT];
+#pragma unroll
+    for (int p_ = 0; p_ < 2; p_++) {
+        f2 col[RPT + 10];
+#pragma unroll
+        for (int k = 0; k < RPT + 10; k++) col[k] = Hq2[p_][(r0 + k) * LT + c];
+#pragma unroll
+        for (int o = 0; o < RPT; o++) {
+            const f2 w = win11_2(col + o);
+            out[2 * p_][o] = w.x; out[2 * p_ + 1][o] = w.y;
+        }
+    }
+#else
     for (int t = tid; t < LIY * (LT / HS); t += 256) {
         const int r = t / (LT / HS), c0 = (t - r * (LT / HS)) * HS;
         float a[HS + 10], b[HS + 10], sq[HS + 10], ab[HS + 10];
@@ -192,6 +325,7 @@ ssim_stats_kernel(int H, int W, View x, View y, float* __restrict__ D, float* __
 #pragma unroll
         for (int o = 0; o < RPT; o++) out[q][o] = win11(col + o);
     }
+#endif
     float l1 = 0.f, ssum = 0.f;
     const size_t plane = (size_t)H * W;
 #pragma unroll
@@ -210,18 +344,30 @@ ssim_stats_kernel(int H, int W, View x, View y, float* __restrict__ D, float* __
             const float d1 = 2.f * mu2 * (a2 - a1) * inv - 2.f * mu1 * S * (b2 - b1) * inv;
             const float d2 = -S / b2;
             const float d3 = 2.f * a1 * inv;
+            if constexpr (FAST) {   // (three uniform plane bases, one 32-bit offset)
+                const uint32_t ob = (uint32_t)(gy * W + gx) * 4u;
+                st32(D + (size_t)ch * plane, ob, d1);
+                st32(D + ((size_t)C_rgb + ch) * plane, ob, d2);
+                st32(D + (2 * (size_t)C_rgb + ch) * plane, ob, d3);
+            } else {
             const size_t o_ = (size_t)ch * plane + (size_t)gy * W + gx;
             D[o_] = d1;
             D[(size_t)C_rgb * plane + o_] = d2;
             D[2 * (size_t)C_rgb * plane + o_] = d3;
+            }
             ssum += S;
+#if GSR_SSIM_PK
+            const f2 ctr = XY[(r0 + o + LR) * LP + c + LR];
+            l1 += fabsf(ctr.x - ctr.y);
+#else
             l1 += fabsf(X[(r0 + o + LR) * LP + c + LR] - Y[(r0 + o + LR) * LP + c + LR]);
+#endif
         }
     }
     const float t_l1 = block_sum_256(l1, red);
     const float t_s = block_sum_256(ssum, red);
     if (tid == 0) {
-        const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const size_t wg = ((size_t)ch * gridDim.y + tby) * gridDim.x + tbx;   // (the tile's slot: the summation order is the map's, not the dispatch's)
         partials[2 * wg] = t_l1;
         partials[2 * wg + 1] = t_s;
     }
@@ -258,6 +404,7 @@ l1_ssim_finalize_kernel(int n_wg, const float* __restrict__ partials, double inv
 }
 
 // ---------------------------------------------------------------- pass 2
+template <bool FAST>
 __global__ void __launch_bounds__(256)
 ssim_grad_kernel(int H, int W, View x, View y, const float* __restrict__ D, float ca, float cb, const float* __restrict__ scale,
                  ViewW g, int C_rgb, DepthPlane dz)
@@ -279,7 +426,9 @@ ssim_grad_kernel(int H, int W, View x, View y, const float* __restrict__ D, floa
     __shared__ float T[3][LIY * LP];
     __shared__ float Hq[3][LIY * LT];
     const int tid = threadIdx.x;
-    const int tx0 = blockIdx.x * LT, ty0 = blockIdx.y * LTY, ch = blockIdx.z;
+    int tbx, tby, ch;
+    xcd_tile(C_rgb, tbx, tby, ch);
+    const int tx0 = tbx * LT, ty0 = tby * LTY;
     const size_t plane = (size_t)H * W, vol = (size_t)C_rgb * plane;
     constexpr int NL = (LIY * LI + 255) / 256;
     float dv[NL][3];
@@ -291,18 +440,25 @@ ssim_grad_kernel(int H, int W, View x, View y, const float* __restrict__ D, floa
         const int wrap = lc0 + k * DC >= LI ? 1 : 0;
         const int r = lr0 + k * DR + wrap, c = lc0 + k * DC - wrap * LI;
         const int gy = ty0 + r - LR, gx = tx0 + c - LR;
-        const bool in = tid + k * 256 < LIY * LI && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const bool in = ((k + 1) * 256 <= LIY * LI || tid + k * 256 < LIY * LI) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        if constexpr (FAST) {   // unconditional loads from an always valid element, masked when they are parked
+            const uint32_t ob = masked_off(in, (uint32_t)(gy * W + gx) * 4u);
+            dv[k][0] = ld32(Db, ob); dv[k][1] = ld32(Db + vol, ob); dv[k][2] = ld32(Db + 2 * vol, ob);
+        } else {
         const size_t o_ = (size_t)((in ? gy : 0) * W + (in ? gx : 0));   // H * W < 2^31 for any image this kernel sees
         dv[k][0] = in ? Db[o_] : 0.f;
         dv[k][1] = in ? Db[vol + o_] : 0.f;
         dv[k][2] = in ? Db[2 * vol + o_] : 0.f;
+        }
     }
 #pragma unroll
     for (int k = 0; k < NL; k++) {
-        if (tid + k * 256 < LIY * LI) {
+        if ((k + 1) * 256 <= LIY * LI || tid + k * 256 < LIY * LI) {
             const int wrap = lc0 + k * DC >= LI ? 1 : 0;
             const int r = lr0 + k * DR + wrap, c = lc0 + k * DC - wrap * LI;
-            T[0][r * LP + c] = dv[k][0]; T[1][r * LP + c] = dv[k][1]; T[2][r * LP + c] = dv[k][2];
+            const int gy = ty0 + r - LR, gx = tx0 + c - LR;
+            const bool in = !FAST || (gy >= 0 && gy < H && gx >= 0 && gx < W);
+            T[0][r * LP + c] = in ? dv[k][0] : 0.f; T[1][r * LP + c] = in ? dv[k][1] : 0.f; T[2][r * LP + c] = in ? dv[k][2] : 0.f;
         }
     }
     __syncthreads();
@@ -333,11 +489,18 @@ ssim_grad_kernel(int H, int W, View x, View y, const float* __restrict__ D, floa
     for (int o = 0; o < RPT; o++) {
         const int gy = ty0 + r0 + o, gx = tx0 + c;
         if (gy < H && gx < W) {
-            const float xv = x.p[ch * x.sc + gy * x.sy + gx * x.sx], yv = y.p[ch * y.sc + gy * y.sy + gx * y.sx];
+            float xv, yv;
+            if constexpr (FAST) {
+                xv = ld32(x.p + ch * x.sc, (uint32_t)(gy * (int)x.sy + gx * (int)x.sx) * 4u);
+                yv = ld32(y.p + ch * y.sc, (uint32_t)(gy * (int)y.sy + gx * (int)y.sx) * 4u);
+            } else {
+                xv = x.p[ch * x.sc + gy * x.sy + gx * x.sx]; yv = y.p[ch * y.sc + gy * y.sy + gx * y.sx];
+            }
             const float d = xv - yv;
             const float sgn = d > 0.f ? 1.f : d < 0.f ? -1.f : 0.f;   // d|x|/dx at 0 is 0 in torch
             const float ds = out[0][o] + 2.f * xv * out[1][o] + yv * out[2][o];
-            g.p[ch * g.sc + gy * g.sy + gx * g.sx] = ca * sgn - cb * ds;
+            if constexpr (FAST) st32(g.p + ch * g.sc, (uint32_t)(gy * (int)g.sy + gx * (int)g.sx) * 4u, ca * sgn - cb * ds);
+            else g.p[ch * g.sc + gy * g.sy + gx * g.sx] = ca * sgn - cb * ds;
         }
     }
 }
@@ -369,7 +532,9 @@ static int launch_ssim_stats(int C, int H, int W, const float* pred, const long 
     const View x{pred, ps[0], ps[1], ps[2]}, y{gt, gs_[0], gs_[1], gs_[2]};
     DepthPlane dz{};
     if (depth) dz = *depth;
-    ssim_stats_kernel<<<grid, 256, 0, st>>>(H, W, x, y, D, partials, C, dz);
+    const bool fast = view_fits_32(pred, ps, C, H, W) && view_fits_32(gt, gs_, C, H, W) && 3 * n < (1ull << 29);
+    if (fast) ssim_stats_kernel<true><<<grid, 256, 0, st>>>(H, W, x, y, D, partials, C, dz);
+    else ssim_stats_kernel<false><<<grid, 256, 0, st>>>(H, W, x, y, D, partials, C, dz);
     return (int)(grid.x * grid.y * C);
 }
 
@@ -381,8 +546,9 @@ void launch_l1_ssim_grad(int C, int H, int W, const float* pred, const long long
     const dim3 grid((W + LT - 1) / LT, (H + LTY - 1) / LTY, C);
     const View x{pred, ps[0], ps[1], ps[2]}, y{gt, gs_[0], gs_[1], gs_[2]};
     const ViewW g{grad, gstr[0], gstr[1], gstr[2]};
-    ssim_grad_kernel<<<grid, 256, 0, st>>>(H, W, x, y, static_cast<const float*>(workspace), (1.f - f) / (float)n, f / (float)n, scale, g,
-                                           C, DepthPlane{});
+    const bool fast = view_fits_32(pred, ps, C, H, W) && view_fits_32(gt, gs_, C, H, W) && view_fits_32(grad, gstr, C, H, W) && 3 * n < (1ull << 29);
+    if (fast) ssim_grad_kernel<true><<<grid, 256, 0, st>>>(H, W, x, y, static_cast<const float*>(workspace), (1.f - f) / (float)n, f / (float)n, scale, g, C, DepthPlane{});
+    else ssim_grad_kernel<false><<<grid, 256, 0, st>>>(H, W, x, y, static_cast<const float*>(workspace), (1.f - f) / (float)n, f / (float)n, scale, g, C, DepthPlane{});
 }
 
 void launch_l1_ssim(int C, int H, int W, const float* pred, const long long* ps, const float* gt, const long long* gs_,
@@ -563,8 +729,9 @@ void launch_rgb_depth_loss_grad(int C, int H, int W, const float* pred, const lo
     dz.H = Hd; dz.W = Wd; dz.pred = dpred; dz.psy = dps[0]; dz.psx = dps[1]; dz.gt = dgt; dz.gsy = dgs[0]; dz.gsx = dgs[1];
     dz.max_depth = max_depth; dz.n_wg = 1; dz.depth_factor = depth_factor; dz.mask_factor = mask_factor; dz.stats = stats;
     dz.scale = scale; dz.grad = dgrad; dz.qsy = dgstr[0]; dz.qsx = dgstr[1];
-    ssim_grad_kernel<<<grid, 256, 0, st>>>(H, W, x, y, static_cast<const float*>(ws_ssim), (1.f - f) / (float)n, f / (float)n, scale, g,
-                                           C, dz);
+    const bool fast = view_fits_32(pred, ps, C, H, W) && view_fits_32(gt, gs_, C, H, W) && view_fits_32(grad, gstr, C, H, W) && 3 * n < (1ull << 29);
+    if (fast) ssim_grad_kernel<true><<<grid, 256, 0, st>>>(H, W, x, y, static_cast<const float*>(ws_ssim), (1.f - f) / (float)n, f / (float)n, scale, g, C, dz);
+    else ssim_grad_kernel<false><<<grid, 256, 0, st>>>(H, W, x, y, static_cast<const float*>(ws_ssim), (1.f - f) / (float)n, f / (float)n, scale, g, C, dz);
 }
 
 }  // namespace gsr
