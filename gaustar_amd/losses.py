@@ -219,9 +219,9 @@ class _RGBDepthLoss(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             ctx.save_for_backward(x, g_full, gd, ws)
         ctx.cfg = (float(dssim_factor), margin, float(max_depth), float(depth_factor), float(mask_factor), img6.dtype)
-        # (the returned loss and parts must not alias what backward reads -- an in-place `loss += reg` or `parts.mul_()` by the
-        # caller is allowed --: the reduction kernel leaves a second copy of the eight numbers in the workspace's tail
-        # (include/gsr.h), which is what backward is handed; `out` goes to the caller outright, no copy kernel)
+        # (what backward reads -- the pixel counts the depth gradient divides by -- is the second copy of the eight numbers the
+        # reduction kernel leaves in the workspace's tail (include/gsr.h), not the vector handed to the caller: `out` goes out
+        # as it is, without the 32-byte device copy that used to separate the two)
         parts = out[:7]
         ctx.mark_non_differentiable(parts)
         ctx.set_materialize_grads(False)   # no zero-filled "gradient" of the parts vector per backward (one fill kernel)

@@ -315,3 +315,31 @@ def test_points_colors_split_validation(hip_lib):
         producers.points_colors_split(pos, cam, dc, rest, 2, None, 1, torch.zeros(7, 1, device="cuda"))
     with pytest.raises(RuntimeError, match="no CPU path"):
         producers.points_colors_split(pos.cpu(), cam, dc, rest, 2)
+
+
+def test_mesh_producer_backward_twice_over_one_graph(hip_lib):
+    """ABI 14: the forward's launch clears the vertex-gradient accumulator of the backward to come (no fill in front of it); the
+    cleared buffer is good for ONE backward -- a second pass over a retained graph takes a fresh one and gives the same gradient."""
+    from gaustar_amd import producers, scene
+    dev = torch.device("cuda:0")
+    v, f = scene.icosphere(2, 1.0, (0.0, 0.0, 0.0))
+    verts = torch.from_numpy(v).float().to(dev).requires_grad_(True)
+    faces = torch.from_numpy(f).long().to(dev)
+    G = 3
+    gen = torch.Generator(device=dev).manual_seed(3)
+    bary = torch.rand(G, 3, device=dev, generator=gen); bary = bary / bary.sum(1, keepdim=True)
+    N = faces.size(0) * G
+    rs = torch.randn(N, 2, device=dev, generator=gen).requires_grad_(True)
+    rc = torch.randn(N, 2, device=dev, generator=gen).requires_grad_(True)
+    pts, sc, qu = producers.mesh_bound_gaussians(verts, faces, bary, rs, rc, 1e-3)
+    wp, ws, wq = (torch.randn(t.shape, device=dev, generator=gen) for t in (pts, sc, qu))
+    loss = (pts * wp).sum() + (sc * ws).sum() + (qu * wq).sum()
+    g1 = torch.autograd.grad(loss, (verts, rs, rc), retain_graph=True)
+    g2 = torch.autograd.grad(loss, (verts, rs, rc))
+    for a, b in zip(g1, g2):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7) and float(a.abs().max()) > 0
+    # ... and a fresh graph (its own pre-cleared accumulator) agrees with both
+    pts, sc, qu = producers.mesh_bound_gaussians(verts, faces, bary, rs, rc, 1e-3)
+    g3 = torch.autograd.grad((pts * wp).sum() + (sc * ws).sum() + (qu * wq).sum(), (verts, rs, rc))
+    for a, b in zip(g1, g3):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
