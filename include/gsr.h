@@ -188,6 +188,9 @@ int gsr_backward(int P, int D, int M, int R, int num_segments, const float* back
 /* Backward of a num_channels render (see gsr_forward_stage2_mt): dL_dpix [num_channels,H,W], dL_dcolor
  * [P,num_channels]; every other gradient is the sum over the targets, i.e. what autograd would accumulate from
  * the separate backward passes of the reference.  num_channels = 3 is gsr_backward.
+ * Precision of the per-pixel sums on the matrix pipe: exact f32 products for 3 and 6 channels and for channels 0, 1 of a
+ * 4-channel render; channels 2 and 3 of a 4-channel render enter their dL_dcolor sums with 16 mantissa bits of dL_dpix (hi + rest
+ * rounded to bf16: relative error <= 2^-17 per term, unbiased) -- every other gradient reads dL_dpix in full f32.
  * grad_scratch_zeroed = 1: the caller guarantees grad_scratch is all zero (gsr_forward_fused cleared it) and the
  * library skips its own fill; 0: the fill is part of the call, as in gsr_backward. */
 int gsr_backward_mt(int P, int D, int M, int R, int num_segments, int num_channels, const float* background, int W,

@@ -27,6 +27,15 @@ _rz.GaussianRasterizer.forward = timed("  in render4: GaussianRasterizer.forward
 _hs.SurfaceGaussians._settings = timed("  in render4: _settings", _hs.SurfaceGaussians._settings)
 torch.cat = timed("  torch.cat", torch.cat)
 torch.sigmoid = timed("  torch.sigmoid", torch.sigmoid)
+_rz.rasterize_gaussians_backward_native = timed("  in backward: rasterize_gaussians_backward_native", _rz.rasterize_gaussians_backward_native)
+_hs._rasterizer.rasterize_gaussians_backward_native = _rz.rasterize_gaussians_backward_native
+_pr._sh_backward_raw = timed("  in backward: _sh_backward_raw", _pr._sh_backward_raw)
+_pr._mesh_backward_raw = timed("  in backward: _mesh_backward_raw", _pr._mesh_backward_raw)
+_pr._mesh_forward_raw = timed("  in render4: _mesh_forward_raw", _pr._mesh_forward_raw)
+_pr._sh_forward_raw = timed("  in render4: _sh_forward_raw", _pr._sh_forward_raw)
+_hs._RenderMeshBound.backward = staticmethod(timed("  in backward: _RenderMeshBound.backward (all of it)", _hs._RenderMeshBound.backward))
+losses._RGBDepthLoss.backward = staticmethod(timed("  in backward: _RGBDepthLoss.backward", losses._RGBDepthLoss.backward))
+_hs._RenderMeshBound.forward = staticmethod(timed("  in render4: _RenderMeshBound.forward (all of it)", _hs._RenderMeshBound.forward))
 _bw = torch.Tensor.backward
 torch.Tensor.backward = timed("backward (autograd engine, all backward launches)", _bw)
 TINY = os.environ.get("WINDOW_PHASES_SIZE") == "tiny"   # tiny: negligible GPU work -- what is timed is the host alone
