@@ -34,6 +34,16 @@ class Adam(torch.optim.Optimizer):
         if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0.0, amsgrad=False))
+        self._step_views = {}   # id(parameter) -> (its state's step tensor, numpy view of it)
+
+    def zero_grad(self, set_to_none: bool = True):
+        """torch.optim.Optimizer.zero_grad; the default (drop the gradients) without the base class's per-call bookkeeping
+        (profiler range, foreach grouping: ~20 us per call for eight tensors, once per iteration of a 0.55 ms loop)."""
+        if not set_to_none:
+            return super().zero_grad(set_to_none=False)
+        for group in self.param_groups:
+            for p in group["params"]:
+                p.grad = None
 
     multi_tensor = True   # one launch per 16 tensors (gsr_adam_step_multi); False: one launch per tensor (gsr_adam_step)
 
@@ -46,6 +56,7 @@ class Adam(torch.optim.Optimizer):
         lib = _lib.load()
         # tensors that share everything but the learning rate go out together: (device, betas, eps, step count) -> entries
         batches = {}
+        step_views = self.__dict__.setdefault("_step_views", {})   # (absent after unpickling)
         for group in self.param_groups:
             lr, (b1, b2), eps = float(group["lr"]), group["betas"], float(group["eps"])
             for p in group["params"]:
@@ -61,9 +72,21 @@ class Adam(torch.optim.Optimizer):
                     st["step"] = torch.tensor(0.0)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
+                # (the step count stays what torch.optim.Adam keeps -- a CPU scalar tensor in the state --, bumped through a cached
+                # numpy view of its one element: `tensor += 1` is a 3.5 us dispatch per parameter tensor and step)
+                step_t = st["step"]
+                view = step_views.get(id(p))
+                if view is None or view[0] is not step_t:
+                    view = (step_t, step_t.numpy()) if (step_t.device.type == "cpu" and step_t.dim() == 0) else (step_t, None)
+                    step_views[id(p)] = view
+                if view[1] is not None:
+                    view[1][...] += 1
+                    step_now = int(view[1])
+                else:
+                    step_t += 1
+                    step_now = int(step_t.item())
                 g = p.grad if (p.grad.dtype == torch.float32 and p.grad.is_contiguous()) else p.grad.float().contiguous()
-                key = (p.device.index, float(b1), float(b2), eps, int(st["step"].item()))
+                key = (p.device.index, float(b1), float(b2), eps, step_now)
                 batches.setdefault(key, []).append((p, g, st["exp_avg"], st["exp_avg_sq"], lr))
         for (dev_index, b1, b2, eps, step), entries in batches.items():
             with _host.on_device(entries[0][0].device):
