@@ -382,6 +382,15 @@ def window_benchmark():
            "gaussians": r["gaussians"], "cameras": r["cameras"], "image": r["image"],
            "what": "tools/bench_window.py: refinement loop of config E's shape at config-C size, one GPU, outside the timed region; "
                    "100 iterations over 160 cameras: no camera is rendered twice, every view is its camera's first (exact binning)"}
+    # the same 2 x 50 iterations with render + losses + backward as ONE graph-free call (harness.SurfaceGaussians.rgbd_step: the
+    # same kernels; without autograd's per-iteration host work the loop is GPU-bound on slow hosts too)
+    r1 = bench_window.run(argparse.Namespace(frames=2, iters=50, level=6, width=1920, height=1080, cameras=160, fused_step=True))
+    out["fused_step"] = {"median_ms_per_iteration": r1["median_ms_per_iteration"], "p90_ms_per_iteration": r1["p90_ms_per_iteration"],
+                         "ms_per_iteration": r1["ms_per_iteration"], "iterations_per_s": r1["iterations_per_s"],
+                         "host_wait_ms_per_iteration": r1.get("host_wait_ms_per_iteration"),
+                         "what": "the same loop through SurfaceGaussians.rgbd_step (no autograd graph: the two Functions' forward / "
+                                 "backward bodies called back to back, .grad set directly); identical kernels and numbers"}
+    out["host_wait_ms_per_iteration"] = r.get("host_wait_ms_per_iteration")
     # The reference refines 2 000 iterations per frame (train_seq.py:45: 12.5 views per camera); 480 per frame = 3 per camera
     # show what a loop that comes back to its cameras pays: the later views are binned by their camera's plan, those the moving
     # Gaussians have outgrown fall back (plan_stats).

@@ -121,6 +121,23 @@ def nerf_camera_from_scene(cam: scene.Camera, znear: float = 1e-4, zfar: float =
     return NerfCamera(c2w=c2w[:3, :], fx=fx, fy=fy, width=cam.W, height=cam.H, znear=znear, zfar=zfar)
 
 
+class _PlainCtx:
+    """Stand-in for an autograd context: lets SurfaceGaussians.rgbd_step run the Functions' forward / backward bodies directly."""
+    __slots__ = ("needs_input_grad", "saved_tensors", "__dict__")
+
+    def __init__(self, needs_input_grad):
+        self.needs_input_grad, self.saved_tensors = needs_input_grad, ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+    def set_materialize_grads(self, value):
+        pass
+
+
 class _RenderMeshBound(torch.autograd.Function):
     """A render of mesh-bound Gaussians as ONE autograd node: the model's parameters in, the image out.  Forward = mesh
     producer -> colour producer (coefficients read from `_sh_coordinates_dc` / `_sh_coordinates_rest` where they live,
@@ -463,6 +480,13 @@ class SurfaceGaussians(nn.Module):
         colour channels; bg has one entry per channel) rendered through ONE autograd node (_RenderMeshBound) -- the
         refinement loop's render.  Values and gradients are those of render_image_gaussian_rasterizer / the composition of
         producers.points_rgb_depth, torch.sigmoid and GaussianRasterizer (tests/test_gpu_harness.py)."""
+        cfg = self._channels_cfg(camera, bg, sh_deg, depth_channels, torch.is_grad_enabled())
+        return _RenderMeshBound.apply(self._points, self._scales, self._quaternions, self.all_densities, self._sh_coordinates_dc,
+                                      self._sh_coordinates_rest, self._delta_t if self._loose_bind else None,
+                                      self._delta_r if self._loose_bind else None, cfg)
+
+    def _channels_cfg(self, camera: NerfCamera, bg: torch.Tensor, sh_deg: Optional[int], depth_channels: int, grad: bool):
+        """What _RenderMeshBound needs besides the parameters (render_channels, rgbd_step)."""
         if depth_channels not in (0, 1, 3):
             raise ValueError("depth_channels must be 0, 1 or 3")
         sh_deg = self.sh_levels - 1 if sh_deg is None else int(sh_deg)
@@ -478,7 +502,7 @@ class SurfaceGaussians(nn.Module):
                "lo": float("-inf") if self.min_gaussian_scale is None else float(self.min_gaussian_scale),
                "hi": float("inf") if self.max_gaussian_scale is None else float(self.max_gaussian_scale), "sh_levels": sh_deg + 1,
                "sink": getattr(self, "grad_sink", None),
-               "grad": torch.is_grad_enabled(),   # (Function.forward cannot tell: see rasterizer._CALL)
+               "grad": bool(grad),   # (Function.forward cannot tell whether the caller runs under no_grad: see rasterizer._CALL)
                "params": (self._points, self._scales, self._quaternions, self.all_densities, self._sh_coordinates_dc,
                           self._sh_coordinates_rest, self._delta_t if self._loose_bind else None,
                           self._delta_r if self._loose_bind else None)}
@@ -486,9 +510,43 @@ class SurfaceGaussians(nn.Module):
             raise RuntimeError("camera matrices must be float32 tensors on the model's device")
         if cfg["sink"] is not None and not (hasattr(cfg["sink"], "grad_views") and hasattr(cfg["sink"], "written") and hasattr(cfg["sink"], "accepts")):
             raise TypeError("grad_sink must provide grad_views(), accepts(p) and written(params) (gaustar_amd.dist.ShardedAdam)")
-        return _RenderMeshBound.apply(self._points, self._scales, self._quaternions, self.all_densities, self._sh_coordinates_dc,
-                                      self._sh_coordinates_rest, self._delta_t if self._loose_bind else None,
-                                      self._delta_r if self._loose_bind else None, cfg)
+        return cfg
+
+    def rgbd_step(self, camera: NerfCamera, bg: torch.Tensor, gt_rgb: torch.Tensor, gt_depth: torch.Tensor, max_depth: float,
+                  dssim_factor: float = 0.2, depth_factor: float = 1.0, mask_factor: float = 1.0, grad_scale: Optional[torch.Tensor] = None,
+                  sh_deg: Optional[int] = None):
+        """One refinement iteration's render + image losses + backward WITHOUT an autograd graph: the 4-channel render of
+        render_channels(depth_channels=1), losses.rgb_depth_loss on it and both backward passes, run back to back through the very
+        functions the autograd path runs (the two Functions' forward / backward bodies, called directly); the parameters' `.grad`
+        are set (added to, if present) exactly as `loss.backward()` would.  -> (loss, image, radii), all detached.
+        For loops whose only loss is this one: what it takes out is host time -- two Function.apply, the engine's thread
+        hand-off and graph walk, eight AccumulateGrad nodes -- about a third of an iteration's Python at config-C size, which
+        is what bounds the loop on a slow host (tools/window_phases.py).  grad_scale: a device scalar d(total)/d(loss), default 1."""
+        from . import losses as _losses
+        with torch.no_grad():
+            cfg = self._channels_cfg(camera, bg, sh_deg, 1, True)
+            params = (self._points, self._scales, self._quaternions, self.all_densities, self._sh_coordinates_dc, self._sh_coordinates_rest,
+                      self._delta_t if self._loose_bind else None, self._delta_r if self._loose_bind else None)
+            rctx = _PlainCtx(tuple(p is not None and p.requires_grad for p in params) + (False,))
+            image, radii = _RenderMeshBound.forward(rctx, *params, cfg)
+            lctx = _PlainCtx((True,) + (False,) * 7)
+            loss, _parts = _losses._RGBDepthLoss.forward(lctx, image, gt_rgb, gt_depth, float(dssim_factor), None, float(max_depth),
+                                                        float(depth_factor), float(mask_factor))
+            if grad_scale is None:
+                one = getattr(self, "_one_cache", None)
+                if one is None or one.device != image.device:
+                    one = self._one_cache = torch.ones((), device=image.device)
+                grad_scale = one
+            d_image = _losses._RGBDepthLoss.backward(lctx, grad_scale, None)[0]
+            grads = _RenderMeshBound.backward(rctx, d_image, None)
+            for p, g in zip(params, grads):
+                if p is None or g is None or not p.requires_grad:
+                    continue
+                if p.grad is None:
+                    p.grad = g
+                else:
+                    p.grad.add_(g)
+        return loss, image, radii
 
     def _bary_rows(self):
         b = getattr(self, "_bary_rows_cache", None)

@@ -251,3 +251,50 @@ def test_refinement_iterations_reduce_the_loss(hip_lib):
     assert r["gaussians"] == 20 * 4 ** 3 * 6
     assert r["loss_first"] == r["loss_first"] and r["loss_last"] == r["loss_last"], "NaN loss"
     assert r["loss_last"] < 0.8 * r["loss_first"], r
+
+
+def test_graph_free_step_equals_the_autograd_iteration(hip_lib):
+    """harness.SurfaceGaussians.rgbd_step = render_channels(depth_channels=1) -> losses.rgb_depth_loss -> backward() without an
+    autograd graph (the same Function bodies called directly): same loss bit for bit, same image, gradients equal up to the
+    order of the backward's float atomics (an analytically zero gradient -- the in-plane rotation's here -- is nothing but that
+    noise: absolute floor 1e-9); a second call ADDS to existing gradients like autograd does."""
+    import torch
+    from gaustar_amd import harness, losses, scene
+    dev = torch.device("cuda:0")
+    v, f = scene.icosphere(3, scene.SUBJECT_RADIUS, scene.SUBJECT_CENTER)
+    model = harness.SurfaceGaussians(torch.from_numpy(v).float().to(dev), torch.from_numpy(f).long().to(dev), 6, 3).to(dev)
+    g = torch.Generator(device=dev).manual_seed(4)
+    with torch.no_grad():
+        model._sh_coordinates_dc.copy_(torch.rand(model.n_points, 1, 3, device=dev, generator=g) * 2 - 1)
+        model._sh_coordinates_rest.copy_(torch.randn(model._sh_coordinates_rest.shape, device=dev, generator=g) * 0.1)
+    cam = harness.nerf_camera_from_scene(scene.ring_cameras(5, 32, 320, 240, focal_px=200.0)[37])
+    bg4 = torch.tensor([0.0, 1.0, 0.0, 10.0], device=dev)
+    gt_rgb = torch.rand(3, 240, 320, device=dev, generator=g)
+    gt_d = torch.rand(240, 320, device=dev, generator=g) * 12.0
+    params = [p for p in model.parameters() if p.requires_grad]
+    img = model.render_channels(cam, bg4, depth_channels=1)[0]
+    loss = losses.rgb_depth_loss(img, gt_rgb, gt_d, 10.0, 0.2, 1.0, 0.5)
+    loss.backward()
+    ref = [None if p.grad is None else p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    loss2, img2, radii2 = model.rgbd_step(cam, bg4, gt_rgb, gt_d, 10.0, 0.2, 1.0, 0.5)
+    assert not loss2.requires_grad and float(loss2) == float(loss) and torch.equal(img2, img.detach())
+    n_with = 0
+    for p, r in zip(params, ref):
+        assert (p.grad is None) == (r is None)
+        if r is not None and r.numel():
+            n_with += 1
+            assert torch.allclose(p.grad, r, rtol=2e-4, atol=1e-4 * float(r.abs().max()) + 1e-9), float((p.grad - r).abs().max())
+    assert n_with >= 6
+    model.rgbd_step(cam, bg4, gt_rgb, gt_d, 10.0, 0.2, 1.0, 0.5)            # gradients accumulate
+    for p, r in zip(params, ref):
+        if r is not None and r.numel():
+            assert torch.allclose(p.grad, 2.0 * r, rtol=4e-4, atol=2e-4 * float(r.abs().max()) + 2e-9)
+    # a device scalar as d(total)/d(loss)
+    for p in params:
+        p.grad = None
+    model.rgbd_step(cam, bg4, gt_rgb, gt_d, 10.0, 0.2, 1.0, 0.5, grad_scale=torch.tensor(-0.5, device=dev))
+    for p, r in zip(params, ref):
+        if r is not None and r.numel():
+            assert torch.allclose(p.grad, -0.5 * r, rtol=2e-4, atol=1e-4 * float(r.abs().max()) + 1e-9)

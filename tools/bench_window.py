@@ -57,6 +57,7 @@ def run(a):
     target.load_state_dict(model.state_dict())
     frames, n_it, per_it = [], 0, []
     one = torch.ones((), device=dev)
+    fused_step = bool(getattr(a, "fused_step", False))
     host_wait_ns = 0
     pts_start = model.points.detach().clone()
     t_total = 0.0
@@ -97,9 +98,12 @@ def run(a):
                 marks[it].record()
                 ci = gdist.shard_views(len(ncams), fi * a.iters + it, rank, world)
                 opt.zero_grad(set_to_none=True)
-                img = render(model, ncams[ci], bg4)
-                loss = losses.rgb_depth_loss(img, gts[ci][0], gts[ci][1], MAX_DEPTH, 0.2, 1.0, 0.5)
-                loss.backward(one)                 # (the seed is handed over: a bare backward() fills a ones_like per call, 4.5 us on the stream)
+                if fused_step:    # render + losses + both backward passes without an autograd graph (harness.SurfaceGaussians.rgbd_step)
+                    loss = model.rgbd_step(ncams[ci], bg4, gts[ci][0], gts[ci][1], MAX_DEPTH, 0.2, 1.0, 0.5)[0]
+                else:
+                    img = render(model, ncams[ci], bg4)
+                    loss = losses.rgb_depth_loss(img, gts[ci][0], gts[ci][1], MAX_DEPTH, 0.2, 1.0, 0.5)
+                    loss.backward(one)                 # (the seed is handed over: a bare backward() fills a ones_like per call, 4.5 us on the stream)
                 if reducer is not None:
                     reducer()                      # the hook in front of sugar_optimizer.py:99-101
                 opt.step()
@@ -136,6 +140,8 @@ def run(a):
                                   "views_per_iteration": world}
     from gaustar_amd import rasterizer as _rz
     extra["plan_stats"] = dict(_rz.PLAN_STATS)
+    if fused_step:
+        extra["fused_step"] = True
     return {**extra, "gaussians": N, "image": [a.width, a.height], "cameras": len(ncams), "frames": frames, "iterations": n_it,
             "iterations_per_s": round(n_it / t_total, 1), "ms_per_iteration": round(t_total / n_it * 1e3, 3),
             # the steady state: median over all iterations of the time between their start marks on the stream (the wall
@@ -155,6 +161,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080); ap.add_argument("--cameras", type=int, default=160)
     ap.add_argument("--exchange", choices=["sharded", "allreduce"], default="sharded")
     ap.add_argument("--composed", action="store_true", help="render through the composition of autograd nodes instead of the one-node render")
+    ap.add_argument("--fused-step", dest="fused_step", action="store_true",
+                    help="render + losses + backward through SurfaceGaussians.rgbd_step (no autograd graph) instead of loss.backward()")
     r = run(ap.parse_args())
     if gdist.rank() == 0:
         print(json.dumps(r))
