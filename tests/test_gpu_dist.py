@@ -150,11 +150,13 @@ def test_bench_two_ranks_over_gloo():
     assert d["config"]["buckets_issued_during_backward"] >= 1
 
 
-def test_refinement_window_two_ranks_over_gloo():
+@pytest.mark.parametrize("extra", [[], ["--fused-step"]], ids=["autograd", "graph-free step"])
+def test_refinement_window_two_ranks_over_gloo(extra):
     """tools/bench_window.py under torchrun: harness parameters (the optimiser's real payload), gradients averaged by
-    dist.GradAllReducer with buckets leaving during backward, every frame's loss falling on an effective batch of two views."""
+    dist.GradAllReducer with buckets leaving during backward, every frame's loss falling on an effective batch of two views.
+    --fused-step: the same with render + losses + backward as SurfaceGaussians.rgbd_step (gradients into the sink without a graph)."""
     d = _torchrun([os.path.join("tools", "bench_window.py"), "--frames", "2", "--iters", "40", "--level", "3", "--width", "320",
-                   "--height", "240", "--cameras", "16"], {})
+                   "--height", "240", "--cameras", "16"] + extra, {})
     assert d["world"] == 2 and d["views_per_iteration"] == 2 and d["buckets_issued_during_backward"] >= 1
     assert d["exchange"] == "sharded"      # reduce-scatter (gloo: all-reduce + shard) -> Adam on each rank's half -> all-gather
     for fr in d["frames"]:
