@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_longlong, c_si
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSR_LIB_PATH", os.path.join(_HERE, "libgsr_hip.so"))   # override: experiment variants
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 ALLOC_FN = ctypes.CFUNCTYPE(c_void_p, c_void_p, c_size_t)
 
 # name -> (restype, argtypes); mirrors include/gsr.h one to one (tests check both directions).
@@ -44,6 +44,9 @@ SIGNATURES = {
                                     c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p,
                                     POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), c_void_p, POINTER(c_int),
                                     POINTER(c_int), c_void_p]),
+    "gsr_camera_key": (c_int, [c_void_p, c_longlong, c_longlong, POINTER(ctypes.c_ulonglong)]),
+    "gsr_camera_key_begin": (c_int, [c_void_p, c_longlong, c_longlong]),
+    "gsr_camera_key_end": (c_int, [POINTER(ctypes.c_ulonglong)]),
     "gsr_release_stream_state": (c_int, [c_void_p]),
     "gsr_forward": (c_int, [ALLOC_FN, ALLOC_FN, ALLOC_FN, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int,
                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,

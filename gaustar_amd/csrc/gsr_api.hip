@@ -101,7 +101,7 @@ int fail_msg(const char* msg)
 
 extern "C" {
 
-int gsr_abi_version(void) { return 14; }
+int gsr_abi_version(void) { return 15; }
 
 const char* gsr_last_error(void) { return g_err.c_str(); }
 
@@ -339,6 +339,7 @@ int forward_stage1_impl(int P, int D, int M, const float* means3D, const float* 
             // platform where device stores to mapped host memory are not coherent must not yield stale totals -- fetch
             // them with an ordinary copy.
             GSR_CHECK(hipMemcpyAsync(g_pinned, im.totals, 16, hipMemcpyDeviceToHost, st));
+            g_pinned[5] = 0xffffffffu;   // (the number of parts did not arrive either: -1 = let stage 2 decide from the sizes)
             GSR_CHECK(hipStreamSynchronize(st));
         }
     } else {
@@ -523,7 +524,12 @@ int forward_fused_impl(int P, int D, int M, int num_channels, int need_backward,
             job.header = pl.header; job.ranges = pl.ranges; job.seg_off = pl.seg_off; job.order = pl.order;
             job.split_from_word = split_from();
             job.level = (uint32_t)(plan_info[4] < 0 ? 0 : plan_info[4] > 3 ? 3 : plan_info[4]);
-            job.host_pad = reinterpret_cast<uint32_t*>(plan_info) + PI_HEADER; job.host_seq = next_seq();
+            job.host_pad = reinterpret_cast<uint32_t*>(plan_info) + PI_HEADER;
+            // (the sequence number belongs to the PLAN, not to the calling thread: a plan_info block may be used from several
+            // host threads, and a thread-local counter that happens to equal the block's stale ARRIVED word would make the next
+            // call adopt the OLD header while the device holds the new plan)
+            job.host_seq = (uint32_t)plan_info[PI_ARRIVED] + 1u;
+            if (job.host_seq == 0u) job.host_seq = 1u;
         }
     }
     if (gsr_binning_bytes_mt(*num_rendered, *num_segments, num_channels) > binning_capacity || (*num_rendered > 0 && !binning_buffer)) {
@@ -1145,6 +1151,82 @@ int gsr_release_stream_state(gsr_stream_t stream)
     if (it->second.base) { GSR_CHECK(hipStreamSynchronize(st)); GSR_CHECK(hipFree(it->second.base)); }
     g_cnt.erase(it);
     return 0;
+}
+
+// ---- gsr_camera_key: the sixteen floats of a view matrix to the host without touching the caller's stream.
+namespace {
+__global__ void __launch_bounds__(64) camera_key_kernel(const float* __restrict__ m, long long s0, long long s1, uint32_t* __restrict__ pad,
+                                                        uint32_t seq)
+{
+    const int lane = threadIdx.x;
+    if (lane < 16) pad[lane] = __float_as_uint(m[(long long)(lane >> 2) * s0 + (long long)(lane & 3) * s1]);
+    __threadfence_system();   // (one wave: its wait covers every lane's store)
+    if (lane == 0) __hip_atomic_store(&pad[16], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+std::mutex g_key_mu;
+std::map<int, hipStream_t> g_key_stream;   // device -> the library's non-blocking side stream
+constexpr int PAD_KEY = 32;                // words [32 .. 48] of the thread's pad: the matrix, then its sequence number
+}  // namespace
+
+namespace {
+thread_local uint32_t g_key_seq = 0;          // sequence number of this thread's read under way (0: none)
+thread_local hipStream_t g_key_side = nullptr;
+}
+int gsr_camera_key_begin(const float* viewmatrix, long long row_stride, long long col_stride)
+{
+    g_err.clear();
+    g_key_seq = 0;
+    if (!viewmatrix) return fail_msg("gsr_camera_key: null pointer");
+    int dev = 0;
+    GSR_CHECK(hipGetDevice(&dev));
+    hipStream_t side = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_key_mu);
+        auto it = g_key_stream.find(dev);
+        if (it == g_key_stream.end()) {
+            GSR_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            g_key_stream[dev] = side;
+        } else {
+            side = it->second;
+        }
+    }
+    if (const int bad = ensure_pad()) return bad;
+    static_assert(PAD_KEY + 17 <= PAD_WORDS, "pad");
+    const uint32_t seq = next_seq();
+    camera_key_kernel<<<1, 64, 0, side>>>(viewmatrix, row_stride, col_stride, g_pinned + PAD_KEY, seq);
+    GSR_CHECK_LAUNCH("camera_key_kernel");
+    g_key_seq = seq;
+    g_key_side = side;
+    return 0;
+}
+
+int gsr_camera_key_end(unsigned long long* key)
+{
+    if (!key) { g_err.clear(); return fail_msg("gsr_camera_key: null pointer"); }
+    if (g_key_seq == 0u) { g_err.clear(); return fail_msg("gsr_camera_key_end: no read under way on this thread"); }
+    const uint32_t seq = g_key_seq;
+    g_key_seq = 0;
+    bool seen = false;
+    if (const int bad = wait_pad_word(g_pinned + PAD_KEY + 16, seq, g_key_side, &seen)) return bad;
+    if (!seen) return fail_msg("gsr_camera_key: the kernel retired without its store showing up in the pinned pad");
+    // FNV-1a over the sixteen words, then a finaliser (the low bits of a float's pattern are what differs between neighbouring
+    // cameras of a rig)
+    unsigned long long h = 1469598103934665603ull;
+    for (int i = 0; i < 16; i++) {
+        uint32_t w = g_pinned[PAD_KEY + i];
+        if (w == 0x80000000u) w = 0u;   // -0.0 == 0.0: the same camera
+        for (int b = 0; b < 4; b++) { h ^= (w >> (8 * b)) & 0xffu; h *= 1099511628211ull; }
+    }
+    h ^= h >> 33; h *= 0xff51afd7ed558ccdull; h ^= h >> 33;
+    *key = h;
+    return 0;
+}
+
+int gsr_camera_key(const float* viewmatrix, long long row_stride, long long col_stride, unsigned long long* key)
+{
+    if (!key) { g_err.clear(); return fail_msg("gsr_camera_key: null pointer"); }
+    if (const int bad = gsr_camera_key_begin(viewmatrix, row_stride, col_stride)) return bad;
+    return gsr_camera_key_end(key);
 }
 
 int gsr_debug_preprocess_occupancy(int* exact, int* planned)

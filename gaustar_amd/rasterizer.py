@@ -19,6 +19,7 @@ import ctypes
 import os
 import sys
 import threading
+import weakref
 from typing import NamedTuple
 
 import torch
@@ -108,9 +109,14 @@ _BINNING_HINT: dict = {}
 _HINT_LOCK = threading.Lock()   # trainer thread + evaluation thread may render on one device
 _FUSED = os.environ.get("GSR_FUSED_FORWARD", "1") != "0"   # 0: always stage 1, allocate exactly, stage 2
 # Plans (include/gsr.h, gsr_forward_planned): per camera the layout of its tiles' buckets, left behind by one view for the
-# next view of that camera.  A camera is recognised by the storage of its view matrix (the reference keeps one tensor per
-# camera: cameras.py:276-310 builds them once, sugar_model.py:1173-1187 hands them over every iteration) on a given stream
-# -- or by an explicit `plan_key`.  A plan is a hint: a wrong or stale one costs the exact path, never a wrong pixel.
+# next view of that camera.  A camera is recognised by the CONTENTS of its view matrix (+ image size and field of view): the
+# reference's mesh-bound caller builds a fresh `torch.Tensor(getWorld2View(...)).transpose(0, 1).cuda()` on every render call
+# (gaustar_scene/sugar_model.py:1149-1150; full_proj_transform derives from it, :1163), so neither the tensor nor its address
+# names the camera -- the caching allocator hands consecutive cameras the same 512-byte block.  _camera_key() below: a tensor
+# seen before (gaussian_renderer.render keeps one per camera, gaussian_splatting/scene/cameras.py:212; so does harness.py) costs
+# a dictionary look-up, a fresh one is read through gsr_camera_key (one-wave kernel on a side stream, ~10 us, the caller's
+# stream is not waited for) -- or the caller names the camera itself (`plan_key`).  A plan is a hint: a wrong or stale one costs
+# the exact path, never a wrong pixel.
 _PLANNED = os.environ.get("GSR_PLANNED", "1") != "0"
 _PLAN_SLOTS = int(os.environ.get("GSR_PLAN_SLOTS", "2048"))
 # Slack level a camera's first plan is made with (include/gsr.h: capacity = count + max(16, count / 8) << level).  Differentiable
@@ -145,28 +151,107 @@ class _Plan:
             pass
 
 
+# Plans that left the table while a builder of theirs may still be on its way to their pinned block: (event recorded on the
+# plan's own stream and device when it left, plan).  The block is recycled (by _Plan.__del__) once the event has passed -- looked
+# at when the next plan is made, nobody waits, and no lock is held across a device synchronisation.
+_PLAN_GRAVE: list = []
+
+
+def _stream_of(dev_index, raw_stream):
+    return torch.cuda.ExternalStream(raw_stream, device=dev_index) if raw_stream else torch.cuda.default_stream(dev_index)
+
+
+def _retire(key, ent):
+    try:
+        ev = torch.cuda.Event()
+        ev.record(_stream_of(key[0], key[1]))
+        _PLAN_GRAVE.append((ev, ent))
+    except Exception:   # (no event: keep the entry alive for good rather than recycle a block that may be written)
+        _PLAN_GRAVE.append((None, ent))
+
+
 def _plan_entry(key, lib, nbytes, byte_opts, level):
     with _HINT_LOCK:
         ent = _PLANS.get(key)
         if ent is not None and ent.buf.numel() == nbytes:
             _PLANS.move_to_end(key)
             return ent
+        if _PLAN_GRAVE:
+            _PLAN_GRAVE[:] = [(ev, e) for ev, e in _PLAN_GRAVE if ev is None or not ev.query()]
+        if ent is not None:
+            _retire(key, ent)
         ent = _Plan(lib, nbytes, byte_opts, level)
         _PLANS[key] = ent
-        if len(_PLANS) > _PLAN_SLOTS:
-            # (a plan's builder may still be on its way to the pinned block of the entry that goes: let the device finish first)
-            torch.cuda.synchronize()
-            while len(_PLANS) > _PLAN_SLOTS:
-                _PLANS.popitem(last=False)
+        while len(_PLANS) > _PLAN_SLOTS:
+            _retire(*_PLANS.popitem(last=False))
         return ent
 
 
 def drop_plans():
     """Forget every camera's plan (the next view of each renders the exact way and re-plans)."""
-    if torch.cuda.is_available():
-        torch.cuda.synchronize()   # (no plan builder may still be writing into a pinned block that is about to be recycled)
     with _HINT_LOCK:
+        devs = {k[0] for k in _PLANS}
+        for k, e in list(_PLANS.items()):
+            _retire(k, e)
         _PLANS.clear()
+    for d in devs:   # (outside the lock; every device that held a plan, not just the current one)
+        torch.cuda.synchronize(d)
+    with _HINT_LOCK:
+        _PLAN_GRAVE[:] = [(ev, e) for ev, e in _PLAN_GRAVE if ev is None or not ev.query()]
+
+
+# id(tensor) -> (weak reference, version counter, data pointer, key): view-matrix tensors whose contents have been read.
+_CAM_KEYS: dict = {}
+CAMERA_KEY_STATS = {"known_tensor": 0, "read": 0}
+
+
+_PENDING = object()
+
+
+def _camera_key_begin(lib, vm, dev):
+    """First half of _camera_key: -> the key if it is known without the device (a tensor seen before, a host matrix, None for a
+    matrix this binding cannot name), or _PENDING with the read launched (gsr_camera_key_begin) -- _camera_key_end then completes
+    it; the caller's own host work in between hides the round trip."""
+    ent = _CAM_KEYS.get(id(vm))
+    if ent is not None and ent[0]() is vm and ent[1] == vm._version and ent[2] == vm.data_ptr():
+        CAMERA_KEY_STATS["known_tensor"] += 1
+        return ent[3]
+    if vm.dim() != 2 or vm.size(0) != 4 or vm.size(1) != 4 or vm.dtype is not _F32:
+        return None
+    if not vm.is_cuda:
+        return _remember(vm, ("host", vm.detach().contiguous().numpy().tobytes()))   # (its bytes are right here)
+    if vm.device != dev:
+        return None
+    _lib.check(lib.gsr_camera_key_begin(vm.data_ptr(), int(vm.stride(0)), int(vm.stride(1))), "gsr_camera_key_begin")
+    return _PENDING
+
+
+def _camera_key_end(lib, vm):
+    k = ctypes.c_ulonglong(0)
+    _lib.check(lib.gsr_camera_key_end(ctypes.byref(k)), "gsr_camera_key_end")
+    CAMERA_KEY_STATS["read"] += 1
+    return _remember(vm, int(k.value))
+
+
+def _remember(vm, key):
+    i = id(vm)
+
+    def _gone(ref, i=i):
+        e = _CAM_KEYS.get(i)
+        if e is not None and e[0] is ref:
+            del _CAM_KEYS[i]
+    try:
+        _CAM_KEYS[i] = (weakref.ref(vm, _gone), vm._version, vm.data_ptr(), key)
+    except TypeError:
+        pass
+    return key
+
+
+def _camera_key(lib, vm, dev):
+    """The camera's identity for its plan: a hash of the view matrix's sixteen floats.  A tensor object seen before, unchanged
+    since (same version counter, same storage), is not read again; None = not a matrix this binding can name (no plan)."""
+    k = _camera_key_begin(lib, vm, dev)
+    return _camera_key_end(lib, vm) if k is _PENDING else k
 
 
 def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rotations, scale_modifier,
@@ -190,8 +275,11 @@ def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rot
                     torch.zeros(0, dtype=torch.int32, device=dev), torch.empty(0, **byte_opts),
                     torch.empty(0, **byte_opts), torch.empty(0, **byte_opts), 0, 0)
         means3D = _dev_f32(means3D, dev)
-        # (the camera's identity for its plan: where the caller keeps the view matrix -- taken before .contiguous() copies it)
-        vm_key = (viewmatrix.untyped_storage().data_ptr(), viewmatrix.storage_offset()) if plan_key is None else None
+        # (the camera's identity is read from the caller's own tensor -- the .contiguous() copy below is a kernel queued on the
+        # caller's stream, the caller's tensor is final -- and the read is launched first thing: the allocations below hide it)
+        vm_in = viewmatrix
+        want_plan = (_PLANNED if use_plan is None else use_plan) and _FUSED and not debug
+        cam_key = plan_key if (plan_key is not None or not want_plan) else _camera_key_begin(lib, vm_in, dev)
         background, viewmatrix, projmatrix, campos = (_dev_f32(x, dev) for x in (background, viewmatrix, projmatrix, campos))
         colors, opacity, scales, rotations, cov3D_precomp, sh = (
             _dev_f32(x, dev) for x in (colors, opacity, scales, rotations, cov3D_precomp, sh))
@@ -221,15 +309,18 @@ def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rot
                 _ptr(geom), _ptr(img), _ptr(binning), hint, _ptr(scratch), _ptr(out_color), ctypes.byref(R),
                 ctypes.byref(maxc), ctypes.byref(nseg), ctypes.byref(blended))
         plan = None
-        if (_PLANNED if use_plan is None else use_plan) and _FUSED and not debug:
-            # (a camera's differentiable renders and its forward-only ones -- ground-truth / evaluation sweeps, often of another
-            # model -- keep separate plans)
-            key = (dev.index, int(st or 0), W, H, bool(need_backward), plan_key if plan_key is not None else vm_key)
-            plan = _plan_entry(key, lib, int(lib.gsr_plan_bytes(W, H)), byte_opts,
-                               int(_PLAN_LEVEL_ENV) if _PLAN_LEVEL_ENV is not None else (2 if need_backward else 0))
-            if plan.skip > 0:         # (a camera whose views keep outgrowing their plans: left alone for a while)
-                plan.skip -= 1
-                plan = None
+        if cam_key is _PENDING:
+            cam_key = _camera_key_end(lib, vm_in)
+        if want_plan:
+            if cam_key is not None:
+                # (a camera's differentiable renders and its forward-only ones -- ground-truth / evaluation sweeps, often of
+                # another model -- keep separate plans; the field of view is part of the camera)
+                key = (dev.index, int(st or 0), W, H, bool(need_backward), float(tan_fovx), float(tan_fovy), cam_key)
+                plan = _plan_entry(key, lib, int(lib.gsr_plan_bytes(W, H)), byte_opts,
+                                   int(_PLAN_LEVEL_ENV) if _PLAN_LEVEL_ENV is not None else (2 if need_backward else 0))
+                if plan.skip > 0:         # (a camera whose views keep outgrowing their plans: left alone for a while)
+                    plan.skip -= 1
+                    plan = None
         if plan is None:
             _lib.check(lib.gsr_forward_fused(*head, st), "gsr_forward_fused")
         else:

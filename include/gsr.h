@@ -154,6 +154,22 @@ int gsr_forward_planned(int P, int D, int M, int num_channels, int need_backward
                         int* num_rendered, int* max_tile_instances, int* num_segments, int* blended, void* plan_buffer,
                         int* plan_info, int* planned, gsr_stream_t stream);
 
+/* CONTENT key of a camera (ABI 15): a 64-bit hash of the sixteen floats of its view matrix, read from wherever the caller
+ * keeps them (row_stride / col_stride in elements: the reference hands over a TRANSPOSED view,
+ * gaustar_scene/sugar_model.py:1149-1150).  What a caller keys its per-camera plans on when it cannot know the camera any other
+ * way: the reference's caller builds a fresh view-matrix tensor on every render call (sugar_model.py:1149-1163), so neither the
+ * tensor nor its address identifies the camera -- its contents do.  The sixteen floats are fetched by a one-wave kernel on a
+ * library-owned NON-BLOCKING stream into the calling thread's pinned pad and the host waits for that kernel only: the caller's
+ * stream is neither waited for nor delayed (work queued on it keeps running underneath).  The read is therefore not ordered
+ * behind kernels of the caller's stream that may still be writing the matrix; a matrix uploaded from the host (the reference's
+ * case: `.cuda()` synchronises) or resident since an earlier call is final.  A key of half-written contents is harmless -- a
+ * plan is a hint (gsr_forward_planned) -- it merely names no camera. */
+int gsr_camera_key(const float* viewmatrix, long long row_stride, long long col_stride, unsigned long long* key);
+/* The same in two halves, so that the caller's own host work (allocating the view's buffers) hides the ~10 us round trip:
+ * _begin launches the read, _end (same host thread, once per _begin) waits for it and returns the key. */
+int gsr_camera_key_begin(const float* viewmatrix, long long row_stride, long long col_stride);
+int gsr_camera_key_end(unsigned long long* key);
+
 /* Frees what the library keeps for (current device, stream) -- the tile-counter block of gsr_forward_fused -- e.g.
  * before the stream is destroyed.  Fails if a gsr_forward_fused on that stream is in flight on another thread. */
 int gsr_release_stream_state(gsr_stream_t stream);

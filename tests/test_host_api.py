@@ -91,3 +91,28 @@ def test_model_copies_leave_the_gradient_sink_behind():
         assert c._points is not m._points
     assert m.grad_sink is not None
     assert [tuple(p.shape) for p in m.grad_ready_order()][-1] == tuple(m._points.shape)
+
+
+def test_camera_key_of_a_host_matrix_is_its_bytes_and_is_cached_by_tensor_identity():
+    """The plan key is a function of the view matrix's CONTENTS (the reference's caller builds a fresh tensor per render call,
+    gaustar_scene/sugar_model.py:1149-1150): a host matrix is keyed by its bytes without touching the device; the same tensor
+    object is not looked at twice until it is written to; an entry disappears with its tensor."""
+    import gc
+    from gaustar_amd import rasterizer as rz
+    dev = torch.device("cuda", 0)
+    a = torch.eye(4)
+    b = torch.eye(4).t()                      # other object, other strides, same contents
+    c = torch.eye(4) * 2.0
+    s0 = dict(rz.CAMERA_KEY_STATS)
+    ka, kb, kc = (rz._camera_key(None, x, dev) for x in (a, b, c))
+    assert ka == kb and ka != kc and ka[0] == "host"
+    assert rz._camera_key(None, a, dev) == ka
+    assert rz.CAMERA_KEY_STATS["known_tensor"] - s0["known_tensor"] == 1
+    a.mul_(3.0)                               # in place: the version counter moves
+    assert rz._camera_key(None, a, dev) != ka
+    assert rz._camera_key(None, torch.zeros(3, 4), dev) is None and rz._camera_key(None, torch.eye(4).double(), dev) is None
+    n = len(rz._CAM_KEYS)
+    ia = id(a)
+    del a
+    gc.collect()
+    assert ia not in rz._CAM_KEYS and len(rz._CAM_KEYS) == n - 1
