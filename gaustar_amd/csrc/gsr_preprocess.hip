@@ -12,6 +12,7 @@
 // unchanged while num_rendered (library-internal) shrinks.  Per-tile counters are bumped with
 // wave-aggregated atomics (one per distinct tile per wave round instead of one per lane).
 #include "gsr_internal.h"
+#include "gsr_ref_order.h"
 
 namespace gsr {
 
@@ -80,31 +81,24 @@ preprocess_kernel(int P, int D, int M, const float* __restrict__ means3D, const 
         const float view_z = view_depth(p, view);
         // Near-plane cull only (auxiliary.h:154; the NDC side test is dead code there).
         if (view_z > NEAR_Z) {
-            const Vec3 ph = xform43(p, proj);
-            const float pw = 1.0f / (xform4w(p, proj) + 0.0000001f);
-            const float ndc_x = ph.x * pw, ndc_y = ph.y * pw;
-
+            // Projected centre, covariance and conic in the reference build's operation order (gsr_ref_order.h): every
+            // alpha >= 1/255 decision downstream is a function of THESE bits.
             float c3[6];
             if (cov3D_precomp) {
 #pragma unroll
                 for (int k = 0; k < 6; k++) c3[k] = cov3D_precomp[6 * (size_t)idx + k];
             } else {
                 const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
-                cov3d_from_scale_rot(load3(scales, idx), scale_modifier, q, c3);
+                cov3d_ref_order(load3(scales, idx), scale_modifier, q, c3);
             }
-            const Ewa e = ewa_rows(p, view, focal_x, focal_y, tan_fovx, tan_fovy);
-            float v0[3], v1[3], ca, cb, cc;
-            cov2d_from(e, c3, v0, v1, ca, cb, cc);
+            const Projected pr = project_ref_order(p, c3, view, proj, focal_x, focal_y, tan_fovx, tan_fovy, W, H);
+            const float ca = pr.cov_a, cc = pr.cov_c;
 
-            const float det = ca * cc - cb * cb;
+            const float det = pr.det;
             if (det != 0.0f) {
-                const float det_inv = 1.f / det;
-                conic_a = cc * det_inv; conic_b = -cb * det_inv; conic_c = ca * det_inv;
-                const float mid = 0.5f * (ca + cc);
-                const float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
-                const float lambda1 = mid + disc, lambda2 = mid - disc;
-                const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
-                px = ndc2pix(ndc_x, W); py = ndc2pix(ndc_y, H);
+                conic_a = pr.conic_a; conic_b = pr.conic_b; conic_c = pr.conic_c;
+                const float my_radius = radius_ref_order(ca, cc, det);
+                px = pr.px; py = pr.py;
                 const int r = (int)my_radius;
                 // Reference tile rect (C truncation toward zero, clamped to the grid).
                 int rx0 = min(gx, max(0, (int)((px - r) / TILE)));

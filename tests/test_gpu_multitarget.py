@@ -169,3 +169,46 @@ def test_four_channels_equal_the_first_four_of_six():
     parity.check_grad(four["dL_dcolors"][:, 3], six["dL_dcolors"][:, 3], "4ch dL_dcolors[depth]")
     for k in SUMMED:
         parity.check_grad(four[k], six[k], f"4ch {k}")
+
+
+def test_four_channel_packed_columns_precision():
+    """GSR_BWD_PACK4 (gsr_blend_bwd.hip): in the 4-channel backward dL_dpix of channels 2 and 3 enters the moment contraction as
+    hi + rounded rest = 16 mantissa bits, channels 0 and 1 as exact three-way splits.  Measured here, not asserted in a comment:
+    long lists (every unit resumes from a snapshot), dL_dpix of channels 2, 3 LARGE and all four channels POSITIVE -- then a
+    Gaussian's dL_dcolor[ch] = sum_px w dL_dpix[ch] has no cancellation and sum |w d| is the sum itself, so the relative error
+    against the oracle's double sums IS the error relative to the summed magnitudes.  Bound: 2^-16 for the packed columns;
+    the exact columns are the yardstick of everything else (f32 accumulation, atomics order)."""
+    from gaustar_amd import scene
+    rng = np.random.default_rng(2025)
+    gs = scene.random_gaussians(2500, rng, scale_range=(0.03, 0.08), box=((-0.2, 0.2), (-0.2, 0.2), (-0.5, 0.5)))
+    gs.opacities[:] = rng.uniform(0.01, 0.05, (gs.P, 1)).astype(np.float32)
+    cam = scene.look_at_camera((0, 0, -4.0), (0, 0, 0), 80, 48, fovx=0.5, znear=0.01)
+    cols = rng.uniform(0, 1, (gs.P, 4)).astype(np.float32)
+    bg4 = np.array([0.2, 0.7, 0.1, 10.0], np.float32)
+    d4 = rng.uniform(0.5, 1.5, size=(4, cam.H, cam.W)).astype(np.float32)
+    d4[2:] *= 1000.0
+    four = parity.run_hip(_kw(gs, cam, bg4, cols), d4)
+    # the oracle restates the reference's 3-channel path: channels (0, 1, 2), then channel 3 alone as the first of three
+    st_a, g_a = parity.run_oracle(_kw(gs, cam, bg4[:3], np.ascontiguousarray(cols[:, :3])), np.ascontiguousarray(d4[:3]))
+    d_b = np.zeros((3, cam.H, cam.W), np.float32)
+    d_b[0] = d4[3]
+    _st_b, g_b = parity.run_oracle(_kw(gs, cam, np.full(3, bg4[3], np.float32), np.repeat(cols[:, 3:4], 3, 1)), d_b)
+    assert (st_a["ranges"][:, 1] - st_a["ranges"][:, 0]).max() > 1000
+    want = np.concatenate([np.asarray(g_a["dL_dcolors"], np.float64), np.asarray(g_b["dL_dcolors"], np.float64)[:, :1]], 1)
+    got = np.asarray(four["dL_dcolors"], np.float64)
+    rel = {}
+    for ch in range(4):
+        big = np.abs(want[:, ch]) > 1e-3 * np.abs(want[:, ch]).max()
+        assert big.sum() > 500
+        r = np.abs(got[big, ch] - want[big, ch]) / np.abs(want[big, ch])
+        rel[ch] = (float(r.max()), float(np.sqrt((r ** 2).mean())))
+    print("[pack4] relative error of dL_dcolors per channel (max, rms) as powers of two: " +
+          ", ".join(f"ch{ch}: 2^{np.log2(max(m, 1e-30)):.1f} / 2^{np.log2(max(q, 1e-30)):.1f}" for ch, (m, q) in rel.items()))
+    for ch in (0, 1):
+        assert rel[ch][0] <= 2.0 ** -18, rel
+    for ch in (2, 3):
+        assert rel[ch][0] <= 2.0 ** -16, rel
+    # everything that does not pass through the packed columns is as close to the oracle as in the 3-channel path
+    both = {k: np.asarray(g_a[k], np.float64) + np.asarray(g_b[k], np.float64) for k in SUMMED}
+    for k in SUMMED:
+        parity.check_grad(four[k], both[k].reshape(four[k].shape), f"pack4 {k} (sum of the two oracle passes)")
