@@ -29,8 +29,11 @@ print("# two rasterizers took differently: *_inputs = the per-Gaussian projected
 print("# *_eval = identical inputs, the margin lies within the rounding of exp / of the product.")
 if before is not None:
     a, t = share(before, lambda k: k.endswith("_inputs"))
-    print("# BEFORE (commit 4ffd22c: straightforward projection formulas): %d of %d flagged elements (%.0f %%) come from differing input bits"
-          % (a, t, 100.0 * a / max(t, 1)))
+    u, _ = share(before, lambda k: k == "unexplained")
+    print("# BEFORE (commit 4ffd22c: straightforward projection formulas): %d flagged elements, %d attributed to a decision (the classifier walks at"
+          % (t, t - u))
+    print("#   most 600 Gaussians per view); of the attributed ones %d (%.0f %%) come from differing input bits"
+          % (a, 100.0 * a / max(t - u, 1)))
     c, t2 = share(before, lambda k: "T_cut" in k)
     print("#   T-cut decisions: %d of %d (%.1f %%); alpha-cut: the rest" % (c, t2, 100.0 * c / max(t2, 1)))
 a, t = share(after, lambda k: "T_cut" in k)
