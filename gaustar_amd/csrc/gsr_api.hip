@@ -35,6 +35,9 @@ constexpr int PAD_WORDS = 64, PAD_VERDICT = 8;
 // a plan as its builder wrote it, [PI_ARRIVED] the builder's sequence number (written behind the header), [PI_PENDING] the
 // sequence number the host expects there (0: no plan under way)
 constexpr int PI_HEADER = 8, PI_ARRIVED = 16, PI_PENDING = 17;
+// [PI_HALF] which half of the caller's plan buffer holds the plan in use (gsr_internal.h carve_plan), [PI_PENDING_HALF] the half
+// the builder on its way writes
+constexpr int PI_HALF = 5, PI_PENDING_HALF = 6;
 static_assert(PI_PENDING < GSR_PLAN_INFO_INTS, "plan_info block");
 std::atomic<long long> g_wait_ns{0}, g_waits{0};   // gsr_debug_host_wait   // pinned, device-mapped landing pad for the stage-1 totals (written by tile_scan)
 
@@ -101,7 +104,7 @@ int fail_msg(const char* msg)
 
 extern "C" {
 
-int gsr_abi_version(void) { return 15; }
+int gsr_abi_version(void) { return 16; }
 
 const char* gsr_last_error(void) { return g_err.c_str(); }
 
@@ -159,11 +162,19 @@ namespace {
 // counters in its own image buffer (one fill per view) instead of interleaving its preprocess with this call's scatter.
 struct Counters {
     uint32_t* base = nullptr; size_t words = 0; bool clean = false; std::atomic<bool> busy{false};
-    // The block: [PLAN_SYNC_WORDS words of the planned forward (the flag of a view that outgrew its plan)] [tile counters /
-    // cursors of the current image size].  The sync words come FIRST: where they lie must not depend on the image size -- a
-    // flag left behind at a small image's offset would read as a tile count of a larger image's view.
+    // The block: [PLAN_SYNC_WORDS words of the planned forward (the flag of a view that outgrew its plan)] [tile counters of the
+    // exact path] [cursor block 0] [cursor block 1].  The sync words come FIRST: where they lie must not depend on the image
+    // size -- a flag left behind at a small image's offset would read as a tile count of a larger image's view.
+    // The two cursor blocks (round 6; one cursor per tile, PLAN_CURSOR_STRIDE words apart): a planned view claims on one of them
+    // and its forward blend leaves the counts standing for the plan job riding in it, while zeroing the tile's cursor in the
+    // OTHER block (the previous planned view's).  cur_dirty[b] = number of leading tiles of block b that may be non-zero --
+    // host-side bookkeeping like `clean`: a block is only claimed on when it is 0, and a view of T tiles leaves the other
+    // block clean up to T (views of different image sizes on one stream cost a fill now and then, never a wrong count).
+    size_t cnt_words = 0, cur_words = 0;
+    size_t cur_dirty[2] = {0, 0};
     uint32_t* sync() const { return base; }
     uint32_t* cnt() const { return base ? base + PLAN_SYNC_WORDS : nullptr; }
+    uint32_t* cursors(int b) const { return base ? base + PLAN_SYNC_WORDS + cnt_words + (b ? cur_words : 0) : nullptr; }
 };
 std::mutex g_cnt_mu;
 std::map<std::pair<int, hipStream_t>, Counters> g_cnt;
@@ -174,8 +185,9 @@ struct CountersLease {   // releases the block on every way out of gsr_forward_f
 };
 
 // -> a zeroed block of at least `words` uint32 for (current device, st), marked in flight and busy; nullptr: use the image buffer
-Counters* acquire_counters(hipStream_t st, size_t words)
+Counters* acquire_counters(hipStream_t st, size_t cnt_words, size_t cur_words)
 {
+    const size_t words = PLAN_SYNC_WORDS + cnt_words + 2 * cur_words;
     const char* e_own = getenv("GSR_OWN_COUNTERS");   // read per call: tools/ab_env.py flips it inside one process
     const bool off = e_own && e_own[0] == '0';
     int dev = 0;
@@ -188,16 +200,23 @@ Counters* acquire_counters(hipStream_t st, size_t words)
         c = &g_cnt[std::make_pair(dev, st)];   // std::map: the address stays valid
         if (c->busy.exchange(true, std::memory_order_acquire)) return nullptr;   // another thread's call owns it right now
     }
-    if (c->words < words) {
+    if (c->cnt_words < cnt_words || c->cur_words < cur_words) {
+        // (a larger image: the regions move, so everything is laid out and filled anew)
         if (c->base) { (void)hipStreamSynchronize(st); (void)hipFree(c->base); }
         c->base = nullptr; c->words = 0; c->clean = false;
-        if (hipMalloc((void**)&c->base, 4 * words) != hipSuccess) {
-            (void)hipGetLastError(); c->base = nullptr; c->busy.store(false); return nullptr;
+        const size_t cw = std::max(cnt_words, c->cnt_words), uw = std::max(cur_words, c->cur_words);
+        const size_t all = PLAN_SYNC_WORDS + cw + 2 * uw;
+        if (hipMalloc((void**)&c->base, 4 * all) != hipSuccess) {
+            (void)hipGetLastError(); c->base = nullptr; c->cnt_words = c->cur_words = 0; c->busy.store(false); return nullptr;
         }
-        c->words = words;
+        c->words = all; c->cnt_words = cw; c->cur_words = uw;
     }
-    if (!c->clean && hipMemsetAsync(c->base, 0, 4 * c->words, st) != hipSuccess) {
-        (void)hipGetLastError(); c->busy.store(false); return nullptr;
+    (void)words;
+    if (!c->clean) {
+        if (hipMemsetAsync(c->base, 0, 4 * c->words, st) != hipSuccess) {
+            (void)hipGetLastError(); c->busy.store(false); return nullptr;
+        }
+        c->cur_dirty[0] = c->cur_dirty[1] = 0;
     }
     c->clean = false;   // in flight
     return c;
@@ -391,7 +410,7 @@ int forward_planned_attempt(int P, int D, int M, int C, int need_backward, const
                             const float* projmatrix, const float* campos, int W, int H, float tan_fovx, float tan_fovy,
                             const float* background, int* radii, void* geom_buffer, void* image_buffer, void* binning_buffer,
                             void* grad_scratch, float* out_color, void* plan_buffer, const int* plan_info, uint32_t* cursors,
-                            uint32_t* sync_words, hipStream_t st, int* fit)
+                            uint32_t* cursors_other, uint32_t* sync_words, hipStream_t st, int* fit, const PlanJob* job)
 {
     *fit = 0;
     g_err.clear();
@@ -406,10 +425,10 @@ int forward_planned_attempt(int P, int D, int M, int C, int need_backward, const
     ImageState im = carve_image(image_buffer, W, H);
     GeomState g = carve_geom(geom_buffer, P);
     BinState b = carve_bin(binning_buffer, plan_info[1], plan_info[2], C);
-    const PlanState pl = carve_plan(plan_buffer, W, H);
+    const PlanState pl = carve_plan(plan_buffer, W, H, plan_info[PI_HALF] & 1);
     PlanRun run;
     run.ranges = pl.ranges; run.seg_off = pl.seg_off; run.order = pl.order;
-    run.cursor = cursors; run.sync = sync_words;
+    run.cursor = cursors; run.cursor_other = cursors_other; run.sync = sync_words;
     run.keys = b.keys; run.unit_info = b.unit_info; run.im_ranges = im.ranges; run.im_seg_off = im.seg_off;
     run.host_pad = g_pinned + PAD_VERDICT; run.host_seq = next_seq(); run.token = next_view_token();
     (void)t;
@@ -424,7 +443,7 @@ int forward_planned_attempt(int P, int D, int M, int C, int need_backward, const
         Scope sc(ST_BLEND_FWD, st);
         launch_blend_fwd_planned(C, W, H, background, feats, g, im, b, out_color, need_backward != 0,
                                  need_backward ? grad_scratch : nullptr,
-                                 need_backward && grad_scratch ? gsr_grad_scratch_bytes(P) : 0, run, st);
+                                 need_backward && grad_scratch ? gsr_grad_scratch_bytes(P) : 0, run, st, job);
     }
     GSR_CHECK_LAUNCH("blend_fwd_kernel");
     bool seen = false;
@@ -456,11 +475,11 @@ int forward_fused_impl(int P, int D, int M, int num_channels, int need_backward,
     hipStream_t st = (hipStream_t)stream;
     const bool sane = W > 0 && H > 0 && (long long)tiles_of(W > 0 ? W : 1, H > 0 ? H : 1).T <= 256ll * 1024 && image_buffer && P > 0;
     const size_t cnt_words = sane ? 2 * (size_t)shard_stride(tiles_of(W, H).T) * NSHARD : 0;
-    // (the planned forward reads the same block as one cursor per tile, PLAN_CURSOR_STRIDE words apart)
-    const size_t blk_words = sane ? std::max(cnt_words, (size_t)tiles_of(W, H).T * PLAN_CURSOR_STRIDE) : 0;
-    Counters* own = sane ? acquire_counters(st, blk_words + PLAN_SYNC_WORDS) : nullptr;
-    CountersLease lease{own};
     const bool keeps_plan = plan_buffer != nullptr && plan_info != nullptr && sane;
+    // (a caller that keeps plans: two blocks of one cursor per tile, PLAN_CURSOR_STRIDE words apart, behind the exact counters)
+    const size_t cur_words = keeps_plan ? (size_t)tiles_of(W, H).T * PLAN_CURSOR_STRIDE : 0;
+    Counters* own = sane ? acquire_counters(st, cnt_words, cur_words) : nullptr;
+    CountersLease lease{own};
     if (keeps_plan && plan_info[PI_PENDING] != 0) {
         // The plan an earlier view of this camera left behind: its header arrives in the caller's pinned words [PI_HEADER ..]
         // some tens of microseconds into that view's forward blend; nobody waited for it then.  Normally it is long there.
@@ -472,25 +491,69 @@ int forward_fused_impl(int P, int D, int M, int num_channels, int need_backward,
         // (a header that is not this image's -- another size's, or not a header at all -- is no plan)
         if (seen && (h[1] != (uint32_t)tiles_of(W, H).T || h[3] != h[2] >> 6 || (h[2] & 63u) != 0u)) seen = false;
         plan_info[0] = seen ? (h[0] == 1u ? 1 : -1) : 0;
-        if (seen) { plan_info[1] = (int)h[2]; plan_info[2] = (int)h[3]; plan_info[3] = (int)h[4]; }
+        if (seen) {
+            plan_info[1] = (int)h[2]; plan_info[2] = (int)h[3]; plan_info[3] = (int)h[4];
+            plan_info[PI_HALF] = plan_info[PI_PENDING_HALF] & 1;
+        }
         plan_info[PI_PENDING] = 0;
     }
+    // The plan workgroup of THIS view (exact or planned) writes the half of the plan buffer that is not in use; its header
+    // lands in the caller's pinned words and is adopted by the camera's next call (above).
+    const auto plan_job = [&](PlanJob& job) {
+        const Tiles t = tiles_of(W, H);
+        const int half = (plan_info[PI_HALF] & 1) ^ 1;
+        const PlanState pl = carve_plan(plan_buffer, W, H, half);
+        job.enabled = 1u; job.T = t.T; job.gx = t.gx; job.gy = t.gy;
+        job.header = pl.header; job.ranges = pl.ranges; job.seg_off = pl.seg_off; job.order = pl.order;
+        job.split_from_word = split_from();
+        job.level = (uint32_t)(plan_info[4] < 0 ? 0 : plan_info[4] > 3 ? 3 : plan_info[4]);
+        job.host_pad = reinterpret_cast<uint32_t*>(plan_info) + PI_HEADER;
+        // (the sequence number belongs to the PLAN, not to the calling thread: a plan_info block may be used from several
+        // host threads, and a thread-local counter that happens to equal the block's stale ARRIVED word would make the next
+        // call adopt the OLD header while the device holds the new plan)
+        job.host_seq = (uint32_t)plan_info[PI_ARRIVED] + 1u;
+        if (job.host_seq == 0u) job.host_seq = 1u;
+        job.cursor = nullptr;
+        // (GSR_PLAN_DIAG builds: the plan being replaced, if the buffer has held one)
+        job.prev_ranges = plan_info[1] > 0 ? carve_plan(plan_buffer, W, H, half ^ 1).ranges : nullptr;
+        return half;
+    };
+    const char* e_rp = getenv("GSR_REPLAN");   // (0: round 5's behaviour; read per call: tools/ab_env.py flips it inside one process)
+    const bool replan = !(e_rp && e_rp[0] == '0');
     if (keeps_plan && own && plan_info[0] == 1 && plan_info[1] > 0 && plan_info[2] > 0 && binning_buffer &&
         num_rendered && max_tile_instances && num_segments && (split_from() & 0x80000000u) == 0u &&
         gsr_binning_bytes_mt(plan_info[1], plan_info[2], num_channels) <= binning_capacity) {
         int fit = 0;
+        // the cursor block this view claims on must be all zero; the other one is handed back zeroed by this view's forward blend
+        const size_t Tn = (size_t)tiles_of(W, H).T;
+        int blk = own->cur_dirty[0] == 0 ? 0 : own->cur_dirty[1] == 0 ? 1 : -1;
+        if (blk < 0) {
+            blk = 0;
+            GSR_CHECK(hipMemsetAsync(own->cursors(0), 0, 4 * own->cur_dirty[0] * PLAN_CURSOR_STRIDE, st));
+            own->cur_dirty[0] = 0;
+        }
+        PlanJob pjob{};
+        int pjob_half = 0;
+        if (replan) {
+            pjob_half = plan_job(pjob);
+            pjob.cursor = own->cursors(blk);
+        }
         const int rc = forward_planned_attempt(P, D, M, num_channels, need_backward, means3D, shs, colors_precomp, opacities, scales,
                                                scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, W, H,
                                                tan_fovx, tan_fovy, background, radii, geom_buffer, image_buffer, binning_buffer,
-                                               grad_scratch, out_color, plan_buffer, plan_info, own->cnt(), own->sync(), st, &fit);
-        if (rc != 0) return rc;
+                                               grad_scratch, out_color, plan_buffer, plan_info, own->cursors(blk),
+                                               own->cursors(blk ^ 1), own->sync(), st, &fit, replan ? &pjob : nullptr);
+        if (rc != 0) return rc;   // (own stays marked dirty: everything is re-filled on its next use)
+        own->cur_dirty[blk] = Tn;
+        if (own->cur_dirty[blk ^ 1] <= Tn) own->cur_dirty[blk ^ 1] = 0;
         if (fit) {
+            if (replan) { plan_info[PI_PENDING] = (int)pjob.host_seq; plan_info[PI_PENDING_HALF] = pjob_half; }
             *num_rendered = plan_info[1];
             *num_segments = plan_info[2];
             *max_tile_instances = plan_info[3];
             *blended = 1;
             *planned = planned ? 1 : 0;
-            own->clean = true;   // every tile's workgroup of the forward blend hands its cursor back zeroed
+            own->clean = true;   // (the exact path's counters were not touched; the cursor blocks are accounted for above)
             return 0;
         }
         // the view outgrew its plan: the exact path below renders it (the queued blend leaves the block clean) and re-plans, with
@@ -514,22 +577,12 @@ int forward_fused_impl(int P, int D, int M, int num_channels, int need_backward,
     // when stage 2 is left to the caller.
     PlanJob job{};
     bool job_rides = false;
+    int job_half = 0;
     if (keeps_plan && plan_info[0] == 0) {
         if ((uint32_t)*max_tile_instances + 16u > PLAN_MAX_LIST) {
             plan_info[0] = -1;
         } else if (*num_rendered > 0) {
-            const Tiles t = tiles_of(W, H);
-            const PlanState pl = carve_plan(plan_buffer, W, H);
-            job.enabled = 1u; job.T = t.T; job.gx = t.gx; job.gy = t.gy;
-            job.header = pl.header; job.ranges = pl.ranges; job.seg_off = pl.seg_off; job.order = pl.order;
-            job.split_from_word = split_from();
-            job.level = (uint32_t)(plan_info[4] < 0 ? 0 : plan_info[4] > 3 ? 3 : plan_info[4]);
-            job.host_pad = reinterpret_cast<uint32_t*>(plan_info) + PI_HEADER;
-            // (the sequence number belongs to the PLAN, not to the calling thread: a plan_info block may be used from several
-            // host threads, and a thread-local counter that happens to equal the block's stale ARRIVED word would make the next
-            // call adopt the OLD header while the device holds the new plan)
-            job.host_seq = (uint32_t)plan_info[PI_ARRIVED] + 1u;
-            if (job.host_seq == 0u) job.host_seq = 1u;
+            job_half = plan_job(job);
         }
     }
     if (gsr_binning_bytes_mt(*num_rendered, *num_segments, num_channels) > binning_capacity || (*num_rendered > 0 && !binning_buffer)) {
@@ -553,7 +606,7 @@ int forward_fused_impl(int P, int D, int M, int num_channels, int need_backward,
         if (own) own->clean = true;   // the forward blend zeroes every tile's counters and cursors
     }
     if (rc2 != 0) return rc2;
-    if (job_rides) plan_info[PI_PENDING] = (int)job.host_seq;
+    if (job_rides) { plan_info[PI_PENDING] = (int)job.host_seq; plan_info[PI_PENDING_HALF] = job_half; }
     return 0;
 }
 }  // namespace

@@ -81,7 +81,8 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     const bool is_part = MODE == 1 || (MODE == 2 && blockIdx.x < part_grid);
     // (MODE 0, exact path, the caller keeps a plan for this camera: workgroup 0 -- dispatched first -- builds the plan of the
     // camera's next view instead of blending a tile, gsr_plan.h; the tiles follow from workgroup 1 on)
-    const bool has_job = MODE == 0 && !PLANNED && job.enabled != 0u;
+    // (PLANNED, round 6: the same workgroup in a planned view, from the view's cursors -- it also reports the view's verdict)
+    const bool has_job = MODE == 0 && job.enabled != 0u;
     const uint32_t tile_block = MODE == 2 ? blockIdx.x - part_grid : blockIdx.x - (has_job ? 1u : 0u);
     // Side job: the backward's accumulation table (48 B per Gaussian) has to be zero before blend_bwd runs.  When the
     // caller hands it over at forward time every workgroup clears its slice here instead of a separate fill (a 5 us blit
@@ -105,9 +106,19 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     float4* const gb = ga + CH;
     RecTail<C>* const gc = reinterpret_cast<RecTail<C>*>(smem + 32 * CH);
     uint32_t (*mk)[NH][64] = reinterpret_cast<uint32_t(*)[NH][64]>(smem + REC_BYTES);
-    if constexpr (MODE == 0 && !PLANNED) {
+    if constexpr (MODE == 0) {
         static_assert(LDS_BYTES >= 4 * PLAN_LDS_T, "the plan job stages the tile counts in the kernel's LDS");
         if (has_job && blockIdx.x == 0) {
+            if constexpr (PLANNED) {
+                // the verdict on the view, for the host (which waits for nothing else): first thing the first workgroup does.
+                // A view that outgrew its plan leaves no plan behind: the exact view the host renders instead does.
+                const bool misfit = plan.sync[9 * PLAN_SYNC_STRIDE] == plan.token;
+                if (threadIdx.x == 0) {
+                    plan.host_pad[0] = misfit ? 2u : 1u;
+                    __hip_atomic_store(&plan.host_pad[1], plan.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                if (misfit) return;
+            }
             plan_build_block<256>(job, ranges, order, reinterpret_cast<uint32_t*>(smem));
             return;
         }
@@ -140,16 +151,18 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     const uint32_t list0 = __builtin_amdgcn_readfirstlane(rg.x);
     uint32_t n_ = rg.y - rg.x;
     if constexpr (PLANNED) {
-        uint32_t* const cur = plan.cursor + (size_t)tile * PLAN_CURSOR_STRIDE;
         const bool misfit = plan.sync[9 * PLAN_SYNC_STRIDE] == plan.token;
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             // the verdict on the view, for the host (which waits for nothing else): first thing the first workgroup does
+            // (a launch that carries the plan job: that workgroup, above)
             plan.host_pad[0] = misfit ? 2u : 1u;
             __hip_atomic_store(&plan.host_pad[1], plan.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        n_ = *cur;
-        __syncthreads();                          // every wave has read the count
-        if (threadIdx.x == 0 && n_ != 0u) *cur = 0u;
+        // The count stays where it is -- nobody writes this view's cursors during the launch, so the plan job reads all of them
+        // whenever it gets to them --; what is handed back zeroed is the tile's cursor in the OTHER block, on which the view before
+        // this one claimed (its launches have retired) and the next one will.
+        n_ = plan.cursor[(size_t)tile * PLAN_CURSOR_STRIDE];
+        if (threadIdx.x == 0) plan.cursor_other[(size_t)tile * PLAN_CURSOR_STRIDE] = 0u;
         if (misfit) return;
     }
     const uint32_t n = __builtin_amdgcn_readfirstlane(n_);
@@ -787,23 +800,26 @@ static void launch_fwd_c(int W, int H, int R, int U, uint32_t max_count, const f
 
 template <int C>
 static void launch_fwd_planned_c(int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
-                                 float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, PlanRun plan, hipStream_t st)
+                                 float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, PlanRun plan, hipStream_t st,
+                                 const PlanJob* job)
 {
     const Tiles t = tiles_of(W, H);
     static const int pad = getenv("GSR_FWD_LDS_PAD") ? atoi(getenv("GSR_FWD_LDS_PAD")) : 0;
-    blend_fwd_kernel<C, FWD_CHUNK, 0, true><<<(unsigned)t.T, 256, pad, st>>>(
+    const bool rides = job != nullptr && job->enabled != 0u;
+    blend_fwd_kernel<C, FWD_CHUNK, 0, true><<<(unsigned)t.T + (rides ? 1u : 0u), 256, pad, st>>>(
         W, H, t.gx, plan.ranges, plan.order, b.point_list, b.keys, g.g0, g.g1, feats, bg, out_color, im.final_T, im.n_contrib,
         plan.seg_off, b.masks, b.snap, b.rec_a, b.rec_b, static_cast<RecTail<C>*>(b.rec_c), b.part_list, im.totals, b.part_fin,
         b.part_last, b.part_ticket, 0u, false, 0xffffffffu, keep_masks, static_cast<float4*>(zero_ptr), (uint32_t)(zero_bytes / 16),
-        nullptr, 0u, g_trace, plan, PlanJob{});
+        nullptr, 0u, g_trace, plan, rides ? *job : PlanJob{});
 }
 
 void launch_blend_fwd_planned(int C, int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
-                              float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, PlanRun plan, hipStream_t st)
+                              float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, PlanRun plan, hipStream_t st,
+                              const PlanJob* job)
 {
-    if (C == 6) launch_fwd_planned_c<6>(W, H, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, plan, st);
-    else if (C == 4) launch_fwd_planned_c<4>(W, H, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, plan, st);
-    else launch_fwd_planned_c<3>(W, H, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, plan, st);
+    if (C == 6) launch_fwd_planned_c<6>(W, H, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, plan, st, job);
+    else if (C == 4) launch_fwd_planned_c<4>(W, H, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, plan, st, job);
+    else launch_fwd_planned_c<3>(W, H, bg, feats, g, im, b, out_color, keep_masks, zero_ptr, zero_bytes, plan, st, job);
 }
 
 // job (may be null): the plan of the camera's next view, built by one extra workgroup of a MODE 0 launch -- *job_rides says

@@ -249,15 +249,24 @@ struct PlanState {
     uint32_t* order;         // [T] launch order of the tiles (the source view's: longest lists first)
     size_t bytes;
 };
-inline PlanState carve_plan(void* base, int W, int H)
+// The caller's plan buffer holds TWO plans (round 6): the one the current view is binned by and the one that view's forward blend
+// builds for the camera's next view (gsr_plan.h) -- a planned view re-plans from its own tile counts, so a plan is never older
+// than one visit.  half = 0 / 1; bytes = the whole buffer (gsr_plan_bytes).
+inline PlanState carve_plan(void* base, int W, int H, int half = 0)
 {
-    PlanState s; size_t o = 0; char* b = (char*)base;
+    PlanState s; size_t o = 0;
     const size_t T = (size_t)tiles_of(W, H).T;
-    s.header = (uint32_t*)(b + o); o = align_up(o + 4 * PLAN_HDR);
-    s.ranges = (uint2*)(b + o); o = align_up(o + 8 * T);
-    s.seg_off = (uint32_t*)(b + o); o = align_up(o + 4 * (T + 1));
-    s.order = (uint32_t*)(b + o); o = align_up(o + 4 * T);
-    s.bytes = o + 256;
+    const size_t o_hdr = o; o = align_up(o + 4 * PLAN_HDR);
+    const size_t o_rng = o; o = align_up(o + 8 * T);
+    const size_t o_seg = o; o = align_up(o + 4 * (T + 1));
+    const size_t o_ord = o; o = align_up(o + 4 * T);
+    const size_t half_bytes = o + 256;
+    char* b = (char*)base + (half ? half_bytes : 0);
+    s.header = (uint32_t*)(b + o_hdr);
+    s.ranges = (uint2*)(b + o_rng);
+    s.seg_off = (uint32_t*)(b + o_seg);
+    s.order = (uint32_t*)(b + o_ord);
+    s.bytes = 2 * half_bytes;
     return s;
 }
 // Words the planned forward keeps in the library's per-stream block behind the tile counters: the flag word (at
@@ -269,6 +278,8 @@ struct PlanRun {             // what the planned kernels get besides the exact p
     const uint32_t* seg_off;
     const uint32_t* order;
     uint32_t* cursor;        // [T * PLAN_CURSOR_STRIDE] entries claimed per tile (library block, zero before preprocess; 1 MB at 1080p)
+    uint32_t* cursor_other;  // the library's SECOND cursor block: the view before this one claimed there; this view's forward blend
+                             //   hands it back zeroed tile by tile and leaves its own counts standing (the plan job reads them)
     uint32_t* sync;          // [PLAN_SYNC_WORDS] tickets + flag (library block)
     uint64_t* keys;          // the binning buffer's key array (capacity R_cap)
     uint4* unit_info;        // the binning buffer's unit table (capacity U_cap): written by the forward blend, tile by tile
@@ -284,7 +295,8 @@ void launch_preprocess_planned(int P, int D, int M, const float* means3D, const 
                                int H, float tan_fovx, float tan_fovy, int* radii, GeomState g, ImageState im, PlanRun plan,
                                hipStream_t st);
 void launch_blend_fwd_planned(int C, int W, int H, const float* bg, const float* feats, GeomState g, ImageState im, BinState b,
-                              float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, PlanRun plan, hipStream_t st);
+                              float* out_color, bool keep_masks, void* zero_ptr, size_t zero_bytes, PlanRun plan, hipStream_t st,
+                              const struct PlanJob* job = nullptr);
 
 // producers of rasterizer inputs (gsr_producers.hip)
 void launch_adam(long long n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float step_size,

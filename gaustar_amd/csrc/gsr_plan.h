@@ -1,7 +1,10 @@
 // gsr_plan.h -- the PLAN of a camera's next view (gsr_internal.h "planned binning"), built by ONE workgroup from the exact
 // ranges and launch order of a view rendered the exact way: plan_build_block.  It rides in the exact path's forward blend as
 // one extra workgroup of that launch (gsr_blend_fwd.hip, dispatched first): no launch of its own, no second stream, nothing on
-// the view's critical path -- a camera's first view costs what it cost before plans existed.  Also home of the wave64 DPP scans
+// the view's critical path -- a camera's first view costs what it cost before plans existed.  Round 6: a PLANNED view carries the
+// same workgroup (counts = the cursors its preprocess claimed on, which its forward blend leaves standing; launch order = the
+// plan's own), writing the OTHER half of the caller's plan buffer: a camera's plan is always one visit old, however the Gaussians
+// move between its visits.  Also home of the wave64 DPP scans
 // the tile-offset scan (gsr_binning.hip) shares with it.
 #pragma once
 #include "gsr_internal.h"
@@ -59,6 +62,9 @@ struct PlanJob {
     uint32_t split_from_word, level;
     uint32_t* host_pad;      // pinned, device-mapped: header words [0..7], then host_seq at [8]
     uint32_t host_seq;
+    const uint32_t* cursor;  // (a PLANNED view re-plans, round 6) the view's tile counts = its cursors, PLAN_CURSOR_STRIDE words apart,
+                             // left standing by the forward blend; nullptr: an exact view, counts from its ranges
+    const uint2* prev_ranges;   // (GSR_PLAN_DIAG builds) the plan this one replaces, nullptr: none
 };
 
 // Capacity of a tile's bucket: its count plus an eighth (at least 16 entries; times 2^level), rounded UP to whole units of 64 --
@@ -67,15 +73,28 @@ struct PlanJob {
 // was not (the surface's silhouette moves by a tile now and then), none otherwise.
 // `level` (0 .. 3) doubles the slack per step: raised for a camera whose views outgrow their plans (the Gaussians move between
 // its visits), see gsr_forward_planned.
-__device__ __forceinline__ uint32_t plan_capacity(uint32_t n, bool near_occupied, uint32_t level)
+// Round 6: the slack also looks at the tile's eight NEIGHBOURS.  What outgrows a bucket when the Gaussians move is not the
+// interior of the surface (counts change by per cent) but the handful of tiles on its silhouette: a tile that held ten entries
+// next to one that holds five hundred holds three hundred once the silhouette has moved a few pixels its way (GSR_PLAN_DIAG:
+// 2-23 tiles per misfit, count / capacity up to 8).  A shift by d pixels mixes a tile's count with its neighbour's in the ratio
+// d / 16, so the slack gets an eighth (times 2^level) of what the LARGEST neighbour has more -- nothing for an interior tile,
+// a few units for a silhouette tile, and only there.
+#ifndef GSR_PLAN_NB_SLACK
+#define GSR_PLAN_NB_SLACK 1
+#endif
+__device__ __forceinline__ uint32_t plan_capacity(uint32_t n, bool near_occupied, uint32_t level, uint32_t nb_max = 0u)
 {
-    if (n == 0u) return near_occupied ? 64u : 0u;
-    const uint32_t want = n + (max(16u, n >> 3) << level);
+    const uint32_t more = GSR_PLAN_NB_SLACK && nb_max > n ? (nb_max - n) >> 3 : 0u;
+    if (n == 0u) {
+        if (!near_occupied) return 0u;
+        return min((64u + (more << level) + 63u) & ~63u, PLAN_MAX_LIST);
+    }
+    const uint32_t want = n + ((max(16u, n >> 3) + more) << level);
     return min((want + 63u) & ~63u, PLAN_MAX_LIST);
 }
 
 // One workgroup of NT threads (a multiple of 64, at most 1 024).  `im_ranges` / `order_in`: the view's exact ranges and launch
-// order (written by tile_scan_kernel before this launch).  cnt_lds: PLAN_LDS_T words of LDS (the counts are staged there for
+// order (written by tile_scan_kernel before this launch); a planned view: job.cursor and the current plan's order.  cnt_lds: PLAN_LDS_T words of LDS (the counts are staged there for
 // images of up to 8 192 tiles -- 1920 x 1088 --: as global loads the neighbour look-ups of the empty tiles made this single
 // workgroup a chain of dependent trips to memory).
 // valid = every list of the source view leaves that slack below 2 048 and the view would not split its long lists
@@ -99,32 +118,50 @@ __device__ __forceinline__ void plan_build_block(const PlanJob& job, const uint2
     __builtin_amdgcn_s_setprio(3);
     const bool staged = T <= PLAN_LDS_T;
     uint32_t vmax = 0, ne = 0, sum_n = 0;
-    for (int t = tid; t < T; t += NT) {
+    const uint32_t* const cursor = job.cursor;
+    const auto count_in = [&](int t) -> uint32_t {
+        if (cursor != nullptr) return cursor[(size_t)t * PLAN_CURSOR_STRIDE];
         const uint2 r = im_ranges[t];
-        const uint32_t n = r.y - r.x;
-        if (staged) cnt_lds[t] = min(n, 0xffffu);       // low half: the count (clipped: above 2 048 the plan is invalid anyway)
-        sum_n += n;
-        vmax = max(vmax, n);
-        ne += n != 0u ? 1u : 0u;
+        return r.y - r.x;
+    };
+    // (eight counts per thread in flight at a time: a planned view's counts are its cursors, one per 128-byte line -- as one
+    // load per loop trip the 32 trips of a 1080p view were 32 dependent trips to memory, most of the blend's span)
+    constexpr int BATCH = 8;
+    for (int t0 = tid; t0 < T; t0 += NT * BATCH) {
+        uint32_t c[BATCH];
+#pragma unroll
+        for (int q = 0; q < BATCH; q++) {
+            const int t = t0 + q * NT;
+            c[q] = t < T ? count_in(t) : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < BATCH; q++) {
+            const int t = t0 + q * NT;
+            if (t >= T) break;
+            const uint32_t n = c[q];
+            if (staged) cnt_lds[t] = min(n, 0xffffu);       // low half: the count (clipped: above 2 048 the plan is invalid anyway)
+            sum_n += n;
+            vmax = max(vmax, n);
+            ne += n != 0u ? 1u : 0u;
+        }
     }
     if (staged) __syncthreads();
     const auto count_of = [&](int t) -> uint32_t {
         if (staged) return cnt_lds[t] & 0xffffu;
-        const uint2 r = im_ranges[t];
-        return r.y - r.x;
+        return count_in(t);
     };
     const auto cap_of = [&](int t) -> uint32_t {
         const uint32_t n = count_of(t);
-        bool near = false;
-        if (n == 0u) {
+        uint32_t nb_max = 0u;
+        if (n == 0u || (GSR_PLAN_NB_SLACK && staged)) {   // (unstaged -- above 8 192 tiles --: empty tiles only, as global look-ups)
             const int ty = t / gx, tx = t - ty * gx;
             for (int dy = -1; dy <= 1; dy++)
                 for (int dx = -1; dx <= 1; dx++) {
                     const int x = tx + dx, y = ty + dy;
-                    if (x >= 0 && x < gx && y >= 0 && y < gy && (dx | dy) != 0) near = near || count_of(y * gx + x) != 0u;
+                    if (x >= 0 && x < gx && y >= 0 && y < gy && (dx | dy) != 0) nb_max = max(nb_max, count_of(y * gx + x));
                 }
         }
-        return plan_capacity(n, near, level);
+        return plan_capacity(n, nb_max != 0u, level, nb_max);
     };
     const int rows = (T + 63) >> 6, rpw = (rows + NW - 1) / NW;      // rows of 64 tiles; rows per wave
     const int r0 = wave * rpw, r1 = min(rows, r0 + rpw);
@@ -161,8 +198,8 @@ __device__ __forceinline__ void plan_build_block(const PlanJob& job, const uint2
         const uint32_t incl = wave_incl_scan(cap, lane);
 #ifdef GSR_PLAN_DIAG   // (devtool build) how this view's counts sit in the plan being replaced: host pad words 10 .. 13 =
                        // tiles over a zero bucket, tiles over a non-zero bucket, entries over, the worst count / capacity in 1/64
-        if (in && job.host_pad) {
-            const uint32_t old = job.ranges[t].y, n = count_of(t);
+        if (in && job.host_pad && job.prev_ranges) {
+            const uint32_t old = job.prev_ranges[t].y, n = count_of(t);
             if (n > old) {
                 atomicAdd(&job.host_pad[old == 0u ? 10 : 11], 1u);
                 atomicAdd(&job.host_pad[12], n - old);

@@ -119,11 +119,15 @@ _FUSED = os.environ.get("GSR_FUSED_FORWARD", "1") != "0"   # 0: always stage 1, 
 # the exact path, never a wrong pixel.
 _PLANNED = os.environ.get("GSR_PLANNED", "1") != "0"
 _PLAN_SLOTS = int(os.environ.get("GSR_PLAN_SLOTS", "2048"))
-# Slack level a camera's first plan is made with (include/gsr.h: capacity = count + max(16, count / 8) << level).  Differentiable
-# renders belong to a training loop whose Gaussians move between a camera's visits: level 2 (count + max(64, count / 2)) -- in the
-# windowed refinement loop (tools/bench_window.py, 3 visits per camera and frame) levels 0 / 1 / 2 / 3 leave 400 / 317 / 133 / 42
-# views outgrowing their plans, and on a static scene the larger buckets cost the backward 1.5 us of empty units.  Forward-only
-# renders (sweeps of a fixed model): level 0.  A view that outgrows its plan raises its camera's level by one.
+# Slack level a camera's first plan is made with (include/gsr.h: capacity = count + (max(16, count / 8) + an eighth of what the
+# largest neighbouring tile holds more) << level).  Differentiable renders belong to a training loop whose Gaussians move between
+# a camera's visits: level 1.  Measured in the windowed refinement loop (tools/replan_ab.sh: tools/bench_window.py, 3 visits per
+# camera and frame, 1 280 views with a plan to try): round 5's per-tile slack left 397 / 316 / 138 views outgrowing their plans at
+# levels 0 / 1 / 2 -- always a handful of SILHOUETTE tiles, whose counts jump by factors when the surface's edge moves a few pixels
+# their way; with the neighbour term (round 6) 104 / 5 / 2, and with every planned view re-planning from its own counts (a plan is
+# one visit old) 29 / 1 / 1.  On a static scene the larger buckets cost the backward empty work items: 0.2283 / 0.2300 / 0.2315 ms
+# per view at levels 0 / 1 / 2.  Forward-only renders (sweeps of a fixed model): level 0.  A view that outgrows its plan raises
+# its camera's level by one.
 _PLAN_LEVEL_ENV = os.environ.get("GSR_PLAN_LEVEL")
 _PLANS: "collections.OrderedDict" = collections.OrderedDict()   # key -> _Plan
 _PLAN_RETRY = 32   # a camera whose view could not be planned (a list too long for the in-kernel sort) is asked again after this many views
@@ -317,7 +321,7 @@ def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rot
                 # another model -- keep separate plans; the field of view is part of the camera)
                 key = (dev.index, int(st or 0), W, H, bool(need_backward), float(tan_fovx), float(tan_fovy), cam_key)
                 plan = _plan_entry(key, lib, int(lib.gsr_plan_bytes(W, H)), byte_opts,
-                                   int(_PLAN_LEVEL_ENV) if _PLAN_LEVEL_ENV is not None else (2 if need_backward else 0))
+                                   int(_PLAN_LEVEL_ENV) if _PLAN_LEVEL_ENV is not None else (1 if need_backward else 0))
                 if plan.skip > 0:         # (a camera whose views keep outgrowing their plans: left alone for a while)
                     plan.skip -= 1
                     plan = None
@@ -354,6 +358,10 @@ def rasterize_gaussians_native(background, means3D, colors, opacity, scales, rot
         need = int(lib.gsr_binning_bytes_mt(R.value, nseg.value, C))
         if plan is not None and plan.info[0] == 1:   # room for the plan's capacities, so that the next view of this camera can use it
             need = max(need, int(lib.gsr_binning_bytes_mt(plan.info[1], plan.info[2], C)))
+            # (and for the plan this view's forward blend is building for that next view, if its header has landed already:
+            # info[8..15] = the header, [16] / [17] = the builder's sequence number arrived / awaited, include/gsr.h)
+            if plan.info[17] != 0 and plan.info[16] == plan.info[17] and plan.info[8] == 1 and 0 < plan.info[10] < (1 << 30):
+                need = max(need, int(lib.gsr_binning_bytes_mt(plan.info[10], plan.info[11], C)))
         # The hint only moves in steps of 32 MB and only comes down when a view needs less than a QUARTER of it (then it
         # halves): every change of the size is a new block for the caching allocator -- a hipMalloc of a few hundred MB costs
         # tens of milliseconds -- and a hint that shrank by 10 % whenever a view needed less than half of it made a rig of

@@ -120,13 +120,16 @@ int gsr_forward_fused(int P, int D, int M, int num_channels, int need_backward, 
 
 /* PLANNED forward (ABI 13): gsr_forward_fused for a camera that is rendered again and again (a training rig: every camera
  * once per epoch, gaustar_trainers/refine.py:534-548).  The caller keeps, per camera, a device buffer of gsr_plan_bytes(W, H)
- * bytes and a plan_info block from gsr_plan_info_new() = {state, R_cap, U_cap, max_cap, slack level, ...} (all zero at first).  A call with plan_info[0] == 0
+ * bytes (ABI 16: room for TWO plans -- the one in use and the one being built for the next view) and a plan_info block from gsr_plan_info_new() = {state, R_cap, U_cap, max_cap, slack level, ...} (all zero at first).  A call with plan_info[0] == 0
  * renders the exact way (as gsr_forward_fused) and leaves a PLAN behind (built by one extra workgroup of that view's forward
  * blend; nobody waits for it: the next call with this plan_info adopts it): per tile the place and capacity of its bucket of
- * instances (this view's count + 1/8, at least 16 -- times 2^level --, rounded up to whole 64-entry units), the tile's first unit and a launch
- * order; plan_info is updated.  A call with plan_info[0] == 1 bins BY THE PLAN: preprocess claims bucket slots and writes the
+ * instances (this view's count + (1/8 of it, at least 16, + 1/8 of what the largest of the tile's eight neighbours holds more -- the
+ * tiles that outgrow a bucket are the few on the surface's silhouette, whose counts jump when it moves a few pixels their way) times
+ * 2^level, rounded up to whole 64-entry units), the tile's first unit and a launch order; plan_info is updated.  A call with plan_info[0] == 1 bins BY THE PLAN: preprocess claims bucket slots and writes the
  * sort keys itself, the forward blend is queued right behind it, and the host only waits for preprocess's verdict -- no
- * tile-offset scan, no scatter pass and no host round trip between the stages (what replaces
+ * tile-offset scan, no scatter pass and no host round trip between the stages; (ABI 16) such a view also RE-PLANS: the same extra
+ * workgroup rides in its forward blend and builds the next view's plan from this view's own tile counts into the other half of the
+ * plan buffer, so a camera's plan is never older than one visit however the Gaussians move between its visits (what replaces
  * DGR/cuda_rasterizer/rasterizer_impl.cu:277-317 -- InclusiveSum, the num_rendered read-back, duplicateWithKeys,
  * identifyTileRanges -- for such a view).  *planned = 1 then, and the sizes the backward needs are the plan's CAPACITIES:
  * *num_rendered = R_cap, *num_segments = U_cap (binning_capacity must hold gsr_binning_bytes_mt(R_cap, U_cap, num_channels),
@@ -142,7 +145,7 @@ size_t gsr_plan_bytes(int W, int H);
 /* A plan_info block: GSR_PLAN_INFO_INTS ints of pinned, device-mapped host memory, zeroed (the builder of a plan writes its
  * header there from the device; ordinary host memory will not do).  [0] state: 0 no plan, 1 valid, -1 this camera's views cannot
  * be planned (reset to 0 to have the next view try again); [1..3] R_cap, U_cap, max_cap of a valid plan; [4] slack level
- * (0..3); the rest belongs to the library.  Free with gsr_plan_info_free once no call using it is in flight. */
+ * (0..3); the rest belongs to the library ([5] / [6]: the half of the plan buffer in use / being written, [8..17] the arriving header).  Free with gsr_plan_info_free once no call using it is in flight. */
 int* gsr_plan_info_new(void);
 void gsr_plan_info_free(int* plan_info);
 int gsr_forward_planned(int P, int D, int M, int num_channels, int need_backward, const float* means3D, const float* shs,

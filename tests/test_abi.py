@@ -54,7 +54,7 @@ def test_ctypes_table_matches_header():
 def test_library_loads_and_exports_every_symbol(hip_lib):
     for name in _declared():
         assert hasattr(hip_lib, name), name
-    assert hip_lib.gsr_abi_version() == 15
+    assert hip_lib.gsr_abi_version() == 16
 
 
 def test_scratch_sizes(hip_lib):

@@ -15,7 +15,7 @@ dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 gdist.bind_to_local_cpus(0)
 gs, cams, bg, params, means2D, rasters, dpix = bench.build_workload(dev, 0)
-step = lambda s: bench.one_step(s, 0, 1, params, means2D, rasters, dpix, None)
+step = lambda s: bench.one_step(s, 0, 1, params, means2D, rasters, dpix)
 for v in (a, b):
     setenv(v)
     for s in range(160): step(s)

@@ -7,7 +7,7 @@ import bench
 
 dev = torch.device("cuda:0")
 gs, cams, bg, params, means2D, rasters, dpix = bench.build_workload(dev, 0)
-step = lambda s: bench.one_step(s, 0, 1, params, means2D, rasters, dpix, None)
+step = lambda s: bench.one_step(s, 0, 1, params, means2D, rasters, dpix)
 for s in range(10): step(s)
 out = {}
 for n in (50, 200):

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 dev = torch.device("cuda:0")
 gs, cams, bg, params, means2D, rasters, dpix = bench.build_workload(dev, 0)
-step = lambda s: bench.one_step(s, 0, 1, params, means2D, rasters, dpix, None)
+step = lambda s: bench.one_step(s, 0, 1, params, means2D, rasters, dpix)
 for s in range(20): step(s)
 out = []
 for r in range(12):
