@@ -192,7 +192,13 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
 #ifndef GSR_FWD_SORT_STAGGER
 #define GSR_FWD_SORT_STAGGER 1
 #endif
+#ifndef GSR_FWD_TAIL_PRIO
+#define GSR_FWD_TAIL_PRIO 0
+#endif
     const auto prio_by_length = [&]() {
+        // (experiment, round 6: a tile of the launch's SECOND generation -- it starts when a first-generation slot frees up, ~50 us
+        // in, and the launch ends with these, tools/fwd_phases.py -- at the highest priority from start to end)
+        if (GSR_FWD_TAIL_PRIO && tile_block >= (uint32_t)GSR_FWD_TAIL_PRIO && n > 0u) { __builtin_amdgcn_s_setprio(3); return; }
         if (n > 1024u) __builtin_amdgcn_s_setprio(3);
         else if (n > 704u) __builtin_amdgcn_s_setprio(2);
         else if (n > 448u) __builtin_amdgcn_s_setprio(1);
@@ -201,7 +207,8 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
     // (the launch order's first thousand tiles are its longest and all sort at once, four per CU, on one LDS pipe; distinct
     // priorities for the sort by the tile's quarter of the launch order let a CU's sorters finish one after the other and move
     // on to phases with another resource mix: blend_fwd 86.5 -> 85.0 us)
-    switch ((tile_block >> 8) & 3u) {
+    if (GSR_FWD_TAIL_PRIO && tile_block >= (uint32_t)GSR_FWD_TAIL_PRIO && n > 0u) __builtin_amdgcn_s_setprio(3);
+    else switch ((tile_block >> 8) & 3u) {
         case 0: __builtin_amdgcn_s_setprio(3); break;
         case 1: __builtin_amdgcn_s_setprio(2); break;
         case 2: __builtin_amdgcn_s_setprio(1); break;

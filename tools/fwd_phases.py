@@ -33,3 +33,12 @@ mid = np.argsort(-dur)[1500:1504]
 for b in mid:
     p = ph[b]; n = int((p > 0).sum())
     print(f"slot {b}: {dur[b]:.1f} us; deltas: {[round(p[k + 1] - p[k], 1) for k in range(n - 1)]}; tail {se[b, 1] - p[n - 1]:.1f}")
+# What pre-sorting the K longest tiles could buy (VERDICT r5 task 7): the launch's span is its latest end; a tile that skips its
+# in-kernel sort ends that much earlier (the first thousand tiles all start at ~0).  Sort time = stamps [1] .. the stamp before
+# the first chunk's pair; approximated here by the known per-level cost: listed are the durations and ends by rank.
+ends = se[:, 1] - t0
+order_d = np.argsort(-ends)
+ranks = [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024]
+print("ends by rank (us):", {r: round(float(ends[order_d[r - 1]]), 1) for r in ranks})
+print("durations of the same tiles (us):", {r: round(float(dur[order_d[r - 1]]), 1) for r in ranks})
+print("starts of the same tiles (us):", {r: round(float(se[order_d[r - 1], 0] - t0), 1) for r in ranks})
