@@ -193,11 +193,13 @@ blend_fwd_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const u
 #define GSR_FWD_SORT_STAGGER 1
 #endif
 #ifndef GSR_FWD_TAIL_PRIO
-#define GSR_FWD_TAIL_PRIO 0
+#define GSR_FWD_TAIL_PRIO 704
 #endif
     const auto prio_by_length = [&]() {
-        // (experiment, round 6: a tile of the launch's SECOND generation -- it starts when a first-generation slot frees up, ~50 us
-        // in, and the launch ends with these, tools/fwd_phases.py -- at the highest priority from start to end)
+        // (round 6: the launch does not end with its longest tiles -- those finish at 70-73 us of 77-81 -- but with tiles of its
+        // SECOND generation: 20-30 us tiles that start when a first-generation slot frees up, ~50 us in, tools/fwd_phases.py
+        // "ends by rank".  From launch position 704 on a non-empty tile runs at the highest priority from start to end:
+        // - 1 us per view, in-process A/B at 512 / 640 / 768 / 896 / 1 024: - 0.6 / - 1.4 / - 1.3 / - 0.5 / - 0.2 us; 0 = off)
         if (GSR_FWD_TAIL_PRIO && tile_block >= (uint32_t)GSR_FWD_TAIL_PRIO && n > 0u) { __builtin_amdgcn_s_setprio(3); return; }
         if (n > 1024u) __builtin_amdgcn_s_setprio(3);
         else if (n > 704u) __builtin_amdgcn_s_setprio(2);
