@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libgsr_hip.so")
-SOURCES = ["gsr_api.hip", "gsr_preprocess.hip", "gsr_binning.hip", "gsr_blend_fwd.hip", "gsr_blend_bwd.hip", "gsr_blend_bwd_uniform.hip",
+SOURCES = ["gsr_api.hip", "gsr_preprocess.hip", "gsr_binning.hip", "gsr_blend_fwd.hip", "gsr_blend_bwd.hip",
            "gsr_geom_bwd.hip", "gsr_loss.hip", "gsr_producers.hip", "gsr_optim.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-slp-vectorize: left on, clang packs neighbouring scalar f32 operations of the per-pair loops into v_pk_*_f32 and

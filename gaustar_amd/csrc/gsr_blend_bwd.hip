@@ -1,5 +1,5 @@
-// gsr_blend_bwd.hip -- backward alpha compositing: per-Gaussian sums of the per-(pixel, Gaussian) terms.  Three and four channels
-// (the reference's render and GauSTAR's RGB + depth render); six channels: gsr_blend_bwd_uniform.hip.
+// gsr_blend_bwd.hip -- backward alpha compositing: per-Gaussian sums of the per-(pixel, Gaussian) terms, for three channels (the
+// reference's NUM_CHANNELS), four (GauSTAR's RGB + depth-as-colour renders in one pass) and six (two targets sharing geometry).
 //
 // Per-pair arithmetic is the reference's renderCUDA backward (DGR/cuda_rasterizer/backward.cu:399-557; SURVEY.md section 9 item
 // 10): back-to-front replay, T recovered by division, accum_rec recurrence, background term with T_final / (1 - alpha), the 0.99
@@ -16,7 +16,7 @@
 //    "positions this pixel replays".  The unit's 64 records arrive as three contiguous rows the forward left in list order (lane i
 //    takes position 63 - i, together with every other load of the unit's head); no geometric test is repeated here;
 //  * (round 6; rounds 1-5: one kept instance on the block's 64 pixels per trip -- 10 of 64 lanes live, 28 dependent trips per
-//    wave, w and r parked in an LDS table and contracted over the pixels on the matrix pipe: gsr_blend_bwd_uniform.hip)
+//    wave, w and r parked in an LDS table and contracted over the pixels on the matrix pipe: tools/variants/gsr_blend_bwd_uniform.hip)
 //    the wave walks the block 4x4 SUB-BLOCK by sub-block, and a trip evaluates FOUR consecutive kept instances of that sub-block
 //    on its 16 pixels:
 //
@@ -51,25 +51,37 @@ namespace gsr {
 #ifndef GSR_QUAD_WAVES
 #define GSR_QUAD_WAVES 7
 #endif
+#ifndef GSR_QUAD_WAVES6
+#define GSR_QUAD_WAVES6 5   // six channels: 96 registers
+#endif
 #ifndef GSR_QUAD_EXP
 #define GSR_QUAD_EXP 0      // (instruction accounting builds: 1 = no trips, 2 = no trips and no per-chunk work)
 #endif
 
 #ifndef GSR_QUAD_Q
-#define GSR_QUAD_Q 32     // (16: +4 us -- twice the per-chunk set-up and more half-empty trips)
+#define GSR_QUAD_Q 32     // (16: +4 us at three channels -- twice the per-chunk set-up and more half-empty trips)
 #endif
-namespace quad {
-constexpr int Q = GSR_QUAD_Q;               // kept instances per chunk (a sub-block's list of a chunk: at most Q / 4 trips)
-static_assert(Q == 16 || Q == 32, "whole trips");
-constexpr int REC_B = 48;                   // bytes per record: {x, y, a', b'} {c', opacity, position, gaussian} {c0, c1, c2, -}
-constexpr int REC = 0;                      // Q + 1 records (the last: a null record for the lanes past a list's end)
-constexpr int MOM = REC + (Q + 1) * REC_B;  // Q + 1 moment records of 12 floats (nine in use)
-constexpr int STG = MOM + (Q + 1) * 48;     // 64 pixels x 32 B: {T, A, last position, T_final bg.dL_dpix} {dL_dpix 0..2, -}
-constexpr int LST = STG + 64 * 32;          // 4 sub-blocks x 4 instances-of-a-trip x Q / 4 trips: slot of the (4 t + j)-th kept instance
-constexpr int ORW = LST + 4 * Q + 16;       // 4 x u64: the sub-blocks' kept words (16 bytes of "null record" behind the lists: look-ahead reads)
-constexpr int TOTAL = ORW + 32;
-static_assert(STG % 16 == 0 && MOM % 16 == 0 && LST % 16 == 0 && ORW % 16 == 0, "16-byte accesses");
-}   // namespace quad
+#ifndef GSR_QUAD_Q6
+#define GSR_QUAD_Q6 32    // six channels: 64-byte records and 48 bytes of pixel state = 7.5 KB, five waves per SIMD -- which its 96
+                          // registers allow anyway (in-process A/B, step time against the uniform loop's 0.291 ms: six waves at 80 registers
+                          // with ten spilled + 20 us, five waves with chunks of 16 - 8 us, five waves with chunks of 32 - 18 us)
+#endif
+// LDS layout of one wave, per channel count
+template <int C> struct QuadLds {
+    static constexpr int Q = C == 6 ? GSR_QUAD_Q6 : GSR_QUAD_Q;   // kept instances per chunk (a sub-block's list of a chunk: at most Q / 4 trips)
+    static_assert(Q == 16 || Q == 32, "whole trips");
+    static constexpr int REC_B = C <= 4 ? 48 : 64;   // record: {x, y, a', b'} {c', opacity, position, gaussian} {c0 .. c3} [{c4, c5, -, -}]
+    static constexpr int MOM_B = C <= 4 ? 48 : 64;   // moment record: 6 + C sums, then pad words (the lanes without a sum add into those)
+    static constexpr int STG_B = C <= 4 ? 32 : 48;   // pixel state: {T, A, last position, T_final bg.dL_dpix} {dL_dpix 0..3} [{4, 5, -, -}]
+    static constexpr int REC = 0;                    // Q + 1 records (the last: a null record for the lanes past a list's end)
+    static constexpr int MOM = REC + (Q + 1) * REC_B;
+    static constexpr int STG = MOM + (Q + 1) * MOM_B;
+    static constexpr int LST = STG + 64 * STG_B;     // 4 sub-blocks x 4 instances-of-a-trip x Q / 4 trips: record offset / 16 of the (4 t + j)-th kept instance
+    static constexpr int ORW = LST + 4 * Q + 16;     // 4 x u64: the sub-blocks' kept words (16 bytes of "null record" behind the lists: look-ahead reads)
+    static constexpr int TOTAL = ORW + 32;
+    static_assert(STG % 16 == 0 && MOM % 16 == 0 && LST % 16 == 0 && ORW % 16 == 0, "16-byte accesses");
+    static_assert((REC_B / 16) * Q < 256 && 6 + C + 2 <= MOM_B / 4, "list bytes; two pad words per moment record");
+};
 
 typedef uint32_t u32x2q __attribute__((ext_vector_type(2)));
 
@@ -93,15 +105,19 @@ __device__ __forceinline__ float fold_quad(float v)
 }
 
 template <int C>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_QUAD_WAVES, 8)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C == 6 ? GSR_QUAD_WAVES6 : GSR_QUAD_WAVES, 8)))
 blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, const float4* __restrict__ snap,
                       const uint2* __restrict__ masks, const uint32_t* __restrict__ point_list, const float4* __restrict__ rec_a,
                       const float4* __restrict__ rec_b, const RecTail<C>* __restrict__ rec_c, const float* __restrict__ bg,
                       const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-                      const float* __restrict__ dL_dpix, float* __restrict__ grad_acc)
+                      const float* __restrict__ dL_dpix, float* __restrict__ grad_acc, uint64_t* __restrict__ trace,
+                      const uint32_t* __restrict__ order)
 {
-    using namespace quad;
-    static_assert(C == 3 || C == 4, "moments 6 + C and two pad words must fit the 12-float record; the record tail holds four colours");
+    using L = QuadLds<C>;
+    const uint64_t t_start = trace ? wall_clock64() : 0;
+    constexpr int Q = L::Q, REC_B = L::REC_B, MOM_B = L::MOM_B, STG_B = L::STG_B, REC = L::REC, MOM = L::MOM, STG = L::STG, LST = L::LST,
+                  ORW = L::ORW, TOTAL = L::TOTAL, RV = REC_B / 16;
+    static_assert(C == 3 || C == 4 || C == 6, "channel counts of the C ABI");
     constexpr int SV = snap_vecs(C), NM = 6 + C;
     __shared__ __attribute__((aligned(16))) unsigned char lds[TOTAL];
     // ---- the product's head, verbatim (gsr_blend_bwd.hip): XCD-aware unit map, one scalar load for the tile, every vector load
@@ -113,6 +129,8 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
     uint32_t wave_sel = slot_id & 3u;
     const uint32_t full = (n_units >> 6) << 6;
     if (blockIdx.x >= full * 4u) { unit = blockIdx.x >> 2; wave_sel = blockIdx.x & 3u; }
+    // (a launch ORDER of the units, when there is one: position in the dispatch sequence -> unit; gsr_debug_set_bwd_order)
+    if (order != nullptr) unit = order[unit];
     const uint4 info = unit_info[unit];
     const int tile = (int)info.x;
     const uint32_t list0 = info.y;
@@ -225,9 +243,10 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
 
     // ---- the pixels' start state, parked per pixel lane; the trips read it in their own lane order
     {
-        float4* st = reinterpret_cast<float4*>(lds + STG) + 2 * lane;
+        float4* st = reinterpret_cast<float4*>(lds + STG + STG_B * lane);
         st[0] = make_float4(T, accd, __uint_as_float((uint32_t)my_lim), tf_bg);
-        st[1] = make_float4(dp[0], dp[1], dp[2], C > 3 ? dp[C - 1] : 0.f);
+        st[1] = make_float4(dp[0], dp[1], dp[2], C > 3 ? dp[3 < C ? 3 : 0] : 0.f);
+        if constexpr (C == 6) st[2] = make_float4(dp[4 < C ? 4 : 0], dp[5 < C ? 5 : 0], 0.f, 0.f);
     }
     // trip lane order: lane = 16 rho + 4 j + kappa
     const int rho = lane >> 4, jj = (lane >> 2) & 3, kap = lane & 3;
@@ -235,6 +254,7 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
     // (the other lanes add garbage to the three pad words of their instance's moment record: no branch around the store)
     const int mom_idx = kap == 0 ? ((rho & 1) * 2 + (rho >> 1))          // rows {0, 2, 1, 3} of fold A: moments 0, 2, 1, 3
                       : kap == 1 ? 4 + ((rho & 1) * 2 + (rho >> 1))      // fold B: moments 4, 6, 5, 7
+                      : (kap == 2 && C == 6) ? 8 + ((rho & 1) * 2 + (rho >> 1))   // fold C of six channels: rows m8, m10, m9, m11
                       : (kap == 2 && rho == 0) ? 8
                       : (kap == 2 && rho == 2 && C == 4) ? 9       // fold C of four channels: rows m8, m8, m9, m9
                                                          : NM + (lane & 1);
@@ -245,7 +265,9 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
     // (the unit's records arrived with the head's loads and feed the FIRST chunk; a later chunk fetches its lanes' records
     // again -- they are in L2 -- instead of keeping ten registers alive across the trips)
     float4 ra_ = ra, rb_ = rb;
-    float rc_ = rc.c[0], rc2_ = C > 3 ? rc.c[C - 3] : 0.f;
+    float rcc[4];   // colour channels 2 .. 5 (0 where the render has fewer)
+#pragma unroll
+    for (int i = 0; i < 4; i++) rcc[i] = i < C - 2 ? rc.c[i < C - 2 ? i : 0] : 0.f;
     uint32_t gid_ = gid;
     for (int q0 = 0; q0 < (GSR_QUAD_EXP == 2 ? 0 : cnt_all); q0 += Q) {
         const int cnt = min(cnt_all - q0, Q);
@@ -256,8 +278,8 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
             ra_ = at32(rec_a + list0 + s0, kl2 * 16u);
             rb_ = at32(rec_b + list0 + s0, kl2 * 16u);
             const RecTail<C> rc2 = at32(rec_c + list0 + s0, kl2 * (uint32_t)sizeof(RecTail<C>));
-            rc_ = rc2.c[0];
-            if constexpr (C > 3) rc2_ = rc2.c[C - 3];
+#pragma unroll
+            for (int i = 0; i < C - 2; i++) rcc[i] = rc2.c[i];
             gid_ = at32(point_list + list0 + s0, kl2 * 4u);
         }
         // records of the chunk, a null record behind them, moment records cleared, lists reset to "the null record"
@@ -265,16 +287,18 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
             float4* r = reinterpret_cast<float4*>(lds + REC + slot * REC_B);
             r[0] = make_float4(ra_.x, ra_.y, ra_.z, ra_.w);
             r[1] = make_float4(rb_.x, rb_.y, __uint_as_float((uint32_t)(s0 + 63 - lane)), __uint_as_float(gid_));
-            r[2] = make_float4(rb_.z, rb_.w, rc_, rc2_);
+            r[2] = make_float4(rb_.z, rb_.w, rcc[0], rcc[1]);
+            if constexpr (C == 6) r[3] = make_float4(rcc[2], rcc[3], 0.f, 0.f);
         }
         if (lane == 0) {
             float4* r = reinterpret_cast<float4*>(lds + REC + Q * REC_B);
             r[0] = make_float4(0.f, 0.f, 0.f, 0.f);
             r[1] = make_float4(0.f, 0.f, __uint_as_float(0x7fffffffu), 0.f);
             r[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (C == 6) r[3] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        for (int i = lane; i < (Q + 1) * 3; i += 64) reinterpret_cast<float4*>(lds + MOM)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lane < Q + 4) reinterpret_cast<uint32_t*>(lds + LST)[lane] = 0x01010101u * (uint32_t)(3 * Q);   // (bytes: 3 x slot = record offset / 16)
+        for (int i = lane; i < (Q + 1) * (MOM_B / 16); i += 64) reinterpret_cast<float4*>(lds + MOM)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < Q + 4) reinterpret_cast<uint32_t*>(lds + LST)[lane] = 0x01010101u * (uint32_t)(RV * Q);   // (bytes: record offset / 16)
         __builtin_amdgcn_wave_barrier();
         int cnt_s[4];
 #pragma unroll
@@ -284,7 +308,7 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
             cnt_s[s] = __popcll(ms);
             if (in_s) {
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ms, 0u));
-                lds[LST + s * Q + (rank & 3) * (Q / 4) + (rank >> 2)] = (unsigned char)(3 * slot);
+                lds[LST + s * Q + (rank & 3) * (Q / 4) + (rank >> 2)] = (unsigned char)(RV * slot);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -295,22 +319,23 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
             // this lane's pixel of sub-block s and its state
             const int bx = s & 1, by = s >> 1;
             const int pl = 8 * (4 * by + rho) + 4 * bx + kap;
-            const float4* st = reinterpret_cast<const float4*>(lds + STG) + 2 * pl;
+            const float4* st = reinterpret_cast<const float4*>(lds + STG + STG_B * pl);
             const float4 s_a = st[0], s_b = st[1];
+            float d4 = 0.f, d5 = 0.f;
+            if constexpr (C == 6) { const float4 s_c = st[2]; d4 = s_c.x; d5 = s_c.y; }
             float Tp = s_a.x, Ap = s_a.y;
             const int lim = (int)__float_as_uint(s_a.z);
             const float tfbg = s_a.w;
             const float d0 = s_b.x, d1 = s_b.y, d2 = s_b.z, d3 = s_b.w;
             const float pxf = (float)(sx + 4 * bx + kap), pyf = (float)(sy + 4 * by + rho);
             const int ntrip = (ns + 3) >> 2;
-            SlotRegs<3> rec;
+            SlotRegs<RV> rec;
             // this lane's list of the sub-block: byte t = slot of its instance in trip t, read two trips ahead
             const uint32_t lst_ad = lds0 + LST + (uint32_t)(s * Q + jj * (Q / 4));
             uint32_t idx_nxt;
             asm volatile("ds_read_u8 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(idx_nxt) : "v"(lst_ad) : "memory");
-            static_assert(REC_B == 48 && 3 * Q < 256, "list bytes are record offsets in units of 16 bytes");
             uint32_t ad = (idx_nxt << 4) + (lds0 + REC);
-            lds_request<3, 0>(rec, ad);
+            lds_request<RV, 0>(rec, ad);
             asm volatile("ds_read_u8 %0, %1 offset:1" : "=v"(idx_nxt) : "v"(lst_ad) : "memory");
 #pragma unroll 1
             for (int t = 0; t < ntrip; t++) {
@@ -334,9 +359,10 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
                 kd = __builtin_fmaf(rec.v[2][1], d1, kd);
                 kd = __builtin_fmaf(rec.v[2][2], d2, kd);
                 if constexpr (C > 3) kd = __builtin_fmaf(rec.v[2][3], d3, kd);
+                if constexpr (C == 6) { kd = __builtin_fmaf(rec.v[RV - 1][0], d4, kd); kd = __builtin_fmaf(rec.v[RV - 1][1], d5, kd); }
                 // (the next trip's records; past the list's end the bytes name the null record)
                 ad = (idx_nxt << 4) + (lds0 + REC);
-                lds_request<3, 0>(rec, ad);   // (everything the trip needs of the old records has been computed above)
+                lds_request<RV, 0>(rec, ad);   // (everything the trip needs of the old records has been computed above)
                 asm volatile("ds_read_u8 %0, %1" : "=v"(idx_nxt) : "v"(lst_ad + (uint32_t)(t + 2)) : "memory");
                 const float ae = live ? alpha : 0.0f;
                 float A = 1.0f - ae;                            // the pair's map on accum_rec . dL_dpix: A' = A x + B
@@ -378,13 +404,16 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
                 const float f01 = fold32(r, p12[0]), f23 = fold32(p12[1], p34[0]), f45 = fold32(p34[1], p5), f67 = fold32(p67[0], p67[1]),
                             f88 = fold32(p8, p8b);
                 float f88b = f88;
-                asm volatile("" : "+v"(f88b));
+                if constexpr (C == 6) f88b = fold32(w * d4, w * d5);   // (six channels: rows m10 | m11)
+                else asm volatile("" : "+v"(f88b));
                 const float gA = fold16(f01, f23);               // rows: m0, m2, m1, m3
                 const float gB = fold16(f45, f67);               // rows: m4, m6, m5, m7
-                const float gC = fold16(f88, f88b);              // rows: m8 everywhere (four channels: m8, m8, m9, m9)
+                const float gC = fold16(f88, f88b);              // rows: m8 everywhere (four channels: m8, m8, m9, m9; six: m8, m10, m9, m11)
                 const float hA = fold_quad(gA), hB = fold_quad(gB), hC = fold_quad(gC);
                 const float val = kap == 0 ? hA : kap == 1 ? hB : hC;
-                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(mom_old) : : "memory");   // (three record reads and the list byte were issued behind it)
+                // (the record reads and the list byte were issued behind it)
+                if constexpr (RV == 3) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(mom_old) : : "memory");
+                else asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(mom_old) : : "memory");
                 const float mom_new = mom_old + val;
                 asm volatile("ds_write_b32 %0, %1" : : "v"(mom_ad), "v"(mom_new) : "memory");
             }
@@ -393,7 +422,7 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
             // (every request has been waited for: nothing stays in flight into a dead register)
             // the pixels' state behind this sub-block's instances of the chunk (lane j = 3 holds it)
             if (jj == 3) {
-                float2* stw = reinterpret_cast<float2*>(lds + STG + 32 * pl);
+                float2* stw = reinterpret_cast<float2*>(lds + STG + STG_B * pl);
                 *stw = make_float2(Tp, Ap);
             }
             __builtin_amdgcn_wave_barrier();
@@ -404,9 +433,13 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
         for (int idx = lane; idx < cnt * NM; idx += 64) {
             const int e = idx / NM, v = idx - e * NM;
             const size_t g = __float_as_uint(reinterpret_cast<const float*>(lds + REC + e * REC_B)[7]);
-            atomic_add_f32(grad_acc + g * GRAD_RS + v, reinterpret_cast<const float*>(lds + MOM + e * 48)[v]);
+            atomic_add_f32(grad_acc + g * GRAD_RS + v, reinterpret_cast<const float*>(lds + MOM + e * MOM_B)[v]);
         }
         __builtin_amdgcn_wave_barrier();
+    }
+    if (trace && lane == 0) {   // (devtools: a unit's start and the end of its last wave -- monotone clock, max via atomic)
+        if (wave == 0) trace[2 * unit] = t_start;
+        atomicMax((unsigned long long*)&trace[2 * unit + 1], (unsigned long long)wall_clock64());
     }
 }
 
@@ -416,9 +449,7 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
 bool launch_blend_bwd_variant(int C, int W, int H, int U, const float* bg, ImageState im, BinState b, const float* dL_dpix, float* grad_acc,
                               hipStream_t st);
 #endif
-void launch_blend_bwd_uniform(int C, int W, int H, int U, const float* bg, ImageState im, BinState b, const float* dL_dpix,
-                              float* grad_acc, hipStream_t st);
-extern const uint32_t* g_bwd_order;   // (experiments: gsr_debug_set_bwd_order; gsr_blend_bwd_uniform.hip)
+const uint32_t* g_bwd_order = nullptr;   // (experiments: gsr_debug_set_bwd_order)
 
 void launch_blend_bwd(int C, int W, int H, int U, const float* bg, const float* feats, GeomState g, ImageState im,
                       BinState b, const float* dL_dpix, float* grad_acc, hipStream_t st)
@@ -428,21 +459,18 @@ void launch_blend_bwd(int C, int W, int H, int U, const float* bg, const float* 
 #ifdef GSR_BWD_VARIANT
     if (launch_blend_bwd_variant(C, W, H, U, bg, im, b, dL_dpix, grad_acc, st)) return;
 #endif
-    // six channels, the devtools' per-wave traces and launch-order experiments, and GSR_BWD_UNIFORM=1 (read per call: tools/ab_env.py
-    // flips it inside one process) take the uniform pair loop
-    const char* e_u = getenv("GSR_BWD_UNIFORM");
-    if ((C != 3 && C != 4) || g_trace != nullptr || g_bwd_order != nullptr || (e_u && e_u[0] == '1')) {
-        launch_blend_bwd_uniform(C, W, H, U, bg, im, b, dL_dpix, grad_acc, st);
-        return;
-    }
     static const int pad = getenv("GSR_BWD_LDS_PAD") ? atoi(getenv("GSR_BWD_LDS_PAD")) : 0;   // residency knob (tuning only)
     const Tiles t = tiles_of(W, H);
+    uint64_t* tr = g_trace ? g_trace + 2 * (size_t)t.T : nullptr;
     if (C == 3)
         blend_bwd_kernel<3><<<4 * U, 64, pad, st>>>(W, H, t.gx, b.unit_info, b.snap, b.masks, b.point_list, b.rec_a, b.rec_b,
-                                                    static_cast<const RecTail<3>*>(b.rec_c), bg, im.final_T, im.n_contrib, dL_dpix, grad_acc);
-    else
+                                                    static_cast<const RecTail<3>*>(b.rec_c), bg, im.final_T, im.n_contrib, dL_dpix, grad_acc, tr, g_bwd_order);
+    else if (C == 4)
         blend_bwd_kernel<4><<<4 * U, 64, pad, st>>>(W, H, t.gx, b.unit_info, b.snap, b.masks, b.point_list, b.rec_a, b.rec_b,
-                                                    static_cast<const RecTail<4>*>(b.rec_c), bg, im.final_T, im.n_contrib, dL_dpix, grad_acc);
+                                                    static_cast<const RecTail<4>*>(b.rec_c), bg, im.final_T, im.n_contrib, dL_dpix, grad_acc, tr, g_bwd_order);
+    else
+        blend_bwd_kernel<6><<<4 * U, 64, pad, st>>>(W, H, t.gx, b.unit_info, b.snap, b.masks, b.point_list, b.rec_a, b.rec_b,
+                                                    static_cast<const RecTail<6>*>(b.rec_c), bg, im.final_T, im.n_contrib, dL_dpix, grad_acc, tr, g_bwd_order);
 }
 
 }  // namespace gsr

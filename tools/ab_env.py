@@ -15,6 +15,14 @@ dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 gdist.bind_to_local_cpus(0)
 gs, cams, bg, params, means2D, rasters, dpix = bench.build_workload(dev, 0)
+if os.environ.get("AB_CHANNELS", "3") != "3":   # (AB_CHANNELS=4 / 6: the multi-target renders)
+    from gaustar_amd import GaussianRasterizer
+    C = int(os.environ["AB_CHANNELS"])
+    g = torch.Generator(device=dev).manual_seed(11)
+    params["colors"] = torch.rand(params["colors"].shape[0], C, device=dev, generator=g).requires_grad_(True)
+    dpix = torch.randn(C, dpix.shape[1], dpix.shape[2], device=dev, generator=g)
+    bgc = torch.rand(C, device=dev, generator=g)
+    rasters = [GaussianRasterizer(r.raster_settings._replace(bg=bgc)) for r in rasters]
 step = lambda s: bench.one_step(s, 0, 1, params, means2D, rasters, dpix)
 for v in (a, b):
     setenv(v)

@@ -1,6 +1,11 @@
-// gsr_blend_bwd_uniform.hip -- backward alpha compositing, the UNIFORM PAIR LOOP: rounds 1-5's product kernel for every channel
-// count; since round 6 the product's kernel for SIX channels only (three and four channels: gsr_blend_bwd.hip, four kept instances
-// per trip), and what GSR_BWD_UNIFORM=1 / the wave-trace devtools / the launch-order experiments select for all of them.
+// gsr_blend_bwd_uniform.hip -- backward alpha compositing, the UNIFORM PAIR LOOP: the product's backward blend of rounds 1-5 (one
+// kept instance on the block's 64 pixels per trip, w and r parked in an LDS table, the moments contracted over the pixels on the
+// matrix pipe).  Round 6 replaced it by four kept instances per trip (gaustar_amd/csrc/gsr_blend_bwd.hip; profiles/
+// r06_bwd_quad_counters.txt); this file is the record and the A/B partner, built only by
+//     python -m gaustar_amd.build --variant uniform --with tools/variants/gsr_blend_bwd_uniform.hip
+// (defines launch_blend_bwd_variant for every channel count; GSR_BWD_UNIFORM=0 in the environment hands the launch back to the
+// product's kernel inside that build: tools/ab_env.py GSR_BWD_UNIFORM 1 0).  The per-wave trace devtools
+// (tests/devtools/trace_bwd_waves.py, -DGSR_TRACE_DETAIL) run on this build.
 //
 // Per-pair arithmetic is the reference's renderCUDA backward (DGR/cuda_rasterizer/backward.cu:399-557;
 // SURVEY.md section 9 item 10): back-to-front replay, T recovered by division, accum_rec recurrence,
@@ -658,25 +663,27 @@ GSR_BWD_SPECIALISE(3, GSR_BWD_WAVES3)
 // Round 5: with the second B tile read from LDS per group (GSR_BWD_B2_LDS) it fits 80 registers without scratch = six waves.
 GSR_BWD_SPECIALISE(4, GSR_BWD_WAVES4)
 
-const uint32_t* g_bwd_order = nullptr;   // (experiments: gsr_debug_set_bwd_order)
 
-void launch_blend_bwd_uniform(int C, int W, int H, int U, const float* bg, ImageState im, BinState b, const float* dL_dpix,
-                              float* grad_acc, hipStream_t st)
+bool launch_blend_bwd_variant(int C, int W, int H, int U, const float* bg, ImageState im, BinState b, const float* dL_dpix, float* grad_acc,
+                              hipStream_t st)
 {
+    const char* e_u = getenv("GSR_BWD_UNIFORM");   // (read per call: tools/ab_env.py flips it inside one process)
+    if (e_u && e_u[0] == '0') return false;
     const Tiles t = tiles_of(W, H);
-    if (U <= 0) return;
+    if (U <= 0) return true;
     // Residency knob: extra dynamic LDS lowers the number of co-resident units per CU (tuning only).
     static const int pad = getenv("GSR_BWD_LDS_PAD") ? atoi(getenv("GSR_BWD_LDS_PAD")) : 0;
     uint64_t* tr = g_trace ? g_trace + 2 * (size_t)t.T : nullptr;
     const auto go = [&](auto tag) {
         constexpr int CC = decltype(tag)::value;
         blend_bwd_uniform_kernel<CC><<<4 * U, 64, pad, st>>>(W, H, t.gx, b.unit_info, b.snap, b.masks, b.point_list, b.rec_a, b.rec_b,
-                                                     static_cast<const RecTail<CC>*>(b.rec_c), bg, im.final_T, im.n_contrib,
-                                                     dL_dpix, grad_acc, tr, g_bwd_order);
+                                                             static_cast<const RecTail<CC>*>(b.rec_c), bg, im.final_T, im.n_contrib,
+                                                             dL_dpix, grad_acc, tr, g_bwd_order);
     };
     if (C == 6) go(std::integral_constant<int, 6>{});
     else if (C == 4) go(std::integral_constant<int, 4>{});
     else go(std::integral_constant<int, 3>{});
+    return true;
 }
 
 }  // namespace gsr
