@@ -303,6 +303,23 @@ def issue_statistics(lib, rs, params, device):
     live = int(np.bitwise_count(live_words).sum())
     kept = np.bitwise_or.reduce(live_words, axis=2)                              # [U, 4]: positions any pixel of the block replays
     trips = int(np.bitwise_count(kept).sum())
+    # The backward blend (gsr_blend_bwd.hip, round 6) walks a block 4x4 sub-block by sub-block, four kept instances of the
+    # sub-block per trip, the unit's kept instances in chunks of 32 (deepest first): trips = sum over (unit, block, chunk,
+    # sub-block) of ceil(kept instances of the sub-block in the chunk / 4).
+    lanes_ = np.arange(64)
+    sub_of = ((lanes_ >> 5) << 1) | ((lanes_ >> 2) & 1)
+    kept_sub = np.stack([np.bitwise_or.reduce(live_words[:, :, sub_of == q], axis=2) for q in range(4)], axis=2)   # [U, 4, 4]
+    sub_pairs = int(np.bitwise_count(kept_sub).sum())
+    pc = np.bitwise_count(kept)
+    quad_trips = int(((np.bitwise_count(kept_sub).astype(np.int64) + 3) // 4)[pc <= 32].sum())
+    for u_, b_ in zip(*np.nonzero(pc > 32)):          # (the few unit-blocks with a second chunk)
+        k_ = int(kept[u_, b_])
+        pos = [i for i in range(63, -1, -1) if (k_ >> i) & 1]                     # deepest first = highest position first
+        for c0 in range(0, len(pos), 32):
+            cm = 0
+            for i in pos[c0:c0 + 32]:
+                cm |= 1 << i
+            quad_trips += sum((bin(int(kept_sub[u_, b_, q]) & cm).count("1") + 3) // 4 for q in range(4))
     # Snapshots (one float4 per pixel and unit, written by the forward when the pixel first consumes a candidate of the unit):
     # NEEDED by the backward = the pixel has a candidate in the unit and its last contributor lies in or behind it (exactly the
     # snapshots of units the pixel reached before its last contributor); WRITTEN beyond those: a pixel walks on behind its
@@ -320,7 +337,12 @@ def issue_statistics(lib, rs, params, device):
              "what": "per (pixel, unit) snapshots of view 0; written = needed + at most one per pixel whose walk went on into a later unit"}
     return {"live_pairs_per_view": live, "bwd_pair_trips_per_view": trips, "bwd_unit_blocks_with_work": int((kept != 0).sum()),
             "snapshots": snaps,
-            "bwd_live_lanes_per_pair_trip": round(live / max(trips, 1), 2), "num_rendered": int(Rn), "units": int(U)}
+            "bwd_live_lanes_per_pair_trip": round(live / max(trips, 1), 2),
+            "bwd_subblock_instances_per_view": sub_pairs, "bwd_trips_per_view": quad_trips,
+            "bwd_live_lanes_per_trip": round(live / max(quad_trips, 1), 2),
+            "bwd_what": "bwd_pair_trips = (kept instance, 8x8 block) pairs = the trips of rounds 1-5's uniform pair loop (one instance "
+                        "on 64 pixels); bwd_trips = trips of round 6's kernel (four kept instances of a 4x4 sub-block on its 16 pixels)",
+            "num_rendered": int(Rn), "units": int(U)}
 
 
 def other_config(name, device, lib, steps=20, repeats=3):
@@ -668,7 +690,23 @@ def main():
             for m_ in mats:
                 rz_plan._camera_key(lib, m_, device)
             key_us = (time.perf_counter() - t0) / len(mats) * 1e6
+            # what the CALLER's own per-call code costs with the GPU idle: the matrix recipe of sugar_model.py:1149-1187 alone
+            # (three .cuda() uploads of pageable memory -- each waits for the stream --, a bmm, the settings object)
+            def caller_only(step_):
+                cam_ = cams[step_ % len(cams)]
+                wv_ = torch.Tensor(cam_._w2v).transpose(0, 1).cuda()
+                pj_ = torch.from_numpy(cam_._proj).transpose(0, 1).cuda()
+                fp_ = (wv_.unsqueeze(0).bmm(pj_.unsqueeze(0))).squeeze(0)
+                cc_ = torch.Tensor(cam_._center).cuda()
+                return wv_, fp_, cc_
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for s_ in range(64):
+                caller_only(s_)
+            torch.cuda.synchronize(device)
+            caller_ms = (time.perf_counter() - t0) / 64 * 1e3
             reference_caller = {
+                "caller_matrices_ms_per_call": round(caller_ms, 4),
                 "value": round(args.steps / med(dts_rc), 2), "ms_per_step": round(med(dts_rc) / args.steps * 1e3, 4), **spread(dts_rc),
                 "exact": {"value": round(args.steps / med(dts_rx), 2), "ms_per_step": round(med(dts_rx) / args.steps * 1e3, 4)},
                 "plan_stats": {k: st1[k] - st0[k] for k in st0}, "camera_keys": {k: k1[k] - k0[k] for k in k0},
@@ -677,7 +715,9 @@ def main():
                         "them (fresh transposed view matrix uploaded with .cuda(), projection, bmm, camera centre; tensors dropped after "
                         "backward); cameras are recognised by gsr_camera_key (contents of the view matrix).  `exact` = the same calls "
                         "with plans off.  The caller's two .cuda() uploads synchronise the stream (PyTorch copies pageable memory "
-                        "synchronously), so unlike single_pipeline the host cannot queue a view behind the previous one's backward"}
+                        "synchronously), so unlike single_pipeline the host cannot queue a view behind the previous one's backward: "
+                        "a step is the view's GPU time PLUS the host time from the uploads to the first launch.  "
+                        "caller_matrices_ms_per_call = the caller's matrix recipe alone on an idle GPU (not rasterizer time)"}
         except Exception as ex:
             reference_caller = {"error": repr(ex)[:300]}
 
@@ -808,7 +848,7 @@ def main():
         out["config"]["conservative"] = {
             "single_pipeline": pick(single, "value", "ms_per_step"),
             "exact_binning": pick(exact_binning, "value", "ms_per_step"),
-            "reference_caller": pick(reference_caller, "value", "ms_per_step", "plan_stats", "camera_key_read_us", "error"),
+            "reference_caller": pick(reference_caller, "value", "ms_per_step", "plan_stats", "camera_key_read_us", "caller_matrices_ms_per_call", "error"),
             "reference_caller_exact": pick((reference_caller or {}).get("exact"), "value", "ms_per_step"),
             "what": "one view at a time with plans / without plans / driven as the reference's sugar_model.py drives the rasterizer "
                     "(matrices rebuilt per call) with and without plans; window and parity figures are added below when those legs run"}
