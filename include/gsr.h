@@ -133,7 +133,10 @@ int gsr_forward_fused(int P, int D, int M, int num_channels, int need_backward, 
  * DGR/cuda_rasterizer/rasterizer_impl.cu:277-317 -- InclusiveSum, the num_rendered read-back, duplicateWithKeys,
  * identifyTileRanges -- for such a view).  *planned = 1 then, and the sizes the backward needs are the plan's CAPACITIES:
  * *num_rendered = R_cap, *num_segments = U_cap (binning_capacity must hold gsr_binning_bytes_mt(R_cap, U_cap, num_channels),
- * otherwise the call takes the exact path); images and gradients are those of the exact path bit for bit (a tile's list is
+ * otherwise the call takes the exact path); images are those of the exact path bit for bit, gradients to the order of the float atomics --
+ * with one exception: a planned view is never SPLIT (gsr_blend_fwd.hip: lists above 1 024 entries blended in parts), whereas the exact
+ * path decides that from the current view's longest list and R; a plan is only valid while its source view would not have split at
+ * three quarters of its R, so the two differ only for a view whose R has fallen below that since, and then by the parts' rounding (a tile's list is
  * the same sorted list; only where it lies differs).  A view that does not fit its plan (a bucket overflows: the Gaussians
  * have moved since the plan was made) is detected by preprocess before anything is blended; the same call then renders it the
  * exact way and re-plans with the slack level raised by one, at most 3 (*planned = -1; 0: no plan was tried).  Only views whose longest list stays within the forward blend's own sort (2 048
@@ -207,9 +210,8 @@ int gsr_backward(int P, int D, int M, int R, int num_segments, const float* back
 /* Backward of a num_channels render (see gsr_forward_stage2_mt): dL_dpix [num_channels,H,W], dL_dcolor
  * [P,num_channels]; every other gradient is the sum over the targets, i.e. what autograd would accumulate from
  * the separate backward passes of the reference.  num_channels = 3 is gsr_backward.
- * Precision of the per-pixel sums on the matrix pipe: exact f32 products for 3 and 6 channels and for channels 0, 1 of a
- * 4-channel render; channels 2 and 3 of a 4-channel render enter their dL_dcolor sums with 16 mantissa bits of dL_dpix (hi + rest
- * rounded to bf16: relative error <= 2^-17 per term, unbiased) -- every other gradient reads dL_dpix in full f32.
+ * Precision of the per-pixel sums: f32 products and f32 sums for every channel of every channel count (ABI 16; the four-channel
+ * kernel of ABI 13-15 took dL_dpix of channels 2 and 3 into the matrix pipe with 16 mantissa bits).
  * grad_scratch_zeroed = 1: the caller guarantees grad_scratch is all zero (gsr_forward_fused cleared it) and the
  * library skips its own fill; 0: the fill is part of the call, as in gsr_backward. */
 int gsr_backward_mt(int P, int D, int M, int R, int num_segments, int num_channels, const float* background, int W,
