@@ -51,6 +51,14 @@ namespace gsr {
 #ifndef GSR_QUAD_WAVES
 #define GSR_QUAD_WAVES 7
 #endif
+#ifndef GSR_QUAD_WAVES4
+#define GSR_QUAD_WAVES4 6   // four channels need 75 registers.  Held at 72 the compiler spills one float4 of the head into SCRATCH, and a
+                            // kernel that touches scratch at all runs ~11 us longer than the residency fit predicts: seven waves with the
+                            // spill against six without: + 5 us (three channels at eight waves with eight registers spilled, none inside
+                            // the trip loop: + 20 us).  Parking the head's record rows in LDS instead (the record / moment tables' bytes
+                            // are free until the first chunk is filled) removes the spill and costs as much: every wave -- the 24 % that
+                            // leave after the head included -- then waits for the record rows before it can look at its candidate words
+#endif
 #ifndef GSR_QUAD_WAVES6
 #define GSR_QUAD_WAVES6 5   // six channels: 96 registers
 #endif
@@ -105,7 +113,7 @@ __device__ __forceinline__ float fold_quad(float v)
 }
 
 template <int C>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C == 6 ? GSR_QUAD_WAVES6 : GSR_QUAD_WAVES, 8)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C == 6 ? GSR_QUAD_WAVES6 : C == 4 ? GSR_QUAD_WAVES4 : GSR_QUAD_WAVES, 8)))
 blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, const float4* __restrict__ snap,
                       const uint2* __restrict__ masks, const uint32_t* __restrict__ point_list, const float4* __restrict__ rec_a,
                       const float4* __restrict__ rec_b, const RecTail<C>* __restrict__ rec_c, const float* __restrict__ bg,
@@ -168,6 +176,15 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
     const int pidx = 16 * (py - ty * TILE) + (px - tx * TILE);
     float Ts, Tf, cs[C], cf[C];
     const auto load_snap32 = [&](const float4* base_u, float& T_, float (&c_)[C]) {
+        if constexpr (C == 4) {
+            // (four channels: T + four colours are five floats of an eight-float slot -- a 16-byte and a 4-byte load instead of two
+            // 16-byte ones: the three pad registers of each of the two snapshots in flight were what pushed the kernel over 72
+            // registers, and a kernel that touches scratch at all loses ~20 us of this launch)
+            const float4 t = at32(base_u, (uint32_t)(pidx * SV) * 16u);
+            const float c3 = at32(reinterpret_cast<const float*>(base_u), (uint32_t)(pidx * SV + 1) * 16u);
+            T_ = t.x; c_[0] = t.y; c_[1] = t.z; c_[2] = t.w; c_[C - 1] = c3;
+            return;
+        }
         float v[4 * SV];
 #pragma unroll
         for (int q = 0; q < SV; q++) {
@@ -240,7 +257,6 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
     }
     const unsigned long long kany = ks[0] | ks[1] | ks[2] | ks[3];
     if (kany == 0ull) return;
-
     // ---- the pixels' start state, parked per pixel lane; the trips read it in their own lane order
     {
         float4* st = reinterpret_cast<float4*>(lds + STG + STG_B * lane);
