@@ -33,8 +33,12 @@ GRAD_TOL = 1e-4
 # side of a blend threshold than in the reference build: measured on MI355X, 1 - 25 image elements per 1080p view (102 at
 # 4K) up to 2.7e-3, and up to 30 of 1.5 - 3 million entries of a gradient tensor (the flipped pair's Gaussian) up to
 # 5.3e-3 of the tensor's maximum.  Allowed there: 1e-5 of the image elements, 5e-5 of a gradient tensor's entries.
-FULL_IMG_OUTLIERS = 1e-5
-FULL_GRAD_OUTLIERS = 5e-5
+# Round 6: with the projection in the reference build's operation order (gsr_ref_order.h) the whole 160-camera rig shows at most 5
+# image elements and 23 entries of a gradient tensor per view outside the tolerance, median 0 (profiles/r06_parity_report.txt):
+# the budgets came down from 1e-5 / 5e-5 to 2e-6 of the image elements (12 of a 1080p image) and 2e-5 of a gradient tensor's entries.
+FULL_IMG_OUTLIERS = 2e-6
+FULL_GRAD_OUTLIERS = 2e-5
+FULL_MIN_OUTLIERS = 4      # a fraction budget never means fewer than this many elements (a 60 000-entry tensor: 2e-5 would be one)
 SMALL_FRAC = 1e-3    # "small" gradient entries: |ref| < SMALL_FRAC * max|ref| ...
 SMALL_TOL = 1e-5     # ... must be within SMALL_TOL * max|ref| + GRAD_TOL * |ref|
 REPORT = []          # (what, measured max normalised error) of every check of this process, for the test log
@@ -61,8 +65,8 @@ def check_image(a, b, what="image", tol=IMG_TOL, max_outlier_frac=0.0, outlier_c
     scale = np.maximum(1.0, np.abs(b))
     err = np.abs(a - b) / scale
     bad = err > tol
-    frac = bad.mean() if bad.size else 0.0
-    assert frac <= max_outlier_frac, f"{what}: {bad.sum()} of {bad.size} elements differ by more than {tol} (max {err.max():.3e})"
+    allowed = max(int(np.ceil(max_outlier_frac * bad.size)), FULL_MIN_OUTLIERS) if max_outlier_frac > 0.0 else 0
+    assert bad.sum() <= allowed, f"{what}: {bad.sum()} of {bad.size} elements differ by more than {tol} (max {err.max():.3e}; allowed {allowed})"
     if bad.any():
         assert err.max() <= outlier_cap, f"{what}: outlier {err.max():.3e} exceeds the threshold-flip cap {outlier_cap}"
     worst = float(err.max()) if err.size else 0.0
@@ -83,9 +87,9 @@ def check_grad(a, b, what="grad", tol=GRAD_TOL, max_outlier_frac=0.0, outlier_ca
         return 0.0
     err = np.abs(a - b) / (ref + 1e-30) - tol * np.abs(b) / ref
     bad = err > tol
-    frac = bad.mean()
-    assert frac <= max_outlier_frac, (f"{what}: {bad.sum()} of {bad.size} elements off by more than {tol} of max|ref| "
-                                      f"(worst {err.max():.3e}, max|ref| {ref:.3e})")
+    allowed = max(int(np.ceil(max_outlier_frac * bad.size)), FULL_MIN_OUTLIERS) if max_outlier_frac > 0.0 else 0
+    assert bad.sum() <= allowed, (f"{what}: {bad.sum()} of {bad.size} elements off by more than {tol} of max|ref| "
+                                  f"(worst {err.max():.3e}, max|ref| {ref:.3e}; allowed {allowed})")
     if bad.any():
         assert err.max() <= outlier_cap, f"{what}: outlier {err.max():.3e} (normalised) exceeds cap {outlier_cap}"
     # entries far below the largest one: a bound 10x tighter in absolute terms (they would pass the test above with
