@@ -137,8 +137,17 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
     uint32_t wave_sel = slot_id & 3u;
     const uint32_t full = (n_units >> 6) << 6;
     if (blockIdx.x >= full * 4u) { unit = blockIdx.x >> 2; wave_sel = blockIdx.x & 3u; }
+#ifdef GSR_EXP_LIVE
+    // (experiment build, tools/dead_exit_exp.py: the debug pointer is not a launch order but a table of live bits per unit -- word
+    // [n_units] = 0: every wave that finds work records its bit; 1: a wave whose bit is clear leaves right here, before any vector load --
+    // what a per-(unit, block) flag written by the forward would buy, without touching the forward)
+    uint32_t* const live_tab = const_cast<uint32_t*>(order);
+    const bool live_use = live_tab != nullptr && live_tab[n_units] == 1u;
+    if (live_use && ((live_tab[unit] >> wave_sel) & 1u) == 0u) return;
+#else
     // (a launch ORDER of the units, when there is one: position in the dispatch sequence -> unit; gsr_debug_set_bwd_order)
     if (order != nullptr) unit = order[unit];
+#endif
     const uint4 info = unit_info[unit];
     const int tile = (int)info.x;
     const uint32_t list0 = info.y;
@@ -257,6 +266,9 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
     }
     const unsigned long long kany = ks[0] | ks[1] | ks[2] | ks[3];
     if (kany == 0ull) return;
+#ifdef GSR_EXP_LIVE
+    if (live_tab != nullptr && !live_use && lane == 0) atomicOr(&live_tab[unit], 1u << wave);
+#endif
     // ---- the pixels' start state, parked per pixel lane; the trips read it in their own lane order
     {
         float4* st = reinterpret_cast<float4*>(lds + STG + STG_B * lane);
