@@ -52,12 +52,12 @@ namespace gsr {
 #define GSR_QUAD_WAVES 7
 #endif
 #ifndef GSR_QUAD_WAVES4
-#define GSR_QUAD_WAVES4 6   // four channels need 75 registers.  Held at 72 the compiler spills one float4 of the head into SCRATCH, and a
-                            // kernel that touches scratch at all runs ~11 us longer than the residency fit predicts: seven waves with the
-                            // spill against six without: + 5 us (three channels at eight waves with eight registers spilled, none inside
-                            // the trip loop: + 20 us).  Parking the head's record rows in LDS instead (the record / moment tables' bytes
-                            // are free until the first chunk is filled) removes the spill and costs as much: every wave -- the 24 % that
-                            // leave after the head included -- then waits for the record rows before it can look at its candidate words
+#define GSR_QUAD_WAVES4 7   // four channels: 72 registers without scratch -- once the lane-derived constants of the trips are computed inside
+                            // the sub-block loop (hoisted to the kernel's head they lived through its register peak: 75).  SCRATCH is poison
+                            // for this launch: seven waves with one float4 of the head spilled ran 5 us SLOWER than six waves without (the
+                            // residency fit says seven waves are worth 5.9 us: a kernel of 54 640 one-wave workgroups that touches scratch at
+                            // all pays ~11 us; three channels at eight waves with eight registers spilled outside the trip loop: + 20 us).
+                            // Parking the head's record rows in LDS, or loading them late, did not remove the spill for less
 #endif
 #ifndef GSR_QUAD_WAVES6
 #define GSR_QUAD_WAVES6 5   // six channels: 96 registers
@@ -276,17 +276,6 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
         st[1] = make_float4(dp[0], dp[1], dp[2], C > 3 ? dp[3 < C ? 3 : 0] : 0.f);
         if constexpr (C == 6) st[2] = make_float4(dp[4 < C ? 4 : 0], dp[5 < C ? 5 : 0], 0.f, 0.f);
     }
-    // trip lane order: lane = 16 rho + 4 j + kappa
-    const int rho = lane >> 4, jj = (lane >> 2) & 3, kap = lane & 3;
-    // which of a trip's 64 lanes carry a finished sum after the fold (see below) and which moment it is
-    // (the other lanes add garbage to the three pad words of their instance's moment record: no branch around the store)
-    const int mom_idx = kap == 0 ? ((rho & 1) * 2 + (rho >> 1))          // rows {0, 2, 1, 3} of fold A: moments 0, 2, 1, 3
-                      : kap == 1 ? 4 + ((rho & 1) * 2 + (rho >> 1))      // fold B: moments 4, 6, 5, 7
-                      : (kap == 2 && C == 6) ? 8 + ((rho & 1) * 2 + (rho >> 1))   // fold C of six channels: rows m8, m10, m9, m11
-                      : (kap == 2 && rho == 0) ? 8
-                      : (kap == 2 && rho == 2 && C == 4) ? 9       // fold C of four channels: rows m8, m8, m9, m9
-                                                         : NM + (lane & 1);
-
     const bool keep = ((kany >> (63 - lane)) & 1ull) != 0ull;
     const unsigned long long m = __ballot(keep);
     const int cnt_all = __popcll(m);
@@ -344,6 +333,22 @@ blend_bwd_kernel(int W, int H, int gx, const uint4* __restrict__ unit_info, cons
         for (int s = 0; s < (GSR_QUAD_EXP ? 0 : 4); s++) {
             const int ns = s == 0 ? cnt_s[0] : s == 1 ? cnt_s[1] : s == 2 ? cnt_s[2] : cnt_s[3];
             if (ns == 0) continue;
+            // trip lane order: lane = 16 rho + 4 j + kappa.  (Derived HERE, from a copy of the lane id the compiler cannot see through:
+            // computed once per wave these constants -- and what follows from them -- were hoisted to the kernel's head and lived through
+            // its register peak, the loads of the unit in flight)
+            // -- four channels only: they then fit the 72 registers of seven waves (75 hoisted); three and six channels have the room
+            // and run 2 - 4 us faster with the constants hoisted
+            int lane_o = lane;
+            if constexpr (C == 4) asm volatile("" : "+v"(lane_o));
+            const int rho = lane_o >> 4, jj = (lane_o >> 2) & 3, kap = lane_o & 3;
+            // which of a trip's 64 lanes carry a finished sum after the fold (see below) and which moment it is
+            // (the other lanes add garbage to the pad words of their instance's moment record: no branch around the store)
+            const int mom_idx = kap == 0 ? ((rho & 1) * 2 + (rho >> 1))          // rows {0, 2, 1, 3} of fold A: moments 0, 2, 1, 3
+                              : kap == 1 ? 4 + ((rho & 1) * 2 + (rho >> 1))      // fold B: moments 4, 6, 5, 7
+                              : (kap == 2 && C == 6) ? 8 + ((rho & 1) * 2 + (rho >> 1))   // fold C of six channels: rows m8, m10, m9, m11
+                              : (kap == 2 && rho == 0) ? 8
+                              : (kap == 2 && rho == 2 && C == 4) ? 9       // fold C of four channels: rows m8, m8, m9, m9
+                                                                 : NM + (lane_o & 1);
             // this lane's pixel of sub-block s and its state
             const int bx = s & 1, by = s >> 1;
             const int pl = 8 * (4 * by + rho) + 4 * bx + kap;
